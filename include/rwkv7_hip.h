@@ -1,0 +1,74 @@
+/*
+ * include/rwkv7_hip.h -- C ABI of librwkv7_hip.so: the MI355X (gfx950) RWKV-7 time-mix hot path.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain device pointers, sizes and a HIP
+ * stream; nothing here knows about torch.  The caller owns ALL memory including outputs and scratch
+ * (as in the reference: y/s/sa/grads are torch.empty_like'd by the Python wrapper,
+ * model/llm/rwkv_s2s_single_ffn.py:22-24,33) and the ops mutate in place and return an int:
+ *      0   success
+ *     <0   argument error (RWKV7_E*)          -- nothing was launched
+ *     >0   hipError_t from the launch          -- hipGetLastError() after the launch
+ * Kernels are stream-ordered, re-entrant and keep no global state, so they may be called from
+ * several host threads on different streams (service/tts_service.py:42-60 runs one thread per engine).
+ *
+ * Tensor conventions (reference: model/llm/cuda/wkv7_cuda.cu:18, rwkv7_state_fwd_fp16.cu:16,27):
+ *   w,q,k,v,a,b,y,dy,d*  [B,T,H,64] contiguous  == [B,T,C] with C = H*64
+ *   w is the PRE-activation: the decay used is exp(-exp(w))            (wkv7_cuda.cu:21)
+ *   s   fp32 [B,H,T/16,64,64], checkpoint of the state after every 16th step, stored TRANSPOSED
+ *       (s[..., j, i] = S[i][j], wkv7_cuda.cu:45-48)
+ *   sa  fp32 [B,T,H,64],  sa[i] = sum_j a[j] * S_{t-1}[i][j]             (wkv7_cuda.cu:27-32)
+ *   state fp32 [B,H,64,64], row = value index, col = key index          (rwkv7_state_fwd_fp16.cu:16)
+ * The *_bf16 functions take bf16 tensors (the reference's only dtype); the *_f32 twins take fp32
+ * tensors and exist for the fp32 logit-parity path.
+ */
+#ifndef RWKV7_HIP_H
+#define RWKV7_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RWKV7_OK 0
+#define RWKV7_EINVAL (-1)   /* null pointer / non-positive size */
+#define RWKV7_ECHUNK (-2)   /* T % 16 != 0   (assert, wkv7_cuda.cu:136; rwkv_s2s_single_ffn.py:19) */
+#define RWKV7_EHEAD  (-3)   /* H*64 != C     (assert, rwkv7_state_fwd_fp16.cu:61) */
+#define RWKV7_ESHAPE (-4)   /* unsupported size for a fused elementwise op */
+
+#define RWKV7_HEAD_SIZE 64
+#define RWKV7_CHUNK_LEN 16
+
+typedef void *rwkv7_stream_t; /* hipStream_t */
+
+/* library identification: "rwkv7_hip <version> gfx950" */
+const char *rwkv7_version(void);
+
+/* ---- WKV7 training forward: torch.ops.wind_backstepping.forward (model/llm/cuda/wkv7_op.cpp:21-22,
+ *      kernel wkv7_cuda.cu:10-52).  Zero initial state.  s and sa may both be NULL (inference). ---- */
+int rwkv7_wkv_fwd_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                       const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream);
+int rwkv7_wkv_fwd_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                      const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream);
+
+/* ---- WKV7 training backward: torch.ops.wind_backstepping.backward (wkv7_op.cpp:23-24,
+ *      kernel wkv7_cuda.cu:54-130).  Output order dw,dq,dk,dv,da,db == reference dw,dq,dk,dv,dz,da. ---- */
+int rwkv7_wkv_bwd_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                       const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                       void *dw, void *dq, void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
+int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                      const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                      void *dw, void *dq, void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
+
+/* ---- state-carrying forward: torch.ops.rwkv7_state_fwd_fp16.forward (rwkv7_state_fwd_fp16.cpp:8-14,
+ *      kernel rwkv7_state_fwd_fp16.cu:9-57) and its B=1 twin torch.ops.wkv7s.forward
+ *      (wkv7s_op.cpp:9-15).  state is read at entry and overwritten at exit; any T >= 1. ---- */
+int rwkv7_wkv_state_fwd_bf16(int B, int T, int C, int H, float *state, const void *r, const void *w,
+                             const void *k, const void *v, const void *a, const void *b, void *y,
+                             rwkv7_stream_t stream);
+int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void *r, const void *w,
+                            const void *k, const void *v, const void *a, const void *b, void *y,
+                            rwkv7_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RWKV7_HIP_H */

@@ -1,0 +1,267 @@
+"""oracle/rwkv7_ref.py -- TEST INFRASTRUCTURE ONLY: eager-PyTorch CPU restatement of the RWKV-7 (x070)
+language-model maths the reference trains and serves.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+
+What it follows (paths relative to /root/reference):
+  wkv7_scan            model/llm/rwkv_s2s_single_ffn.py:499-502 (and the "cuda-free method" :526-533)
+  tmix_seq             model/llm/rwkv_s2s_single_ffn.py:158-196 (training Tmix, incl. mask handling);
+                       stateful variant model/llm/rwkv_asr_cuda_whisper.py:181-215
+  cmix_seq             model/llm/rwkv_s2s_single_ffn.py:223-230 ; stateful rwkv_asr_cuda_whisper.py:277-285
+  block_seq / backbone model/llm/rwkv_s2s_single_ffn.py:251-259,296-330 ; rwkv_asr_cuda_whisper.py:438-472
+Parameter names are the rwkvfla ones (left-hand side of utils/convert_rwkv.py:17-30), LoRA weights are
+stored [out,in] (transposed vs the in-tree w1/w2, utils/convert_rwkv.py:26-27).
+
+Third-party arithmetic: the backbone the reference actually trains is rwkv-fla==0.7.202503140658
+(requirements.txt:213), absent from /root/reference and from this image.  Its semantics that are not
+restated in-tree (GroupNorm eps = head_dim*1e-5 = 64e-5, decay w = -e^{-0.5}*sigmoid(.)) coincide with
+the in-tree inference twin (rwkv_s2s_single_ffn.py:497,504).
+
+Parity pin: oracle/pin_against_reference.py imports the reference's RWKV_x070_TMix_one / CMix_one /
+RWKV_Tmix_x070 / RWKV_CMix_x070 / Block in the authoring container and checks this file against them;
+the vectors are committed in tests/golden/.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+HEAD_SIZE = 64
+GN_EPS = 64e-5  # rwkv_s2s_single_ffn.py:504,538 ; fla: head_dim * norm_eps
+
+
+@dataclass
+class RefConfig:
+    hidden_size: int
+    num_hidden_layers: int
+    vocab_size: int = 0
+    head_dim: int = HEAD_SIZE
+    decay_low_rank_dim: int = 64
+    a_low_rank_dim: int = 64
+    v_low_rank_dim: int = 32
+    gate_low_rank_dim: int = 128
+    intermediate_size: Optional[int] = None
+    norm_eps: float = 1e-5
+    gn_eps: float = GN_EPS
+
+    @property
+    def num_heads(self):
+        return self.hidden_size // self.head_dim
+
+    @property
+    def ffn_dim(self):
+        return self.intermediate_size or 4 * self.hidden_size
+
+
+# ------------------------------------------------------------------------------------------------
+# parameters (rwkvfla key layout)
+# ------------------------------------------------------------------------------------------------
+def init_params(cfg: RefConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Random but *realistic* parameters: the time-mix vectors follow the reference's own
+    initialisation (rwkv_s2s_single_ffn.py:74-138) so that the decay lands in its trained range;
+    the dense matrices are N(0, 0.02^2) scaled so that activations stay O(1)."""
+    g = torch.Generator().manual_seed(seed)
+    D, L, H, N = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_heads, cfg.head_dim
+    p: Dict[str, torch.Tensor] = {}
+
+    def rnd(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    if cfg.vocab_size:
+        p["model.embeddings.weight"] = rnd(cfg.vocab_size, D, std=0.5)
+    for i in range(L):
+        pre = f"model.layers.{i}."
+        r01 = i / max(L - 1, 1)
+        r10 = 1.0 - i / L
+        ddd = torch.arange(D, dtype=torch.float32) / D
+        lin = torch.arange(D, dtype=torch.float32) / max(D - 1, 1) - 0.5
+        n = torch.arange(D) % N
+        zig = (n.float() - (N - 1) / 2) / ((N - 1) / 2)
+        zig = zig * zig.abs()
+        www = -6 + 6 * (torch.arange(D, dtype=torch.float32) / max(D - 1, 1)) ** (1 + r01 ** 0.3)
+        if i == 0:
+            p[pre + "pre_norm.weight"] = 1 + rnd(D, std=0.1)
+            p[pre + "pre_norm.bias"] = rnd(D, std=0.1)
+        for nm in ("attn_norm", "ffn_norm"):
+            p[pre + nm + ".weight"] = 1 + rnd(D, std=0.1)
+            p[pre + nm + ".bias"] = rnd(D, std=0.1)
+        at = pre + "attn."
+        for nm, e in (("r", 0.2), ("w", 0.9), ("k", 0.7), ("v", 0.7), ("a", 0.9), ("g", 0.2)):
+            p[at + f"x_{nm}"] = (1.0 - torch.pow(ddd, e * r10)).view(1, 1, D)
+        p[at + "k_k"] = 0.71 - lin * 0.1
+        p[at + "k_a"] = torch.full((D,), 1.02)
+        p[at + "r_k"] = torch.full((H, N), -0.04) + rnd(H, N, std=0.02)
+        s = 1.0 / math.sqrt(D)
+        p[at + "r_proj.weight"] = rnd(D, D, std=s)
+        p[at + "k_proj.weight"] = rnd(D, D, std=s)
+        p[at + "v_proj.weight"] = rnd(D, D, std=s)
+        p[at + "o_proj.weight"] = rnd(D, D, std=s)
+        lora = (("w", cfg.decay_low_rank_dim, www + 0.5 + zig * 2.5),
+                ("a", cfg.a_low_rank_dim, -0.19 + zig * 0.3 + lin * 0.4),
+                ("v", cfg.v_low_rank_dim, 0.73 - lin * 0.4),
+                ("g", cfg.gate_low_rank_dim, None))
+        for nm, rank, bias in lora:
+            if nm == "v" and i == 0:
+                continue  # layer 0 has no value-residual LoRA (rwkv_s2s_single_ffn.py:123-127)
+            p[at + f"{nm}_lora.lora.0.weight"] = rnd(rank, D, std=s)
+            p[at + f"{nm}_lora.lora.2.weight"] = rnd(D, rank, std=0.1 / math.sqrt(rank) * 3)
+            if bias is not None:
+                p[at + f"{nm}_lora.lora.2.bias"] = bias.clone()
+        p[at + "g_norm.weight"] = 1 + rnd(D, std=0.1)
+        p[at + "g_norm.bias"] = rnd(D, std=0.1)
+        ff = pre + "ffn."
+        p[ff + "x_k"] = 1.0 - torch.pow(ddd, r10 ** 4)
+        p[ff + "key.weight"] = rnd(cfg.ffn_dim, D, std=s)
+        p[ff + "value.weight"] = rnd(D, cfg.ffn_dim, std=1.0 / math.sqrt(cfg.ffn_dim))
+    p["model.norm.weight"] = 1 + rnd(D, std=0.1)
+    p["model.norm.bias"] = rnd(D, std=0.1)
+    return {k: v.to(dtype).contiguous() for k, v in p.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# WKV7 scan in plain torch (differentiable: used to cross-check the analytic backward)
+# ------------------------------------------------------------------------------------------------
+def wkv7_scan(r, w, k, v, a, b, state=None):
+    """r,w,k,v,a,b: [B,T,H,N] fp32; w is the *pre-activation* the kernels take (w~ = exp(-exp(w))).
+    state: [B,H,N,N] (row = value idx, col = key idx) or None (zeros).  Returns y [B,T,H,N], state.
+    Per step (rwkv_s2s_single_ffn.py:499-502): S = S*w~ + (S a) b^T + v k^T ; y = S r."""
+    B, T, H, N = r.shape
+    S = torch.zeros(B, H, N, N, dtype=r.dtype) if state is None else state
+    wt = torch.exp(-torch.exp(w))
+    ys = []
+    for t in range(T):
+        sa = torch.einsum("bhij,bhj->bhi", S, a[:, t])
+        S = S * wt[:, t].unsqueeze(-2) + sa.unsqueeze(-1) * b[:, t].unsqueeze(-2) \
+            + v[:, t].unsqueeze(-1) * k[:, t].unsqueeze(-2)
+        ys.append(torch.einsum("bhij,bhj->bhi", S, r[:, t]))
+    return torch.stack(ys, dim=1), S
+
+
+# ------------------------------------------------------------------------------------------------
+# layer pieces
+# ------------------------------------------------------------------------------------------------
+def _lin(x, w):
+    return x @ w.t()
+
+
+def _lora(p, pre, x, act=None):
+    h = _lin(x, p[pre + ".lora.0.weight"])
+    if act is not None:
+        h = act(h)
+    h = _lin(h, p[pre + ".lora.2.weight"])
+    b = p.get(pre + ".lora.2.bias")
+    return h if b is None else h + b
+
+
+def _shift(x, x_prev):
+    """token shift: x_{t-1}, with x_prev (or zeros) at t=0 (rwkv_s2s_single_ffn.py:162 / :511)."""
+    first = torch.zeros_like(x[:, :1]) if x_prev is None else x_prev.unsqueeze(1)
+    return torch.cat([first, x[:, :-1]], dim=1)
+
+
+def tmix_seq(p, cfg: RefConfig, layer_id: int, x, mask, v_first, x_prev=None, state=None,
+             wkv=None, full_mask=True):
+    """x [B,T,D] (already LayerNorm'ed), mask [B,T,1] float.  Returns out, v_first, x_last, state.
+    full_mask=True masks r,w,k,v,kk as rwkv_s2s_single_ffn.py:175-178,188; False = the
+    rwkv_asr_cuda_whisper.py:181-215 variant (x and v only)."""
+    at = f"model.layers.{layer_id}.attn."
+    B, T, D = x.shape
+    H, N = cfg.num_heads, cfg.head_dim
+    x = x * mask
+    xx = _shift(x, x_prev) - x
+    xr, xw, xk, xv, xa, xg = (x + xx * p[at + f"x_{n}"].view(1, 1, D) for n in "rwkvag")
+    r = _lin(xr, p[at + "r_proj.weight"])
+    w = -F.softplus(-_lora(p, at + "w_lora", xw, torch.tanh)) - 0.5
+    k = _lin(xk, p[at + "k_proj.weight"])
+    v = _lin(xv, p[at + "v_proj.weight"])
+    if full_mask:
+        r, w, k, v = r * mask, w * mask, k * mask, v * mask
+    if layer_id == 0:
+        v_first = v
+    else:
+        v = v + (v_first - v) * torch.sigmoid(_lora(p, at + "v_lora", xv))
+    a = torch.sigmoid(_lora(p, at + "a_lora", xa))
+    g = _lora(p, at + "g_lora", xg, torch.sigmoid)
+    kk = F.normalize((k * p[at + "k_k"].view(1, 1, D)).view(B, T, H, N), dim=-1, p=2.0).view(B, T, D)
+    if full_mask:
+        kk = kk * mask
+    k = k * (1 + (a - 1) * p[at + "k_a"].view(1, 1, D))
+    v = v * mask
+    hv = lambda z: z.reshape(B, T, H, N).contiguous()
+    if wkv is None:
+        y, state = wkv7_scan(hv(r), hv(w), hv(k), hv(v), hv(-kk), hv(kk * a), state)
+    else:
+        y, state = wkv(hv(r), hv(w), hv(k), hv(v), hv(-kk), hv(kk * a), state)
+    y = y.reshape(B * T, D)
+    y = F.group_norm(y, H, p[at + "g_norm.weight"], p[at + "g_norm.bias"], eps=cfg.gn_eps).view(B, T, D)
+    bonus = (hv(r) * hv(k) * p[at + "r_k"].view(1, 1, H, N)).sum(-1, keepdim=True) * hv(v)
+    y = y + bonus.view(B, T, D)
+    out = _lin(y * g, p[at + "o_proj.weight"])
+    return out, v_first, x[:, -1], state
+
+
+def cmix_seq(p, cfg: RefConfig, layer_id: int, x, mask, x_prev=None):
+    ff = f"model.layers.{layer_id}.ffn."
+    x = x * mask
+    xx = _shift(x, x_prev) - x
+    k = x + xx * p[ff + "x_k"].view(1, 1, -1)
+    k = torch.relu(_lin(k, p[ff + "key.weight"])) ** 2
+    return _lin(k, p[ff + "value.weight"]), x[:, -1]
+
+
+def _ln(p, pre, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), p[pre + ".weight"], p[pre + ".bias"], eps)
+
+
+def backbone(p, cfg: RefConfig, x, mask=None, states: Optional[List] = None, wkv=None, full_mask=True):
+    """inputs_embeds [B,T,D] -> hidden [B,T,D] after the final norm.  states: list of 3*L entries
+    [att_x_prev (B,D), att_kv (B,H,N,N), ffn_x_prev (B,D)] per layer (rwkv_asr_cuda_whisper.py:443-447)
+    or None for the stateless training forward.  Returns hidden, new_states."""
+    B, T, D = x.shape
+    if mask is None:
+        mask = torch.ones(B, T, 1, dtype=x.dtype)
+    elif mask.dim() == 2:
+        mask = mask.unsqueeze(-1).to(x.dtype)
+    new_states = []
+    v_first = None
+    for i in range(cfg.num_hidden_layers):
+        pre = f"model.layers.{i}."
+        st = states[3 * i:3 * i + 3] if states is not None else (None, None, None)
+        if i == 0:
+            x = _ln(p, pre + "pre_norm", x, cfg.norm_eps)
+        att, v_first, ax, kv = tmix_seq(p, cfg, i, _ln(p, pre + "attn_norm", x, cfg.norm_eps), mask,
+                                        v_first, st[0], st[1], wkv, full_mask)
+        x = x + att
+        ffn, fx = cmix_seq(p, cfg, i, _ln(p, pre + "ffn_norm", x, cfg.norm_eps), mask, st[2])
+        x = x + ffn
+        new_states += [ax, kv, fx]
+    return _ln(p, "model.norm", x, cfg.norm_eps), new_states
+
+
+def zero_states(cfg: RefConfig, B: int, dtype=torch.float32):
+    out = []
+    for _ in range(cfg.num_hidden_layers):
+        out += [torch.zeros(B, cfg.hidden_size, dtype=dtype),
+                torch.zeros(B, cfg.num_heads, cfg.head_dim, cfg.head_dim, dtype=torch.float32),
+                torch.zeros(B, cfg.hidden_size, dtype=dtype)]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# heads (Spark first; Cosy / XY are added next to their HIP-side twins)
+# ------------------------------------------------------------------------------------------------
+def spark_forward(p, cfg: RefConfig, inputs_embeds, attention_mask=None, labels=None, states=None,
+                  wkv=None):
+    """model/llm/spark_llm.py:105-172 in eval mode: backbone -> lm_head ; labels shifted by one with
+    ignore_index=-100 and mean CE (spark_llm.py:154-160)."""
+    h, st = backbone(p, cfg, inputs_embeds, attention_mask, states, wkv)
+    logits = _lin(h, p["lm_head.weight"])
+    loss = None
+    if labels is not None:
+        lab = torch.cat([labels[..., 1:], torch.full_like(labels[:, :1], -100)], 1)
+        loss = F.cross_entropy(logits.view(lab.numel(), -1), lab.view(-1), ignore_index=-100)
+    return loss, logits, st

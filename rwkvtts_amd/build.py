@@ -1,0 +1,70 @@
+"""Ahead-of-time build of librwkv7_hip.so for gfx950 (no import-time JIT, unlike the reference's
+torch.utils.cpp_extension.load at model/llm/rwkv_s2s_single_ffn.py:13).
+
+hipcc cross-compiles without a GPU; the .so is written in-tree (rwkvtts_amd/lib/) so that it travels
+with the repo snapshot to the GPU box and is visible to the driver's "which .so was loaded" audit.
+
+    python -m rwkvtts_amd.build [--force] [--verbose]
+"""
+import argparse
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+SO = os.path.join(LIBDIR, "librwkv7_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+         "-Wno-unused-result", "-Wno-pass-failed"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(SO):
+        return True
+    mt = os.path.getmtime(SO)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+        glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    return any(os.path.getmtime(p) > mt for p in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra=()) -> str:
+    if not force and not _stale():
+        return SO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: librwkv7_hip.so cannot be built (and there is no fallback)")
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src).replace(".hip", ".o"))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+                os.path.getmtime(p) for p in [src] + glob.glob(os.path.join(CSRC, "*.h"))):
+            cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *extra, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", SO, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--resource-usage", action="store_true", help="print VGPR/LDS/occupancy per kernel")
+    a = ap.parse_args()
+    extra = ["-Rpass-analysis=kernel-resource-usage"] if a.resource_usage else []
+    print(build(force=a.force or a.resource_usage, verbose=a.verbose, extra=extra))
+    sys.exit(0)

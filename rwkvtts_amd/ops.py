@@ -1,0 +1,189 @@
+"""Host-side mirror of the reference's WKV7 operator interface, backed by librwkv7_hip.so.
+
+Same names, argument order and error behaviour as the reference so that its call sites work unchanged:
+
+    torch.ops.wind_backstepping.forward / .backward      model/llm/cuda/wkv7_op.cpp:21-29
+    torch.ops.rwkv7_state_fwd_fp16.forward               model/llm/cuda/rwkv7_state_fwd_fp16.cpp:8-14
+    torch.ops.wkv7s.forward                              model/llm/cuda/wkv7s_op.cpp:9-15
+    WindBackstepping, RUN_CUDA_RWKV7g                    model/llm/rwkv_s2s_single_ffn.py:15-40
+    WKV_7 / RWKV7_OP, WKV_7_batch / RWKV7_BATCH_OP       model/llm/rwkv_asr_cuda_whisper.py:50-81
+
+The ops are registered for the CUDA dispatch key (which is HIP on ROCm) only -- exactly like the
+reference (wkv7_op.cpp:26-29) -- so CPU tensors raise NotImplementedError instead of silently
+running somewhere else.  PyTorch is plumbing here: it owns the device memory and the stream.
+
+Extension over the reference: fp32 tensors are accepted everywhere bf16 is (routed to the *_f32
+C entry points); that is what the fp32 logit-parity tests use.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+HEAD_SIZE = 64
+CHUNK_LEN = 16
+DTYPE = torch.bfloat16
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _sfx(ts, what):
+    dt = ts[0].dtype
+    if dt not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"{what}: tensors must be bfloat16 (reference) or float32, got {dt}")
+    for t in ts:
+        if t.dtype != dt:
+            raise TypeError(f"{what}: mixed dtypes {dt} / {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError(f"{what}: tensors must be contiguous (rwkv_s2s_single_ffn.py:21)")
+        if not t.is_cuda:
+            raise NotImplementedError(f"{what}: HIP device tensors only (no CPU path)")
+    return "bf16" if dt == torch.bfloat16 else "f32"
+
+
+# ------------------------------------------------------------------------------------------------
+# raw ops (caller allocates everything, ops mutate in place and return None)
+# ------------------------------------------------------------------------------------------------
+def _wb_forward(w, q, k, v, z, a, y, s, sa):
+    B, T, H, C = w.shape
+    sfx = _sfx([w, q, k, v, z, a, y], "wind_backstepping.forward")
+    assert C == HEAD_SIZE and s.dtype == torch.float32 and sa.dtype == torch.float32
+    with torch.cuda.device_of(w):
+        rc = getattr(_lib.lib(), "rwkv7_wkv_fwd_" + sfx)(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a),
+                                                       _p(y), _p(s), _p(sa), _stream(w))
+    _lib.check(rc, "wind_backstepping.forward")
+
+
+def _wb_backward(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
+    B, T, H, C = w.shape
+    sfx = _sfx([w, q, k, v, z, a, dy, dw, dq, dk, dv, dz, da], "wind_backstepping.backward")
+    with torch.cuda.device_of(w):
+        rc = getattr(_lib.lib(), "rwkv7_wkv_bwd_" + sfx)(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a),
+                                                       _p(dy), _p(s), _p(sa), _p(dw), _p(dq), _p(dk), _p(dv),
+                                                       _p(dz), _p(da), _stream(w))
+    _lib.check(rc, "wind_backstepping.backward")
+
+
+def _state_forward(B, T, C, H, state, r, w, k, v, a, b, y):
+    sfx = _sfx([r, w, k, v, a, b, y], "rwkv7_state_fwd.forward")
+    if state.dtype != torch.float32 or not state.is_contiguous():
+        raise TypeError("rwkv7_state_fwd.forward: state must be contiguous float32 [B,H,64,64]")
+    with torch.cuda.device_of(r):
+        rc = getattr(_lib.lib(), "rwkv7_wkv_state_fwd_" + sfx)(int(B), int(T), int(C), int(H), _p(state), _p(r),
+                                                             _p(w), _p(k), _p(v), _p(a), _p(b), _p(y), _stream(r))
+    _lib.check(rc, "rwkv7_state_fwd.forward")
+
+
+def _wkv7s_forward(B, T, C, H, state, r, w, k, v, a, b, y):
+    assert B == 1, "wkv7s is the B=1 operator (wkv7s.cu:62)"
+    _state_forward(B, T, C, H, state, r, w, k, v, a, b, y)
+
+
+_registered = []
+
+
+def _register():
+    """Define the three reference op namespaces and bind them to the HIP library."""
+    if _registered:
+        return
+    defs = [
+        ("wind_backstepping",
+         [("forward(Tensor w, Tensor q, Tensor k, Tensor v, Tensor z, Tensor a, Tensor(a!) y, Tensor(b!) s, "
+           "Tensor(c!) sa) -> ()", "forward", _wb_forward),
+          ("backward(Tensor w, Tensor q, Tensor k, Tensor v, Tensor z, Tensor a, Tensor dy, Tensor s, Tensor sa, "
+           "Tensor(a!) dw, Tensor(b!) dq, Tensor(c!) dk, Tensor(d!) dv, Tensor(e!) dz, Tensor(f!) da) -> ()",
+           "backward", _wb_backward)]),
+        ("rwkv7_state_fwd_fp16",
+         [("forward(int B, int T, int C, int H, Tensor(a!) state, Tensor r, Tensor w, Tensor k, Tensor v, "
+           "Tensor a, Tensor b, Tensor(b!) y) -> ()", "forward", _state_forward)]),
+        ("wkv7s",
+         [("forward(int B, int T, int C, int H, Tensor(a!) state, Tensor r, Tensor w, Tensor k, Tensor v, "
+           "Tensor a, Tensor b, Tensor(b!) y) -> ()", "forward", _wkv7s_forward)]),
+    ]
+    for ns, ops in defs:
+        lib = torch.library.Library(ns, "DEF")
+        for schema, name, fn in ops:
+            lib.define(schema)
+            lib.impl(name, fn, "CUDA")
+        _registered.append(lib)  # keep alive
+
+
+_register()
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd wrapper and call-site helpers (reference names)
+# ------------------------------------------------------------------------------------------------
+class WindBackstepping(torch.autograd.Function):
+    """rwkv_s2s_single_ffn.py:15-35.  Argument order (w,q,k,v,z,b) with z == a, b == b."""
+
+    @staticmethod
+    def forward(ctx, w, q, k, v, z, b):
+        B, T, H, C = w.shape
+        assert T % CHUNK_LEN == 0, f"T={T} must be a multiple of {CHUNK_LEN}"
+        assert all(i.dtype == w.dtype for i in [w, q, k, v, z, b])
+        assert all(i.is_contiguous() for i in [w, q, k, v, z, b])
+        y = torch.empty_like(v)
+        s = torch.empty(B, H, T // CHUNK_LEN, C, C, dtype=torch.float32, device=w.device)
+        sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device)
+        torch.ops.wind_backstepping.forward(w, q, k, v, z, b, y, s, sa)
+        ctx.save_for_backward(w, q, k, v, z, b, s, sa)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        w, q, k, v, z, b, s, sa = ctx.saved_tensors
+        assert dy.dtype == w.dtype
+        dw, dq, dk, dv, dz, db = [torch.empty_like(x) for x in [w, q, k, v, z, b]]
+        torch.ops.wind_backstepping.backward(w, q, k, v, z, b, dy, s, sa, dw, dq, dk, dv, dz, db)
+        return dw, dq, dk, dv, dz, db
+
+
+def RUN_CUDA_RWKV7g(q, w, k, v, a, b):
+    """rwkv_s2s_single_ffn.py:37-40: [B,T,H*64] in, [B,T,H*64] out, differentiable."""
+    B, T, HC = q.shape
+    q, w, k, v, a, b = [i.view(B, T, HC // HEAD_SIZE, HEAD_SIZE) for i in [q, w, k, v, a, b]]
+    return WindBackstepping.apply(w, q, k, v, a, b).view(B, T, HC)
+
+
+def wkv7_forward_nograd(q, w, k, v, a, b):
+    """Inference-only zero-state scan: no checkpoints, no sa (s = sa = NULL in the C ABI)."""
+    B, T, HC = q.shape
+    H = HC // HEAD_SIZE
+    sfx = _sfx([w, q, k, v, a, b], "wkv7_forward_nograd")
+    if T % CHUNK_LEN != 0:
+        raise ValueError("T must be a multiple of 16; use the state-carrying op for ragged lengths")
+    y = torch.empty_like(v)
+    with torch.cuda.device_of(w):
+        rc = getattr(_lib.lib(), "rwkv7_wkv_fwd_" + sfx)(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b),
+                                                       _p(y), None, None, _stream(w))
+    _lib.check(rc, "wkv7_forward_nograd")
+    return y
+
+
+def RWKV7_OP(state, r, w, k, v, a, b):
+    """rwkv_s2s_single_ffn.py:45-59 (torch.ops.wkv7s): r..b [T,C], state [H,64,64] updated in place."""
+    with torch.no_grad():
+        T, C = r.shape
+        H = C // HEAD_SIZE
+        y = torch.empty((T, C), device=k.device, dtype=r.dtype)
+        torch.ops.wkv7s.forward(1, T, C, H, state, r, w, k, v, a, b, y)
+        return y
+
+
+def RWKV7_BATCH_OP(state, r, w, k, v, a, b):
+    """rwkv_asr_cuda_whisper.py:67-81: r..b [B,T,C], state [B,H,64,64] fp32 updated in place."""
+    with torch.no_grad():
+        B, T, C = r.shape
+        H = C // HEAD_SIZE
+        y = torch.empty((B, T, C), device=k.device, dtype=r.dtype)
+        torch.ops.rwkv7_state_fwd_fp16.forward(B, T, C, H, state, r, w, k, v, a, b, y)
+        return y

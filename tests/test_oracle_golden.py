@@ -1,0 +1,132 @@
+"""CPU: the oracle (oracle/wkv7_oracle.c + oracle/rwkv7_ref.py) against the committed golden vectors.
+
+The vectors are outputs of the reference's own functions, produced in the authoring container by
+oracle/pin_against_reference.py (see its docstring for which reference function made which file).
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import rwkv7_ref as R
+
+
+def _params(g):
+    return {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+
+
+def _close(got, want, tol):
+    err = (got - want).abs().max().item()
+    assert err <= tol * max(want.abs().max().item(), 1.0), f"max|d|={err:.3e}"
+
+
+def _c_wkv(c_oracle):
+    def f(r, w, k, v, a, b, state):
+        B, T, H, N = r.shape
+        st = torch.zeros(B, H, N, N) if state is None else state.clone()
+        y = c_oracle.wkv7_state_fwd(st, *[t.reshape(B, T, H * N).contiguous() for t in (r, w, k, v, a, b)])
+        return y.view(B, T, H, N), st
+    return f
+
+
+@pytest.mark.parametrize("use_c", [False, True])
+def test_tmix_cmix_one_chain(c_oracle, use_c):
+    """RWKV_x070_TMix_one / CMix_one chained over T (rwkv_s2s_single_ffn.py:482-506,545-549)."""
+    g = load_golden("tmix_cmix_one_chain.npz")
+    cfg = R.RefConfig(hidden_size=128, num_hidden_layers=2, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=16, gate_low_rank_dim=32)
+    p = _params(g)
+    T = g["x"].shape[0]
+    mask = torch.ones(1, T, 1)
+    for layer in (0, 1):
+        out, vf, x_last, st = R.tmix_seq(p, cfg, layer, g["x"][None], mask, g["vfirst_in"][None],
+                                         g["x_prev0"][None], g["state0"][None].clone(),
+                                         _c_wkv(c_oracle) if use_c else None)
+        _close(out[0], g[f"tmix{layer}.out"], 2e-5)
+        _close(st[0], g[f"tmix{layer}.state"], 2e-5)
+        _close(vf[0], g[f"tmix{layer}.v_first"], 2e-6)
+        assert torch.equal(x_last[0], g["x"][-1])
+        out, _ = R.cmix_seq(p, cfg, layer, g["x"][None], mask, g["x_prev0"][None])
+        _close(out[0], g[f"cmix{layer}.out"], 2e-5)
+
+
+def test_block_modules(c_oracle):
+    """Reference Block/RWKV_Tmix_x070/RWKV_CMix_x070 (rwkv_s2s_single_ffn.py:61-259), left-padded mask."""
+    g = load_golden("block_module.npz")
+    cfg = R.RefConfig(hidden_size=128, num_hidden_layers=2, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=32, gate_low_rank_dim=128)
+    p = _params(g)
+    p["model.norm.weight"], p["model.norm.bias"] = torch.ones(128), torch.zeros(128)
+
+    def c_fwd(r, w, k, v, a, b, state):
+        y, _, _ = c_oracle.wkv7_fwd(w, r, k, v, a, b, save=False)
+        return y, None
+
+    hid, _ = R.backbone(p, cfg, g["x"], g["mask"], None, c_fwd)
+    _close(hid, torch.nn.functional.layer_norm(g["hidden_l1"], (128,)), 3e-5)
+    hid_t, _ = R.backbone(p, cfg, g["x"], g["mask"], None, None)  # torch scan instead of the C kernel
+    _close(hid_t, hid, 3e-5)
+
+
+def test_forward_batch_prefill_decode(c_oracle):
+    """Reference Block.forward_batch prefill (T=16) + 3 decode steps (rwkv_asr_cuda_whisper.py:181-326)."""
+    g = load_golden("forward_batch.npz")
+    cfg = R.RefConfig(hidden_size=128, num_hidden_layers=2, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=32, gate_low_rank_dim=128)
+    p = _params(g)
+    p["model.norm.weight"], p["model.norm.bias"] = torch.ones(128), torch.zeros(128)
+    states = R.zero_states(cfg, 2)
+    for step in range(4):
+        x = g[f"x{step}"]
+        mask = torch.ones(x.shape[0], x.shape[1], 1)
+        hid, states = R.backbone(p, cfg, x, mask, states, _c_wkv(c_oracle), full_mask=False)
+        _close(hid, torch.nn.functional.layer_norm(g[f"hidden{step}"], (128,)), 3e-5)
+        for i in range(6):
+            if i % 3 == 0:
+                # the reference hands back the attention OUTPUT as token-shift state (quirk documented in
+                # oracle/pin_against_reference.py and DESIGN.md); feed its value forward, do not compare
+                states[i] = g[f"state{step}.{i}"].clone()
+            else:
+                _close(states[i], g[f"state{step}.{i}"], 3e-5)
+
+
+def test_wkv7_scan_regression(c_oracle):
+    """C oracle vs its committed bf16 vectors, and vs torch.autograd through the fp32 torch scan."""
+    g = load_golden("wkv7_scan.npz")
+    for tag in ("B1T16H1", "B2T64H3"):
+        ins = [g[f"{tag}.{n}"] for n in ("w", "q", "k", "v", "a", "b")]
+        y, s, sa = c_oracle.wkv7_fwd(*ins)
+        assert torch.equal(y.view(torch.int16), g[f"{tag}.y"].view(torch.int16))
+        assert torch.equal(sa, g[f"{tag}.sa"])
+        assert torch.equal(s[:, :, -1], g[f"{tag}.s_last"])
+        grads = c_oracle.wkv7_bwd(*ins, g[f"{tag}.dy"], s, sa)
+        for n, gr in zip(("dw", "dq", "dk", "dv", "da", "db"), grads):
+            assert torch.equal(gr.view(torch.int16), g[f"{tag}.{n}"].view(torch.int16)), n
+        # analytic backward == autograd of the forward recurrence (fp32 I/O)
+        f = [t.float() for t in ins]
+        y32, s32, sa32 = c_oracle.wkv7_fwd(*f)
+        leaves = [t.clone().requires_grad_(True) for t in f]
+        yt, _ = R.wkv7_scan(leaves[1], leaves[0], leaves[2], leaves[3], leaves[4], leaves[5])
+        _close(y32, yt.detach(), 1e-5)
+        dy = g[f"{tag}.dy"].float()
+        yt.backward(dy)
+        for n, gc, lf in zip(("dw", "dq", "dk", "dv", "da", "db"), c_oracle.wkv7_bwd(*f, dy, s32, sa32), leaves):
+            _close(gc, lf.grad, 2e-4)
+
+
+def test_state_carry_split_equals_one_call(c_oracle):
+    """G2: the state-carrying op over [0,T) equals two calls over [0,T1) and [T1,T) (ragged T1)."""
+    from rwkvtts_amd.synthetic import make_wkv_inputs
+    B, T, H = 2, 48, 2
+    w, q, k, v, a, b = [t.view(B, T, H * 64) for t in make_wkv_inputs(B, T, H, seed=3, dtype=torch.float32)]
+    st1 = torch.zeros(B, H, 64, 64)
+    y1 = c_oracle.wkv7_state_fwd(st1, q, w, k, v, a, b)
+    st2 = torch.zeros(B, H, 64, 64)
+    T1 = 13
+    ya = c_oracle.wkv7_state_fwd(st2, *[t[:, :T1].contiguous() for t in (q, w, k, v, a, b)])
+    yb = c_oracle.wkv7_state_fwd(st2, *[t[:, T1:].contiguous() for t in (q, w, k, v, a, b)])
+    assert torch.equal(torch.cat([ya, yb], 1), y1) and torch.equal(st1, st2)
+    # and the zero-state training forward is the same recurrence; the reference adds the three terms in a
+    # different order there (wkv7_cuda.cu:39 s*w+sa*b+k*v vs rwkv7_state_fwd_fp16.cu:48 s*w+k*v+sa*b),
+    # which the oracle keeps, so this one is equal only to fp32 rounding
+    y3, _, _ = c_oracle.wkv7_fwd(*[t.view(B, T, H, 64) for t in (w, q, k, v, a, b)], save=False)
+    _close(y3.view(B, T, H * 64), y1, 1e-6)

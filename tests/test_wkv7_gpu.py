@@ -1,0 +1,186 @@
+"""GPU (-m gpu): the HIP WKV7 operators, called through the reference's op names (which go through the
+C ABI), against the CPU oracle on the same seeded inputs, the committed golden vectors, and -- at
+BASELINE.json's full size -- size-independent properties plus oracle checks on head slices.
+
+Tolerances (floating point; the reference itself rounds every output to bf16, wkv7_cuda.cu:42,89,108-111):
+  bf16 I/O : |hip - oracle| <= 2^-7 * max(|oracle|, floor) elementwise  (one bf16 ulp at the value's scale;
+             the two sides differ only in fp32 summation order and expf vs v_exp_f32)
+  fp32 I/O : forward 2e-5 * max|oracle|; backward 5e-4 * max|oracle| (the state reconstruction
+             S_{t-1} = (S_t - ...)/w~ amplifies fp32 rounding by up to (1/w~)^15 inside a 16-step chunk)
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from rwkvtts_amd import ops
+from rwkvtts_amd.synthetic import make_wkv_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NAMES = ("dw", "dq", "dk", "dv", "da", "db")
+
+
+def _assert_bf16_close(got, want, what, ulps=1.0):
+    got, want = got.float().cpu(), want.float()
+    floor = want.abs().mean().item() * 0.25 + 1e-6
+    tol = ulps * 2.0 ** -7 * torch.clamp(want.abs(), min=floor)
+    bad = ((got - want).abs() > tol)
+    assert not bad.any(), f"{what}: {bad.sum().item()}/{bad.numel()} beyond {ulps} bf16 ulp, " \
+                          f"max|d|={(got - want).abs().max().item():.3e} max|ref|={want.abs().max().item():.3e}"
+
+
+def _assert_f32_close(got, want, what, tol):
+    got = got.cpu()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= tol * max(ref, 1e-3), f"{what}: max|d|={err:.3e} max|ref|={ref:.3e} tol={tol}"
+
+
+def _hip_fwd_bwd(ins_cpu, dy_cpu):
+    ins = [t.to(DEV).requires_grad_(True) for t in ins_cpu]
+    y = ops.WindBackstepping.apply(*ins)
+    y.backward(dy_cpu.to(DEV))
+    torch.cuda.synchronize()
+    return y.detach(), [t.grad for t in ins]
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 16, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_fwd_bwd_vs_oracle(c_oracle, B, T, H, seed, dtype):
+    ins = make_wkv_inputs(B, T, H, seed, dtype)
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).to(dtype)
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    g_o = c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)
+    y, grads = _hip_fwd_bwd(ins, dy)
+    if dtype == torch.bfloat16:
+        _assert_bf16_close(y, y_o, "y")
+        for n, g, go in zip(NAMES, grads, g_o):
+            _assert_bf16_close(g, go, n, ulps=2.0)
+    else:
+        _assert_f32_close(y, y_o, "y", 2e-5)
+        for n, g, go in zip(NAMES, grads, g_o):
+            _assert_f32_close(g, go, n, 5e-4)
+
+
+def test_saved_tensors_match_reference_layout(c_oracle):
+    """s is [B,H,T/16,64,64] stored transposed, sa is [B,T,H,64] fp32 (wkv7_cuda.cu:32,45-48)."""
+    B, T, H = 2, 64, 3
+    ins = make_wkv_inputs(B, T, H, 5, torch.float32)
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    d = [t.to(DEV) for t in ins]
+    y = torch.empty_like(d[0])
+    s = torch.empty(B, H, T // 16, 64, 64, device=DEV)
+    sa = torch.empty(B, T, H, 64, device=DEV)
+    torch.ops.wind_backstepping.forward(*d, y, s, sa)
+    _assert_f32_close(s, s_o, "s", 2e-5)
+    _assert_f32_close(sa, sa_o, "sa", 2e-5)
+    _assert_f32_close(y, y_o, "y", 2e-5)
+
+
+def test_golden_bf16_vectors():
+    g = load_golden("wkv7_scan.npz")
+    for tag in ("B1T16H1", "B2T64H3"):
+        ins = [g[f"{tag}.{n}"] for n in ("w", "q", "k", "v", "a", "b")]
+        y, grads = _hip_fwd_bwd(ins, g[f"{tag}.dy"])
+        _assert_bf16_close(y, g[f"{tag}.y"], f"{tag}.y")
+        for n, gr in zip(NAMES, grads):
+            _assert_bf16_close(gr, g[f"{tag}.{n}"], f"{tag}.{n}", ulps=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,H", [(1, 1, 1), (3, 7, 2), (2, 16, 4), (2, 37, 3), (32, 1, 16), (1, 128, 2)])
+def test_state_fwd_vs_oracle(c_oracle, B, T, H, dtype):
+    """rwkv7_state_fwd_fp16.forward: ragged T, T=1 decode, in-place state update."""
+    w, q, k, v, a, b = [t.view(B, T, H * 64) for t in make_wkv_inputs(B, T, H, 7, dtype)]
+    st0 = torch.randn(B, H, 64, 64, generator=torch.Generator().manual_seed(1)) * 0.1
+    st_o = st0.clone()
+    y_o = c_oracle.wkv7_state_fwd(st_o, q, w, k, v, a, b)
+    st = st0.to(DEV)
+    y = ops.RWKV7_BATCH_OP(st, *[t.to(DEV) for t in (q, w, k, v, a, b)])
+    torch.cuda.synchronize()
+    if dtype == torch.bfloat16:
+        _assert_bf16_close(y, y_o, "y")
+    else:
+        _assert_f32_close(y, y_o, "y", 2e-5)
+    _assert_f32_close(st, st_o, "state", 2e-5)
+
+
+def test_wkv7s_b1_op(c_oracle):
+    T, H = 24, 2
+    w, q, k, v, a, b = [t.view(T, H * 64) for t in make_wkv_inputs(1, T, H, 11, torch.bfloat16)]
+    st_o = torch.zeros(1, H, 64, 64)
+    y_o = c_oracle.wkv7_state_fwd(st_o, *[t.view(1, T, H * 64) for t in (q, w, k, v, a, b)])
+    st = torch.zeros(H, 64, 64, device=DEV)
+    y = ops.RWKV7_OP(st, *[t.to(DEV) for t in (q, w, k, v, a, b)])
+    _assert_bf16_close(y, y_o.view(T, H * 64), "y")
+    _assert_f32_close(st, st_o[0], "state", 2e-5)
+
+
+def test_state_carry_split_is_bit_identical():
+    """G2: one call over T == two calls over T1 + (T-T1), bit for bit, and == the zero-state training fwd."""
+    B, T, H = 2, 256, 4
+    w, q, k, v, a, b = [t.to(DEV) for t in make_wkv_inputs(B, T, H, 13, torch.bfloat16)]
+    f = lambda t: t.view(B, T, H * 64)
+    st1 = torch.zeros(B, H, 64, 64, device=DEV)
+    y1 = ops.RWKV7_BATCH_OP(st1, f(q), f(w), f(k), f(v), f(a), f(b))
+    st2 = torch.zeros(B, H, 64, 64, device=DEV)
+    T1 = 100
+    ya = ops.RWKV7_BATCH_OP(st2, *[f(t)[:, :T1].contiguous() for t in (q, w, k, v, a, b)])
+    yb = ops.RWKV7_BATCH_OP(st2, *[f(t)[:, T1:].contiguous() for t in (q, w, k, v, a, b)])
+    assert torch.equal(torch.cat([ya, yb], 1), y1)
+    assert torch.equal(st1, st2)
+    y3 = ops.wkv7_forward_nograd(f(q), f(w), f(k), f(v), f(a), f(b))
+    assert torch.equal(y3, y1)
+
+
+def test_error_behaviour_on_device():
+    x = torch.zeros(1, 24, 1, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(AssertionError):  # T % 16, rwkv_s2s_single_ffn.py:19
+        ops.WindBackstepping.apply(x, x, x, x, x, x)
+    y = torch.empty_like(x)
+    s = torch.empty(1, 1, 1, 64, 64, device=DEV)
+    sa = torch.empty(1, 24, 1, 64, device=DEV)
+    with pytest.raises(ValueError):  # C ABI returns RWKV7_ECHUNK instead of aborting (wkv7_cuda.cu:136)
+        torch.ops.wind_backstepping.forward(x, x, x, x, x, x, y, s, sa)
+    with pytest.raises(ValueError):  # non-contiguous, rwkv_s2s_single_ffn.py:21
+        xt = torch.zeros(1, 16, 64, 1, dtype=torch.bfloat16, device=DEV).transpose(2, 3)
+        torch.ops.wind_backstepping.forward(xt, xt, xt, xt, xt, xt, xt.contiguous(), s, sa[:, :16].contiguous())
+
+
+def test_full_size_config2_properties_and_slices(c_oracle):
+    """BASELINE.json configs[1]: B=8, T=4096, H=16 bf16.  (i) the recurrence is linear in v for fixed
+    w,q,k,a,b: y(v1+v2) == y(v1)+y(v2) up to bf16 rounding; (ii) zero-state forward == state-carrying
+    forward in two halves, bit for bit; (iii) forward+backward of two (batch, head) slices equal the
+    oracle run on exactly those slices."""
+    B, T, H = 8, 4096, 16
+    ins = make_wkv_inputs(B, T, H, 1234, torch.bfloat16)
+    w, q, k, v, a, b = [t.to(DEV) for t in ins]
+    dy_cpu = torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(99)).bfloat16()
+    leaves = [t.clone().requires_grad_(True) for t in (w, q, k, v, a, b)]
+    y = ops.WindBackstepping.apply(*leaves)
+    y.backward(dy_cpu.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    for n, lf in zip(NAMES, leaves):
+        assert torch.isfinite(lf.grad.float()).all(), n
+    # (iii) oracle on slices
+    for (bi, hi) in ((0, 0), (5, 11)):
+        sl = [t[bi:bi + 1, :, hi:hi + 1].contiguous() for t in ins]
+        y_o, s_o, sa_o = c_oracle.wkv7_fwd(*sl)
+        g_o = c_oracle.wkv7_bwd(*sl, dy_cpu[bi:bi + 1, :, hi:hi + 1].contiguous(), s_o, sa_o)
+        _assert_bf16_close(y[bi:bi + 1, :, hi:hi + 1], y_o, f"y[{bi},{hi}]")
+        for n, lf, go in zip(NAMES, leaves, g_o):
+            _assert_bf16_close(lf.grad[bi:bi + 1, :, hi:hi + 1], go, f"{n}[{bi},{hi}]", ulps=2.0)
+    # (ii) split == whole
+    f = lambda t: t.view(B, T, H * 64)
+    st = torch.zeros(B, H, 64, 64, device=DEV)
+    halves = [ops.RWKV7_BATCH_OP(st, *[f(t)[:, i * 2048:(i + 1) * 2048].contiguous() for t in (q, w, k, v, a, b)])
+              for i in range(2)]
+    assert torch.equal(torch.cat(halves, 1).view(B, T, H, 64), y.detach())
+    # (i) linearity in v (fp32 I/O so that the check is not dominated by bf16 output rounding)
+    sub = [t[:2, :1024].float().contiguous() for t in (w, q, k, v, a, b)]
+    v2 = torch.randn_like(sub[3])
+    fq = lambda vv: ops.wkv7_forward_nograd(*[t.view(2, 1024, H * 64) for t in (sub[1], sub[0], sub[2], vv, sub[4], sub[5])])
+    lhs = fq(sub[3] + v2)
+    rhs = fq(sub[3]) + fq(v2)
+    assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()

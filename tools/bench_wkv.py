@@ -1,0 +1,68 @@
+"""Kernel-only timing of the WKV7 ops at BASELINE.json sizes (HIP events on the launch stream).
+
+    python tools/bench_wkv.py [--B 8 --T 4096 --H 16 --iters 10 --dtype bf16]
+Prints ms per launch, algorithmic GB/s (896 B fwd / 1664 B bwd per token-head)
+and the fraction of the 8 TB/s HBM roofline.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rwkvtts_amd import ops  # noqa: E402
+from rwkvtts_amd.synthetic import make_wkv_inputs  # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in ev:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in ev)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--T", type=int, default=4096)
+    ap.add_argument("--H", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    esz = 2 if a.dtype == "bf16" else 4
+    B, T, H = a.B, a.T, a.H
+    dev = "cuda:0"
+    w, q, k, v, aa, b = make_wkv_inputs(B, T, H, 1234, dt, dev)
+    dy = torch.randn(B, T, H, 64, device=dev).to(dt)
+    y = torch.empty_like(v)
+    s = torch.empty(B, H, T // 16, 64, 64, device=dev)
+    sa = torch.empty(B, T, H, 64, device=dev)
+    grads = [torch.empty_like(w) for _ in range(6)]
+    th = B * T * H
+    fwd = lambda: torch.ops.wind_backstepping.forward(w, q, k, v, aa, b, y, s, sa)
+    bwd = lambda: torch.ops.wind_backstepping.backward(w, q, k, v, aa, b, dy, s, sa, *grads)
+    st = torch.zeros(B, H, 64, 64, device=dev)
+    f3 = lambda t: t.view(B, T, H * 64)
+    yy = torch.empty(B, T, H * 64, device=dev, dtype=dt)
+    sfw = lambda: torch.ops.rwkv7_state_fwd_fp16.forward(B, T, H * 64, H, st, f3(q), f3(w), f3(k), f3(v), f3(aa), f3(b), yy)
+    for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz), ("wkv7_bwd", bwd, 13 * 64 * esz),
+                                ("wkv7_state_fwd", sfw, 7 * 64 * esz)):
+        med, best = timeit(fn, a.iters)
+        gbs = th * bytes_per / (med * 1e-3) / 1e9
+        print(f"{name:22s} B={B} T={T} H={H} {a.dtype}: median {med:8.3f} ms  best {best:8.3f} ms  "
+              f"algorithmic {gbs:8.1f} GB/s  = {gbs * 1e9 / HBM_PEAK * 100:5.2f}% of 8 TB/s")
+
+
+if __name__ == "__main__":
+    main()
