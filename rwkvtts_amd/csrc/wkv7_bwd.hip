@@ -108,8 +108,18 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
         const int t0 = n * kTB;
         if (n > 0) issue(t0 - kTB);
 
+        {
+            // a stage is exactly one checkpoint chunk (kTB == kChunk): reload S_{t0+15} from the fp32
+            // checkpoint, stored transposed s[j][i] (wkv7_cuda.cu:45-48,76-82)
+            const float *sp = s_ + (((long)bh * nchunk + n) * kN + c0) * kN + r0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float4 x = *reinterpret_cast<const float4 *>(sp + (long)c * kN);
+                S[0][c] = x.x; S[1][c] = x.y; S[2][c] = x.z; S[3][c] = x.w;
+            }
+        }
+#pragma unroll 4
         for (int tt = kTB - 1; tt >= 0; tt--) {
-            const int t = t0 + tt;
             const float4 wt4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_W][c0]);
             const float4 iw4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_IW][c0]);
             const float4 q4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_Q][c0]);
@@ -128,16 +138,6 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
             const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
             const float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
             const float sav[4] = {sa4.x, sa4.y, sa4.z, sa4.w};
-
-            if (((t + 1) & (kChunk - 1)) == 0) {
-                // checkpoint is stored transposed: s[j][i] (wkv7_cuda.cu:45-48,76-82)
-                const float *sp = s_ + (((long)bh * nchunk + t / kChunk) * kN + c0) * kN + r0;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float4 x = *reinterpret_cast<const float4 *>(sp + (long)c * kN);
-                    S[0][c] = x.x; S[1][c] = x.y; S[2][c] = x.z; S[3][c] = x.w;
-                }
-            }
 
             float colp[NOUT][4];  // dq, dw, dk, db, da partial sums over this lane's 4 rows
 #pragma unroll
@@ -182,23 +182,23 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
                 }
                 colp[4][c] = da;
             }
-            // column partials: sum over the 4 row groups (til) of this wave, lanes l ^ 16, l ^ 32
+            // column partials -> wave totals, over the 4 row groups (til) of this wave.  Transposing
+            // butterfly: v_permlane32_swap pairs column c with c+2 (lanes <32 keep c, lanes >=32 keep c+2),
+            // v_permlane16_swap pairs c with c+1 (even DPP rows keep c, odd rows keep c+1): 15 swaps + 15
+            // adds for 20 values, and row `til` ends up owning column c0 + til of all 5 outputs -- every lane
+            // then stores its 5 totals (64 distinct consecutive addresses per output), no exec-masked store.
 #pragma unroll
-            for (int o = 0; o < NOUT; o++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    float x = colp[o][c];
-                    x += __shfl_xor(x, 16);
-                    x += __shfl_xor(x, 32);
-                    colp[o][c] = x;
-                }
-            if (til == 0) {
-#pragma unroll
-                for (int o = 0; o < NOUT; o++)
-                    *reinterpret_cast<float4 *>(&sh_part[wave][tt][o][c0]) =
-                        make_float4(colp[o][0], colp[o][1], colp[o][2], colp[o][3]);
+            for (int o = 0; o < NOUT; o++) {
+                const float x0 = swap32_sum(colp[o][0], colp[o][2]);
+                const float x1 = swap32_sum(colp[o][1], colp[o][3]);
+                sh_part[wave][tt][o][c0 + til] = swap16_sum(x0, x1);
             }
-            if (tj == 0) *reinterpret_cast<float4 *>(&sh_dv[tt][r0]) = make_float4(dvv[0], dvv[1], dvv[2], dvv[3]);
+            {
+                // dv[r] totals are replicated over the 16 lanes of the DPP row: lane tj stores row r0 + (tj&3)
+                const int rs = tj & 3;
+                const float d = rs == 0 ? dvv[0] : rs == 1 ? dvv[1] : rs == 2 ? dvv[2] : dvv[3];
+                sh_dv[tt][r0 + rs] = d;
+            }
         }
         __syncthreads();
         {

@@ -119,6 +119,20 @@ __device__ __forceinline__ float sum16(float x) {
     return x;
 }
 
+// ---- transposing pair reductions across DPP rows (gfx950 v_permlane{16,32}_swap) ----------------------
+// swap32_sum(lo, hi): lanes 0-31 return lo[l] + lo[l+32], lanes 32-63 return hi[l-32] + hi[l].
+// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second.
+__device__ __forceinline__ float swap32_sum(float lo, float hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// swap16_sum(lo, hi): even 16-lane rows return lo[l] + lo[l+16], odd rows return hi[l-16] + hi[l].
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second.
+__device__ __forceinline__ float swap16_sum(float lo, float hi) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
 }  // namespace rwkv7

@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void wkv7_fwd_kernel(int T_, int H, const T *_
                                                        float *__restrict__ state_) {
     __shared__ __attribute__((aligned(16))) float sh_vec[kTB][5][kN];  // w~, q, k, a, b  (20 KiB)
     __shared__ __attribute__((aligned(16))) float sh_v[kTB][32];
-    __shared__ __attribute__((aligned(16))) float sh_y[kTB][32];
-    __shared__ __attribute__((aligned(16))) float sh_sa[kTB][32];
+    __shared__ __attribute__((aligned(16))) float sh_y[2][kTB][32];   // double-buffered: stored one stage late
+    __shared__ __attribute__((aligned(16))) float sh_sa[2][kTB][32];
 
     const int half = blockIdx.x & 1;  // which 32 rows of the head
     const int bh = blockIdx.x >> 1;
@@ -67,15 +67,15 @@ __global__ __launch_bounds__(256) void wkv7_fwd_kernel(int T_, int H, const T *_
     Raw2<T> rvv;
 
     auto issue = [&](int t0) {
-        const int t = t0 + st;
-        const bool ok = t < T_;
-        const long off = head_base + (long)(ok ? t : 0) * tstride;
-        rv[0] = ld4<T>(w_ + off + sc, ok);
-        rv[1] = ld4<T>(q_ + off + sc, ok);
-        rv[2] = ld4<T>(k_ + off + sc, ok);
-        rv[3] = ld4<T>(a_ + off + sc, ok);
-        rv[4] = ld4<T>(b_ + off + sc, ok);
-        rvv = ld2<T>(v_ + off + half * 32 + sr, ok);
+        // rows past T (ragged tail of the state-carrying op) re-read row T-1: valid memory, never used
+        const int t = min(t0 + st, T_ - 1);
+        const long off = head_base + (long)t * tstride;
+        rv[0] = ld4<T>(w_ + off + sc, true);
+        rv[1] = ld4<T>(q_ + off + sc, true);
+        rv[2] = ld4<T>(k_ + off + sc, true);
+        rv[3] = ld4<T>(a_ + off + sc, true);
+        rv[4] = ld4<T>(b_ + off + sc, true);
+        rvv = ld2<T>(v_ + off + half * 32 + sr, true);
     };
     auto stage = [&]() {
         float4 f = cvt4(rv[0]);
@@ -89,6 +89,22 @@ __global__ __launch_bounds__(256) void wkv7_fwd_kernel(int T_, int H, const T *_
         *reinterpret_cast<float2 *>(&sh_v[st][sr]) = cvt2(rvv);
     };
 
+    float Sck[8];
+    auto flush = [&](int n) {
+        if (SAVE) {
+            // reference layout is transposed, s[j][i] (wkv7_cuda.cu:44-50)
+            float *sp = s_ + (((long)bh * (T_ / kChunk) + n) * kN + c0) * kN + row;
+#pragma unroll
+            for (int c = 0; c < 8; c++) sp[(long)c * kN] = Sck[c];
+        }
+        const int t = n * kTB + st;
+        if (t < T_) {
+            const long off = head_base + (long)t * tstride + half * 32 + sr;
+            st2(y_ + off, *reinterpret_cast<const float2 *>(&sh_y[n & 1][st][sr]));
+            if (SAVE) *reinterpret_cast<float2 *>(sa_ + off) = *reinterpret_cast<const float2 *>(&sh_sa[n & 1][st][sr]);
+        }
+    };
+
     const int nblk = (T_ + kTB - 1) / kTB;
     issue(0);
     stage();
@@ -97,25 +113,43 @@ __global__ __launch_bounds__(256) void wkv7_fwd_kernel(int T_, int H, const T *_
     for (int n = 0; n < nblk; n++) {
         const int t0 = n * kTB;
         if (n + 1 < nblk) issue(t0 + kTB);
+        // y/sa of the PREVIOUS stage go out now, so that their write latency runs under this stage's
+        // recurrence: gfx950 has one vmcnt for loads and stores, and the next s_waitcnt vmcnt (for the
+        // prefetched inputs, a whole stage from here) would otherwise also drain stores issued just before it.
+        if (n > 0) flush(n - 1);
         const int steps = min(kTB, T_ - t0);
 
-        for (int tt = 0; tt < steps; tt++) {
-            const float4 w0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][0][c0]);
-            const float4 w1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][0][c0 + 4]);
-            const float4 q0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][1][c0]);
-            const float4 q1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][1][c0 + 4]);
-            const float4 k0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][2][c0]);
-            const float4 k1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][2][c0 + 4]);
-            const float4 a0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][3][c0]);
-            const float4 a1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][3][c0 + 4]);
-            const float4 b0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][4][c0]);
-            const float4 b1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][4][c0 + 4]);
-            const float vv = sh_v[tt][rib];
-            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        // Operands of one time step for this lane: its 8 columns of w~,q,k,a,b and its row's v.
+        struct StepOps {
+            float4 w0, w1, q0, q1, k0, k1, a0, a1, b0, b1;
+            float v;
+        };
+        auto load_ops = [&](const int tt) {
+            StepOps o;
+            o.w0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][0][c0]);
+            o.w1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][0][c0 + 4]);
+            o.q0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][1][c0]);
+            o.q1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][1][c0 + 4]);
+            o.k0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][2][c0]);
+            o.k1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][2][c0 + 4]);
+            o.a0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][3][c0]);
+            o.a1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][3][c0 + 4]);
+            o.b0 = *reinterpret_cast<const float4 *>(&sh_vec[tt][4][c0]);
+            o.b1 = *reinterpret_cast<const float4 *>(&sh_vec[tt][4][c0 + 4]);
+            o.v = sh_v[tt][rib];
+            return o;
+        };
+        // y/sa of step tt are kept by lane cg == tt%8 of the row group (two register slots for the
+        // 16 steps) and written to LDS once per stage: no exec-masked store, hence no branch, inside the
+        // recurrence -- a branch per step would pin every step's ds_reads behind the previous step.
+        float ykeep0 = 0.f, ykeep1 = 0.f, sakeep0 = 0.f, sakeep1 = 0.f;
+        auto step = [&](const StepOps &o, const int tt) {
+            const float wv[8] = {o.w0.x, o.w0.y, o.w0.z, o.w0.w, o.w1.x, o.w1.y, o.w1.z, o.w1.w};
+            const float qv[8] = {o.q0.x, o.q0.y, o.q0.z, o.q0.w, o.q1.x, o.q1.y, o.q1.z, o.q1.w};
+            const float kv[8] = {o.k0.x, o.k0.y, o.k0.z, o.k0.w, o.k1.x, o.k1.y, o.k1.z, o.k1.w};
+            const float av[8] = {o.a0.x, o.a0.y, o.a0.z, o.a0.w, o.a1.x, o.a1.y, o.a1.z, o.a1.w};
+            const float bv[8] = {o.b0.x, o.b0.y, o.b0.z, o.b0.w, o.b1.x, o.b1.y, o.b1.z, o.b1.w};
+            const float vv = o.v;
 
             float sa0 = 0.f, sa1 = 0.f;
 #pragma unroll
@@ -134,31 +168,47 @@ __global__ __launch_bounds__(256) void wkv7_fwd_kernel(int T_, int H, const T *_
                 y1 = fmaf(S[c + 1], qv[c + 1], y1);
             }
             const float y = sum8(y0 + y1);
-            if (cg == 0) {
-                sh_y[tt][rib] = y;
-                if (SAVE) sh_sa[tt][rib] = sa;
+            const bool mine = (cg == (tt & 7));
+            if (tt < 8) {
+                ykeep0 = mine ? y : ykeep0;
+                if (SAVE) sakeep0 = mine ? sa : sakeep0;
+            } else {
+                ykeep1 = mine ? y : ykeep1;
+                if (SAVE) sakeep1 = mine ? sa : sakeep1;
             }
-            if (SAVE) {
-                const int t = t0 + tt;
-                if (((t + 1) & (kChunk - 1)) == 0) {  // wkv7_cuda.cu:44-50, transposed layout [j][i]
-                    float *sp = s_ + (((long)bh * (T_ / kChunk) + t / kChunk) * kN + c0) * kN + row;
+        };
+        if (steps == kTB) {
+            // full stage: unrolled, operands of step tt+1 are fetched from LDS under the FMA chain of step tt
+            StepOps cur = load_ops(0);
 #pragma unroll
-                    for (int c = 0; c < 8; c++) sp[(long)c * kN] = S[c];
-                }
+            for (int tt = 0; tt < kTB; tt++) {
+                StepOps nxt = cur;
+                if (tt + 1 < kTB) nxt = load_ops(tt + 1);
+                // pin the order: hipcc's scheduler otherwise sinks these ds_reads down to their first use
+                // in step tt+1 and the wave (alone on its SIMD) sits in s_waitcnt for the LDS latency
+                __builtin_amdgcn_sched_barrier(0);
+                step(cur, tt);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             }
+        } else {
+            for (int tt = 0; tt < steps; tt++) step(load_ops(tt), tt);
+        }
+        sh_y[n & 1][cg][rib] = ykeep0;
+        sh_y[n & 1][cg + 8][rib] = ykeep1;
+        if (SAVE) {
+            sh_sa[n & 1][cg][rib] = sakeep0;
+            sh_sa[n & 1][cg + 8][rib] = sakeep1;
+            // state checkpoint after every 16th step (t0 is a multiple of 16 and T % 16 == 0 here): copied
+            // to spare registers now, stored with the delayed y/sa flush
+#pragma unroll
+            for (int c = 0; c < 8; c++) Sck[c] = S[c];
         }
         __syncthreads();
-        {
-            const int t = t0 + st;
-            if (t < T_) {
-                const long off = head_base + (long)t * tstride + half * 32 + sr;
-                st2(y_ + off, *reinterpret_cast<const float2 *>(&sh_y[st][sr]));
-                if (SAVE) *reinterpret_cast<float2 *>(sa_ + off) = *reinterpret_cast<const float2 *>(&sh_sa[st][sr]);
-            }
-        }
         if (n + 1 < nblk) stage();
         __syncthreads();
     }
+    flush(nblk - 1);
 
     if (STATE) {
         float *sp = state_ + ((long)bh * kN + row) * kN + c0;
