@@ -6,6 +6,12 @@ exception.  Nothing in this package routes through oracle/ or through a CPU/eage
 import ctypes
 import os
 
+# torch must be imported BEFORE librwkv7_hip.so is dlopen'ed: the .so needs libamdhip64.so.7, and the process
+# must end up with exactly one HIP runtime -- the one PyTorch-ROCm bundles (torch/lib/libamdhip64.so, same
+# SONAME).  Loaded the other way round, /opt/rocm's runtime gets in first, torch's libraries bind to it, and
+# launches fail with hipErrorNoDevice (seen on the GPU box).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "librwkv7_hip.so")
 

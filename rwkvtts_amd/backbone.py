@@ -1,0 +1,375 @@
+"""RWKV-7 backbone for MI355X: the model the reference trains/serves through rwkvfla
+(RWKV7Model / RWKV7Block / RWKV7Attention / RWKV7FeedForward / LoRA / Cache), rebuilt on the HIP ops.
+
+Call sites in the reference: model/llm/spark_llm.py:24,126-136 ; cosy_llm.py:31,132-141 ; xy_llm.py:155,219-227.
+Arithmetic spec (in-tree twin): model/llm/rwkv_s2s_single_ffn.py:158-259 (training), :417-445,482-556 (stateful),
+model/llm/rwkv_asr_cuda_whisper.py:181-326 (batched stateful).
+
+state_dict keys are rwkvfla's (left-hand side of utils/convert_rwkv.py:17-30): both the fused `attn.x_x [6,D]`
+(order r,w,k,v,a,g -- third_party/cosyvoice/cli/model.py:99-111) and the split `attn.x_r .. x_g [1,1,D]`
+checkpoints load.  LoRA weights are [out,in] (utils/convert_rwkv.py:26-27).
+
+Host code is PyTorch-ROCm plumbing (device memory, streams, autograd tape, library GEMMs for the dense
+projections); the recurrence and the fused elementwise stages run in librwkv7_hip.so (rwkvtts_amd/ops.py,
+rwkvtts_amd/fused.py).  There is no CPU path: tensors must live on the HIP device.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import asdict, dataclass, field
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import fused, ops
+
+HEAD_SIZE = 64
+
+
+@dataclass
+class RWKV7Config:
+    """Subset of rwkvfla's RWKV7Config that the reference's checkpoints use (model/test/audio_rwkv.config)."""
+    hidden_size: int = 1024
+    num_hidden_layers: int = 24
+    head_dim: int = 64
+    vocab_size: int = 8193
+    decay_low_rank_dim: int = 64
+    a_low_rank_dim: int = 64
+    v_low_rank_dim: int = 32
+    gate_low_rank_dim: int = 128
+    hidden_ratio: float = 4.0
+    intermediate_size: Optional[int] = None
+    norm_eps: float = 1e-5
+    norm_bias: bool = True
+    fuse_cross_entropy: bool = True
+    initializer_range: float = 0.006
+    model_type: str = "rwkv7"
+    extra: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        if self.intermediate_size is None:
+            self.intermediate_size = int(self.hidden_size * self.hidden_ratio)
+        assert self.head_dim == HEAD_SIZE, "the HIP kernels are built for head size 64 (reference: -D_N_=64)"
+        assert self.hidden_size % self.head_dim == 0
+
+    @property
+    def num_heads(self):
+        return self.hidden_size // self.head_dim
+
+    @classmethod
+    def from_dict(cls, d: dict):
+        names = set(cls.__dataclass_fields__) - {"extra"}
+        known = {k: v for k, v in d.items() if k in names}
+        cfg = cls(**known)
+        cfg.extra = {k: v for k, v in d.items() if k not in names}
+        return cfg
+
+    def to_dict(self):
+        d = asdict(self)
+        extra = d.pop("extra")
+        d.update(extra)
+        return d
+
+    @classmethod
+    def from_pretrained(cls, path):
+        with open(os.path.join(path, "config.json")) as f:
+            return cls.from_dict(json.load(f))
+
+
+# canonical sizes (read config.json for real checkpoints)
+def config_0p1b(**kw):
+    return RWKV7Config(hidden_size=768, num_hidden_layers=12, **kw)
+
+
+def config_0p4b(**kw):
+    return RWKV7Config(hidden_size=1024, num_hidden_layers=24, **kw)
+
+
+def config_1p5b(**kw):
+    return RWKV7Config(hidden_size=2048, num_hidden_layers=24, decay_low_rank_dim=96, a_low_rank_dim=96,
+                       v_low_rank_dim=64, gate_low_rank_dim=256, **kw)
+
+
+class LoRA(nn.Module):
+    """rwkvfla LoRA: Linear(in,r,bias=False) -> act -> Linear(r,out,bias) ; keys lora.0.weight / lora.2.{weight,bias}."""
+
+    def __init__(self, in_dim, out_dim, rank, activation: Optional[str], bias: bool):
+        super().__init__()
+        act = {None: nn.Identity(), "tanh": nn.Tanh(), "sigmoid": nn.Sigmoid()}[activation]
+        self.lora = nn.Sequential(nn.Linear(in_dim, rank, bias=False), act, nn.Linear(rank, out_dim, bias=bias))
+
+    def forward(self, x):
+        return self.lora(x)
+
+
+class LayerState:
+    """Per-layer recurrent state (reference: rwkv_asr_cuda_whisper.py:443-447; fla Cache entries
+    conv_state / recurrent_state / ffn_state, model/llm/llm.py:250-252).
+      att_x_prev [B,D]  last input of the time-mix block      (fla: conv_state)
+      att_kv     [B,H,64,64] fp32, row = value idx, col = key idx (fla: recurrent_state, transposed)
+      ffn_x_prev [B,D]  last input of the channel-mix block   (fla: ffn_state)"""
+    __slots__ = ("att_x_prev", "att_kv", "ffn_x_prev")
+
+    def __init__(self, att_x_prev, att_kv, ffn_x_prev):
+        self.att_x_prev, self.att_kv, self.ffn_x_prev = att_x_prev, att_kv, ffn_x_prev
+
+    # dict-style access with the fla names, as the reference pokes at them (llm.py:250-252)
+    def __getitem__(self, k):
+        return {"conv_state": self.att_x_prev, "recurrent_state": self.att_kv, "ffn_state": self.ffn_x_prev}[k]
+
+
+class Cache:
+    """Minimal stand-in for rwkvfla's Cache: a list of LayerState plus seen_tokens (llm.py:254)."""
+
+    def __init__(self, states: Optional[List[LayerState]] = None, seen_tokens: int = 0):
+        self.states = states or []
+        self.seen_tokens = seen_tokens
+
+    def __len__(self):
+        return len(self.states)
+
+    def __getitem__(self, i):
+        return self.states[i]
+
+    @classmethod
+    def zeros(cls, cfg: RWKV7Config, B, device, dtype):
+        H = cfg.num_heads
+        return cls([LayerState(torch.zeros(B, cfg.hidden_size, device=device, dtype=dtype),
+                               torch.zeros(B, H, HEAD_SIZE, HEAD_SIZE, device=device, dtype=torch.float32),
+                               torch.zeros(B, cfg.hidden_size, device=device, dtype=dtype))
+                    for _ in range(cfg.num_hidden_layers)])
+
+
+class RWKV7Attention(nn.Module):
+    """Time-mix block (rwkv_s2s_single_ffn.py:158-196; Appendix A of SURVEY.md)."""
+
+    def __init__(self, cfg: RWKV7Config, layer_idx: int):
+        super().__init__()
+        D, H, N = cfg.hidden_size, cfg.num_heads, cfg.head_dim
+        self.layer_idx, self.hidden_size, self.num_heads, self.head_dim = layer_idx, D, H, N
+        for n in "rwkvag":
+            setattr(self, f"x_{n}", nn.Parameter(torch.zeros(1, 1, D)))
+        self.k_k = nn.Parameter(torch.zeros(D))
+        self.k_a = nn.Parameter(torch.zeros(D))
+        self.r_k = nn.Parameter(torch.zeros(H, N))
+        self.r_proj = nn.Linear(D, D, bias=False)
+        self.k_proj = nn.Linear(D, D, bias=False)
+        self.v_proj = nn.Linear(D, D, bias=False)
+        self.o_proj = nn.Linear(D, D, bias=False)
+        self.w_lora = LoRA(D, D, cfg.decay_low_rank_dim, "tanh", True)
+        if layer_idx != 0:
+            self.v_lora = LoRA(D, D, cfg.v_low_rank_dim, None, True)
+        self.a_lora = LoRA(D, D, cfg.a_low_rank_dim, None, True)
+        self.g_lora = LoRA(D, D, cfg.gate_low_rank_dim, "sigmoid", False)
+        self.g_norm = nn.GroupNorm(H, D, eps=N * cfg.norm_eps)  # 64e-5, rwkv_s2s_single_ffn.py:504
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kw):
+        # fused x_x [6,D] checkpoints (RWKV7Attention "version 1", cosyvoice/cli/model.py:99-111)
+        key = prefix + "x_x"
+        if key in state_dict:
+            x_x = state_dict.pop(key)
+            for i, n in enumerate("rwkvag"):
+                state_dict[prefix + f"x_{n}"] = x_x[i].reshape(1, 1, -1)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kw)
+
+    def forward(self, x, mask, v_first, state: Optional[LayerState] = None):
+        """x [B,T,D] (LayerNorm'ed), mask [B,T,1] or None.  Returns (out, v_first).
+        With `state`, token shift and the WKV state are carried (and updated in place)."""
+        B, T, D = x.shape
+        H, N = self.num_heads, self.head_dim
+        if mask is not None:
+            x = x * mask
+        x_prev = None if state is None else state.att_x_prev
+        xr, xw, xk, xv, xa, xg = fused.token_shift_mix6(x, x_prev, self.x_r, self.x_w, self.x_k, self.x_v,
+                                                        self.x_a, self.x_g)
+        r = self.r_proj(xr)
+        k = self.k_proj(xk)
+        v = self.v_proj(xv)
+        w_pre = self.w_lora(xw)
+        a_pre = self.a_lora(xa)
+        g = self.g_lora(xg)
+        v_pre = self.v_lora(xv) if self.layer_idx != 0 else None
+        if self.layer_idx == 0:
+            if mask is not None:
+                v = v * mask  # rwkv_s2s_single_ffn.py:178: v is masked before it becomes v_first
+            v_first = v
+        w, k2, v2, a_in, b_in = fused.tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, self.k_k, self.k_a, mask,
+                                                   H, self.layer_idx == 0)
+        if mask is not None:
+            r = r * mask
+        if state is None:
+            if torch.is_grad_enabled() and (r.requires_grad or w.requires_grad):
+                y = ops.RUN_CUDA_RWKV7g(r, w, k2, v2, a_in, b_in)
+            else:
+                y = ops.wkv7_forward_nograd(r, w, k2, v2, a_in, b_in)
+        else:
+            y = ops.RWKV7_BATCH_OP(state.att_kv, r.contiguous(), w, k2, v2, a_in, b_in)
+            state.att_x_prev = x[:, -1].detach().clone()
+        y = fused.tmix_post(y, r, k2, v2, g, self.g_norm.weight, self.g_norm.bias, self.r_k, H, self.g_norm.eps)
+        return self.o_proj(y), v_first
+
+
+class RWKV7FeedForward(nn.Module):
+    """Channel-mix block (rwkv_s2s_single_ffn.py:223-230): relu(key(x + (shift(x)-x) x_k))^2 -> value."""
+
+    def __init__(self, cfg: RWKV7Config, layer_idx: int):
+        super().__init__()
+        self.x_k = nn.Parameter(torch.zeros(cfg.hidden_size))
+        self.key = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.value = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+
+    def forward(self, x, mask, state: Optional[LayerState] = None):
+        if mask is not None:
+            x = x * mask
+        x_prev = None if state is None else state.ffn_x_prev
+        kx = fused.token_shift_mix1(x, x_prev, self.x_k)
+        if state is not None:
+            state.ffn_x_prev = x[:, -1].detach().clone()
+        return self.value(fused.relu_sq(self.key(kx)))
+
+
+class RWKV7Block(nn.Module):
+    def __init__(self, cfg: RWKV7Config, layer_idx: int):
+        super().__init__()
+        self.layer_idx = layer_idx
+        D = cfg.hidden_size
+        if layer_idx == 0:
+            self.pre_norm = nn.LayerNorm(D, eps=cfg.norm_eps, bias=cfg.norm_bias)
+        self.attn_norm = nn.LayerNorm(D, eps=cfg.norm_eps, bias=cfg.norm_bias)
+        self.attn = RWKV7Attention(cfg, layer_idx)
+        self.ffn_norm = nn.LayerNorm(D, eps=cfg.norm_eps, bias=cfg.norm_bias)
+        self.ffn = RWKV7FeedForward(cfg, layer_idx)
+
+    def forward(self, x, mask, v_first, state: Optional[LayerState] = None):
+        if self.layer_idx == 0:
+            x = self.pre_norm(x)
+        att, v_first = self.attn(self.attn_norm(x), mask, v_first, state)
+        x = x + att
+        x = x + self.ffn(self.ffn_norm(x), mask, state)
+        return x, v_first
+
+
+class ModelOutput(dict):
+    """Attribute + index access like transformers' ModelOutput (the reference reads .loss/.logits/
+    .past_key_values, train_spark_rwkv7speech.py:238-242, and indexes outputs[0], spark_llm.py:138)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in self.values() if v is not None][k]
+        return super().__getitem__(k)
+
+
+class RWKV7Model(nn.Module):
+    """Backbone: embeddings -> L blocks -> final LayerNorm.  forward() mirrors
+    RWKV7Model(input_ids|inputs_embeds, attention_mask, past_key_values, use_cache) (llm.py:148-155)."""
+
+    def __init__(self, cfg: RWKV7Config):
+        super().__init__()
+        self.config = cfg
+        self.embeddings = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList([RWKV7Block(cfg, i) for i in range(cfg.num_hidden_layers)])
+        self.norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.norm_eps, bias=cfg.norm_bias)
+        self.gradient_checkpointing = False
+
+    def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, past_key_values: Optional[Cache] = None,
+                use_cache: Optional[bool] = None, **kwargs):
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        x = self.embeddings(input_ids) if inputs_embeds is None else inputs_embeds
+        B, T, D = x.shape
+        if not x.is_cuda:
+            raise RuntimeError("RWKV7Model runs on the HIP device only (no CPU path); move the model and inputs to cuda")
+        mask = None
+        if attention_mask is not None:
+            mask = attention_mask[:, -T:].to(x.dtype).unsqueeze(-1)
+        if use_cache and past_key_values is None:
+            past_key_values = Cache.zeros(self.config, B, x.device, x.dtype)
+        stateful = past_key_values is not None and len(past_key_values) > 0
+        pad = 0
+        if not stateful and T % ops.CHUNK_LEN != 0:
+            # the training kernel needs T % 16 == 0: left-pad with masked zeros (rwkv_asr_cuda_whisper.py:482-486)
+            pad = ops.CHUNK_LEN - T % ops.CHUNK_LEN
+            x = torch.cat([x.new_zeros(B, pad, D), x], 1)
+            m = torch.ones(B, T, 1, dtype=x.dtype, device=x.device) if mask is None else mask
+            mask = torch.cat([m.new_zeros(B, pad, 1), m], 1)
+        v_first = None
+        for i, layer in enumerate(self.layers):
+            st = past_key_values[i] if stateful else None
+            if self.gradient_checkpointing and self.training and not stateful:
+                x, v_first = torch.utils.checkpoint.checkpoint(layer, x, mask, v_first, None, use_reentrant=False)
+            else:
+                x, v_first = layer(x, mask, v_first, st)
+        x = self.norm(x)
+        if pad:
+            x = x[:, pad:]
+        if stateful:
+            past_key_values.seen_tokens += T
+        return ModelOutput(last_hidden_state=x, past_key_values=past_key_values if stateful else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# initialisation: the reference's own time-mix init (rwkv_s2s_single_ffn.py:74-156) so that random-init
+# models have decays/gates in the trained range (used by the synthetic benchmarks)
+# ------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def init_weights(model: nn.Module, cfg: RWKV7Config, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    D, L, N = cfg.hidden_size, cfg.num_hidden_layers, cfg.head_dim
+
+    def normal_(t, std):
+        t.copy_(torch.randn(t.shape, generator=g) * std)
+
+    for mod in model.modules():
+        if isinstance(mod, nn.Embedding):
+            normal_(mod.weight, 0.02)
+        elif isinstance(mod, nn.Linear):
+            normal_(mod.weight, 0.02)
+            if mod.bias is not None:
+                mod.bias.zero_()
+        elif isinstance(mod, (nn.LayerNorm, nn.GroupNorm)):
+            mod.weight.fill_(1.0)
+            if mod.bias is not None:
+                mod.bias.zero_()
+    blocks = [m for m in model.modules() if isinstance(m, RWKV7Block)]
+    for blk in blocks:
+        i = blk.layer_idx
+        r01 = i / max(L - 1, 1)
+        r10 = 1.0 - i / L
+        ddd = torch.arange(D, dtype=torch.float32) / D
+        lin = torch.arange(D, dtype=torch.float32) / max(D - 1, 1) - 0.5
+        n = torch.arange(D) % N
+        zig = (n.float() - (N - 1) / 2) / ((N - 1) / 2)
+        zig = zig * zig.abs()
+        www = -6 + 6 * (torch.arange(D, dtype=torch.float32) / max(D - 1, 1)) ** (1 + r01 ** 0.3)
+        at = blk.attn
+        for nm, e in (("r", 0.2), ("w", 0.9), ("k", 0.7), ("v", 0.7), ("a", 0.9), ("g", 0.2)):
+            getattr(at, f"x_{nm}").copy_((1.0 - torch.pow(ddd, e * r10)).view(1, 1, D))
+        at.k_k.copy_(0.71 - lin * 0.1)
+        at.k_a.fill_(1.02)
+        at.r_k.fill_(-0.04)
+        at.w_lora.lora[2].bias.copy_(www + 0.5 + zig * 2.5)
+        at.a_lora.lora[2].bias.copy_(-0.19 + zig * 0.3 + lin * 0.4)
+        if i != 0:
+            at.v_lora.lora[2].bias.copy_(0.73 - lin * 0.4)
+        for lo in (at.w_lora, at.a_lora, at.g_lora) + ((at.v_lora,) if i != 0 else ()):
+            normal_(lo.lora[0].weight, 0.02)
+            normal_(lo.lora[2].weight, 0.1 / math.sqrt(lo.lora[2].weight.shape[1]))
+        s = 1.0 / math.sqrt(D)
+        normal_(at.r_proj.weight, 0.5 * s)
+        normal_(at.k_proj.weight, 0.5 * s)
+        normal_(at.v_proj.weight, 0.5 * s)
+        normal_(at.o_proj.weight, 0.5 * s)
+        blk.ffn.x_k.copy_(1.0 - torch.pow(ddd, r10 ** 4))
+        normal_(blk.ffn.key.weight, 0.5 * s)
+        normal_(blk.ffn.value.weight, 0.5 / math.sqrt(cfg.intermediate_size))
+    return model

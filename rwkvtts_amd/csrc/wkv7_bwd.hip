@@ -245,6 +245,7 @@ static int launch_bwd(int B, int T_, int H, const void *w, const void *q, const 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    (void)hipGetLastError();  // drop any stale error left by an earlier runtime call of the host program
     hipLaunchKernelGGL((wkv7_bwd_kernel<T>), dim3(B * H), dim3(256), kBwdSmemBytes, stream, T_, H, (const T *)w,
                        (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, (const T *)dy, s, sa,
                        (T *)dw, (T *)dq, (T *)dk, (T *)dv, (T *)da, (T *)db);

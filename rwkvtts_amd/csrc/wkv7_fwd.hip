@@ -222,6 +222,7 @@ static int launch_fwd(int B, int T_, int H, const void *w, const void *q, const 
                       const void *a, const void *b, void *y, float *s, float *sa, float *state,
                       hipStream_t stream) {
     const dim3 grid(B * H * 2), block(256);
+    (void)hipGetLastError();  // drop any stale error left by an earlier runtime call of the host program
     const T *W = (const T *)w, *Q = (const T *)q, *K = (const T *)k, *V = (const T *)v, *A = (const T *)a,
             *Bv = (const T *)b;
     if (state) {

@@ -1,0 +1,100 @@
+"""Loss heads of the three layouts.
+
+fused_linear_cross_entropy : stands in for rwkvfla's FusedLinearCrossEntropyLoss (model/llm/spark_llm.py:8,146-160):
+    lm_head GEMM + softmax-CE computed chunk by chunk over the tokens so the [B*T, V] logits (512 MiB at
+    B=8,T=4096,V=8193 bf16) are never materialised; gradients w.r.t. hidden and weight are produced in the
+    same pass and scaled by the incoming grad in backward.
+label_smoothing_kl         : third_party/cosyvoice/transformer/label_smoothing_loss.py:21-96 (Cosy layout).
+th_accuracy                : third_party/cosyvoice/utils/common.py:76-95.
+"""
+import torch
+import torch.nn.functional as F
+
+
+class _FusedLinearCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, labels, ignore_index, chunk, label_smoothing):
+        N, D = hidden.shape
+        valid = labels != ignore_index
+        n_valid = valid.sum().clamp(min=1)
+        inv = 1.0 / n_valid.float()
+        loss = torch.zeros((), dtype=torch.float32, device=hidden.device)
+        need = ctx.needs_input_grad
+        dh = torch.empty_like(hidden) if need[0] else None
+        dw = torch.zeros_like(weight, dtype=torch.float32) if need[1] else None
+        db = torch.zeros_like(bias, dtype=torch.float32) if (bias is not None and need[2]) else None
+        for s in range(0, N, chunk):
+            h = hidden[s:s + chunk]
+            lab = labels[s:s + chunk]
+            logits = (h @ weight.t()).float()
+            if bias is not None:
+                logits = logits + bias.float()
+            lse = torch.logsumexp(logits, dim=-1)
+            vmask = lab != ignore_index
+            safe = lab.clamp(min=0)
+            tgt = logits.gather(1, safe.unsqueeze(1)).squeeze(1)
+            nll = lse - tgt
+            if label_smoothing > 0:
+                smooth = lse - logits.mean(dim=-1)
+                per = (1 - label_smoothing) * nll + label_smoothing * smooth
+            else:
+                per = nll
+            loss += (per * vmask).sum()
+            if need[0] or need[1]:
+                p = torch.softmax(logits, dim=-1)
+                if label_smoothing > 0:
+                    p = p - label_smoothing / logits.shape[-1]
+                    p.scatter_add_(1, safe.unsqueeze(1), torch.full_like(tgt, -(1 - label_smoothing)).unsqueeze(1))
+                else:
+                    p.scatter_add_(1, safe.unsqueeze(1), torch.full_like(tgt, -1.0).unsqueeze(1))
+                p = p * (vmask.unsqueeze(1) * inv)
+                pd = p.to(hidden.dtype)
+                if need[0]:
+                    dh[s:s + chunk] = pd @ weight
+                if need[1]:
+                    dw += (pd.t() @ h).float()
+                if db is not None:
+                    db += p.sum(0)
+        ctx.save_for_backward(dh, dw, db)
+        ctx.wdtype = weight.dtype
+        return loss * inv
+
+    @staticmethod
+    def backward(ctx, g):
+        dh, dw, db = ctx.saved_tensors
+        return (dh * g.to(dh.dtype) if dh is not None else None,
+                (dw * g).to(ctx.wdtype) if dw is not None else None,
+                (db * g).to(ctx.wdtype) if db is not None else None, None, None, None, None)
+
+
+def fused_linear_cross_entropy(hidden, labels, weight, bias=None, ignore_index=-100, chunk=4096,
+                               label_smoothing=0.0):
+    """hidden [..., D], labels [...] (already shifted by the caller) -> mean CE over labels != ignore_index."""
+    D = hidden.shape[-1]
+    return _FusedLinearCE.apply(hidden.reshape(-1, D), weight, bias, labels.reshape(-1), ignore_index, chunk,
+                                label_smoothing)
+
+
+def label_smoothing_kl(logits, target, size, padding_idx, smoothing, normalize_length=False):
+    """LabelSmoothingLoss.forward (cosyvoice/transformer/label_smoothing_loss.py:68-96): KL(true_dist || softmax)
+    with true_dist = smoothing/(size-1) off-target, 1-smoothing on target; ignored rows zeroed; divided by the
+    number of valid tokens (normalize_length) or by the batch size."""
+    B = logits.shape[0]
+    x = logits.reshape(-1, size)
+    t = target.reshape(-1)
+    ignore = t == padding_idx
+    total = t.numel() - ignore.sum()
+    t = t.masked_fill(ignore, 0)
+    true_dist = torch.full_like(x, smoothing / (size - 1), dtype=torch.float32)
+    true_dist.scatter_(1, t.unsqueeze(1), 1.0 - smoothing)
+    kl = F.kl_div(torch.log_softmax(x.float(), dim=1), true_dist, reduction="none")
+    denom = total if normalize_length else B
+    return kl.masked_fill(ignore.unsqueeze(1), 0).sum() / denom
+
+
+def th_accuracy(pad_outputs, pad_targets, ignore_label):
+    """cosyvoice/utils/common.py:76-95."""
+    pred = pad_outputs.view(pad_targets.size(0), pad_targets.size(1), pad_outputs.size(1)).argmax(2)
+    mask = pad_targets != ignore_label
+    num = torch.sum(pred.masked_select(mask) == pad_targets.masked_select(mask))
+    return (num / torch.sum(mask)).detach()

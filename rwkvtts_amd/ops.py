@@ -26,6 +26,28 @@ CHUNK_LEN = 16
 DTYPE = torch.bfloat16
 
 
+# bench.py sets this to a dict to time individual launches with HIP events recorded on the launch stream
+# (torch's current stream IS the stream handed to the C ABI): name -> [(start_event, end_event), ...]
+KERNEL_TIMERS = None
+
+
+class _timed:
+    def __init__(self, name, ref):
+        self.name, self.on = name, KERNEL_TIMERS is not None
+        if self.on:
+            st = torch.cuda.current_stream(ref.device)
+            self.s, self.e, self.st = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), st
+
+    def __enter__(self):
+        if self.on:
+            self.s.record(self.st)
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e.record(self.st)
+            KERNEL_TIMERS.setdefault(self.name, []).append((self.s, self.e))
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
@@ -55,7 +77,7 @@ def _wb_forward(w, q, k, v, z, a, y, s, sa):
     B, T, H, C = w.shape
     sfx = _sfx([w, q, k, v, z, a, y], "wind_backstepping.forward")
     assert C == HEAD_SIZE and s.dtype == torch.float32 and sa.dtype == torch.float32
-    with torch.cuda.device_of(w):
+    with torch.cuda.device_of(w), _timed("wkv7_fwd", w):
         rc = getattr(_lib.lib(), "rwkv7_wkv_fwd_" + sfx)(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a),
                                                        _p(y), _p(s), _p(sa), _stream(w))
     _lib.check(rc, "wind_backstepping.forward")
@@ -64,7 +86,7 @@ def _wb_forward(w, q, k, v, z, a, y, s, sa):
 def _wb_backward(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
     B, T, H, C = w.shape
     sfx = _sfx([w, q, k, v, z, a, dy, dw, dq, dk, dv, dz, da], "wind_backstepping.backward")
-    with torch.cuda.device_of(w):
+    with torch.cuda.device_of(w), _timed("wkv7_bwd", w):
         rc = getattr(_lib.lib(), "rwkv7_wkv_bwd_" + sfx)(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a),
                                                        _p(dy), _p(s), _p(sa), _p(dw), _p(dq), _p(dk), _p(dv),
                                                        _p(dz), _p(da), _stream(w))

@@ -1,0 +1,260 @@
+"""Spark-layout TTS language model on the HIP backbone: drop-in for model/llm/spark_llm.py (RWKV7ForSpeech).
+
+Same constructor/config fields, attribute names (`model`, `lm_head`, `text_embedder`, `global_embedder`,
+`tts_tag_embedder`, `dropout`), `forward(...)` kwargs and return fields, `generate(...)` kwargs used by
+inference/rwkv7speech_inference.py:99-107 and utils/utilities.py:101-117, `prepare_inputs_for_generation`,
+`copy_state_dict` and the rwkvfla state_dict key layout -- so train_scripts/train_spark_rwkv7speech.py:234-246
+and data/utils/spark_dataset.py:163-239 can drive it unchanged.
+
+The reference inherits transformers.GenerationMixin (pinned 4.51.3, requirements.txt:245); the image has
+transformers 5.x whose Cache/generate internals moved, so `generate` is a small self-contained loop over the
+persistent-state decode path (greedy / top-k / top-p / temperature / suppress_tokens / min_new_tokens).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .backbone import Cache, ModelOutput, RWKV7Config, RWKV7Model, init_weights
+from .losses import fused_linear_cross_entropy
+
+
+class RWKV7SpeechConfig(RWKV7Config):
+    """spark_llm.py:13-17: RWKV7Config + text_vocab_size + audio_global_vocab_size."""
+
+    def __init__(self, text_vocab_size=65536, audio_global_vocab_size=4096, **kw):
+        super().__init__(**{k: v for k, v in kw.items() if k in RWKV7Config.__dataclass_fields__ and k != "extra"})
+        self.extra = {k: v for k, v in kw.items() if k not in RWKV7Config.__dataclass_fields__}
+        self.text_vocab_size = text_vocab_size
+        self.audio_global_vocab_size = audio_global_vocab_size
+
+    def to_dict(self):
+        d = super().to_dict()
+        d.update(text_vocab_size=self.text_vocab_size, audio_global_vocab_size=self.audio_global_vocab_size,
+                 architectures=["RWKV7ForSpeech"])
+        return d
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(**d)
+
+
+class _GenerateOutput(ModelOutput):
+    pass
+
+
+class RWKV7ForSpeech(nn.Module):
+    config_class = RWKV7SpeechConfig
+
+    def __init__(self, config: RWKV7SpeechConfig):
+        super().__init__()
+        self.config = config
+        self.model = RWKV7Model(config)
+        self.vocab_size = config.vocab_size
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)  # 8192 + eos (spark_llm.py:26)
+        self.criterion = None
+        self.text_embedder = nn.Embedding(config.text_vocab_size, config.hidden_size)
+        self.global_embedder = nn.Embedding(config.audio_global_vocab_size, config.hidden_size)
+        self.tts_tag_embedder = nn.Embedding(3, config.hidden_size)  # GLOBAL=0, SEMANTIC=1, START_TTS=2
+        self.dropout = nn.Dropout(0.02)
+
+    # ---- HF-style conveniences the reference scripts touch ---------------------------------------
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    def get_input_embeddings(self):
+        return self.model.embeddings
+
+    def set_input_embeddings(self, value):
+        self.model.embeddings = value
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def set_output_embeddings(self, new_embeddings):
+        self.lm_head = new_embeddings
+
+    def get_decoder(self):
+        return self.model
+
+    def set_decoder(self, decoder):
+        self.model = decoder
+
+    def gradient_checkpointing_enable(self, *a, **k):
+        self.model.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.model.gradient_checkpointing = False
+
+    def init_weights(self, seed=0):
+        init_weights(self, self.config, seed)
+        return self
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, past_key_values: Optional[Cache] = None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
+                logits_to_keep: Optional[int] = 0, **kwargs):
+        """spark_llm.py:105-172.  labels are shifted by one HERE (spark_llm.py:156), on top of whatever the batch
+        builder did (data/utils/spark_dataset.py:223-233 pre-shifts) -- reproduced as is, not "fixed"."""
+        return_dict = True if return_dict is None else return_dict
+        if self.training and inputs_embeds is not None:
+            inputs_embeds = self.dropout(inputs_embeds)
+        outputs = self.model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
+                             past_key_values=past_key_values, use_cache=use_cache, **kwargs)
+        hidden_states = outputs[0]
+        fuse = self.config.fuse_cross_entropy and self.training
+        loss, logits = None, None
+        if not fuse or labels is None:
+            h = hidden_states if not logits_to_keep else hidden_states[:, -logits_to_keep:]
+            logits = self.lm_head(h)
+        if labels is not None:
+            ignore_index = getattr(self.criterion, "ignore_index", -100)
+            labels = labels.to(hidden_states.device)
+            labels = torch.cat((labels[..., 1:], torch.full_like(labels[:, :1], ignore_index)), 1)
+            if fuse:
+                loss = fused_linear_cross_entropy(hidden_states, labels, self.lm_head.weight, self.lm_head.bias,
+                                                  ignore_index)
+            elif self.criterion is not None:
+                loss = self.criterion(logits.view(labels.numel(), -1), labels.view(-1))
+            else:
+                loss = F.cross_entropy(logits.view(labels.numel(), -1).float(), labels.view(-1),
+                                       ignore_index=ignore_index)
+        if not return_dict:
+            out = (logits, outputs.past_key_values)
+            return (loss,) + out if loss is not None else out
+        return ModelOutput(loss=loss, logits=logits, past_key_values=outputs.past_key_values, hidden_states=None,
+                           attentions=None)
+
+    def prepare_inputs_for_generation(self, input_ids=None, past_key_values=None, attention_mask=None,
+                                      inputs_embeds=None, use_cache=True, logits_to_keep=None, **kwargs):
+        """spark_llm.py:70-102: embeddings on the first step only, afterwards the last generated id."""
+        if past_key_values is not None and len(past_key_values) > 0 and past_key_values.seen_tokens > 0:
+            input_ids = input_ids[:, -1:]
+        if inputs_embeds is not None and (past_key_values is None or past_key_values.seen_tokens == 0):
+            model_inputs = {"inputs_embeds": inputs_embeds}
+        else:
+            model_inputs = {"input_ids": input_ids.contiguous()}
+        model_inputs.update(past_key_values=past_key_values, use_cache=use_cache, attention_mask=attention_mask,
+                            logits_to_keep=logits_to_keep)
+        return model_inputs
+
+    # ---- generation ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids=None, inputs_embeds=None, attention_mask=None, max_new_tokens=None, max_length=None,
+                 do_sample=False, top_k=0, top_p=1.0, temperature=1.0, eos_token_id=None, pad_token_id=None,
+                 suppress_tokens=None, min_new_tokens=0, return_dict_in_generate=False, use_cache=True,
+                 generator: Optional[torch.Generator] = None, **unused):
+        """Prefill on the state-carrying kernel, then one persistent-state step per token.
+        With inputs_embeds only, the returned sequences hold the NEW tokens only (HF semantics the reference
+        relies on, inference/rwkv7speech_inference.py:108-118)."""
+        was_training = self.training
+        self.eval()
+        if inputs_embeds is None:
+            assert input_ids is not None
+            B, P = input_ids.shape
+        else:
+            B, P = inputs_embeds.shape[:2]
+        if max_new_tokens is None:
+            max_new_tokens = (max_length or 20) - (0 if inputs_embeds is not None and input_ids is None else P)
+        eos = [] if eos_token_id is None else ([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id))
+        pad = pad_token_id if pad_token_id is not None else (eos[0] if eos else 0)
+        dev = self.device
+        cache = Cache.zeros(self.config, B, dev, self.dtype)
+        out = self(input_ids=input_ids if inputs_embeds is None else None, inputs_embeds=inputs_embeds,
+                   attention_mask=attention_mask, past_key_values=cache, use_cache=True, logits_to_keep=1)
+        logits = out.logits[:, -1].float()
+        unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+        new_tokens = []
+        for step in range(max_new_tokens):
+            if suppress_tokens:
+                logits[:, suppress_tokens] = float("-inf")
+            if eos and step < min_new_tokens:
+                logits[:, eos] = float("-inf")
+            nxt = sample_next(logits, do_sample, top_k, top_p, temperature, generator)
+            nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+            new_tokens.append(nxt)
+            for e in eos:
+                unfinished &= nxt != e
+            if eos and not bool(unfinished.any()):
+                break
+            out = self(input_ids=nxt.unsqueeze(1), past_key_values=cache, use_cache=True)
+            logits = out.logits[:, -1].float()
+        seq = torch.stack(new_tokens, 1) if new_tokens else torch.empty(B, 0, dtype=torch.long, device=dev)
+        if input_ids is not None and inputs_embeds is None:
+            seq = torch.cat([input_ids, seq], 1)
+        if was_training:
+            self.train()
+        if return_dict_in_generate:
+            return _GenerateOutput(sequences=seq, past_key_values=cache)
+        return seq
+
+    # ---- checkpoints -----------------------------------------------------------------------------------
+    def copy_state_dict(self, state_dict: dict):
+        """spark_llm.py:174-201: take backbone weights from a base RWKV-7 LM; its token embedding becomes
+        text_embedder; embeddings and lm_head of the speech model are left untouched."""
+        target = self.state_dict()
+        new_sd = {}
+        for key, val in state_dict.items():
+            if key == "model.embeddings.weight":
+                new_sd["text_embedder.weight"] = val
+                continue
+            if "embeddings" in key or "lm_head" in key:
+                continue
+            if key in target or key.endswith("attn.x_x"):
+                new_sd[key] = val
+        info = self.load_state_dict(new_sd, strict=False)
+        print(info)
+        return self
+
+    def save_pretrained(self, path):
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.config.to_dict(), f, indent=2)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(path, "model.safetensors"))
+
+    @classmethod
+    def from_pretrained(cls, path, torch_dtype=None, device=None, **unused):
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = cls.config_class.from_dict(json.load(f))
+        model = cls(cfg)
+        sd = load_file(os.path.join(path, "model.safetensors"))
+        model.load_state_dict(sd, strict=True)
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        if device is not None:
+            model = model.to(device)
+        return model
+
+
+def sample_next(logits, do_sample=False, top_k=0, top_p=1.0, temperature=1.0, generator=None):
+    """Greedy (argmax, first max wins like torch.argmax) or temperature/top-k/top-p multinomial sampling,
+    in HF's processor order: temperature -> top-k -> top-p."""
+    if not do_sample:
+        return torch.argmax(logits, dim=-1)
+    if temperature and temperature != 1.0:
+        logits = logits / temperature
+    if top_k and top_k > 0:
+        k = min(top_k, logits.shape[-1])
+        kth = torch.topk(logits, k, dim=-1).values[..., -1:]
+        logits = logits.masked_fill(logits < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_idx = torch.sort(logits, descending=False, dim=-1)
+        cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1 - top_p)
+        remove[..., -1:] = False
+        logits = logits.masked_fill(remove.scatter(1, sorted_idx, remove), float("-inf"))
+    probs = torch.softmax(logits, dim=-1)
+    return torch.multinomial(probs, 1, generator=generator).squeeze(1)

@@ -1,0 +1,185 @@
+"""Batch-sharded data-parallel training step: one process per GPU, RCCL over xGMI.
+
+What it replaces in the reference: the DeepSpeed engine of train_scripts/train_spark_rwkv7speech.py:483-516,
+566-572 (ZeRO-2, bf16 grads, reduce bucket 5e6 elements, overlap_comm False) and its step semantics
+(:621-691): forward -> NaN flag all_reduce(MAX) (:664-670) -> backward -> gradient reduction -> AdamW
+(betas .9/.95, eps 1e-18, weight_decay 0, :178-197) with the linear warmup/decay schedule (:219-232).
+
+MI355X-first choices:
+  * the model is replicated (0.4B: 0.8 GB bf16 + 4.8 GB fp32 master/Adam; 1.5B: ~27 GB) -- 288 GB of HBM
+    per GPU makes ZeRO sharding/offload pointless at these sizes;
+  * parameters and gradients live in two flat bf16 buffers; gradients are all-reduced (AVG) in buckets of
+    ~32 MiB fired from post-accumulate-grad hooks in backward order, asynchronously on RCCL's stream, so
+    the exchange overlaps the rest of backward; xGMI is point-to-point (7 links/GPU), so few large
+    buckets beat DeepSpeed's 10 MB ones;
+  * fp32 master weights + fused AdamW on one flat tensor, then one bf16 copy back.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run contract).  Returns
+    (rank, local_rank, world).  No-op for world size 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class FlatBuffers:
+    """Re-homes every parameter (and its .grad) of `model` into two contiguous buffers."""
+
+    def __init__(self, model: torch.nn.Module):
+        params = [p for p in model.parameters() if p.requires_grad]
+        assert params, "no trainable parameters"
+        dt, dev = params[0].dtype, params[0].device
+        assert all(p.dtype == dt for p in params), "mixed parameter dtypes"
+        self.params = params
+        self.offsets, n = [], 0
+        for p in params:
+            self.offsets.append(n)
+            n += (p.numel() + 127) // 128 * 128  # 256-B aligned slices
+        self.numel = n
+        self.flat_param = torch.zeros(n, dtype=dt, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=dt, device=dev)
+        for p, o in zip(params, self.offsets):
+            self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + p.numel()].view_as(p)
+            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):  # autograd may have replaced .grad; re-attach the views
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
+
+class BucketedAllReduce:
+    """Gradient all-reduce in buckets, launched from backward hooks as soon as a bucket is complete."""
+
+    def __init__(self, flat: FlatBuffers, bucket_bytes: int = 32 << 20, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        esz = flat.flat_grad.element_size()
+        # buckets follow backward order: last parameters first
+        self.buckets: List[List[int]] = []  # each: [start, end, n_params]
+        self.param_bucket = [0] * len(flat.params)
+        cur_end, cur_start, cnt = flat.numel, flat.numel, 0
+        for i in range(len(flat.params) - 1, -1, -1):
+            cur_start = flat.offsets[i]
+            self.param_bucket[i] = len(self.buckets)
+            cnt += 1
+            if (cur_end - cur_start) * esz >= bucket_bytes or i == 0:
+                self.buckets.append([cur_start, cur_end, cnt])
+                cur_end, cnt = cur_start, 0
+        self.pending = [b[2] for b in self.buckets]
+        self.works = []
+        self.enabled = self.world > 1
+        if self.enabled:
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            b = self.param_bucket[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        view = self.flat.flat_grad[s:e]
+        if self.backend == "nccl":
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        else:  # gloo (CPU tests): no AVG, and bf16 support varies -> reduce in fp32
+            tmp = view.float()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_((tmp / self.world).to(view.dtype))
+
+    def finish(self):
+        """Wait for every bucket (also launches buckets whose hooks never fired, e.g. unused params)."""
+        if not self.enabled:
+            return
+        for b, left in enumerate(self.pending):
+            if left > 0:
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.pending = [b[2] for b in self.buckets]
+
+
+def linear_warmup_decay(step, total_steps, warmup_steps, lr, lr_final):
+    """train_spark_rwkv7speech.py:219-232."""
+    if step < warmup_steps:
+        return lr * float(step) / float(max(1, warmup_steps))
+    progress = float(step - warmup_steps) / float(max(1, total_steps - warmup_steps))
+    return lr * max(lr_final / lr, 1.0 - progress * (1.0 - lr_final / lr))
+
+
+class DataParallelTrainer:
+    def __init__(self, model: torch.nn.Module, lr=1e-4, lr_final=1e-5, warmup_steps=100, total_steps=100000,
+                 weight_decay=0.0, betas=(0.9, 0.95), eps=1e-18, bucket_bytes=32 << 20, nan_guard=True,
+                 master_fp32=True):
+        self.model = model
+        self.flat = FlatBuffers(model)
+        self.reducer = BucketedAllReduce(self.flat, bucket_bytes)
+        self.world = self.reducer.world
+        self.master = self.flat.flat_param.float() if master_fp32 and self.flat.flat_param.dtype != torch.float32 \
+            else self.flat.flat_param
+        self.master_grad = torch.zeros_like(self.master) if self.master is not self.flat.flat_param else None
+        self.master.grad = self.master_grad if self.master_grad is not None else self.flat.flat_grad
+        fused = self.master.is_cuda
+        self.opt = torch.optim.AdamW([self.master], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                     fused=fused)
+        self.lr, self.lr_final, self.warmup_steps, self.total_steps = lr, lr_final, warmup_steps, total_steps
+        self.nan_guard = nan_guard
+        self.step_idx = 0
+
+    def step(self, **batch):
+        """One optimisation step on this rank's shard of the batch.  Returns the (detached) loss tensor."""
+        self.flat.zero_grad()
+        out = self.model(**batch)
+        loss = out.loss
+        skip = False
+        if self.nan_guard:
+            flag = (~torch.isfinite(loss.detach())).float().reshape(1)
+            if self.world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # 1-element NaN flag, :664-670
+            skip = bool(flag.item())
+        if skip:
+            # the reference backpropagates loss*0 on every rank (:676-687); the update it then applies has zero
+            # gradient.  Same effect, without propagating NaN*0: no backward, zero gradient, optimizer step.
+            self.reducer.finish()
+        else:
+            loss.backward()
+            self.reducer.finish()
+        lr = linear_warmup_decay(self.step_idx, self.total_steps, self.warmup_steps, self.lr, self.lr_final)
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+        if self.master_grad is not None:
+            self.master_grad.copy_(self.flat.flat_grad)
+        self.opt.step()
+        if self.master is not self.flat.flat_param:
+            self.flat.flat_param.copy_(self.master)
+        self.step_idx += 1
+        return loss.detach()
