@@ -38,14 +38,15 @@ def cpu_baseline(seconds_budget=25.0):
     0.4B Spark model, fp32, fwd+bwd on B=1 sequences of T=128."""
     from oracle import rwkv7_ref as R
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    # the per-token scan is thousands of tiny ops: beyond ~16 threads the fork/join cost of each op dominates
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     cfg = R.RefConfig(hidden_size=1024, num_hidden_layers=24, vocab_size=8193)
     p = R.init_params(cfg, seed=0)
     p["lm_head.weight"] = torch.randn(8193, 1024) * 0.02
     for v in p.values():
         v.requires_grad_(True)
-    B, T = 1, 128
+    B, T = 1, 32
     x = torch.randn(B, T, 1024) * 0.5
     labels = torch.randint(0, 8192, (B, T))
     t0 = time.time()
@@ -54,7 +55,7 @@ def cpu_baseline(seconds_budget=25.0):
         loss, _, _ = R.spark_forward(p, cfg, x, None, labels)
         loss.backward()
         n += 1
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 8:
             break
     dt = time.time() - t0
     return {"value": round(n * B * T / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
@@ -106,8 +107,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params, B={B} T={T}")
     for i in range(a.warmup):
         loss = one_step(i)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done, loss {float(loss):.4f}, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     ops.KERNEL_TIMERS = {}
     t0 = time.perf_counter()
