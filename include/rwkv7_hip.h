@@ -68,6 +68,78 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
                             const void *k, const void *v, const void *a, const void *b, void *y,
                             rwkv7_stream_t stream);
 
+/* =====================================================================================================
+ * Fused elementwise stages of the time-mix / channel-mix blocks.  Activations are [rows = B*T, D]
+ * row-major, same dtype as the parameters (bf16 or fp32); `mask` is [rows] of that dtype or NULL;
+ * D % 64 == 0 and D <= 8192.  `nblocks` = number of workgroups walking the rows; backward kernels
+ * write per-workgroup fp32 partials of the parameter gradients, dparams_partial[nblocks][P][D], which
+ * the caller sums over the first axis.
+ * ===================================================================================================== */
+
+/* token shift + nmix lerps (nmix = 6: x_r,x_w,x_k,x_v,x_a,x_g -- rwkv_s2s_single_ffn.py:160-169;
+ * nmix = 1: channel-mix x_k -- :224-227):  xm = x*mask ; out[i] = xm + (shift(xm) - xm) * params[i].
+ * x_prev [B,D] (carried token-shift state, rwkv_asr_cuda_whisper.py:185) or NULL = zeros.
+ * out is [nmix][rows][D]. */
+int rwkv7_mix_fwd_bf16(int B, int T, int D, int nmix, const void *x, const void *x_prev, const void *mask,
+                       const void *params, void *out, int nblocks, rwkv7_stream_t stream);
+int rwkv7_mix_fwd_f32(int B, int T, int D, int nmix, const void *x, const void *x_prev, const void *mask,
+                      const void *params, void *out, int nblocks, rwkv7_stream_t stream);
+int rwkv7_mix_bwd_bf16(int B, int T, int D, int nmix, const void *grad_out, const void *x, const void *x_prev,
+                       const void *mask, const void *params, void *dx, float *dparams_partial, int nblocks,
+                       rwkv7_stream_t stream);
+int rwkv7_mix_bwd_f32(int B, int T, int D, int nmix, const void *grad_out, const void *x, const void *x_prev,
+                      const void *mask, const void *params, void *dx, float *dparams_partial, int nblocks,
+                      rwkv7_stream_t stream);
+
+/* everything between the projections and the scan (rwkv_s2s_single_ffn.py:172-190):
+ *   w = (-softplus(-w_pre) - 0.5)*mask ; k,v *= mask ; v += (v_first - v)*sigmoid(v_pre) (v_pre != NULL)
+ *   a = sigmoid(a_pre) ; kk = l2norm_head(k*k_k)*mask ; k2 = k*(1 + (a-1)*k_a) ; v2 = v*mask
+ * outputs w, k2, v2, ain = -kk, bin = kk*a (the scan's w,k,v,a,b).  v_pre/v_first NULL for layer 0.
+ * backward partials: P = 2 (dk_k, dk_a). */
+int rwkv7_tmix_prepare_fwd_bf16(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
+                                const void *v_pre, const void *v_first, const void *mask, const void *k_k,
+                                const void *k_a, void *w, void *k2, void *v2, void *ain, void *bin, int nblocks,
+                                rwkv7_stream_t stream);
+int rwkv7_tmix_prepare_fwd_f32(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
+                               const void *v_pre, const void *v_first, const void *mask, const void *k_k,
+                               const void *k_a, void *w, void *k2, void *v2, void *ain, void *bin, int nblocks,
+                               rwkv7_stream_t stream);
+int rwkv7_tmix_prepare_bwd_bf16(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
+                                const void *v_pre, const void *v_first, const void *mask, const void *k_k,
+                                const void *k_a, const void *d_w, const void *d_k2, const void *d_v2,
+                                const void *d_ain, const void *d_bin, void *d_wpre, void *d_k, void *d_v,
+                                void *d_apre, void *d_vpre, void *d_vfirst, float *dparams_partial, int nblocks,
+                                rwkv7_stream_t stream);
+int rwkv7_tmix_prepare_bwd_f32(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
+                               const void *v_pre, const void *v_first, const void *mask, const void *k_k,
+                               const void *k_a, const void *d_w, const void *d_k2, const void *d_v2,
+                               const void *d_ain, const void *d_bin, void *d_wpre, void *d_k, void *d_v,
+                               void *d_apre, void *d_vpre, void *d_vfirst, float *dparams_partial, int nblocks,
+                               rwkv7_stream_t stream);
+
+/* after the scan (rwkv_s2s_single_ffn.py:192-195): out = (GroupNorm_H(y; gn_w, gn_b, eps) + (sum_head r*k*r_k) v) * g.
+ * r_k is [H*64] flattened.  backward partials: P = 3 (d gn_w, d gn_b, d r_k). */
+int rwkv7_tmix_post_fwd_bf16(long rows, int D, const void *y, const void *r, const void *k, const void *v,
+                             const void *g, const void *gn_w, const void *gn_b, const void *r_k, float eps, void *out,
+                             int nblocks, rwkv7_stream_t stream);
+int rwkv7_tmix_post_fwd_f32(long rows, int D, const void *y, const void *r, const void *k, const void *v,
+                            const void *g, const void *gn_w, const void *gn_b, const void *r_k, float eps, void *out,
+                            int nblocks, rwkv7_stream_t stream);
+int rwkv7_tmix_post_bwd_bf16(long rows, int D, const void *dout, const void *y, const void *r, const void *k,
+                             const void *v, const void *g, const void *gn_w, const void *gn_b, const void *r_k,
+                             float eps, void *d_y, void *d_r, void *d_k, void *d_v, void *d_g, float *dparams_partial,
+                             int nblocks, rwkv7_stream_t stream);
+int rwkv7_tmix_post_bwd_f32(long rows, int D, const void *dout, const void *y, const void *r, const void *k,
+                            const void *v, const void *g, const void *gn_w, const void *gn_b, const void *r_k,
+                            float eps, void *d_y, void *d_r, void *d_k, void *d_v, void *d_g, float *dparams_partial,
+                            int nblocks, rwkv7_stream_t stream);
+
+/* channel-mix activation relu(x)^2 (rwkv_s2s_single_ffn.py:228) and dx = 2 relu(x) dy; n % 8 == 0 */
+int rwkv7_relusq_fwd_bf16(long n, const void *x, void *y, rwkv7_stream_t stream);
+int rwkv7_relusq_fwd_f32(long n, const void *x, void *y, rwkv7_stream_t stream);
+int rwkv7_relusq_bwd_bf16(long n, const void *x, const void *dy, void *dx, rwkv7_stream_t stream);
+int rwkv7_relusq_bwd_f32(long n, const void *x, const void *dy, void *dx, rwkv7_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -181,11 +181,9 @@ class RWKV7Attention(nn.Module):
         With `state`, token shift and the WKV state are carried (and updated in place)."""
         B, T, D = x.shape
         H, N = self.num_heads, self.head_dim
-        if mask is not None:
-            x = x * mask
         x_prev = None if state is None else state.att_x_prev
         xr, xw, xk, xv, xa, xg = fused.token_shift_mix6(x, x_prev, self.x_r, self.x_w, self.x_k, self.x_v,
-                                                        self.x_a, self.x_g)
+                                                        self.x_a, self.x_g, mask)
         r = self.r_proj(xr)
         k = self.k_proj(xk)
         v = self.v_proj(xv)
@@ -208,7 +206,8 @@ class RWKV7Attention(nn.Module):
                 y = ops.wkv7_forward_nograd(r, w, k2, v2, a_in, b_in)
         else:
             y = ops.RWKV7_BATCH_OP(state.att_kv, r.contiguous(), w, k2, v2, a_in, b_in)
-            state.att_x_prev = x[:, -1].detach().clone()
+            last = x[:, -1].detach()
+            state.att_x_prev = (last * mask[:, -1] if mask is not None else last).clone()
         y = fused.tmix_post(y, r, k2, v2, g, self.g_norm.weight, self.g_norm.bias, self.r_k, H, self.g_norm.eps)
         return self.o_proj(y), v_first
 
@@ -223,12 +222,11 @@ class RWKV7FeedForward(nn.Module):
         self.value = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
 
     def forward(self, x, mask, state: Optional[LayerState] = None):
-        if mask is not None:
-            x = x * mask
         x_prev = None if state is None else state.ffn_x_prev
-        kx = fused.token_shift_mix1(x, x_prev, self.x_k)
+        kx = fused.token_shift_mix1(x, x_prev, self.x_k, mask)
         if state is not None:
-            state.ffn_x_prev = x[:, -1].detach().clone()
+            last = x[:, -1].detach()
+            state.ffn_x_prev = (last * mask[:, -1] if mask is not None else last).clone()
         return self.value(fused.relu_sq(self.key(kx)))
 
 
@@ -290,7 +288,9 @@ class RWKV7Model(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("RWKV7Model runs on the HIP device only (no CPU path); move the model and inputs to cuda")
         mask = None
-        if attention_mask is not None:
+        if attention_mask is not None and not bool(attention_mask[:, -T:].all()):
+            # an all-ones mask (unpadded batches, the common training case) is dropped: multiplying by it is
+            # the identity and only costs HBM traffic
             mask = attention_mask[:, -T:].to(x.dtype).unsqueeze(-1)
         if use_cache and past_key_values is None:
             past_key_values = Cache.zeros(self.config, B, x.device, x.dtype)

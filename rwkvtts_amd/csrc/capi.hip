@@ -16,6 +16,16 @@ int wkv_bwd_bf16(int, int, int, const void *, const void *, const void *, const 
 int wkv_bwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                 const void *, const float *, const float *, void *, void *, void *, void *, void *, void *,
                 hipStream_t);
+
+struct bf16_t;
+template <typename T> int mix_fwd(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, hipStream_t);
+template <typename T> int mix_bwd(int, int, int, int, const void *, const void *, const void *, const void *, const void *, void *, float *, int, hipStream_t);
+template <typename T> int tmix_prepare_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, int, hipStream_t);
+template <typename T> int tmix_prepare_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
+template <typename T> int tmix_post_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, int, hipStream_t);
+template <typename T> int tmix_post_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, void *, void *, void *, void *, float *, int, hipStream_t);
+template <typename T> int relusq_fwd(long, const void *, void *, hipStream_t);
+template <typename T> int relusq_bwd(long, const void *, const void *, void *, hipStream_t);
 }  // namespace rwkv7
 
 namespace {
@@ -77,5 +87,82 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
                             rwkv7_stream_t stream) {
     STATE_BODY(wkv_fwd_f32)
 }
+
+
+// ---- fused elementwise stages ----------------------------------------------------------------------------------
+#define SHAPE_OK(D) ((D) > 0 && (D) % 64 == 0 && (D) <= 8192)
+#define EW_DEFINE(SFX, TY)                                                                                           \
+    int rwkv7_mix_fwd_##SFX(int B, int T, int D, int nmix, const void *x, const void *x_prev, const void *mask,       \
+                            const void *params, void *out, int nblocks, rwkv7_stream_t stream) {                      \
+        if (B <= 0 || T <= 0 || nblocks <= 0 || any_null({x, params, out})) return RWKV7_EINVAL;                      \
+        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
+        return rwkv7::mix_fwd<TY>(B, T, D, nmix, x, x_prev, mask, params, out, nblocks, (hipStream_t)stream);         \
+    }                                                                                                                 \
+    int rwkv7_mix_bwd_##SFX(int B, int T, int D, int nmix, const void *g, const void *x, const void *x_prev,          \
+                            const void *mask, const void *params, void *dx, float *dpart, int nblocks,                \
+                            rwkv7_stream_t stream) {                                                                  \
+        if (B <= 0 || T <= 0 || nblocks <= 0 || any_null({g, x, params, dx, dpart})) return RWKV7_EINVAL;             \
+        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
+        return rwkv7::mix_bwd<TY>(B, T, D, nmix, g, x, x_prev, mask, params, dx, dpart, nblocks, (hipStream_t)stream); \
+    }                                                                                                                 \
+    int rwkv7_tmix_prepare_fwd_##SFX(long rows, int D, const void *w_pre, const void *k, const void *v,               \
+                                     const void *a_pre, const void *v_pre, const void *v_first, const void *mask,     \
+                                     const void *k_k, const void *k_a, void *w, void *k2, void *v2, void *ain,        \
+                                     void *bin, int nblocks, rwkv7_stream_t stream) {                                 \
+        if (rows <= 0 || nblocks <= 0 || any_null({w_pre, k, v, a_pre, k_k, k_a, w, k2, v2, ain, bin}))               \
+            return RWKV7_EINVAL;                                                                                      \
+        if ((v_pre == nullptr) != (v_first == nullptr)) return RWKV7_EINVAL;                                          \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::tmix_prepare_fwd<TY>(rows, D, w_pre, k, v, a_pre, v_pre, v_first, mask, k_k, k_a, w, k2, v2,    \
+                                           ain, bin, nblocks, (hipStream_t)stream);                                   \
+    }                                                                                                                 \
+    int rwkv7_tmix_prepare_bwd_##SFX(long rows, int D, const void *w_pre, const void *k, const void *v,               \
+                                     const void *a_pre, const void *v_pre, const void *v_first, const void *mask,     \
+                                     const void *k_k, const void *k_a, const void *d_w, const void *d_k2,             \
+                                     const void *d_v2, const void *d_ain, const void *d_bin, void *d_wpre, void *d_k, \
+                                     void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, float *dpart,             \
+                                     int nblocks, rwkv7_stream_t stream) {                                            \
+        if (rows <= 0 || nblocks <= 0 ||                                                                              \
+            any_null({w_pre, k, v, a_pre, k_k, k_a, d_w, d_k2, d_v2, d_ain, d_bin, d_wpre, d_k, d_v, d_apre, dpart})) \
+            return RWKV7_EINVAL;                                                                                      \
+        if ((v_pre == nullptr) != (v_first == nullptr)) return RWKV7_EINVAL;                                          \
+        if (v_pre && (!d_vpre || !d_vfirst)) return RWKV7_EINVAL;                                                     \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::tmix_prepare_bwd<TY>(rows, D, w_pre, k, v, a_pre, v_pre, v_first, mask, k_k, k_a, d_w, d_k2,    \
+                                           d_v2, d_ain, d_bin, d_wpre, d_k, d_v, d_apre, d_vpre, d_vfirst, dpart,     \
+                                           nblocks, (hipStream_t)stream);                                             \
+    }                                                                                                                 \
+    int rwkv7_tmix_post_fwd_##SFX(long rows, int D, const void *y, const void *r, const void *k, const void *v,       \
+                                  const void *g, const void *gn_w, const void *gn_b, const void *r_k, float eps,      \
+                                  void *out, int nblocks, rwkv7_stream_t stream) {                                    \
+        if (rows <= 0 || nblocks <= 0 || any_null({y, r, k, v, g, gn_w, gn_b, r_k, out})) return RWKV7_EINVAL;        \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::tmix_post_fwd<TY>(rows, D, y, r, k, v, g, gn_w, gn_b, r_k, eps, out, nblocks,                   \
+                                        (hipStream_t)stream);                                                         \
+    }                                                                                                                 \
+    int rwkv7_tmix_post_bwd_##SFX(long rows, int D, const void *dout, const void *y, const void *r, const void *k,    \
+                                  const void *v, const void *g, const void *gn_w, const void *gn_b, const void *r_k,  \
+                                  float eps, void *d_y, void *d_r, void *d_k, void *d_v, void *d_g, float *dpart,     \
+                                  int nblocks, rwkv7_stream_t stream) {                                               \
+        if (rows <= 0 || nblocks <= 0 ||                                                                              \
+            any_null({dout, y, r, k, v, g, gn_w, gn_b, r_k, d_y, d_r, d_k, d_v, d_g, dpart}))                         \
+            return RWKV7_EINVAL;                                                                                      \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::tmix_post_bwd<TY>(rows, D, dout, y, r, k, v, g, gn_w, gn_b, r_k, eps, d_y, d_r, d_k, d_v, d_g,  \
+                                        dpart, nblocks, (hipStream_t)stream);                                         \
+    }                                                                                                                 \
+    int rwkv7_relusq_fwd_##SFX(long n, const void *x, void *y, rwkv7_stream_t stream) {                               \
+        if (n <= 0 || any_null({x, y})) return RWKV7_EINVAL;                                                          \
+        if (n % 8 != 0) return RWKV7_ESHAPE;                                                                          \
+        return rwkv7::relusq_fwd<TY>(n, x, y, (hipStream_t)stream);                                                   \
+    }                                                                                                                 \
+    int rwkv7_relusq_bwd_##SFX(long n, const void *x, const void *dy, void *dx, rwkv7_stream_t stream) {              \
+        if (n <= 0 || any_null({x, dy, dx})) return RWKV7_EINVAL;                                                     \
+        if (n % 8 != 0) return RWKV7_ESHAPE;                                                                          \
+        return rwkv7::relusq_bwd<TY>(n, x, dy, dx, (hipStream_t)stream);                                              \
+    }
+
+EW_DEFINE(bf16, rwkv7::bf16_t)
+EW_DEFINE(f32, float)
 
 }  // extern "C"

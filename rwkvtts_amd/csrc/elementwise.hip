@@ -1,0 +1,579 @@
+// rwkvtts_amd/csrc/elementwise.hip -- the HBM-bound stages around the WKV7 scan, fused for gfx950.
+//
+// What they replace (reference: model/llm/rwkv_s2s_single_ffn.py, ~20 separate elementwise launches per layer,
+// each re-reading [B,T,D] activations from HBM):
+//   mix        :162-169 / :225-227   token shift + 6 (time-mix) or 1 (channel-mix) lerps, with the mask multiply (:160)
+//   tmix_prepare :172-190            decay soft-clamp, masks, value residual, a/kk/k' and the scan's a,b operands
+//   tmix_post  :192-195              GroupNorm over each head + (r.k.r_k) v bonus + gate
+//   relusq     :228                  relu(x)^2
+// each with its backward.  Layout: activations are [rows = B*T, D] row-major; one workgroup walks rows with
+// D/8 threads, each thread owning 8 consecutive channels (one 16-byte bf16 load/store per tensor per row --
+// the coalescing sweet spot, cdna_hip_programming.md G13); a head is 64 channels = 8 consecutive lanes, so all
+// per-head reductions (l2 norm, GroupNorm moments, bonus dot product) are 8-lane DPP sums, no LDS.
+// Parameter gradients are accumulated per thread over the rows a workgroup walks and written as per-workgroup
+// partials [nblocks, P, D] (fp32); the host sums the partials (deterministic, no atomics).
+#include "wkv7_common.h"
+
+namespace rwkv7 {
+
+template <typename T>
+struct V8;
+template <>
+struct V8<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t *p, float (&f)[8]) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(p);
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t *p, const float (&f)[8]) {
+        uint4 r;
+        r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+        r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+        r.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+        r.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+        *reinterpret_cast<uint4 *>(p) = r;
+    }
+    static __device__ __forceinline__ float ld1(const bf16_t *p) { return bf2f(p->x); }
+};
+template <>
+struct V8<float> {
+    static __device__ __forceinline__ void ld(const float *p, float (&f)[8]) {
+        const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    static __device__ __forceinline__ void st(float *p, const float (&f)[8]) {
+        *reinterpret_cast<float4 *>(p) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    static __device__ __forceinline__ float ld1(const float *p) { return *p; }
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------------
+// mix: out_i[t] = xm[t] + (xm[t-1] - xm[t]) * p_i,   xm = x * mask,   xm[-1] = x_prev (or 0)
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int NMIX>
+__global__ void mix_fwd_kernel(int B, int T_, int D, const T *__restrict__ x, const T *__restrict__ x_prev,
+                               const T *__restrict__ mask, const T *__restrict__ params, T *__restrict__ out) {
+    const int c = threadIdx.x * 8;
+    const long rows = (long)B * T_;
+    float p[NMIX][8];
+#pragma unroll
+    for (int i = 0; i < NMIX; i++) V8<T>::ld(params + (long)i * D + c, p[i]);
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int t = (int)(row % T_);
+        float xc[8], xp[8];
+        V8<T>::ld(x + row * D + c, xc);
+        if (mask) {
+            const float m = V8<T>::ld1(mask + row);
+#pragma unroll
+            for (int j = 0; j < 8; j++) xc[j] *= m;
+        }
+        if (t > 0) {
+            V8<T>::ld(x + (row - 1) * D + c, xp);
+            if (mask) {
+                const float m = V8<T>::ld1(mask + row - 1);
+#pragma unroll
+                for (int j = 0; j < 8; j++) xp[j] *= m;
+            }
+        } else if (x_prev) {
+            V8<T>::ld(x_prev + (row / T_) * D + c, xp);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) xp[j] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NMIX; i++) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = fmaf(xp[j] - xc[j], p[i][j], xc[j]);
+            V8<T>::st(out + ((long)i * rows + row) * D + c, o);
+        }
+    }
+}
+
+// dxm[t] = sum_i g_i[t] (1 - p_i) + sum_i g_i[t+1] p_i ; dx = dxm * mask ; dp_i = sum_rows g_i[t] (xm[t-1] - xm[t])
+template <typename T, int NMIX>
+__global__ void mix_bwd_kernel(int B, int T_, int D, const T *__restrict__ g, const T *__restrict__ x,
+                               const T *__restrict__ x_prev, const T *__restrict__ mask, const T *__restrict__ params,
+                               T *__restrict__ dx, float *__restrict__ dpart) {
+    const int c = threadIdx.x * 8;
+    const long rows = (long)B * T_;
+    float p[NMIX][8], dp[NMIX][8];
+#pragma unroll
+    for (int i = 0; i < NMIX; i++) {
+        V8<T>::ld(params + (long)i * D + c, p[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dp[i][j] = 0.f;
+    }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int t = (int)(row % T_);
+        float xc[8], xp[8], acc[8];
+        V8<T>::ld(x + row * D + c, xc);
+        float m = 1.f;
+        if (mask) {
+            m = V8<T>::ld1(mask + row);
+#pragma unroll
+            for (int j = 0; j < 8; j++) xc[j] *= m;
+        }
+        if (t > 0) {
+            V8<T>::ld(x + (row - 1) * D + c, xp);
+            if (mask) {
+                const float mp = V8<T>::ld1(mask + row - 1);
+#pragma unroll
+                for (int j = 0; j < 8; j++) xp[j] *= mp;
+            }
+        } else if (x_prev) {
+            V8<T>::ld(x_prev + (row / T_) * D + c, xp);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) xp[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NMIX; i++) {
+            float gc[8];
+            V8<T>::ld(g + ((long)i * rows + row) * D + c, gc);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                acc[j] = fmaf(gc[j], 1.f - p[i][j], acc[j]);
+                dp[i][j] = fmaf(gc[j], xp[j] - xc[j], dp[i][j]);
+            }
+            if (t + 1 < T_) {
+                float gn[8];
+                V8<T>::ld(g + ((long)i * rows + row + 1) * D + c, gn);
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] = fmaf(gn[j], p[i][j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] *= m;
+        V8<T>::st(dx + row * D + c, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < NMIX; i++) V8<float>::st(dpart + ((long)blockIdx.x * NMIX + i) * D + c, dp[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// tmix_prepare (rwkv_s2s_single_ffn.py:172-190)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_(float u) { return u > 20.f ? u : log1pf(__expf(u)); }
+
+template <typename T>
+__global__ void tmix_prepare_fwd_kernel(long rows, int D, const T *__restrict__ w_pre, const T *__restrict__ k,
+                                        const T *__restrict__ v, const T *__restrict__ a_pre,
+                                        const T *__restrict__ v_pre, const T *__restrict__ v_first,
+                                        const T *__restrict__ mask, const T *__restrict__ k_k,
+                                        const T *__restrict__ k_a, T *__restrict__ w_out, T *__restrict__ k_out,
+                                        T *__restrict__ v_out, T *__restrict__ a_out, T *__restrict__ b_out) {
+    const int c = threadIdx.x * 8;
+    float kk_p[8], ka_p[8];
+    V8<T>::ld(k_k + c, kk_p);
+    V8<T>::ld(k_a + c, ka_p);
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long o = row * D + c;
+        const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+        float z[8], kx[8], vx[8], ap[8];
+        V8<T>::ld(w_pre + o, z);
+        V8<T>::ld(k + o, kx);
+        V8<T>::ld(v + o, vx);
+        V8<T>::ld(a_pre + o, ap);
+        float wo[8], ko[8], vo[8], ao[8], bo[8], kkr[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            wo[j] = (-softplus_(-z[j]) - 0.5f) * m;
+            kx[j] *= m;
+            vx[j] *= m;
+            kkr[j] = kx[j] * kk_p[j];
+            ss = fmaf(kkr[j], kkr[j], ss);
+        }
+        if (v_pre) {
+            float vp[8], vf[8];
+            V8<T>::ld(v_pre + o, vp);
+            V8<T>::ld(v_first + o, vf);
+#pragma unroll
+            for (int j = 0; j < 8; j++) vx[j] = fmaf(vf[j] - vx[j], sigmoidf_(vp[j]), vx[j]);
+        }
+        ss = sum8(ss);
+        const float inv = m / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps, then kk * mask
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float a = sigmoidf_(ap[j]);
+            const float kk = kkr[j] * inv;
+            ko[j] = kx[j] * fmaf(a - 1.f, ka_p[j], 1.f);
+            vo[j] = vx[j] * m;
+            ao[j] = -kk;
+            bo[j] = kk * a;
+        }
+        V8<T>::st(w_out + o, wo);
+        V8<T>::st(k_out + o, ko);
+        V8<T>::st(v_out + o, vo);
+        V8<T>::st(a_out + o, ao);
+        V8<T>::st(b_out + o, bo);
+    }
+}
+
+template <typename T>
+__global__ void tmix_prepare_bwd_kernel(long rows, int D, const T *__restrict__ w_pre, const T *__restrict__ k,
+                                        const T *__restrict__ v, const T *__restrict__ a_pre,
+                                        const T *__restrict__ v_pre, const T *__restrict__ v_first,
+                                        const T *__restrict__ mask, const T *__restrict__ k_k,
+                                        const T *__restrict__ k_a, const T *__restrict__ d_w,
+                                        const T *__restrict__ d_k2, const T *__restrict__ d_v2,
+                                        const T *__restrict__ d_ain, const T *__restrict__ d_bin,
+                                        T *__restrict__ d_wpre, T *__restrict__ d_k, T *__restrict__ d_v,
+                                        T *__restrict__ d_apre, T *__restrict__ d_vpre, T *__restrict__ d_vfirst,
+                                        float *__restrict__ dpart /* [nblk][2][D]: dk_k, dk_a */) {
+    const int c = threadIdx.x * 8;
+    float kk_p[8], ka_p[8], dkk_acc[8], dka_acc[8];
+    V8<T>::ld(k_k + c, kk_p);
+    V8<T>::ld(k_a + c, ka_p);
+#pragma unroll
+    for (int j = 0; j < 8; j++) dkk_acc[j] = dka_acc[j] = 0.f;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long o = row * D + c;
+        const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+        float z[8], kx[8], vx[8], ap[8], gw[8], gk2[8], gv2[8], ga[8], gb[8];
+        V8<T>::ld(w_pre + o, z);
+        V8<T>::ld(k + o, kx);
+        V8<T>::ld(v + o, vx);
+        V8<T>::ld(a_pre + o, ap);
+        V8<T>::ld(d_w + o, gw);
+        V8<T>::ld(d_k2 + o, gk2);
+        V8<T>::ld(d_v2 + o, gv2);
+        V8<T>::ld(d_ain + o, ga);
+        V8<T>::ld(d_bin + o, gb);
+        float kkr[8], a[8], du[8], u[8], o1[8], o2[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            kx[j] *= m;
+            vx[j] *= m;
+            kkr[j] = kx[j] * kk_p[j];
+            ss = fmaf(kkr[j], kkr[j], ss);
+            a[j] = sigmoidf_(ap[j]);
+        }
+        ss = sum8(ss);
+        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            u[j] = kkr[j] * rn;                            // unit vector; kk = u * m
+            du[j] = (gb[j] * a[j] - ga[j]) * m;            // dL/du
+            dot = fmaf(du[j], u[j], dot);
+        }
+        dot = sum8(dot);
+        // d_wpre
+#pragma unroll
+        for (int j = 0; j < 8; j++) o1[j] = gw[j] * m * sigmoidf_(-z[j]);
+        V8<T>::st(d_wpre + o, o1);
+        // d_k, d_apre, parameter partials
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float dkkr = (du[j] - u[j] * dot) * rn;
+            const float kk = u[j] * m;
+            const float da = gk2[j] * kx[j] * ka_p[j] + gb[j] * kk;
+            const float dkx = gk2[j] * fmaf(a[j] - 1.f, ka_p[j], 1.f) + dkkr * kk_p[j];
+            dkk_acc[j] = fmaf(dkkr, kx[j], dkk_acc[j]);
+            dka_acc[j] = fmaf(gk2[j] * kx[j], a[j] - 1.f, dka_acc[j]);
+            o1[j] = dkx * m;
+            o2[j] = da * a[j] * (1.f - a[j]);
+        }
+        V8<T>::st(d_k + o, o1);
+        V8<T>::st(d_apre + o, o2);
+        // value path
+        if (v_pre) {
+            float vp[8], vf[8], o3[8];
+            V8<T>::ld(v_pre + o, vp);
+            V8<T>::ld(v_first + o, vf);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float s = sigmoidf_(vp[j]);
+                const float g2 = gv2[j] * m;
+                o1[j] = g2 * (1.f - s) * m;              // d_v
+                o2[j] = g2 * (vf[j] - vx[j]) * s * (1.f - s);  // d_vpre
+                o3[j] = g2 * s;                          // d_vfirst
+            }
+            V8<T>::st(d_v + o, o1);
+            V8<T>::st(d_vpre + o, o2);
+            V8<T>::st(d_vfirst + o, o3);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) o1[j] = gv2[j] * m * m;
+            V8<T>::st(d_v + o, o1);
+        }
+    }
+    V8<float>::st(dpart + ((long)blockIdx.x * 2 + 0) * D + c, dkk_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 2 + 1) * D + c, dka_acc);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// tmix_post (rwkv_s2s_single_ffn.py:192-195): out = (GroupNorm_head(y) + (sum_head r k r_k) v) * g
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void tmix_post_fwd_kernel(long rows, int D, const T *__restrict__ y, const T *__restrict__ r,
+                                     const T *__restrict__ k, const T *__restrict__ v, const T *__restrict__ g,
+                                     const T *__restrict__ gn_w, const T *__restrict__ gn_b,
+                                     const T *__restrict__ r_k, float eps, T *__restrict__ out) {
+    const int c = threadIdx.x * 8;
+    float gw[8], gb[8], rk[8];
+    V8<T>::ld(gn_w + c, gw);
+    V8<T>::ld(gn_b + c, gb);
+    V8<T>::ld(r_k + c, rk);
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long o = row * D + c;
+        float yy[8], rr[8], kk[8], vv[8], gg[8], oo[8];
+        V8<T>::ld(y + o, yy);
+        V8<T>::ld(r + o, rr);
+        V8<T>::ld(k + o, kk);
+        V8<T>::ld(v + o, vv);
+        V8<T>::ld(g + o, gg);
+        float s1 = 0.f, dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            s1 += yy[j];
+            dot = fmaf(rr[j] * kk[j], rk[j], dot);
+        }
+        const float mean = sum8(s1) * (1.0f / 64.0f);
+        dot = sum8(dot);
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float d = yy[j] - mean;
+            s2 = fmaf(d, d, s2);
+        }
+        const float rstd = rsqrtf(sum8(s2) * (1.0f / 64.0f) + eps);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            oo[j] = (fmaf((yy[j] - mean) * rstd, gw[j], gb[j]) + dot * vv[j]) * gg[j];
+        V8<T>::st(out + o, oo);
+    }
+}
+
+template <typename T>
+__global__ void tmix_post_bwd_kernel(long rows, int D, const T *__restrict__ dout, const T *__restrict__ y,
+                                     const T *__restrict__ r, const T *__restrict__ k, const T *__restrict__ v,
+                                     const T *__restrict__ g, const T *__restrict__ gn_w, const T *__restrict__ gn_b,
+                                     const T *__restrict__ r_k, float eps, T *__restrict__ d_y, T *__restrict__ d_r,
+                                     T *__restrict__ d_k, T *__restrict__ d_v, T *__restrict__ d_g,
+                                     float *__restrict__ dpart /* [nblk][3][D]: d gn_w, d gn_b, d r_k */) {
+    const int c = threadIdx.x * 8;
+    float gw[8], gb[8], rk[8], a_w[8], a_b[8], a_rk[8];
+    V8<T>::ld(gn_w + c, gw);
+    V8<T>::ld(gn_b + c, gb);
+    V8<T>::ld(r_k + c, rk);
+#pragma unroll
+    for (int j = 0; j < 8; j++) a_w[j] = a_b[j] = a_rk[j] = 0.f;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long o = row * D + c;
+        float go[8], yy[8], rr[8], kk[8], vv[8], gg[8];
+        V8<T>::ld(dout + o, go);
+        V8<T>::ld(y + o, yy);
+        V8<T>::ld(r + o, rr);
+        V8<T>::ld(k + o, kk);
+        V8<T>::ld(v + o, vv);
+        V8<T>::ld(g + o, gg);
+        float s1 = 0.f, dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            s1 += yy[j];
+            dot = fmaf(rr[j] * kk[j], rk[j], dot);
+        }
+        const float mean = sum8(s1) * (1.0f / 64.0f);
+        dot = sum8(dot);
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float d = yy[j] - mean;
+            s2 = fmaf(d, d, s2);
+        }
+        const float rstd = rsqrtf(sum8(s2) * (1.0f / 64.0f) + eps);
+        float xh[8], dt[8], dxh[8], o1[8], o2[8];
+        float ds = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            xh[j] = (yy[j] - mean) * rstd;
+            const float tval = fmaf(xh[j], gw[j], gb[j]) + dot * vv[j];
+            o1[j] = go[j] * tval;          // d_g
+            dt[j] = go[j] * gg[j];         // dL/d(yn + bonus)
+            ds = fmaf(dt[j], vv[j], ds);
+            dxh[j] = dt[j] * gw[j];
+            m1 += dxh[j];
+            m2 = fmaf(dxh[j], xh[j], m2);
+            a_w[j] = fmaf(dt[j], xh[j], a_w[j]);
+            a_b[j] += dt[j];
+        }
+        V8<T>::st(d_g + o, o1);
+        ds = sum8(ds);
+        m1 = sum8(m1) * (1.0f / 64.0f);
+        m2 = sum8(m2) * (1.0f / 64.0f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            o1[j] = rstd * (dxh[j] - m1 - xh[j] * m2);  // d_y
+            o2[j] = dt[j] * dot;                        // d_v
+        }
+        V8<T>::st(d_y + o, o1);
+        V8<T>::st(d_v + o, o2);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            o1[j] = ds * kk[j] * rk[j];  // d_r
+            o2[j] = ds * rr[j] * rk[j];  // d_k
+            a_rk[j] = fmaf(ds, rr[j] * kk[j], a_rk[j]);
+        }
+        V8<T>::st(d_r + o, o1);
+        V8<T>::st(d_k + o, o2);
+    }
+    V8<float>::st(dpart + ((long)blockIdx.x * 3 + 0) * D + c, a_w);
+    V8<float>::st(dpart + ((long)blockIdx.x * 3 + 1) * D + c, a_b);
+    V8<float>::st(dpart + ((long)blockIdx.x * 3 + 2) * D + c, a_rk);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// relu(x)^2 and its derivative 2 relu(x) dy
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void relusq_fwd_kernel(long n8, const T *__restrict__ x, T *__restrict__ y) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float f[8];
+        V8<T>::ld(x + i * 8, f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float r = fmaxf(f[j], 0.f);
+            f[j] = r * r;
+        }
+        V8<T>::st(y + i * 8, f);
+    }
+}
+template <typename T>
+__global__ void relusq_bwd_kernel(long n8, const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ dx) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float f[8], g[8];
+        V8<T>::ld(x + i * 8, f);
+        V8<T>::ld(dy + i * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; j++) f[j] = 2.f * fmaxf(f[j], 0.f) * g[j];
+        V8<T>::st(dx + i * 8, f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------------
+static inline int finish() { return (int)hipGetLastError(); }
+
+template <typename T>
+int mix_fwd(int B, int T_, int D, int nmix, const void *x, const void *x_prev, const void *mask, const void *params,
+            void *out, int nblocks, hipStream_t st) {
+    (void)hipGetLastError();
+    const dim3 grid(nblocks), block(D / 8);
+    if (nmix == 6)
+        hipLaunchKernelGGL((mix_fwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, (const T *)x, (const T *)x_prev,
+                           (const T *)mask, (const T *)params, (T *)out);
+    else
+        hipLaunchKernelGGL((mix_fwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, (const T *)x, (const T *)x_prev,
+                           (const T *)mask, (const T *)params, (T *)out);
+    return finish();
+}
+template <typename T>
+int mix_bwd(int B, int T_, int D, int nmix, const void *g, const void *x, const void *x_prev, const void *mask,
+            const void *params, void *dx, float *dpart, int nblocks, hipStream_t st) {
+    (void)hipGetLastError();
+    const dim3 grid(nblocks), block(D / 8);
+    if (nmix == 6)
+        hipLaunchKernelGGL((mix_bwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, (const T *)g, (const T *)x,
+                           (const T *)x_prev, (const T *)mask, (const T *)params, (T *)dx, dpart);
+    else
+        hipLaunchKernelGGL((mix_bwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, (const T *)g, (const T *)x,
+                           (const T *)x_prev, (const T *)mask, (const T *)params, (T *)dx, dpart);
+    return finish();
+}
+template <typename T>
+int tmix_prepare_fwd(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
+                     const void *v_pre, const void *v_first, const void *mask, const void *k_k, const void *k_a,
+                     void *w, void *k2, void *v2, void *ain, void *bin, int nblocks, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((tmix_prepare_fwd_kernel<T>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)w_pre,
+                       (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre, (const T *)v_first,
+                       (const T *)mask, (const T *)k_k, (const T *)k_a, (T *)w, (T *)k2, (T *)v2, (T *)ain, (T *)bin);
+    return finish();
+}
+template <typename T>
+int tmix_prepare_bwd(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
+                     const void *v_pre, const void *v_first, const void *mask, const void *k_k, const void *k_a,
+                     const void *d_w, const void *d_k2, const void *d_v2, const void *d_ain, const void *d_bin,
+                     void *d_wpre, void *d_k, void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, float *dpart,
+                     int nblocks, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((tmix_prepare_bwd_kernel<T>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)w_pre,
+                       (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre, (const T *)v_first,
+                       (const T *)mask, (const T *)k_k, (const T *)k_a, (const T *)d_w, (const T *)d_k2,
+                       (const T *)d_v2, (const T *)d_ain, (const T *)d_bin, (T *)d_wpre, (T *)d_k, (T *)d_v,
+                       (T *)d_apre, (T *)d_vpre, (T *)d_vfirst, dpart);
+    return finish();
+}
+template <typename T>
+int tmix_post_fwd(long rows, int D, const void *y, const void *r, const void *k, const void *v, const void *g,
+                  const void *gn_w, const void *gn_b, const void *r_k, float eps, void *out, int nblocks,
+                  hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((tmix_post_fwd_kernel<T>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)y,
+                       (const T *)r, (const T *)k, (const T *)v, (const T *)g, (const T *)gn_w, (const T *)gn_b,
+                       (const T *)r_k, eps, (T *)out);
+    return finish();
+}
+template <typename T>
+int tmix_post_bwd(long rows, int D, const void *dout, const void *y, const void *r, const void *k, const void *v,
+                  const void *g, const void *gn_w, const void *gn_b, const void *r_k, float eps, void *d_y, void *d_r,
+                  void *d_k, void *d_v, void *d_g, float *dpart, int nblocks, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((tmix_post_bwd_kernel<T>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)dout,
+                       (const T *)y, (const T *)r, (const T *)k, (const T *)v, (const T *)g, (const T *)gn_w,
+                       (const T *)gn_b, (const T *)r_k, eps, (T *)d_y, (T *)d_r, (T *)d_k, (T *)d_v, (T *)d_g,
+                       dpart);
+    return finish();
+}
+template <typename T>
+int relusq_fwd(long n, const void *x, void *y, hipStream_t st) {
+    (void)hipGetLastError();
+    const long n8 = n / 8;
+    const int grid = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL((relusq_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, n8, (const T *)x, (T *)y);
+    return finish();
+}
+template <typename T>
+int relusq_bwd(long n, const void *x, const void *dy, void *dx, hipStream_t st) {
+    (void)hipGetLastError();
+    const long n8 = n / 8;
+    const int grid = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL((relusq_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, n8, (const T *)x, (const T *)dy, (T *)dx);
+    return finish();
+}
+
+#define INSTANTIATE(T)                                                                                              \
+    template int mix_fwd<T>(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, \
+                            hipStream_t);                                                                           \
+    template int mix_bwd<T>(int, int, int, int, const void *, const void *, const void *, const void *, const void *, \
+                            void *, float *, int, hipStream_t);                                                     \
+    template int tmix_prepare_fwd<T>(long, int, const void *, const void *, const void *, const void *, const void *, \
+                                     const void *, const void *, const void *, const void *, void *, void *, void *, \
+                                     void *, void *, int, hipStream_t);                                             \
+    template int tmix_prepare_bwd<T>(long, int, const void *, const void *, const void *, const void *, const void *, \
+                                     const void *, const void *, const void *, const void *, const void *,          \
+                                     const void *, const void *, const void *, const void *, void *, void *, void *, \
+                                     void *, void *, void *, float *, int, hipStream_t);                            \
+    template int tmix_post_fwd<T>(long, int, const void *, const void *, const void *, const void *, const void *,  \
+                                  const void *, const void *, const void *, float, void *, int, hipStream_t);       \
+    template int tmix_post_bwd<T>(long, int, const void *, const void *, const void *, const void *, const void *,  \
+                                  const void *, const void *, const void *, const void *, float, void *, void *,    \
+                                  void *, void *, void *, float *, int, hipStream_t);                               \
+    template int relusq_fwd<T>(long, const void *, void *, hipStream_t);                                            \
+    template int relusq_bwd<T>(long, const void *, const void *, void *, hipStream_t);
+INSTANTIATE(bf16_t)
+INSTANTIATE(float)
+
+}  // namespace rwkv7

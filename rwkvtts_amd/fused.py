@@ -1,68 +1,184 @@
-"""Elementwise stages around the WKV7 scan (reference: model/llm/rwkv_s2s_single_ffn.py:160-195,224-229).
+"""Fused elementwise stages around the WKV7 scan, served by hand-written HIP kernels in librwkv7_hip.so
+(rwkvtts_amd/csrc/elementwise.hip; C ABI in include/rwkv7_hip.h).
 
-Each function is one fused stage of the time-mix / channel-mix block.  They run on the HIP device;
-stages that have a hand-written kernel in librwkv7_hip.so dispatch to it (see HIP_STAGES), the rest are
-expressed with device tensor ops.  There is no CPU route: inputs must be HIP tensors.
+Reference formulas: model/llm/rwkv_s2s_single_ffn.py:160-169 (token shift + 6 lerps), :172-190 (decay / value
+residual / kk / k' / scan operands), :192-195 (GroupNorm + bonus + gate), :224-228 (channel-mix shift, relu^2).
+Each stage is one kernel forward and one backward (torch.autograd.Function); parameter gradients come back as
+per-workgroup fp32 partials that are summed here.  HIP tensors only -- there is no CPU or eager route.
 """
+import ctypes
+
 import torch
-import torch.nn.functional as F
 
-HIP_STAGES = set()  # names of the stages currently served by hand-written HIP kernels
+from . import _lib
 
-
-def _shift(x, x_prev):
-    """x_{t-1}; zeros (training, rwkv_s2s_single_ffn.py:162 ZeroPad2d) or the carried row at t = 0."""
-    if x_prev is None:
-        return F.pad(x, (0, 0, 1, -1))
-    return torch.cat([x_prev.unsqueeze(1).to(x.dtype), x[:, :-1]], dim=1)
+_FWD_BLOCKS = 4096   # workgroups walking the rows (D/8 threads each)
+_BWD_BLOCKS = 1024   # also the number of parameter-gradient partials
 
 
-def token_shift_mix6(x, x_prev, x_r, x_w, x_k, x_v, x_a, x_g):
-    """xx = shift(x) - x ; x + xx * x_?  for ? in r,w,k,v,a,g   (rwkv_s2s_single_ffn.py:162-169)."""
-    xx = _shift(x, x_prev) - x
-    return tuple(torch.addcmul(x, xx, p.view(1, 1, -1)) for p in (x_r, x_w, x_k, x_v, x_a, x_g))
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def token_shift_mix1(x, x_prev, x_k):
-    """channel-mix input: x + (shift(x) - x) * x_k   (rwkv_s2s_single_ffn.py:225-227)."""
-    xx = _shift(x, x_prev) - x
-    return torch.addcmul(x, xx, x_k.view(1, 1, -1))
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _sfx(t):
+    if not t.is_cuda:
+        raise NotImplementedError("fused RWKV-7 stages run on the HIP device only (no CPU path)")
+    if t.dtype == torch.bfloat16:
+        return "bf16"
+    if t.dtype == torch.float32:
+        return "f32"
+    raise TypeError(f"bf16 or fp32 expected, got {t.dtype}")
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _call(name, ref, *args):
+    with torch.cuda.device_of(ref):
+        rc = getattr(_lib.lib(), f"rwkv7_{name}_{_sfx(ref)}")(*args, _stream(ref))
+    _lib.check(rc, name)
+
+
+def _mask_rows(mask, like):
+    """mask [B,T,1] / [B,T] / None  ->  contiguous [B*T] tensor of like.dtype, or None."""
+    if mask is None:
+        return None
+    return mask.reshape(-1).to(like.dtype).contiguous()
+
+
+class _Mix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x_prev, mask, params):
+        B, T, D = x.shape
+        x, params = _c(x), _c(params)
+        nmix = params.shape[0]
+        out = torch.empty(nmix, B, T, D, dtype=x.dtype, device=x.device)
+        xp = None if x_prev is None else _c(x_prev.to(x.dtype))
+        _call("mix_fwd", x, B, T, D, nmix, _p(x), _p(xp), _p(mask), _p(params), _p(out), min(B * T, _FWD_BLOCKS))
+        ctx.save_for_backward(x, xp, mask, params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xp, mask, params = ctx.saved_tensors
+        B, T, D = x.shape
+        nmix = params.shape[0]
+        g = _c(g)
+        nb = min(B * T, _BWD_BLOCKS)
+        dx = torch.empty_like(x)
+        part = torch.empty(nb, nmix, D, dtype=torch.float32, device=x.device)
+        _call("mix_bwd", x, B, T, D, nmix, _p(g), _p(x), _p(xp), _p(mask), _p(params), _p(dx), _p(part), nb)
+        return dx, None, None, part.sum(0).to(params.dtype)
+
+
+def token_shift_mix6(x, x_prev, x_r, x_w, x_k, x_v, x_a, x_g, mask=None):
+    """xm = x*mask ; xx = shift(xm) - xm ; returns xm + xx*x_? for ? in r,w,k,v,a,g  (6 tensors [B,T,D])."""
+    D = x.shape[-1]
+    params = torch.cat([p.reshape(1, D) for p in (x_r, x_w, x_k, x_v, x_a, x_g)], 0).to(x.dtype)
+    return _Mix.apply(x, x_prev, _mask_rows(mask, x), params).unbind(0)
+
+
+def token_shift_mix1(x, x_prev, x_k, mask=None):
+    return _Mix.apply(x, x_prev, _mask_rows(mask, x), x_k.reshape(1, -1).to(x.dtype))[0]
+
+
+class _ReluSq(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        _call("relusq_fwd", x, ctypes.c_long(x.numel()), _p(x), _p(y))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        _call("relusq_bwd", x, ctypes.c_long(x.numel()), _p(x), _p(dy), _p(dx))
+        return dx
 
 
 def relu_sq(x):
-    """relu(x)^2   (rwkv_s2s_single_ffn.py:228)."""
-    return torch.relu(x).square()
+    return _ReluSq.apply(x)
+
+
+class _TmixPrepare(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a, mask):
+        B, T, D = k.shape
+        w_pre, k, v, a_pre = _c(w_pre), _c(k), _c(v), _c(a_pre)
+        v_pre = None if v_pre is None else _c(v_pre)
+        v_first = None if v_first is None else _c(v_first)
+        k_k, k_a = _c(k_k.to(k.dtype)), _c(k_a.to(k.dtype))
+        outs = [torch.empty_like(k) for _ in range(5)]
+        rows = B * T
+        _call("tmix_prepare_fwd", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first), _p(mask),
+              _p(k_k), _p(k_a), *[_p(o) for o in outs], min(rows, _FWD_BLOCKS))
+        ctx.save_for_backward(w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a, mask)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_w, d_k2, d_v2, d_a, d_b):
+        w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a, mask = ctx.saved_tensors
+        B, T, D = k.shape
+        rows = B * T
+        nb = min(rows, _BWD_BLOCKS)
+        gs = [_c(g) for g in (d_w, d_k2, d_v2, d_a, d_b)]
+        d_wpre, d_k, d_v, d_apre = [torch.empty_like(k) for _ in range(4)]
+        d_vpre = torch.empty_like(k) if v_pre is not None else None
+        d_vf = torch.empty_like(k) if v_pre is not None else None
+        part = torch.empty(nb, 2, D, dtype=torch.float32, device=k.device)
+        _call("tmix_prepare_bwd", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first), _p(mask),
+              _p(k_k), _p(k_a), *[_p(g) for g in gs], _p(d_wpre), _p(d_k), _p(d_v), _p(d_apre), _p(d_vpre), _p(d_vf),
+              _p(part), nb)
+        dp = part.sum(0).to(k.dtype)
+        return d_wpre, d_k, d_v, d_apre, d_vpre, d_vf, dp[0], dp[1], None
 
 
 def tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a, mask, H, is_layer0):
-    """Everything between the projections and the scan (rwkv_s2s_single_ffn.py:172-190):
-        w  = (-softplus(-w_pre) - 0.5) * mask
-        k  = k * mask ; v = v * mask
-        v  = v + (v_first - v) * sigmoid(v_pre)                    (layers > 0)
-        a  = sigmoid(a_pre)
-        kk = l2norm_per_head(k * k_k) * mask
-        k2 = k * (1 + (a - 1) * k_a) ; v2 = v * mask
-    returns w, k2, v2, -kk, kk * a   (the scan's w, k, v, a, b operands)."""
-    B, T, D = k.shape
-    w = -F.softplus(-w_pre) - 0.5
-    if mask is not None:
-        w, k, v = w * mask, k * mask, v * mask
-    if not is_layer0:
-        v = v + (v_first - v) * torch.sigmoid(v_pre)
-    a = torch.sigmoid(a_pre)
-    kk = F.normalize((k * k_k.view(1, 1, D)).view(B, T, H, -1), dim=-1, p=2.0).view(B, T, D)
-    if mask is not None:
-        kk = kk * mask
-    k2 = k * (1 + (a - 1) * k_a.view(1, 1, D))
-    if mask is not None:
-        v = v * mask
-    return w.contiguous(), k2.contiguous(), v.contiguous(), (-kk).contiguous(), (kk * a).contiguous()
+    """returns w, k2, v2, -kk, kk*a : the scan's w, k, v, a, b operands (see module docstring)."""
+    assert k.shape[-1] == H * 64
+    if is_layer0:
+        v_pre = v_first = None
+    return _TmixPrepare.apply(w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a, _mask_rows(mask, k))
+
+
+class _TmixPost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, r, k, v, g, gn_w, gn_b, r_k, eps):
+        B, T, D = y.shape
+        y, r, k, v, g = _c(y), _c(r), _c(k), _c(v), _c(g)
+        gn_w, gn_b, r_k = _c(gn_w.to(y.dtype)), _c(gn_b.to(y.dtype)), _c(r_k.reshape(-1).to(y.dtype))
+        out = torch.empty_like(y)
+        rows = B * T
+        _call("tmix_post_fwd", y, ctypes.c_long(rows), D, _p(y), _p(r), _p(k), _p(v), _p(g), _p(gn_w), _p(gn_b), _p(r_k),
+              ctypes.c_float(eps), _p(out), min(rows, _FWD_BLOCKS))
+        ctx.save_for_backward(y, r, k, v, g, gn_w, gn_b, r_k)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, r, k, v, g, gn_w, gn_b, r_k = ctx.saved_tensors
+        B, T, D = y.shape
+        rows = B * T
+        nb = min(rows, _BWD_BLOCKS)
+        dout = _c(dout)
+        d_y, d_r, d_k, d_v, d_g = [torch.empty_like(y) for _ in range(5)]
+        part = torch.empty(nb, 3, D, dtype=torch.float32, device=y.device)
+        _call("tmix_post_bwd", y, ctypes.c_long(rows), D, _p(dout), _p(y), _p(r), _p(k), _p(v), _p(g), _p(gn_w), _p(gn_b), _p(r_k),
+              ctypes.c_float(ctx.eps), _p(d_y), _p(d_r), _p(d_k), _p(d_v), _p(d_g), _p(part), nb)
+        dp = part.sum(0).to(y.dtype)
+        return d_y, d_r, d_k, d_v, d_g, dp[0], dp[1], dp[2], None
 
 
 def tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, eps):
-    """After the scan (rwkv_s2s_single_ffn.py:192-195): GroupNorm over each head, the (r.k.r_k) v bonus, gate."""
-    B, T, D = y.shape
-    N = D // H
-    yn = F.group_norm(y.reshape(B * T, D), H, gn_weight, gn_bias, eps).view(B, T, D)
-    bonus = (r.view(B, T, H, N) * k.view(B, T, H, N) * r_k.view(1, 1, H, N)).sum(-1, keepdim=True) * v.view(B, T, H, N)
-    return (yn + bonus.view(B, T, D)) * g
+    """(GroupNorm_H(y) + (sum_head r*k*r_k) * v) * g ; r_k is [H,64]."""
+    return _TmixPost.apply(y, r, k, v, g, gn_weight, gn_bias, r_k.reshape(-1), eps)

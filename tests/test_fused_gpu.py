@@ -1,0 +1,160 @@
+"""GPU (-m gpu): the fused elementwise HIP stages (rwkvtts_amd/fused.py -> librwkv7_hip.so) against the plain
+PyTorch restatement of the reference formulas (tests/ref_fused.py, fp32 on CPU), forward and backward
+(reference gradients by torch.autograd).
+
+Tolerances: fp32 kernels 2e-5 * max|ref| (forward) / 1e-4 (backward: long fp32 reductions over B*T rows for the
+parameter gradients); bf16 kernels: inputs are bf16-exact, the kernel computes in fp32 and rounds once, so
+outputs must be within 1 bf16 ulp of the fp32 reference (2^-7 relative, with an absolute floor)."""
+import pytest
+import torch
+
+import ref_fused as RF
+from rwkvtts_amd import fused
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cmp(got, want, tol, what):
+    got = got.detach().float().cpu()
+    want = want.detach().float()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= tol * max(ref, 1e-3), f"{what}: max|d|={err:.3e} max|ref|={ref:.3e} tol={tol}"
+
+
+def _cmp_bf16(got, want, what, ulps=1.0):
+    got = got.detach().float().cpu()
+    want = want.detach().float()
+    floor = want.abs().mean().item() * 0.25 + 1e-6
+    tol = ulps * 2.0 ** -7 * torch.clamp(want.abs(), min=floor)
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f"{what}: {bad.sum().item()}/{bad.numel()} beyond {ulps} bf16 ulp"
+
+
+def _mk(shape, g, scale=1.0, dtype=torch.float32):
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).float()  # values exactly representable in dtype
+
+
+def _run_both(fn_hip, fn_ref, inputs, dtype, grad_names, fwd_tol, bwd_tol):
+    """inputs: dict name -> fp32 CPU tensor (already rounded to dtype) or non-tensor."""
+    ref_in = {k: (v.clone().requires_grad_(k in grad_names) if torch.is_tensor(v) else v) for k, v in inputs.items()}
+    hip_in = {k: (v.to(DEV, dtype).requires_grad_(k in grad_names) if torch.is_tensor(v) else v)
+              for k, v in inputs.items()}
+    out_r = fn_ref(**ref_in)
+    out_h = fn_hip(**hip_in)
+    out_r = out_r if isinstance(out_r, (tuple, list)) else (out_r,)
+    out_h = out_h if isinstance(out_h, (tuple, list)) else (out_h,)
+    g = torch.Generator().manual_seed(77)
+    douts = [_mk(o.shape, g, 1.0, dtype) for o in out_r]
+    for i, (a, b) in enumerate(zip(out_h, out_r)):
+        if dtype == torch.bfloat16:
+            _cmp_bf16(a, b, f"out[{i}]")
+        else:
+            _cmp(a, b, fwd_tol, f"out[{i}]")
+    torch.autograd.backward(list(out_r), douts)
+    torch.autograd.backward(list(out_h), [d.to(DEV, dtype) for d in douts])
+    for n in grad_names:
+        gr, gh = ref_in[n].grad, hip_in[n].grad
+        assert gh is not None, n
+        if dtype == torch.bfloat16:
+            # gradients of broadcast parameters are sums over B*T rows rounded once to bf16
+            _cmp(gh, gr, 2.0 ** -6, f"d{n}")
+        else:
+            _cmp(gh, gr, bwd_tol, f"d{n}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,D,with_prev,with_mask", [(2, 33, 128, False, False), (3, 16, 768, True, True),
+                                                        (1, 1, 1024, True, False)])
+def test_token_shift_mix6_and_mix1(dtype, B, T, D, with_prev, with_mask):
+    g = torch.Generator().manual_seed(1)
+    x = _mk((B, T, D), g, 1.0, dtype)
+    xp = _mk((B, D), g, 1.0, dtype) if with_prev else None
+    mask = None
+    if with_mask:
+        mask = torch.ones(B, T, 1)
+        mask[0, :3] = 0
+    ps = {f"x_{n}": _mk((1, 1, D), g, 0.5, dtype) for n in "rwkvag"}
+
+    def ref(x, x_r, x_w, x_k, x_v, x_a, x_g):
+        xm = x if mask is None else x * mask
+        return RF.token_shift_mix6(xm, xp, x_r, x_w, x_k, x_v, x_a, x_g)
+
+    def hip(x, x_r, x_w, x_k, x_v, x_a, x_g):
+        return fused.token_shift_mix6(x, None if xp is None else xp.to(DEV, dtype), x_r, x_w, x_k, x_v, x_a, x_g,
+                                      None if mask is None else mask.to(DEV))
+
+    _run_both(hip, ref, dict(x=x, **ps), dtype, ["x"] + list(ps), 2e-6, 1e-4)
+
+    def ref1(x, x_k):
+        xm = x if mask is None else x * mask
+        return RF.token_shift_mix1(xm, xp, x_k)
+
+    def hip1(x, x_k):
+        return fused.token_shift_mix1(x, None if xp is None else xp.to(DEV, dtype), x_k,
+                                      None if mask is None else mask.to(DEV))
+
+    _run_both(hip1, ref1, dict(x=x, x_k=_mk((D,), g, 0.5, dtype)), dtype, ["x", "x_k"], 2e-6, 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layer0,with_mask", [(True, False), (False, False), (False, True), (True, True)])
+def test_tmix_prepare(dtype, layer0, with_mask):
+    B, T, H = 2, 24, 3
+    D = H * 64
+    g = torch.Generator().manual_seed(2)
+    ins = dict(w_pre=_mk((B, T, D), g, 2.0, dtype), k=_mk((B, T, D), g, 1.0, dtype), v=_mk((B, T, D), g, 1.0, dtype),
+               a_pre=_mk((B, T, D), g, 1.0, dtype), v_pre=_mk((B, T, D), g, 1.0, dtype),
+               v_first=_mk((B, T, D), g, 1.0, dtype), k_k=_mk((D,), g, 0.3, dtype) + 0.7,
+               k_a=_mk((D,), g, 0.1, dtype) + 1.0)
+    ins["k_k"] = ins["k_k"].to(dtype).float()
+    ins["k_a"] = ins["k_a"].to(dtype).float()
+    mask = None
+    if with_mask:
+        mask = torch.ones(B, T, 1)
+        mask[1, :5] = 0
+    grads = ["w_pre", "k", "v", "a_pre", "k_k", "k_a"] + ([] if layer0 else ["v_pre", "v_first"])
+
+    def ref(w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a):
+        return RF.tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a, mask, H, layer0)
+
+    def hip(w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a):
+        return fused.tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, k_k, k_a,
+                                  None if mask is None else mask.to(DEV), H, layer0)
+
+    _run_both(hip, ref, ins, dtype, grads, 5e-6, 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tmix_post(dtype):
+    B, T, H = 2, 40, 2
+    D = H * 64
+    g = torch.Generator().manual_seed(3)
+    ins = dict(y=_mk((B, T, D), g, 2.0, dtype), r=_mk((B, T, D), g, 1.0, dtype), k=_mk((B, T, D), g, 1.0, dtype),
+               v=_mk((B, T, D), g, 1.0, dtype), g=_mk((B, T, D), g, 1.0, dtype),
+               gn_weight=(_mk((D,), g, 0.2, dtype) + 1.0).to(dtype).float(), gn_bias=_mk((D,), g, 0.2, dtype),
+               r_k=_mk((H, 64), g, 0.1, dtype))
+
+    def ref(y, r, k, v, g, gn_weight, gn_bias, r_k):
+        return RF.tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, 64e-5)
+
+    def hip(y, r, k, v, g, gn_weight, gn_bias, r_k):
+        return fused.tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, 64e-5)
+
+    _run_both(hip, ref, ins, dtype, list(ins), 1e-5, 2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_relu_sq(dtype):
+    g = torch.Generator().manual_seed(4)
+    x = _mk((3, 17, 256), g, 1.0, dtype)
+    _run_both(lambda x: fused.relu_sq(x), lambda x: RF.relu_sq(x), dict(x=x), dtype, ["x"], 1e-6, 1e-6)
+
+
+def test_shape_and_device_errors():
+    x = torch.zeros(1, 4, 100, device=DEV)  # D % 64 != 0
+    with pytest.raises(ValueError):
+        fused.token_shift_mix1(x, None, torch.zeros(100, device=DEV))
+    with pytest.raises(NotImplementedError):
+        fused.relu_sq(torch.zeros(8))
