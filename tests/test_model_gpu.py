@@ -1,0 +1,178 @@
+"""GPU (-m gpu): the HIP backbone + Spark head against the oracle (oracle/rwkv7_ref.py) and the golden vectors.
+Tolerance (north_star): logits within 1e-3 fp32 of the reference CPU path, greedy token ids bit-exact."""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import rwkv7_ref as R
+from rwkvtts_amd.backbone import Cache, RWKV7Config, RWKV7Model
+from rwkvtts_amd.losses import fused_linear_cross_entropy
+from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SMALL = dict(hidden_size=128, num_hidden_layers=2, decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=16,
+             gate_low_rank_dim=32)
+
+
+def _spark_pair(seed=3, vocab=257):
+    cfg = RWKV7SpeechConfig(vocab_size=vocab, text_vocab_size=300, audio_global_vocab_size=64, **SMALL)
+    rcfg = R.RefConfig(vocab_size=vocab, **SMALL)
+    p = R.init_params(rcfg, seed=seed)
+    p["lm_head.weight"] = torch.randn(vocab, 128, generator=torch.Generator().manual_seed(seed)) * 0.05
+    model = RWKV7ForSpeech(cfg)
+    sd = dict(p)
+    for n in ("text_embedder", "global_embedder", "tts_tag_embedder"):
+        sd[n + ".weight"] = getattr(model, n).weight.detach().clone()
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV).eval(), p, rcfg
+
+
+def test_golden_block_modules_through_hip_backbone():
+    """tests/golden/block_module.npz = outputs of the reference's Block/RWKV_Tmix_x070/RWKV_CMix_x070 classes."""
+    g = load_golden("block_module.npz")
+    cfg = RWKV7Config(hidden_size=128, num_hidden_layers=2, vocab_size=16, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=32, gate_low_rank_dim=128)
+    model = RWKV7Model(cfg)
+    sd = {k[2 + len("model."):]: v for k, v in g.items() if k.startswith("p.model.")}
+    sd["embeddings.weight"] = torch.zeros(16, 128)
+    sd["norm.weight"], sd["norm.bias"] = torch.ones(128), torch.zeros(128)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model(inputs_embeds=g["x"].to(DEV), attention_mask=g["mask"].to(DEV))
+    want = torch.nn.functional.layer_norm(g["hidden_l1"], (128,))
+    err = (out.last_hidden_state.cpu() - want).abs().max().item()
+    assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("T", [48, 37, 5])
+def test_logits_match_oracle_with_left_padding(T):
+    model, p, rcfg = _spark_pair()
+    B = 3
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, 128, generator=g) * 0.5
+    mask = torch.ones(B, T, dtype=torch.long)
+    if T > 4:
+        mask[1, :4] = 0
+        mask[2, :1] = 0
+    labels = torch.randint(0, 256, (B, T), generator=g)
+    with torch.no_grad():
+        out = model(inputs_embeds=x.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV))
+        loss_o, logits_o, _ = R.spark_forward(p, rcfg, x, mask, labels)
+    valid = mask.bool()
+    err = (out.logits.cpu() - logits_o)[valid].abs().max().item()
+    assert err < 1e-3, err
+    assert torch.equal(out.logits.argmax(-1).cpu()[valid], logits_o.argmax(-1)[valid])
+    assert abs(out.loss.item() - loss_o.item()) < 1e-3
+
+
+def test_stateful_prefill_decode_equals_full_forward_and_oracle():
+    model, p, rcfg = _spark_pair(seed=5)
+    B, P, S = 2, 19, 6
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, P + S, 128, generator=g) * 0.5
+    with torch.no_grad():
+        full = model(inputs_embeds=x.to(DEV)).logits.cpu()
+        cache = Cache.zeros(model.config, B, DEV, torch.float32)
+        outs = [model(inputs_embeds=x[:, :P].to(DEV), past_key_values=cache, use_cache=True).logits.cpu()]
+        for t in range(P, P + S):
+            outs.append(model(inputs_embeds=x[:, t:t + 1].to(DEV), past_key_values=cache, use_cache=True).logits.cpu())
+        inc = torch.cat(outs, 1)
+        _, logits_o, _ = R.spark_forward(p, rcfg, x, None, None)
+    assert (inc - full).abs().max().item() < 1e-4
+    assert (inc - logits_o).abs().max().item() < 1e-3
+    assert cache.seen_tokens == P + S
+
+
+def test_greedy_generate_ids_bit_exact_vs_oracle():
+    """config 5 in miniature: left-padded prompt embeddings -> greedy decode on the persistent state."""
+    model, p, rcfg = _spark_pair(seed=7)
+    B, P, NEW = 3, 12, 24
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, P, 128, generator=g) * 0.5
+    mask = torch.ones(B, P, dtype=torch.long)
+    mask[0, :5] = 0
+    x = x * mask.unsqueeze(-1)
+    ids = model.generate(inputs_embeds=x.to(DEV), attention_mask=mask.to(DEV), max_new_tokens=NEW, do_sample=False,
+                         eos_token_id=256, pad_token_id=256, suppress_tokens=[256]).cpu()
+    # oracle: prefill then one step at a time on its own state list
+    states = R.zero_states(rcfg, B)
+    h, states = R.backbone(p, rcfg, x, mask, states)
+    want = []
+    emb = p["model.embeddings.weight"]
+    for _ in range(NEW):
+        logits = h[:, -1] @ p["lm_head.weight"].t()
+        logits[:, 256] = float("-inf")
+        nxt = logits.argmax(-1)
+        want.append(nxt)
+        h, states = R.backbone(p, rcfg, emb[nxt].unsqueeze(1), None, states)
+    assert torch.equal(ids, torch.stack(want, 1))
+
+
+def test_backward_matches_oracle_autograd():
+    model, p, rcfg = _spark_pair(seed=9)
+    model.train()
+    model.config.fuse_cross_entropy = True
+    model.dropout.p = 0.0
+    B, T = 2, 32
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, T, 128, generator=g) * 0.5
+    labels = torch.randint(0, 256, (B, T), generator=g)
+    out = model(inputs_embeds=x.to(DEV), labels=labels.to(DEV))
+    out.loss.backward()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss_o, _, _ = R.spark_forward(pr, rcfg, x, None, labels)
+    loss_o.backward()
+    assert abs(out.loss.item() - loss_o.item()) < 1e-4
+    named = dict(model.named_parameters())
+    checked = 0
+    for k, v in pr.items():
+        if v.grad is None or k == "model.embeddings.weight":
+            continue
+        gh = named[k].grad.cpu()
+        scale = max(v.grad.abs().max().item(), 1e-6)
+        err = (gh - v.grad).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-7, f"{k}: {err:.3e} vs scale {scale:.3e}"
+        checked += 1
+    assert checked > 40
+
+
+def test_fused_linear_ce_equals_plain():
+    g = torch.Generator().manual_seed(3)
+    h = (torch.randn(300, 64, generator=g)).to(DEV).requires_grad_(True)
+    w = (torch.randn(97, 64, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    lab = torch.randint(0, 97, (300,), generator=g).to(DEV)
+    lab[::7] = -100
+    l1 = fused_linear_cross_entropy(h, lab, w, None, -100, chunk=128)
+    l1.backward()
+    g1 = (h.grad.clone(), w.grad.clone())
+    h.grad = w.grad = None
+    l2 = torch.nn.functional.cross_entropy(h @ w.t(), lab, ignore_index=-100)
+    l2.backward()
+    assert abs(l1.item() - l2.item()) < 1e-5
+    assert (g1[0] - h.grad).abs().max().item() < 1e-6 and (g1[1] - w.grad).abs().max().item() < 1e-5
+
+
+def test_state_dict_keys_are_rwkvfla_and_fused_x_x_loads():
+    cfg = RWKV7SpeechConfig(vocab_size=33, text_vocab_size=40, audio_global_vocab_size=8, **SMALL)
+    m = RWKV7ForSpeech(cfg)
+    keys = set(m.state_dict())
+    for k in ("model.embeddings.weight", "model.layers.0.pre_norm.weight", "model.layers.1.attn_norm.bias",
+              "model.layers.1.attn.x_r", "model.layers.1.attn.k_k", "model.layers.1.attn.r_k",
+              "model.layers.1.attn.r_proj.weight", "model.layers.1.attn.w_lora.lora.0.weight",
+              "model.layers.1.attn.w_lora.lora.2.bias", "model.layers.1.attn.v_lora.lora.2.weight",
+              "model.layers.1.attn.g_lora.lora.2.weight", "model.layers.1.attn.g_norm.weight",
+              "model.layers.1.ffn.x_k", "model.layers.1.ffn.key.weight", "model.layers.1.ffn.value.weight",
+              "model.norm.weight", "lm_head.weight", "text_embedder.weight", "global_embedder.weight",
+              "tts_tag_embedder.weight"):
+        assert k in keys, k
+    assert "model.layers.0.attn.v_lora.lora.0.weight" not in keys  # layer 0 has no value-residual LoRA
+    assert "model.layers.1.attn.g_lora.lora.2.bias" not in keys
+    sd = m.state_dict()
+    for i in range(2):  # convert to the fused "version 1" layout (cosyvoice/cli/model.py:99-111) and reload
+        pre = f"model.layers.{i}.attn."
+        sd[pre + "x_x"] = torch.cat([sd.pop(pre + f"x_{n}").reshape(1, -1) for n in "rwkvag"], 0) + 0.5
+    m2 = RWKV7ForSpeech(cfg)
+    m2.load_state_dict(sd, strict=True)
+    assert torch.allclose(m2.model.layers[1].attn.x_k, m.model.layers[1].attn.x_k + 0.5)
