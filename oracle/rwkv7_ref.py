@@ -265,3 +265,53 @@ def spark_forward(p, cfg: RefConfig, inputs_embeds, attention_mask=None, labels=
         lab = torch.cat([labels[..., 1:], torch.full_like(labels[:, :1], -100)], 1)
         loss = F.cross_entropy(logits.view(lab.numel(), -1), lab.view(-1), ignore_index=-100)
     return loss, logits, st
+
+
+def label_smoothing_kl_ref(logits, target, size, padding_idx, smoothing, normalize_length):
+    """third_party/cosyvoice/transformer/label_smoothing_loss.py:82-96, line by line."""
+    batch_size = logits.size(0)
+    x = logits.reshape(-1, size)
+    target = target.reshape(-1)
+    true_dist = torch.zeros_like(x)
+    true_dist.fill_(smoothing / (size - 1))
+    ignore = target == padding_idx
+    total = len(target) - ignore.sum().item()
+    target = target.masked_fill(ignore, 0)
+    true_dist.scatter_(1, target.unsqueeze(1), 1.0 - smoothing)
+    kl = F.kl_div(torch.log_softmax(x, dim=1), true_dist, reduction="none")
+    denom = total if normalize_length else batch_size
+    return kl.masked_fill(ignore.unsqueeze(1), 0).sum() / denom
+
+
+def cosy_forward(p, cfg: RefConfig, batch, speech_token_size, lsm_weight=0.0, length_normalized_loss=True, wkv=None):
+    """model/llm/cosy_llm.py:92-148 / llm.py:84-133: [sos, text, task_id, speech] right-padded with -1, target
+    [-1 x (2+text_len), speech, EOS] shifted by one, LabelSmoothing KL loss + th_accuracy."""
+    tt, tl, st, sl = batch["text_token"], batch["text_token_len"], batch["speech_token"], batch["speech_token_len"]
+    B = tt.shape[0]
+    seqs, tgts = [], []
+    for i in range(B):
+        seqs.append(torch.cat([p["llm_embedding.weight"][0:1], p["text_embedding.weight"][tt[i, :int(tl[i])].long()],
+                               p["llm_embedding.weight"][1:2], p["speech_embedding.weight"][st[i, :int(sl[i])].long()]]))
+        tgts.append(torch.tensor([-1] * (2 + int(tl[i])) + st[i, :int(sl[i])].tolist() + [speech_token_size]))
+    x = torch.nn.utils.rnn.pad_sequence(seqs, batch_first=True, padding_value=-1.0)
+    mask = torch.nn.utils.rnn.pad_sequence([torch.ones(s.shape[0]) for s in seqs], batch_first=True)
+    target = torch.nn.utils.rnn.pad_sequence(tgts, batch_first=True, padding_value=-1)[:, 1:]
+    h, _ = backbone(p, cfg, x, mask, None, wkv)
+    logits = _lin(h, p["lm_head.weight"]) + p["lm_head.bias"]
+    loss = label_smoothing_kl_ref(logits, target, speech_token_size + 1, -1, lsm_weight, length_normalized_loss)
+    pred = logits.argmax(-1)
+    m = target != -1
+    acc = (pred[m] == target[m]).float().mean()
+    return loss, acc, logits
+
+
+def xy_forward(p, cfg: RefConfig, input_ids, attention_mask, labels, num_channels, lsm_weight=0.0, wkv=None):
+    """model/llm/xy_llm.py:203-240: sum of channel embeddings, 8 biased heads, sum of per-channel CE, no shift."""
+    x = sum(p[f"embs.{i}.weight"][input_ids[:, :, i]] for i in range(num_channels))
+    h, _ = backbone(p, cfg, x, attention_mask, None, wkv)
+    logits = [_lin(h, p[f"heads.{i}.weight"]) + p[f"heads.{i}.bias"] for i in range(num_channels)]
+    loss = None
+    if labels is not None:
+        loss = sum(F.cross_entropy(l.reshape(-1, l.shape[-1]), labels[:, :, i].reshape(-1), label_smoothing=lsm_weight)
+                   for i, l in enumerate(logits))
+    return loss, logits

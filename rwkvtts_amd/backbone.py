@@ -373,3 +373,28 @@ def init_weights(model: nn.Module, cfg: RWKV7Config, seed: int = 0):
         normal_(blk.ffn.key.weight, 0.5 * s)
         normal_(blk.ffn.value.weight, 0.5 / math.sqrt(cfg.intermediate_size))
     return model
+
+
+class RWKV7ForCausalLM(nn.Module):
+    """rwkvfla's RWKV7ForCausalLM as the reference uses it (model/llm/llm.py:44-50, after
+    train_functions.alter_emb_and_head): backbone + lm_head, logits for every position, optional shifted-label CE."""
+
+    def __init__(self, cfg: RWKV7Config, head_size: Optional[int] = None, head_bias: bool = False):
+        super().__init__()
+        self.config = cfg
+        self.model = RWKV7Model(cfg)
+        self.lm_head = nn.Linear(cfg.hidden_size, head_size or cfg.vocab_size, bias=head_bias)
+
+    def get_input_embeddings(self):
+        return self.model.embeddings
+
+    def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, past_key_values=None, labels=None,
+                use_cache=None, **kwargs):
+        out = self.model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
+                         past_key_values=past_key_values, use_cache=use_cache)
+        logits = self.lm_head(out[0])
+        loss = None
+        if labels is not None:
+            lab = torch.cat((labels[..., 1:], torch.full_like(labels[:, :1], -100)), 1)
+            loss = F.cross_entropy(logits.view(lab.numel(), -1).float(), lab.view(-1), ignore_index=-100)
+        return ModelOutput(loss=loss, logits=logits, past_key_values=out.past_key_values)

@@ -1,0 +1,251 @@
+"""Cosy-2.0-layout TTS language model on the HIP backbone: drop-in for model/llm/cosy_llm.py (RWKV7CosyLM)
+and the nn.Module wrapper model/llm/llm.py (RWKV7LM).
+
+Layout (cosy_llm.py:64-73,98-130 / llm.py:73-83,101-130): one sample is the embedding sequence
+    [sos_eos, text..., task_id, speech...]      (llm_embedding rows 0/1, text_embedding, speech_embedding)
+right-padded with the VALUE -1 (pad_sequence(..., padding_value=IGNORE_ID), cosy_llm.py:71) and masked;
+target = [-1 x (2 + text_len), speech..., EOS = speech_token_size], shifted by one (lm_target[:, 1:]);
+loss = LabelSmoothingLoss (KL form, cosyvoice/transformer/label_smoothing_loss.py:68-96), accuracy = th_accuracy.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, List, Optional
+
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import pad_sequence, unpad_sequence
+
+from .backbone import Cache, ModelOutput, RWKV7Config, RWKV7Model
+from .hf_api import HFModelMixin
+from .losses import label_smoothing_kl, th_accuracy
+
+IGNORE_ID = -1  # cosyvoice/utils/common.py:24
+
+
+class RWKV7CosyConfig(RWKV7Config):
+    """cosy_llm.py:13-22."""
+    _EXTRA = dict(llm_input_size=None, llm_output_size=None, speech_token_size=6561, length_normalized_loss=True,
+                  lsm_weight=0.0, mix_ratio=(5, 15), drop_ratio=0.0)
+
+    def __init__(self, **kw):
+        base = {k: v for k, v in kw.items() if k in RWKV7Config.__dataclass_fields__ and k != "extra"}
+        super().__init__(**base)
+        for k, dflt in self._EXTRA.items():
+            setattr(self, k, kw.get(k, dflt))
+        self.llm_input_size = self.llm_input_size or self.hidden_size
+        self.llm_output_size = self.llm_output_size or self.hidden_size
+        self.mix_ratio = list(self.mix_ratio)
+        self.extra = {k: v for k, v in kw.items() if k not in base and k not in self._EXTRA}
+
+    def to_dict(self):
+        d = super().to_dict()
+        d.update({k: getattr(self, k) for k in self._EXTRA}, architectures=["RWKV7CosyLM"])
+        return d
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(**d)
+
+
+def ras_sampling(weighted_scores, decoded_tokens, sampling, top_p=0.8, top_k=25, win_size=10, tau_r=0.1,
+                 generator=None):
+    """Repetition-aware sampling (cosyvoice/utils/common.py:109-137): nucleus (top-p AND top-k) sample; if it
+    repeats >= win_size*tau_r times in the last win_size tokens, resample from the full distribution."""
+    top_ids = nucleus_sampling(weighted_scores, top_p, top_k, generator)
+    rep_num = (torch.tensor(decoded_tokens[-win_size:], device=weighted_scores.device) == top_ids).sum().item()
+    if rep_num >= win_size * tau_r:
+        top_ids = weighted_scores.softmax(dim=0).multinomial(1, replacement=True, generator=generator)
+    return top_ids
+
+
+def nucleus_sampling(weighted_scores, top_p=0.8, top_k=25, generator=None):
+    sorted_value, sorted_idx = weighted_scores.softmax(dim=0).sort(descending=True, stable=True)
+    # keep while cum_prob (before adding) < top_p and fewer than top_k kept (common.py:121-128), vectorised
+    cum_before = torch.cumsum(sorted_value, 0) - sorted_value
+    keep = (cum_before < top_p) & (torch.arange(sorted_value.numel(), device=sorted_value.device) < top_k)
+    n = int(keep.long().cumprod(0).sum().item())
+    prob, indices = sorted_value[:n], sorted_idx[:n]
+    return indices[prob.multinomial(1, replacement=True, generator=generator)]
+
+
+class RWKV7CosyLM(HFModelMixin, nn.Module):
+    config_class = RWKV7CosyConfig
+
+    def __init__(self, config: RWKV7CosyConfig):
+        super().__init__()
+        self.config = config
+        self.model = RWKV7Model(config)
+        self.sos_eos, self.task_id, self.fill_token = 0, 1, 2
+        self.llm_embedding = nn.Embedding(2, config.llm_input_size)
+        self.text_embedding = nn.Embedding(config.vocab_size, config.llm_input_size)
+        self.speech_embedding = nn.Embedding(config.speech_token_size + 1, config.llm_input_size)
+        self.lm_head = nn.Linear(config.hidden_size, config.speech_token_size + 1)
+        self.dropout = nn.Dropout(config.drop_ratio) if config.drop_ratio > 0 else None
+        self.sampling: Optional[Callable] = ras_sampling
+        self.mix_ratio = config.mix_ratio
+        self.speech_token_size = config.speech_token_size
+
+    def criterion_ce(self, logits, target):
+        return label_smoothing_kl(logits, target, self.speech_token_size + 1, IGNORE_ID, self.config.lsm_weight,
+                                  self.config.length_normalized_loss)
+
+    def pad_unpad_sequence(self, sos_eos_emb, text_token, text_token_len, task_id_emb, speech_token, speech_token_len):
+        """cosy_llm.py:64-73 (note the padding VALUE -1 in the embeddings; masked positions)."""
+        device = text_token.device
+        text_token = unpad_sequence(text_token, text_token_len.cpu(), batch_first=True)
+        speech_token = unpad_sequence(speech_token, speech_token_len.cpu(), batch_first=True)
+        lm_input = [torch.concat([sos_eos_emb.squeeze(dim=0), text_token[i], task_id_emb.squeeze(dim=0), speech_token[i]],
+                                 dim=0) for i in range(len(text_token))]
+        attention_mask = [torch.ones(i.size(0), device=device, dtype=torch.int32) for i in lm_input]
+        lm_input = pad_sequence(lm_input, batch_first=True, padding_value=IGNORE_ID)
+        attention_mask = pad_sequence(attention_mask, batch_first=True, padding_value=0)
+        return lm_input, attention_mask
+
+    def build_inputs(self, batch):
+        """cosy_llm.py:92-120: batch dict -> (inputs_embeds, attention_mask, labels)."""
+        text_token, text_token_len = batch["text_token"], batch["text_token_len"]
+        speech_token, speech_token_len = batch["speech_token"], batch["speech_token_len"]
+        lm_target = [torch.tensor([IGNORE_ID] * (2 + int(text_token_len[i])) +
+                                  speech_token[i, :int(speech_token_len[i])].tolist() + [self.speech_token_size])
+                     for i in range(text_token.size(0))]
+        lm_target = pad_sequence(lm_target, batch_first=True, padding_value=IGNORE_ID).to(text_token.device)
+        text_emb = self.text_embedding(text_token)
+        sos_eos_emb = self.llm_embedding.weight[self.sos_eos].reshape(1, 1, -1)
+        task_id_emb = self.llm_embedding.weight[self.task_id].reshape(1, 1, -1)
+        speech_emb = self.speech_embedding(speech_token)
+        inputs_embeds, attention_mask = self.pad_unpad_sequence(sos_eos_emb, text_emb, text_token_len, task_id_emb,
+                                                                speech_emb, speech_token_len)
+        return inputs_embeds, attention_mask, lm_target[:, 1:].contiguous()
+
+    def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, past_key_values: Optional[Cache] = None,
+                labels=None, use_cache=None, return_dict=None, max_tokens_k: Optional[int] = None, **kwargs):
+        """cosy_llm.py:75-160, incl. the `batch=` form and the max_tokens_k batch slicing (:122-130)."""
+        return_dict = True if return_dict is None else return_dict
+        if "batch" in kwargs:
+            inputs_embeds, attention_mask, labels = self.build_inputs(kwargs["batch"])
+            if self.dropout is not None:
+                inputs_embeds = self.dropout(inputs_embeds)
+            if max_tokens_k is not None:
+                max_tokens = max_tokens_k * 1024
+                bsz, seq_len, _ = inputs_embeds.shape
+                max_bsz = max_tokens // seq_len
+                if max_bsz < bsz:
+                    inputs_embeds, labels, attention_mask = inputs_embeds[:max_bsz], labels[:max_bsz], attention_mask[:max_bsz]
+        outputs = self.model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
+                             past_key_values=past_key_values, use_cache=use_cache)
+        logits = self.lm_head(outputs[0])
+        loss = self.criterion_ce(logits, labels) if labels is not None else None
+        if not return_dict:
+            return ((loss,) if loss is not None else ()) + (logits, outputs.past_key_values)
+        return ModelOutput(loss=loss, logits=logits, past_key_values=outputs.past_key_values, hidden_states=None,
+                           attentions=None)
+
+    def forward_one_step(self, xs, masks, cache=None):
+        """cosy_llm.py:274-286 / llm.py:146-158."""
+        input_masks = masks[:, -1, :]
+        outs = self.model(inputs_embeds=xs, attention_mask=input_masks, use_cache=True, past_key_values=cache)
+        return self.lm_head(outs.last_hidden_state), outs.past_key_values
+
+    def sampling_ids(self, weighted_scores, decoded_tokens: List, sampling: int, ignore_eos: bool = True):
+        """cosy_llm.py:162-178: resample (<= 100 times) while EOS comes out and it must be ignored."""
+        num_trials, max_trials = 0, 100
+        while True:
+            top_ids = self.sampling(weighted_scores, decoded_tokens, sampling)
+            if (not ignore_eos) or (self.speech_token_size not in top_ids):
+                break
+            num_trials += 1
+            if num_trials > max_trials:
+                raise RuntimeError(f"sampling reaches max_trials {max_trials} and still get eos when ignore_eos is True, "
+                                   "check your input!")
+        return top_ids
+
+    @torch.inference_mode()
+    def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len,
+                  embedding=None, sampling: int = 25, max_token_text_ratio: float = 20, min_token_text_ratio: float = 0.5,
+                  cache=None):
+        """Streaming generator of speech token ids (cosy_llm.py:180-272): prefill [sos, prompt_text+text, task_id,
+        prompt_speech], then one persistent-state step per token; ids >= speech_token_size are EOS / skipped."""
+        device = text.device
+        text = torch.concat([prompt_text, text], dim=1)
+        text_len = text_len + prompt_text_len
+        original_text_len = int(text_len.item())
+        end_of_prompt_id = 65531
+        idx = (text == end_of_prompt_id).nonzero()
+        content_length = text_len
+        if idx.size(0) > 0:
+            instruction_length = idx[0, 1].item()
+            content_length = text_len - (instruction_length + 1)
+            original_text_len -= (instruction_length + 1)
+        text_emb = self.text_embedding(text)
+        sos_eos_emb = self.llm_embedding.weight[self.sos_eos].reshape(1, 1, -1)
+        task_id_emb = self.llm_embedding.weight[self.task_id].reshape(1, 1, -1)
+        if int(prompt_speech_token_len) != 0:
+            prompt_speech_token_emb = self.speech_embedding(prompt_speech_token)
+        else:
+            prompt_speech_token_emb = torch.zeros(1, 0, self.config.llm_input_size, dtype=text_emb.dtype, device=device)
+        lm_input = torch.concat([sos_eos_emb, text_emb, task_id_emb, prompt_speech_token_emb], dim=1)
+        min_len = int(content_length * min_token_text_ratio)
+        max_len = int(content_length * max_token_text_ratio)
+        out_tokens = []
+        if cache is None:
+            cache = Cache.zeros(self.config, 1, device, lm_input.dtype)
+        for i in range(max_len):
+            masks = torch.ones((1, lm_input.shape[1], lm_input.shape[1]), device=device, dtype=torch.bool)
+            logits, cache = self.forward_one_step(lm_input, masks=masks, cache=cache)
+            logp = logits[:, -1].float().log_softmax(dim=-1)
+            top_ids = int(self.sampling_ids(logp.squeeze(dim=0), out_tokens, sampling,
+                                            ignore_eos=(i + original_text_len < min_len)).item())
+            if top_ids == self.speech_token_size:
+                for st in cache.states:  # cosy_llm.py:247-251: token-shift states are zeroed at end of utterance
+                    st.att_x_prev = torch.zeros_like(st.att_x_prev)
+                    st.ffn_x_prev = torch.zeros_like(st.ffn_x_prev)
+                break
+            if top_ids > self.speech_token_size:
+                continue
+            yield top_ids
+            out_tokens.append(top_ids)
+            lm_input = self.speech_embedding.weight[top_ids].reshape(1, 1, -1)
+
+
+class RWKV7LM(nn.Module):
+    """model/llm/llm.py:17-133: wrapper whose forward(batch) returns {'loss', 'acc'}.  `llm` is a RWKV7CosyLM-like
+    causal LM (here: backbone + lm_head); text embeddings come from llm.get_input_embeddings()."""
+
+    def __init__(self, llm_input_size, llm_output_size, speech_token_size, llm: RWKV7CosyLM, sampling: Callable = None,
+                 length_normalized_loss=True, lsm_weight=0.0, mix_ratio=(5, 15), drop_ratio=0.0):
+        super().__init__()
+        self.llm_input_size, self.llm_output_size, self.speech_token_size = llm_input_size, llm_output_size, speech_token_size
+        self.sos_eos, self.task_id, self.fill_token = 0, 1, 2
+        self.llm_embedding = nn.Embedding(2, llm_input_size)
+        self.llm = llm
+        self.text_embedding = llm.get_input_embeddings()
+        self.speech_embedding = nn.Embedding(speech_token_size + 1, llm_input_size)
+        self.length_normalized_loss, self.lsm_weight = length_normalized_loss, lsm_weight
+        self.sampling = sampling or ras_sampling
+        self.mix_ratio = list(mix_ratio)
+        self.dropout = nn.Dropout(drop_ratio) if drop_ratio > 0 else None
+
+    pad_unpad_sequence = RWKV7CosyLM.pad_unpad_sequence
+
+    def forward(self, batch: dict):
+        text_token, text_token_len = batch["text_token"], batch["text_token_len"]
+        speech_token, speech_token_len = batch["speech_token"], batch["speech_token_len"]
+        lm_target = [torch.tensor([IGNORE_ID] * (2 + int(text_token_len[i])) +
+                                  speech_token[i, :int(speech_token_len[i])].tolist() + [self.speech_token_size])
+                     for i in range(text_token.size(0))]
+        lm_target = pad_sequence(lm_target, batch_first=True, padding_value=IGNORE_ID).to(text_token.device)
+        text_emb = self.text_embedding(text_token)
+        sos_eos_emb = self.llm_embedding.weight[self.sos_eos].reshape(1, 1, -1)
+        task_id_emb = self.llm_embedding.weight[self.task_id].reshape(1, 1, -1)
+        speech_emb = self.speech_embedding(speech_token)
+        lm_input, attention_mask = self.pad_unpad_sequence(sos_eos_emb, text_emb, text_token_len, task_id_emb, speech_emb,
+                                                           speech_token_len)
+        if self.dropout is not None:
+            lm_input = self.dropout(lm_input)
+        logits = self.llm(inputs_embeds=lm_input, attention_mask=attention_mask).logits
+        lm_target = lm_target[:, 1:].contiguous()
+        loss = label_smoothing_kl(logits, lm_target, self.speech_token_size + 1, IGNORE_ID, self.lsm_weight,
+                                  self.length_normalized_loss)
+        acc = th_accuracy(logits.view(-1, self.speech_token_size + 1), lm_target, ignore_label=IGNORE_ID)
+        return {"loss": loss, "acc": acc}

@@ -57,3 +57,180 @@ def synthetic_spark_batch(llm, B: int, T: int = 4096, seed: int = 1234, n_text: 
     labels[:, T - n_sem:] = sem
     mask = torch.ones(B, T, dtype=torch.long, device=dev)
     return dict(inputs_embeds=embs, attention_mask=mask, labels=labels)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Spark training batches
+# ----------------------------------------------------------------------------------------------------------
+def _unpad_left(ids, mask):
+    n = int(mask.sum().item())
+    return ids[-n:] if n > 0 else ids[:0]
+
+
+def process_single_batch(batch, rwkv7speech_model, eos_token_id=8192):
+    """data/utils/spark_dataset.py:163-239.  batch: left-padded id tensors `input_ids`, `global_tokens_ids`,
+    `semantic_tokens_ids` with their `attention_mask_input_ids` / `global_tokens_attention_mask` /
+    `semantic_tokens_attention_mask`.  Returns left-padded `input_embs`, `attention_mask`, and labels that are
+    ALREADY shifted by one (label[p] = token at p+1, EOS on the last position) -- the model shifts once more
+    (spark_llm.py:156); reproduced as is."""
+    llm = rwkv7speech_model
+    device = llm.device
+    B = batch["input_ids"].shape[0]
+    embs, sems = [], []
+    for i in range(B):
+        text = _unpad_left(batch["input_ids"][i], batch["attention_mask_input_ids"][i])
+        glob = _unpad_left(batch["global_tokens_ids"][i], batch["global_tokens_attention_mask"][i])
+        sem = _unpad_left(batch["semantic_tokens_ids"][i], batch["semantic_tokens_attention_mask"][i])
+        embs.append(spark_embed_sample(llm, text.tolist(), glob.tolist(), sem.tolist()))
+        sems.append(sem)
+    L = max(e.shape[1] for e in embs)
+    attention_mask = torch.zeros(B, L, dtype=torch.long, device=device)
+    labels = torch.full((B, L), -100, dtype=torch.long, device=device)
+    out = []
+    for i, e in enumerate(embs):
+        attention_mask[i, L - e.shape[1]:] = 1
+        out.append(torch.cat([e.new_zeros(1, L - e.shape[1], e.shape[2]), e], dim=1))
+        n = sems[i].numel()
+        labels[i, -n - 1:-1] = sems[i].to(device)
+        labels[i, -1] = eos_token_id
+    return {"input_embs": torch.cat(out, dim=0), "attention_mask": attention_mask, "labels": labels}
+
+
+def process_single_batch_culens(batch, rwkv7speech_model, eos_token_id=8192, max_cu_seqlens=8192):
+    """data/utils/spark_dataset.py:111-162: samples packed back to back into ONE row [1, sum T, D] with
+    cu_seqlens; packing stops (after appending the overflowing sample's tensors, as the reference does) once the
+    running length would exceed max_cu_seqlens."""
+    llm = rwkv7speech_model
+    device = llm.device
+    B = batch["input_ids"].shape[0]
+    embs, labels, cu = [], [], [0]
+    for i in range(B):
+        text = _unpad_left(batch["input_ids"][i], batch["attention_mask_input_ids"][i])
+        glob = _unpad_left(batch["global_tokens_ids"][i], batch["global_tokens_attention_mask"][i])
+        sem = _unpad_left(batch["semantic_tokens_ids"][i], batch["semantic_tokens_attention_mask"][i])
+        e = spark_embed_sample(llm, text.tolist(), glob.tolist(), sem.tolist())[0]
+        embs.append(e)
+        n = e.shape[0]
+        lab = torch.full((n,), -100, dtype=torch.long, device=device)
+        lab[-sem.numel() - 1:-1] = sem.to(device)
+        lab[-1] = eos_token_id
+        labels.append(lab)
+        if cu[-1] + n > max_cu_seqlens:
+            break
+        cu.append(cu[-1] + n)
+    return {"input_embs": torch.cat(embs, 0).unsqueeze(0), "labels": torch.cat(labels, 0).unsqueeze(0),
+            "cu_seqlens": torch.tensor(cu, dtype=torch.long, device=device)}
+
+
+def create_inputs_and_labels(text_ids: List[Sequence[int]], global_tokens: List[Sequence[int]],
+                             semantic_tokens: List[Sequence[int]], model, eos_token_id):
+    """utils/multiple_jsonl.py:4-74 with pre-tokenised text: semantic ids + EOS are INPUTS too, labels are
+    aligned with the inputs (the model's forward shifts), right padding, mask of ones over the real length."""
+    dev = model.device
+    embs, labs = [], []
+    for t, g, s in zip(text_ids, global_tokens, semantic_tokens):
+        s_pred = list(s) + [eos_token_id]
+        embs.append(spark_embed_sample(model, t, g, s_pred)[0])
+        prefix = 1 + len(t) + 1 + len(g) + 1
+        labs.append(torch.cat([torch.full((prefix,), -100, dtype=torch.long, device=dev),
+                               torch.tensor(s_pred, dtype=torch.long, device=dev)]))
+    lengths = [e.shape[0] for e in embs]
+    mask = torch.zeros(len(embs), max(lengths), dtype=torch.long, device=dev)
+    for i, n in enumerate(lengths):
+        mask[i, :n] = 1
+    return {"input_embs": torch.nn.utils.rnn.pad_sequence(embs, batch_first=True, padding_value=0.0),
+            "labels": torch.nn.utils.rnn.pad_sequence(labs, batch_first=True, padding_value=-100),
+            "attention_mask": mask}
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Cosy batches (data/utils/llm_dataset.py:118-188 after tokenisation)
+# ----------------------------------------------------------------------------------------------------------
+def cosy_collate(text_tokens: List[Sequence[int]], speech_tokens: List[Sequence[int]], pad_to_max_length=True,
+                 max_length=2048):
+    """text/speech id lists (prompt already concatenated in front, llm_dataset.py:150-160) -> the dict
+    RWKV7CosyLM.forward(batch=...) / RWKV7LM.forward(batch) consume.  int32 tensors, zero right-padding, `skip`
+    when the longest sample exceeds max_length; with pad_to_max_length the speech tensor is padded so that the
+    longest sample reaches max_length (llm_dataset.py:176-180)."""
+    tt = [torch.tensor(list(t), dtype=torch.int32) for t in text_tokens]
+    st = [torch.tensor(list(s), dtype=torch.int32) for s in speech_tokens]
+    my_max = max(len(a) + len(b) for a, b in zip(tt, st))
+    skip = my_max > max_length
+    text = torch.nn.utils.rnn.pad_sequence(tt, batch_first=True, padding_value=0)
+    speech = torch.nn.utils.rnn.pad_sequence(st, batch_first=True, padding_value=0)
+    if pad_to_max_length and not skip and max_length - my_max > 0:
+        speech = torch.nn.functional.pad(speech, (0, max_length - my_max), value=0)
+    return {"text_token": text, "text_token_len": torch.tensor([len(t) for t in tt], dtype=torch.int32),
+            "speech_token": speech, "speech_token_len": torch.tensor([len(s) for s in st], dtype=torch.int32),
+            "skip": skip}
+
+
+def synthetic_cosy_batch(B: int, n_text: int = 126, n_speech: int = 384, text_vocab=65548, speech_vocab=6561,
+                         seed: int = 1234):
+    """BASELINE.json configs[0]: [sos, 126 text ids, task, 384 speech ids] = 512 positions."""
+    g = torch.Generator().manual_seed(seed)
+    text = [torch.randint(0, text_vocab, (n_text,), generator=g).tolist() for _ in range(B)]
+    speech = [torch.randint(0, speech_vocab, (n_speech,), generator=g).tolist() for _ in range(B)]
+    return cosy_collate(text, speech, pad_to_max_length=False)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# XY batches (utils/xy_data_processor.py:30-130 == data/utils/collator.py:8-132 == train_xy_llm.py:90-215)
+# ----------------------------------------------------------------------------------------------------------
+class XYDataProcessor:
+    """utils/xy_data_processor.py:7-130 with pre-tokenised text.  `text_tokens[i]` must already be the ids of
+    "[S0]" + text + "[CTL0]" (:43,52); `audio_tokens[i]` is [num_channels][T2]."""
+
+    def __init__(self, text_vocab_size, num_channels, text_shift_size, speech_vocab_size):
+        self.num_channels = num_channels
+        self.text_shift_size = text_shift_size
+        self.speech_vocab_size = speech_vocab_size
+        self.audio_token_pad_token_id = speech_vocab_size - 1
+        self.text_token_pad_token_id = text_vocab_size - 1
+        self.ignore_id = -100
+
+    def process_batch(self, text_tokens: List[Sequence[int]], audio_tokens: List[Sequence[Sequence[int]]]):
+        C, apad, tpad, ign = self.num_channels, self.audio_token_pad_token_id, self.text_token_pad_token_id, self.ignore_id
+        ids_l, lab_l, msk_l = [], [], []
+        for tt, at in zip(text_tokens, audio_tokens):
+            text = torch.tensor(list(tt), dtype=torch.long)
+            speech = torch.tensor(at, dtype=torch.long).clone()
+            speech[0, :] += self.text_shift_size
+            T1, T2 = text.numel(), speech.shape[1]
+            total = T1 + T2 + C - 1
+            input_ids = torch.full((total, C), apad, dtype=torch.long)
+            labels = torch.full((total, C), ign, dtype=torch.long)
+            input_ids[:T1, 0] = text
+            input_ids[T1:, 0] = tpad
+            for ch in range(C):  # channel ch is delayed by ch steps
+                input_ids[T1 + ch: T1 + ch + T2, ch] = speech[ch]
+            labels[:-1, :] = input_ids[1:, :]
+            labels[:T1 - 1, :] = ign
+            labels[labels == apad] = ign
+            labels[labels == tpad] = ign
+            for i in range(C):
+                labels[T1 + T2 - 1 + i, i] = tpad if i == 0 else apad
+            ids_l.append(input_ids)
+            lab_l.append(labels)
+            msk_l.append(torch.ones(total, dtype=torch.long))
+        if not ids_l:
+            return {}
+        L = max(x.shape[0] for x in ids_l)
+        for i in range(len(ids_l)):
+            pad = L - ids_l[i].shape[0]
+            if pad > 0:
+                p = torch.full((pad, C), apad, dtype=torch.long)
+                p[:, 0] = tpad
+                ids_l[i] = torch.cat([ids_l[i], p], 0)
+                lab_l[i] = torch.cat([lab_l[i], torch.full((pad, C), ign, dtype=torch.long)], 0)
+                msk_l[i] = torch.cat([msk_l[i], torch.zeros(pad, dtype=torch.long)], 0)
+        return {"input_ids": torch.stack(ids_l), "labels": torch.stack(lab_l), "attention_mask": torch.stack(msk_l)}
+
+
+def synthetic_xy_batch(B: int, T1: int = 128, T2: int = 8057, num_channels=8, text_vocab=66661, speech_vocab=1025,
+                       text_shift=65536, seed: int = 1234):
+    """BASELINE.json configs[3]: 128 text steps + 8057 frames x 8 channels (+7 delay) = 8192 steps."""
+    g = torch.Generator().manual_seed(seed)
+    text = [torch.randint(0, 65536, (T1,), generator=g).tolist() for _ in range(B)]
+    audio = [torch.randint(0, speech_vocab - 1, (num_channels, T2), generator=g).tolist() for _ in range(B)]
+    return XYDataProcessor(text_vocab, num_channels, text_shift, speech_vocab).process_batch(text, audio)

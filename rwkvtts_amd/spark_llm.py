@@ -12,15 +12,14 @@ persistent-state decode path (greedy / top-k / top-p / temperature / suppress_to
 """
 from __future__ import annotations
 
-import json
-import os
 from typing import Optional
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .backbone import Cache, ModelOutput, RWKV7Config, RWKV7Model, init_weights
+from .backbone import Cache, ModelOutput, RWKV7Config, RWKV7Model
+from .hf_api import HFModelMixin
 from .losses import fused_linear_cross_entropy
 
 
@@ -48,7 +47,7 @@ class _GenerateOutput(ModelOutput):
     pass
 
 
-class RWKV7ForSpeech(nn.Module):
+class RWKV7ForSpeech(HFModelMixin, nn.Module):
     config_class = RWKV7SpeechConfig
 
     def __init__(self, config: RWKV7SpeechConfig):
@@ -62,43 +61,6 @@ class RWKV7ForSpeech(nn.Module):
         self.global_embedder = nn.Embedding(config.audio_global_vocab_size, config.hidden_size)
         self.tts_tag_embedder = nn.Embedding(3, config.hidden_size)  # GLOBAL=0, SEMANTIC=1, START_TTS=2
         self.dropout = nn.Dropout(0.02)
-
-    # ---- HF-style conveniences the reference scripts touch ---------------------------------------
-    @property
-    def device(self):
-        return next(self.parameters()).device
-
-    @property
-    def dtype(self):
-        return next(self.parameters()).dtype
-
-    def get_input_embeddings(self):
-        return self.model.embeddings
-
-    def set_input_embeddings(self, value):
-        self.model.embeddings = value
-
-    def get_output_embeddings(self):
-        return self.lm_head
-
-    def set_output_embeddings(self, new_embeddings):
-        self.lm_head = new_embeddings
-
-    def get_decoder(self):
-        return self.model
-
-    def set_decoder(self, decoder):
-        self.model = decoder
-
-    def gradient_checkpointing_enable(self, *a, **k):
-        self.model.gradient_checkpointing = True
-
-    def gradient_checkpointing_disable(self):
-        self.model.gradient_checkpointing = False
-
-    def init_weights(self, seed=0):
-        init_weights(self, self.config, seed)
-        return self
 
     # ---- forward -------------------------------------------------------------------------------------
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, past_key_values: Optional[Cache] = None,
@@ -215,28 +177,6 @@ class RWKV7ForSpeech(nn.Module):
         info = self.load_state_dict(new_sd, strict=False)
         print(info)
         return self
-
-    def save_pretrained(self, path):
-        from safetensors.torch import save_file
-        os.makedirs(path, exist_ok=True)
-        with open(os.path.join(path, "config.json"), "w") as f:
-            json.dump(self.config.to_dict(), f, indent=2)
-        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
-                  os.path.join(path, "model.safetensors"))
-
-    @classmethod
-    def from_pretrained(cls, path, torch_dtype=None, device=None, **unused):
-        from safetensors.torch import load_file
-        with open(os.path.join(path, "config.json")) as f:
-            cfg = cls.config_class.from_dict(json.load(f))
-        model = cls(cfg)
-        sd = load_file(os.path.join(path, "model.safetensors"))
-        model.load_state_dict(sd, strict=True)
-        if torch_dtype is not None:
-            model = model.to(torch_dtype)
-        if device is not None:
-            model = model.to(device)
-        return model
 
 
 def sample_next(logits, do_sample=False, top_k=0, top_p=1.0, temperature=1.0, generator=None):

@@ -1,0 +1,133 @@
+"""GPU (-m gpu): Cosy and XY heads on the HIP backbone against the oracle restatement (oracle/rwkv7_ref.py
+cosy_forward / xy_forward).  fp32 models: logits within 1e-3, losses within 1e-4, greedy ids equal."""
+import pytest
+import torch
+
+from oracle import rwkv7_ref as R
+from rwkvtts_amd import layouts as L
+from rwkvtts_amd.cosy_llm import RWKV7CosyConfig, RWKV7CosyLM, RWKV7LM
+from rwkvtts_amd.xy_llm import RWKV7XYConfig, RWKV7XYLM
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SMALL = dict(hidden_size=128, num_hidden_layers=2, decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=16,
+             gate_low_rank_dim=32)
+
+
+def _to(batch, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def test_cosy_forward_loss_acc_and_batch_slicing():
+    cfg = RWKV7CosyConfig(vocab_size=200, speech_token_size=50, lsm_weight=0.1, **SMALL)
+    rcfg = R.RefConfig(vocab_size=0, **SMALL)
+    p = R.init_params(rcfg, seed=4)
+    g = torch.Generator().manual_seed(4)
+    p.update({"llm_embedding.weight": torch.randn(2, 128, generator=g) * 0.5,
+              "text_embedding.weight": torch.randn(200, 128, generator=g) * 0.5,
+              "speech_embedding.weight": torch.randn(51, 128, generator=g) * 0.5,
+              "lm_head.weight": torch.randn(51, 128, generator=g) * 0.05, "lm_head.bias": torch.randn(51, generator=g) * 0.1,
+              "model.embeddings.weight": torch.zeros(200, 128)})
+    model = RWKV7CosyLM(cfg)
+    model.load_state_dict(p, strict=True)
+    model = model.to(DEV).eval()
+    batch = L.cosy_collate([[3, 4, 5, 6], [7, 8]], [[10, 11, 12, 13, 14, 15, 16], [20, 21, 22]], pad_to_max_length=False)
+    with torch.no_grad():
+        out = model(batch=_to(batch, DEV))
+        loss_o, acc_o, logits_o = R.cosy_forward(p, rcfg, batch, 50, 0.1, True)
+    emb, mask, labels = model.build_inputs(_to(batch, DEV))
+    valid = mask.bool().cpu()
+    assert (out.logits.cpu() - logits_o)[valid].abs().max().item() < 1e-3
+    assert abs(out.loss.item() - loss_o.item()) < 1e-4
+    assert (emb[1, -1] == -1).all()  # padding VALUE is -1 (cosy_llm.py:71), masked out
+    # RWKV7LM wrapper: same numbers through forward(batch) -> {'loss','acc'}
+    wrapper = RWKV7LM(128, 128, 50, model, lsm_weight=0.1).to(DEV).eval()
+    wrapper.llm_embedding.weight.data.copy_(p["llm_embedding.weight"])
+    wrapper.speech_embedding.weight.data.copy_(p["speech_embedding.weight"])
+    wrapper.text_embedding = model.text_embedding
+    with torch.no_grad():
+        r = wrapper(_to(batch, DEV))
+    assert abs(r["loss"].item() - loss_o.item()) < 1e-4 and abs(r["acc"].item() - acc_o.item()) < 1e-6
+    # max_tokens_k slicing (cosy_llm.py:122-130): 1 "k-token" = 1024 positions; seq_len 13 -> whole batch kept
+    with torch.no_grad():
+        assert model(batch=_to(batch, DEV), max_tokens_k=1).logits.shape[0] == 2
+
+
+def test_cosy_streaming_inference_matches_greedy_oracle():
+    cfg = RWKV7CosyConfig(vocab_size=200, speech_token_size=50, **SMALL)
+    model = RWKV7CosyLM(cfg).init_weights(seed=1).to(DEV).eval()
+    model.sampling = lambda scores, decoded, sampling: scores.argmax().reshape(1)  # greedy
+    text = torch.tensor([[5, 6, 7, 8]], device=DEV)
+    gen = model.inference(text, torch.tensor([4], device=DEV), torch.zeros(1, 0, dtype=torch.long, device=DEV),
+                          torch.tensor([0], device=DEV), torch.zeros(1, 0, dtype=torch.long, device=DEV),
+                          torch.tensor([0], device=DEV), max_token_text_ratio=5, min_token_text_ratio=0)
+    ids = list(gen)
+    # oracle: same weights, full re-forward of the growing sequence each step (no state), greedy
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rcfg = R.RefConfig(vocab_size=0, **SMALL)
+    seq = torch.cat([p["llm_embedding.weight"][0:1], p["text_embedding.weight"][text[0].cpu()],
+                     p["llm_embedding.weight"][1:2]])[None]
+    want = []
+    for _ in range(20):
+        h, _ = R.backbone(p, rcfg, seq, None, None)
+        nxt = int((h[0, -1] @ p["lm_head.weight"].t() + p["lm_head.bias"]).argmax())
+        if nxt >= 50:
+            break
+        want.append(nxt)
+        seq = torch.cat([seq, p["speech_embedding.weight"][nxt][None, None]], 1)
+    assert ids == want[:len(ids)] and len(ids) >= min(len(want), 1)
+
+
+def _xy_pair(lsm=0.0):
+    cfg = RWKV7XYConfig(vocab_size=120, speech_vocab_size=16, num_channels=4, text_shift_size=100, lsm_weight=lsm, **SMALL)
+    model = RWKV7XYLM(cfg).init_weights(seed=2)
+    with torch.no_grad():
+        for h in model.heads:
+            h.bias.normal_(0, 0.1)
+    model.zero_embs()
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model.to(DEV), p, R.RefConfig(vocab_size=0, **SMALL)
+
+
+@pytest.mark.parametrize("lsm", [0.0, 0.1])
+def test_xy_forward_and_fused_training_loss(lsm):
+    model, p, rcfg = _xy_pair(lsm)
+    g = torch.Generator().manual_seed(0)
+    text = [[101 + i for i in range(5)], [90, 91, 92]]
+    audio = [torch.randint(0, 15, (4, n), generator=g).tolist() for n in (9, 5)]
+    batch = L.XYDataProcessor(120, 4, 100, 16).process_batch(text, audio)
+    assert (model.embs[0].weight[119] == 0).all() and (model.embs[1].weight[15] == 0).all()  # zero_embs
+    model.eval()
+    with torch.no_grad():
+        out = model(**_to(batch, DEV))
+        loss_o, logits_o = R.xy_forward(p, rcfg, batch["input_ids"], batch["attention_mask"], batch["labels"], 4, lsm)
+    valid = batch["attention_mask"].bool()
+    for a, b in zip(out.logits, logits_o):
+        assert (a.cpu() - b)[valid].abs().max().item() < 1e-3
+    assert abs(out.loss.item() - loss_o.item()) < 1e-4
+    # training mode: chunked fused linear+CE (N4), logits not materialised, same loss, gradients flow to all heads
+    model.train()
+    out2 = model(**_to(batch, DEV))
+    assert out2.logits is None and abs(out2.loss.item() - loss_o.item()) < 1e-4
+    out2.loss.backward()
+    assert all(h.weight.grad is not None and torch.isfinite(h.weight.grad).all() for h in model.heads)
+    with pytest.raises(ValueError):
+        model(input_ids=batch["input_ids"][:, :, :3].to(DEV))
+
+
+def test_xy_generate_channel0_mask_and_shapes():
+    model, p, rcfg = _xy_pair()
+    model.eval()
+    prompt = L.XYDataProcessor(120, 4, 100, 16).process_batch([[101, 102, 103]], [[[1, 2], [3, 4], [5, 6], [7, 8]]])
+    ids = prompt["input_ids"][:, :5].to(DEV)
+    out = model.generate(ids, max_new_tokens=6, do_sample=False)
+    assert out.shape == (1, 11, 4)
+    new = out[0, 5:]
+    assert ((new[:, 0] >= 100) & (new[:, 0] < 116)).all()  # channel 0 constrained to [text_shift, +speech_vocab)
+    # greedy parity with the oracle on the first generated step
+    _, logits_o = R.xy_forward(p, rcfg, ids.cpu(), None, None, 4)
+    l0 = logits_o[0][0, -1].clone()
+    l0[:100] = float("-inf")
+    l0[116:] = float("-inf")
+    assert int(new[0, 0]) == int(l0.argmax()) and [int(new[0, i]) for i in (1, 2, 3)] == \
+        [int(logits_o[i][0, -1].argmax()) for i in (1, 2, 3)]
