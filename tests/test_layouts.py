@@ -31,7 +31,7 @@ def test_spark_create_inputs_left_pad():
     g = load_golden("layouts.npz")
     e, m = L.create_inputs(TEXT, GLOB, SEM, Duck(g))
     assert torch.equal(e, g["ci.emb"].to(e.dtype)) and torch.equal(m, g["ci.mask"])
-    assert m[2].tolist() == [0] * 5 + [1] * 11  # shortest sample is padded on the LEFT
+    assert m[2].tolist() == [0] * 4 + [1] * 11  # shortest sample is padded on the LEFT
 
 
 def test_spark_process_single_batch_and_culens():
