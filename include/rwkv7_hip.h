@@ -140,6 +140,31 @@ int rwkv7_relusq_fwd_f32(long n, const void *x, void *y, rwkv7_stream_t stream);
 int rwkv7_relusq_bwd_bf16(long n, const void *x, const void *dy, void *dx, rwkv7_stream_t stream);
 int rwkv7_relusq_bwd_f32(long n, const void *x, const void *dy, void *dx, rwkv7_stream_t stream);
 
+/* =====================================================================================================
+ * Chunked (MFMA) WKV7 -- the training fast path.  Same operator as rwkv7_wkv_fwd/bwd (reference
+ * wkv7_cuda.cu:10-130), evaluated 32 steps at a time on the matrix cores (algebra: csrc/chunk_common.h).
+ * Requires T % 32 == 0 and exp(w) <= ~2 per step (the model's soft-clamped decay satisfies it:
+ * w <= -0.5, rwkv_s2s_single_ffn.py:172).  Scratch / saved tensors, all caller-allocated fp32:
+ *   tinv [B,H,T/32,32,32]   (I - A_ab)^-1 per chunk, written by _prep, read by _fwd and _bwd
+ *   sa   [B,T,H,64]         u_t = S_{t-1} a_t (same meaning as the scalar op's `sa`)
+ *   hs   [B,H,T/32,64,64]   state at the START of each chunk, [value][key]
+ * sa and hs may both be NULL in _fwd (inference).
+ * ===================================================================================================== */
+#define RWKV7_CHUNK_T 32
+int rwkv7_wkv_chunk_prep_bf16(int B, int T, int H, const void *w, const void *a, const void *b, float *tinv,
+                              rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_prep_f32(int B, int T, int H, const void *w, const void *a, const void *b, float *tinv,
+                             rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_fwd_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                             const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                             rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_fwd_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                            const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                            rwkv7_stream_t stream);
+/* unit-test hook for the MFMA fragment layouts: D[32][32] = X[32][64] Y[32][64]^T (fp32 in, bf16-split MFMA),
+ * DT = the same tile after the transposed LDS write-back (hi+lo planes re-joined). */
+int rwkv7_debug_mma32(const float *X, const float *Y, float *D, float *DT, rwkv7_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

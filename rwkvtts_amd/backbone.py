@@ -280,10 +280,12 @@ class RWKV7Model(nn.Module):
         self.gradient_checkpointing = False
 
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, past_key_values: Optional[Cache] = None,
-                use_cache: Optional[bool] = None, **kwargs):
+                use_cache: Optional[bool] = None, cu_seqlens=None, **kwargs):
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         x = self.embeddings(input_ids) if inputs_embeds is None else inputs_embeds
+        if cu_seqlens is not None:
+            return self._forward_packed(x, cu_seqlens)
         B, T, D = x.shape
         if not x.is_cuda:
             raise RuntimeError("RWKV7Model runs on the HIP device only (no CPU path); move the model and inputs to cuda")
@@ -315,6 +317,27 @@ class RWKV7Model(nn.Module):
         if stateful:
             past_key_values.seen_tokens += T
         return ModelOutput(last_hidden_state=x, past_key_values=past_key_values if stateful else None)
+
+
+    def _forward_packed(self, x, cu_seqlens):
+        """Packed variable-length batch (data/utils/spark_dataset.py:111-162,
+        train_spark_rwkv7speech.py:238-239): x is ONE row [1, sum T, D], sequence i occupies
+        [cu_seqlens[i], cu_seqlens[i+1]); WKV state and token shift restart at every boundary.  Sequences never
+        interact, so the row is unpacked into a right-padded masked batch, run, and packed again; positions past
+        cu_seqlens[-1] (the reference's builder may append one overflowing sample) come back as zeros."""
+        assert x.shape[0] == 1, "cu_seqlens expects a packed [1, total, D] row"
+        cu = cu_seqlens.tolist()
+        lens = [b - a for a, b in zip(cu[:-1], cu[1:])]
+        seqs = list(x[0, :cu[-1]].split(lens))
+        xb = torch.nn.utils.rnn.pad_sequence(seqs, batch_first=True)
+        mask = torch.zeros(len(lens), xb.shape[1], dtype=torch.long, device=x.device)
+        for i, n in enumerate(lens):
+            mask[i, :n] = 1
+        out = self.forward(inputs_embeds=xb, attention_mask=mask).last_hidden_state
+        packed = torch.cat([out[i, :n] for i, n in enumerate(lens)], 0)
+        if packed.shape[0] < x.shape[1]:
+            packed = torch.cat([packed, packed.new_zeros(x.shape[1] - packed.shape[0], packed.shape[1])], 0)
+        return ModelOutput(last_hidden_state=packed.unsqueeze(0), past_key_values=None)
 
 
 # ------------------------------------------------------------------------------------------------

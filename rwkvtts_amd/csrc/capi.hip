@@ -17,6 +17,13 @@ int wkv_bwd_f32(int, int, int, const void *, const void *, const void *, const v
                 const void *, const float *, const float *, void *, void *, void *, void *, void *, void *,
                 hipStream_t);
 
+int chunk_prep_bf16(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
+int chunk_prep_f32(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
+int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
+                   const float *, void *, float *, float *, hipStream_t);
+int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
+                  const float *, void *, float *, float *, hipStream_t);
+int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 struct bf16_t;
 template <typename T> int mix_fwd(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, hipStream_t);
 template <typename T> int mix_bwd(int, int, int, int, const void *, const void *, const void *, const void *, const void *, void *, float *, int, hipStream_t);
@@ -164,5 +171,30 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
 
 EW_DEFINE(bf16, rwkv7::bf16_t)
 EW_DEFINE(f32, float)
+
+
+// ---- chunked (MFMA) WKV7 -----------------------------------------------------------------------------------------
+#define CHUNK_DEFINE(SFX)                                                                                          \
+    int rwkv7_wkv_chunk_prep_##SFX(int B, int T, int H, const void *w, const void *a, const void *b, float *tinv,   \
+                                   rwkv7_stream_t stream) {                                                         \
+        if (B <= 0 || T <= 0 || H <= 0 || any_null({w, a, b, tinv})) return RWKV7_EINVAL;                           \
+        if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;                                                            \
+        return rwkv7::chunk_prep_##SFX(B, T, H, w, a, b, tinv, (hipStream_t)stream);                                \
+    }                                                                                                               \
+    int rwkv7_wkv_chunk_fwd_##SFX(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,  \
+                                  const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,   \
+                                  rwkv7_stream_t stream) {                                                          \
+        if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
+        if ((sa == nullptr) != (hs == nullptr)) return RWKV7_EINVAL;                                                \
+        if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;                                                            \
+        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, (hipStream_t)stream);             \
+    }
+CHUNK_DEFINE(bf16)
+CHUNK_DEFINE(f32)
+
+int rwkv7_debug_mma32(const float *X, const float *Y, float *D, float *DT, rwkv7_stream_t stream) {
+    if (any_null({X, Y, D, DT})) return RWKV7_EINVAL;
+    return rwkv7::chunk_debug_mma(X, Y, D, DT, (hipStream_t)stream);
+}
 
 }  // extern "C"

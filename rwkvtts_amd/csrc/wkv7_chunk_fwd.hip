@@ -1,0 +1,425 @@
+// rwkvtts_amd/csrc/wkv7_chunk_fwd.hip -- chunked (MFMA) WKV7 forward for gfx950: the training fast path.
+//
+// Same operator as wkv7_fwd.hip (reference wkv7_cuda.cu:10-52) but evaluated 32 steps at a time as small matrix
+// products on the matrix cores instead of 64x64 scalar FMAs per step -- see chunk_common.h for the algebra.
+// The scalar recurrence needs ~9*64^2 flop per token-head at the fp32 VALU rate (157 TF/s chip-wide) and its
+// per-step dependency chain leaves one wave per SIMD latency-bound; here the only sequential object is the
+// 64x64 state between chunks, everything else is MFMA work and the part that does not depend on the state
+// (the 32x32 triangular inverse) is hoisted into a fully parallel kernel.
+//
+//   wkv7c_prep_kernel : grid B*H*(T/32), one wave per chunk: a~, b^ -> A_ab -> T = (I - A_ab)^-1 (fp32, row-wise
+//                       back substitution with v_readlane scalars) -> Tinv[b,h,c,32,32]   (also used by backward)
+//   wkv7c_fwd_kernel  : grid B*H*2 (two workgroups per head, 32 value columns each -- value columns never
+//                       interact in the forward), 4 waves; per chunk: decay cumsum + operand scaling into bf16
+//                       hi/lo planes -> A_ak, A_qb, A_qk (3 waves) + T planes (4th) -> R -> U -> Y | state update.
+// Saved for backward: U (= the scalar kernel's `sa`, fp32 [B,T,H,64]) and the state at the START of every chunk,
+// hs fp32 [B,H,T/32,64(v),64(k)].
+#include "chunk_common.h"
+
+namespace rwkv7 {
+
+template <typename T>
+__device__ __forceinline__ float ld_scalar(const T *p);
+template <>
+__device__ __forceinline__ float ld_scalar<bf16_t>(const bf16_t *p) { return bf2f(p->x); }
+template <>
+__device__ __forceinline__ float ld_scalar<float>(const float *p) { return *p; }
+
+// --------------------------------------------------------------------------------------------------------------
+// T = (I - A_ab)^-1 per chunk
+// --------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void wkv7c_prep_kernel(int T_, int H, const T *__restrict__ w_, const T *__restrict__ a_,
+                                                        const T *__restrict__ b_, float *__restrict__ tinv_) {
+    constexpr int LD = kN + kPad;
+    __shared__ __attribute__((aligned(16))) uint16_t ATh[kC * LD], ATl[kC * LD], BHh[kC * LD], BHl[kC * LD];
+    const int nc = T_ / kC;
+    const int bh = blockIdx.x / nc, c = blockIdx.x - bh * nc;
+    const int bb = bh / H, hh = bh - bb * H;
+    const int lane = threadIdx.x;
+    const long base = (((long)bb * T_ + (long)c * kC) * H + hh) * kN + lane;
+    const long tstride = (long)H * kN;
+    float G = 0.f;
+#pragma unroll 4
+    for (int t = 0; t < kC; t++) {
+        const long idx = base + t * tstride;
+        const float lw = -fast_exp(ld_scalar<T>(w_ + idx));
+        const float at = ld_scalar<T>(a_ + idx) * fast_exp(G);  // a * gamma_{t-1}
+        G += lw;
+        const float bh_ = ld_scalar<T>(b_ + idx) * fast_exp(-G);  // b / gamma_t
+        split2(at, ATh[t * LD + lane], ATl[t * LD + lane]);
+        split2(bh_, BHh[t * LD + lane], BHl[t * LD + lane]);
+    }
+    __syncthreads();
+    f32x16 acc = zero16();
+    mma_tile3<kN>(acc, BHh, BHl, LD, ATh, ATl, LD, lane);  // D[m = s][n = t] = b^_s . a~_t = A_ab[t][s]
+    mask_lower_T<true>(acc, lane);
+    // every lane (and its twin lane^32) gathers the whole row t = lane&31 of A_ab
+    const int h = lane >> 5;
+    float Arow[kC];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float other = __shfl_xor(acc[r], 32);
+        const int s0 = (r & 3) + 8 * (r >> 2);
+        Arow[s0] = h == 0 ? acc[r] : other;
+        Arow[s0 + 4] = h == 0 ? other : acc[r];
+    }
+    // T = I + T A  =>  T[t][r] = delta(t,r) + sum_{q>r} T[t][q] A[q][r], r = 31..0; A[q][r] is a wave-uniform scalar
+    const int t = lane & 31;
+    float Trow[kC];
+#pragma unroll
+    for (int r = kC - 1; r >= 0; r--) {
+        float s0 = (t == r) ? 1.f : 0.f, s1 = 0.f;
+#pragma unroll
+        for (int q = r + 1; q < kC; q++) {
+            const float aqr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Arow[r]), q));
+            if ((q - r) & 1) s0 = fmaf(Trow[q], aqr, s0);
+            else s1 = fmaf(Trow[q], aqr, s1);
+        }
+        Trow[r] = s0 + s1;
+    }
+    // lane t stores columns [16h, 16h+16) of its row
+    float *out = tinv_ + ((long)blockIdx.x * kC + t) * kC + 16 * h;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float4 v4;
+        v4.x = h == 0 ? Trow[4 * j + 0] : Trow[16 + 4 * j + 0];
+        v4.y = h == 0 ? Trow[4 * j + 1] : Trow[16 + 4 * j + 1];
+        v4.z = h == 0 ? Trow[4 * j + 2] : Trow[16 + 4 * j + 2];
+        v4.w = h == 0 ? Trow[4 * j + 3] : Trow[16 + 4 * j + 3];
+        *reinterpret_cast<float4 *>(out + 4 * j) = v4;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// forward
+// --------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int LDK = kN + kPad;  // planes with K = 64 columns
+constexpr int LDC = kC + kPad;  // planes with K = 32 columns
+constexpr int VH = 32;          // value columns per workgroup
+
+struct FwdSmem {  // all offsets in uint16 units; every plane 16-byte aligned
+    static constexpr int QTh = 0, QTl = QTh + kC * LDK, ATh = QTl + kC * LDK, ATl = ATh + kC * LDK;
+    static constexpr int KHh = ATl + kC * LDK, KHl = KHh + kC * LDK, BHh = KHl + kC * LDK, BHl = BHh + kC * LDK;
+    static constexpr int KTh = BHl + kC * LDK, KTl = KTh + kN * LDC, BTh = KTl + kN * LDC, BTl = BTh + kN * LDC;
+    static constexpr int Vt = BTl + kN * LDC, Vtl = Vt + VH * LDC;  // Vtl: low part, fp32 inputs only
+    static constexpr int Sh = Vtl + VH * LDC, Sl = Sh + VH * LDK;
+    static constexpr int AKh = Sl + VH * LDK, AKl = AKh + kC * LDC, QBh = AKl + kC * LDC, QBl = QBh + kC * LDC;
+    static constexpr int QKh = QBl + kC * LDC, QKl = QKh + kC * LDC, TMh = QKl + kC * LDC, TMl = TMh + kC * LDC;
+    static constexpr int Rh = TMl + kC * LDC, Rl = Rh + VH * LDC, Uh = Rl + VH * LDC, Ul = Uh + VH * LDC;
+    static constexpr int end16 = Ul + VH * LDC;
+    // fp32 region (offsets in floats from the start of the fp32 area)
+    static constexpr int fG = 0, fSeg = fG + kC * kN, fGC = fSeg + 4 * kN, fend = fGC + kN;
+    static constexpr size_t bytes = (size_t)end16 * 2 + (size_t)fend * 4;
+};
+static_assert(FwdSmem::end16 % 8 == 0, "fp32 area must stay 16-byte aligned");
+}  // namespace
+
+template <typename T, bool SAVE>
+__global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *__restrict__ w_, const T *__restrict__ q_,
+                                                        const T *__restrict__ k_, const T *__restrict__ v_,
+                                                        const T *__restrict__ a_, const T *__restrict__ b_,
+                                                        const float *__restrict__ tinv_, T *__restrict__ y_,
+                                                        float *__restrict__ sa_, float *__restrict__ hs_) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
+    float *fm = reinterpret_cast<float *>(sm + FwdSmem::end16);
+    float *sh_G = fm + FwdSmem::fG, *sh_seg = fm + FwdSmem::fSeg, *sh_gC = fm + FwdSmem::fGC;
+    using L = FwdSmem;
+    constexpr bool VEXACT = sizeof(T) == 2;  // bf16 tensors: v needs no hi/lo split
+    // acc += X V^T-plane product with X split; V exact (bf16 I/O) or split (fp32 I/O)
+    auto mma_xv = [&](f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int lane_) {
+        if (VEXACT) mma_tile2x<kC>(acc, Xh, Xl, LDC, sm + L::Vt, LDC, lane_);
+        else mma_tile3<kC>(acc, Xh, Xl, LDC, sm + L::Vt, sm + L::Vtl, LDC, lane_);
+    };
+
+    const int vh = blockIdx.x & 1;
+    const int bh = blockIdx.x >> 1;
+    const int bb = bh / H, hh = bh - bb * H;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nc = T_ / kC;
+    const long tstride = (long)H * kN;
+    const long head_base = ((long)bb * T_ * H + hh) * kN;
+
+    // phase-1/2 roles: one time step x 8 channels per thread
+    const int pt = tid >> 3, pk = (tid & 7) * 8;
+    const int pv = (tid & 7) * 4;  // 4 value columns of this workgroup's half
+
+    // zero the state planes (chunk 0 starts from S = 0)
+    for (int i = tid; i < 2 * VH * LDK; i += 256) sm[L::Sh + i] = 0;
+
+    f32x16 Smaster = zero16();  // waves 1,2: D-layout tile [k-tile rows][v cols] of the fp32 state
+
+    Raw4<T> rw[2], rq[2], rk[2], ra[2], rb[2], rv;
+    auto issue = [&](int c) {
+        const long off = head_base + (long)(c * kC + pt) * tstride;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            rw[i] = ld4<T>(w_ + off + pk + 4 * i, true);
+            rq[i] = ld4<T>(q_ + off + pk + 4 * i, true);
+            rk[i] = ld4<T>(k_ + off + pk + 4 * i, true);
+            ra[i] = ld4<T>(a_ + off + pk + 4 * i, true);
+            rb[i] = ld4<T>(b_ + off + pk + 4 * i, true);
+        }
+        rv = ld4<T>(v_ + off + vh * VH + pv, true);
+    };
+    issue(0);
+    __syncthreads();
+
+    for (int c = 0; c < nc; c++) {
+        // ---- phase 1: log-decay and its cumulative sum over the chunk ---------------------------------------
+        float lw[8], qv[8], kv[8], av[8], bv[8], vv[4];
+        {
+            const float4 w0 = cvt4(rw[0]), w1 = cvt4(rw[1]);
+            const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) lw[j] = -fast_exp(wr[j]);
+            const float4 q0 = cvt4(rq[0]), q1 = cvt4(rq[1]), k0 = cvt4(rk[0]), k1 = cvt4(rk[1]);
+            const float4 a0 = cvt4(ra[0]), a1 = cvt4(ra[1]), b0 = cvt4(rb[0]), b1 = cvt4(rb[1]), v0 = cvt4(rv);
+            qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+            kv[0] = k0.x; kv[1] = k0.y; kv[2] = k0.z; kv[3] = k0.w; kv[4] = k1.x; kv[5] = k1.y; kv[6] = k1.z; kv[7] = k1.w;
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+            vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w;
+        }
+        *reinterpret_cast<float4 *>(&sh_G[pt * kN + pk]) = make_float4(lw[0], lw[1], lw[2], lw[3]);
+        *reinterpret_cast<float4 *>(&sh_G[pt * kN + pk + 4]) = make_float4(lw[4], lw[5], lw[6], lw[7]);
+        __syncthreads();
+        {
+            // thread (channel = tid & 63, segment = wave): inclusive cumsum over its 8 steps, segment total aside
+            const int ch = tid & 63;
+            float run = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                run += sh_G[(wave * 8 + i) * kN + ch];
+                sh_G[(wave * 8 + i) * kN + ch] = run;
+            }
+            sh_seg[wave * kN + ch] = run;
+        }
+        __syncthreads();
+        if (c + 1 < nc) issue(c + 1);  // next chunk's raw inputs fly during phases 2-6
+        // ---- phase 2: scaled operands into bf16 hi/lo planes ------------------------------------------------
+        {
+            const int seg = pt >> 3;
+            float G[8];
+            {
+                const float4 g0 = *reinterpret_cast<const float4 *>(&sh_G[pt * kN + pk]);
+                const float4 g1 = *reinterpret_cast<const float4 *>(&sh_G[pt * kN + pk + 4]);
+                G[0] = g0.x; G[1] = g0.y; G[2] = g0.z; G[3] = g0.w; G[4] = g1.x; G[5] = g1.y; G[6] = g1.z; G[7] = g1.w;
+                for (int s = 0; s < seg; s++) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) G[j] += sh_seg[s * kN + pk + j];
+                }
+            }
+            uint16_t qh[8], ql[8], ah[8], al[8], kh[8], kl[8], bhh[8], bl[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float gam = fast_exp(G[j]), gprev = fast_exp(G[j] - lw[j]), ig = fast_exp(-G[j]);
+                split2(qv[j] * gam, qh[j], ql[j]);
+                split2(av[j] * gprev, ah[j], al[j]);
+                split2(kv[j] * ig, kh[j], kl[j]);
+                split2(bv[j] * ig, bhh[j], bl[j]);
+                if (pt == kC - 1) sh_gC[pk + j] = gam;
+            }
+            auto pack = [](const uint16_t (&x)[8]) {
+                return make_uint4((uint32_t)x[0] | ((uint32_t)x[1] << 16), (uint32_t)x[2] | ((uint32_t)x[3] << 16),
+                                  (uint32_t)x[4] | ((uint32_t)x[5] << 16), (uint32_t)x[6] | ((uint32_t)x[7] << 16));
+            };
+            const int o = pt * LDK + pk;
+            *reinterpret_cast<uint4 *>(&sm[L::QTh + o]) = pack(qh);
+            *reinterpret_cast<uint4 *>(&sm[L::QTl + o]) = pack(ql);
+            *reinterpret_cast<uint4 *>(&sm[L::ATh + o]) = pack(ah);
+            *reinterpret_cast<uint4 *>(&sm[L::ATl + o]) = pack(al);
+            *reinterpret_cast<uint4 *>(&sm[L::KHh + o]) = pack(kh);
+            *reinterpret_cast<uint4 *>(&sm[L::KHl + o]) = pack(kl);
+            *reinterpret_cast<uint4 *>(&sm[L::BHh + o]) = pack(bhh);
+            *reinterpret_cast<uint4 *>(&sm[L::BHl + o]) = pack(bl);
+            // channel-major copies of k^, b^ (the state update contracts over time) and of v
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int ot = (pk + j) * LDC + pt;
+                sm[L::KTh + ot] = kh[j];
+                sm[L::KTl + ot] = kl[j];
+                sm[L::BTh + ot] = bhh[j];
+                sm[L::BTl + ot] = bl[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint16_t vhi, vlo;
+                split2(vv[j], vhi, vlo);
+                sm[L::Vt + (pv + j) * LDC + pt] = vhi;
+                if (!VEXACT) sm[L::Vtl + (pv + j) * LDC + pt] = vlo;  // bf16 inputs: v is exact, no low plane
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: intra-chunk matrices (one per wave) ---------------------------------------------------
+        if (wave == 0) {
+            f32x16 acc = zero16();  // D[m = s][n = t] = k^_s . a~_t = A_ak[t][s]
+            mma_tile3<kN>(acc, sm + L::KHh, sm + L::KHl, LDK, sm + L::ATh, sm + L::ATl, LDK, lane);
+            mask_lower_T<true>(acc, lane);
+            store_T_split(acc, sm + L::AKh, sm + L::AKl, LDC, lane);
+        } else if (wave == 1) {
+            f32x16 acc = zero16();  // b^_s . q~_t = A_qb[t][s]
+            mma_tile3<kN>(acc, sm + L::BHh, sm + L::BHl, LDK, sm + L::QTh, sm + L::QTl, LDK, lane);
+            mask_lower_T<false>(acc, lane);
+            store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
+        } else if (wave == 2) {
+            f32x16 acc = zero16();  // k^_s . q~_t = A_qk[t][s]
+            mma_tile3<kN>(acc, sm + L::KHh, sm + L::KHl, LDK, sm + L::QTh, sm + L::QTl, LDK, lane);
+            mask_lower_T<false>(acc, lane);
+            store_T_split(acc, sm + L::QKh, sm + L::QKl, LDC, lane);
+        } else {
+            // T = (I - A_ab)^-1 of this chunk (wkv7c_prep_kernel), fp32 [32][32] -> planes Tm[t][r]
+            const float *tp = tinv_ + ((long)bh * nc + c) * kC * kC;
+            const int tr = lane >> 1, tc = (lane & 1) * 16;
+            uint16_t hi[16], lo[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 x = *reinterpret_cast<const float4 *>(tp + tr * kC + tc + 4 * j);
+                split2(x.x, hi[4 * j + 0], lo[4 * j + 0]);
+                split2(x.y, hi[4 * j + 1], lo[4 * j + 1]);
+                split2(x.z, hi[4 * j + 2], lo[4 * j + 2]);
+                split2(x.w, hi[4 * j + 3], lo[4 * j + 3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int o = tr * LDC + tc + 8 * j;
+                *reinterpret_cast<uint4 *>(&sm[L::TMh + o]) =
+                    make_uint4((uint32_t)hi[8 * j] | ((uint32_t)hi[8 * j + 1] << 16), (uint32_t)hi[8 * j + 2] | ((uint32_t)hi[8 * j + 3] << 16),
+                               (uint32_t)hi[8 * j + 4] | ((uint32_t)hi[8 * j + 5] << 16), (uint32_t)hi[8 * j + 6] | ((uint32_t)hi[8 * j + 7] << 16));
+                *reinterpret_cast<uint4 *>(&sm[L::TMl + o]) =
+                    make_uint4((uint32_t)lo[8 * j] | ((uint32_t)lo[8 * j + 1] << 16), (uint32_t)lo[8 * j + 2] | ((uint32_t)lo[8 * j + 3] << 16),
+                               (uint32_t)lo[8 * j + 4] | ((uint32_t)lo[8 * j + 5] << 16), (uint32_t)lo[8 * j + 6] | ((uint32_t)lo[8 * j + 7] << 16));
+            }
+        }
+        __syncthreads();
+        // ---- phase 4: R = A~ H0 + A_ak V   (D[t][v]) ---------------------------------------------------------
+        if (wave == 0) {
+            f32x16 acc = zero16();
+            mma_tile3<kN>(acc, sm + L::ATh, sm + L::ATl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
+            mma_xv(acc, sm + L::AKh, sm + L::AKl, lane);
+            store_T_split(acc, sm + L::Rh, sm + L::Rl, LDC, lane);
+        }
+        __syncthreads();
+        // ---- phase 5: U = T R ----------------------------------------------------------------------------------
+        if (wave == 0) {
+            f32x16 acc = zero16();
+            mma_tile3<kC>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::Rh, sm + L::Rl, LDC, lane);
+            store_T_split(acc, sm + L::Uh, sm + L::Ul, LDC, lane);
+            if (SAVE) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    sa_[head_base + (long)(c * kC + d_row(r, lane)) * tstride + vh * VH + (lane & 31)] = acc[r];
+            }
+        }
+        __syncthreads();
+        // ---- phase 6: Y (wave 0) and the state update (waves 1,2) ---------------------------------------------
+        if (wave == 0) {
+            f32x16 acc = zero16();
+            mma_tile3<kN>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
+            mma_tile3<kC>(acc, sm + L::QBh, sm + L::QBl, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
+            mma_xv(acc, sm + L::QKh, sm + L::QKl, lane);
+            T *yp = y_ + head_base + (long)(c * kC) * tstride + vh * VH + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float val = acc[r];
+                if constexpr (sizeof(T) == 2) reinterpret_cast<uint16_t *>(yp)[(long)d_row(r, lane) * tstride] = f2bf(val);
+                else reinterpret_cast<float *>(yp)[(long)d_row(r, lane) * tstride] = val;
+            }
+        } else if (wave <= 2) {
+            const int kt = wave - 1;  // rows (key channels) [32 kt, 32 kt + 32)
+            if (SAVE) {
+                // state at the START of chunk c, hs[b,h,c][v][k]: lane = v, registers = k
+                float *hp = hs_ + (((long)bh * nc + c) * kN + vh * VH + (lane & 31)) * kN + kt * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float4 *>(hp + 8 * j) =
+                        make_float4(Smaster[4 * j], Smaster[4 * j + 1], Smaster[4 * j + 2], Smaster[4 * j + 3]);
+            }
+            f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
+            mma_tile3<kC>(acc, sm + L::BTh + kt * 32 * LDC, sm + L::BTl + kt * 32 * LDC, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
+            mma_xv(acc, sm + L::KTh + kt * 32 * LDC, sm + L::KTl + kt * 32 * LDC, lane);
+#pragma unroll
+            for (int r = 0; r < 16; r++) Smaster[r] = sh_gC[kt * 32 + d_row(r, lane)] * (Smaster[r] + acc[r]);
+        }
+        __syncthreads();
+        // ---- phase 7: publish the new state planes S[v][k] ---------------------------------------------------
+        if (wave == 1 || wave == 2) store_T_split(Smaster, sm + L::Sh + (wave - 1) * 32, sm + L::Sl + (wave - 1) * 32, LDK, lane);
+        // (ordered against phase 4 of the next chunk by that chunk's phase-1/2/3 barriers)
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// debug: one 32x32 tile product through the same primitives (GPU unit test of the fragment layouts)
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void chunk_debug_mma_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+                                                             float *__restrict__ D, float *__restrict__ DT) {
+    constexpr int LD = kN + kPad;
+    __shared__ __attribute__((aligned(16))) uint16_t Xh[kC * LD], Xl[kC * LD], Yh[kC * LD], Yl[kC * LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Oh[kC * LDC], Ol[kC * LDC];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < kC * kN; i += 64) {
+        const int r = i / kN, c = i % kN;
+        split2(X[i], Xh[r * LD + c], Xl[r * LD + c]);
+        split2(Y[i], Yh[r * LD + c], Yl[r * LD + c]);
+    }
+    __syncthreads();
+    f32x16 acc = zero16();
+    mma_tile3<kN>(acc, Xh, Xl, LD, Yh, Yl, LD, lane);
+#pragma unroll
+    for (int r = 0; r < 16; r++) D[d_row(r, lane) * kC + (lane & 31)] = acc[r];
+    store_T_split(acc, Oh, Ol, LDC, lane);
+    __syncthreads();
+    for (int i = lane; i < kC * kC; i += 64) DT[i] = bf2f(Oh[(i / kC) * LDC + i % kC]) + bf2f(Ol[(i / kC) * LDC + i % kC]);
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// launchers
+// --------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_prep(int B, int T_, int H, const void *w, const void *a, const void *b, float *tinv, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((wkv7c_prep_kernel<T>), dim3(B * H * (T_ / kC)), dim3(64), 0, st, T_, H, (const T *)w, (const T *)a,
+                       (const T *)b, tinv);
+    return (int)hipGetLastError();
+}
+
+template <typename T, bool SAVE>
+static int launch_fwd_t(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                        const void *b, const float *tinv, void *y, float *sa, float *hs, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_fwd_kernel<T, SAVE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FwdSmem::bytes);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((wkv7c_fwd_kernel<T, SAVE>), dim3(B * H * 2), dim3(256), FwdSmem::bytes, st, T_, H, (const T *)w,
+                       (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, tinv, (T *)y, sa, hs);
+    return (int)hipGetLastError();
+}
+
+int chunk_prep_bf16(int B, int T_, int H, const void *w, const void *a, const void *b, float *tinv, hipStream_t st) {
+    return launch_prep<bf16_t>(B, T_, H, w, a, b, tinv, st);
+}
+int chunk_prep_f32(int B, int T_, int H, const void *w, const void *a, const void *b, float *tinv, hipStream_t st) {
+    return launch_prep<float>(B, T_, H, w, a, b, tinv, st);
+}
+int chunk_fwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                   const void *b, const float *tinv, void *y, float *sa, float *hs, hipStream_t st) {
+    return (sa && hs) ? launch_fwd_t<bf16_t, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, st)
+                      : launch_fwd_t<bf16_t, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, st);
+}
+int chunk_fwd_f32(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                  const void *b, const float *tinv, void *y, float *sa, float *hs, hipStream_t st) {
+    return (sa && hs) ? launch_fwd_t<float, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, st)
+                      : launch_fwd_t<float, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, st);
+}
+int chunk_debug_mma(const float *X, const float *Y, float *D, float *DT, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(chunk_debug_mma_kernel, dim3(1), dim3(64), 0, st, X, Y, D, DT);
+    return (int)hipGetLastError();
+}
+
+}  // namespace rwkv7

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 _FWD_BLOCKS = 4096   # workgroups walking the rows (D/8 threads each)
-_BWD_BLOCKS = 1024   # also the number of parameter-gradient partials
+_BWD_BLOCKS = 2048   # also the number of parameter-gradient partials
 
 
 def _p(t):

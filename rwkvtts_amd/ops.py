@@ -209,3 +209,47 @@ def RWKV7_BATCH_OP(state, r, w, k, v, a, b):
         y = torch.empty((B, T, C), device=k.device, dtype=r.dtype)
         torch.ops.rwkv7_state_fwd_fp16.forward(B, T, C, H, state, r, w, k, v, a, b, y)
         return y
+
+
+# ------------------------------------------------------------------------------------------------
+# chunked (MFMA) WKV7: the training fast path (csrc/chunk_common.h, wkv7_chunk_fwd.hip, wkv7_chunk_bwd.hip)
+# ------------------------------------------------------------------------------------------------
+CHUNK_T = 32
+
+
+def wkv7_chunk_prep(w, a, b):
+    """(I - A_ab)^-1 of every 32-step chunk: fp32 [B,H,T/32,32,32].  w,a,b: [B,T,H,64]."""
+    B, T, H, C = w.shape
+    sfx = _sfx([w, a, b], "wkv7_chunk_prep")
+    tinv = torch.empty(B, H, T // CHUNK_T, CHUNK_T, CHUNK_T, dtype=torch.float32, device=w.device)
+    with torch.cuda.device_of(w), _timed("wkv7c_prep", w):
+        rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_prep_" + sfx)(B, T, H, _p(w), _p(a), _p(b), _p(tinv), _stream(w))
+    _lib.check(rc, "wkv7_chunk_prep")
+    return tinv
+
+
+def wkv7_chunk_forward(w, q, k, v, a, b, save=True):
+    """Chunked forward.  Returns y, and (tinv, sa, hs) when save (what the chunked backward consumes)."""
+    B, T, H, C = w.shape
+    sfx = _sfx([w, q, k, v, a, b], "wkv7_chunk_forward")
+    if T % CHUNK_T != 0:
+        raise ValueError(f"chunked WKV7 needs T % {CHUNK_T} == 0, got T={T}")
+    tinv = wkv7_chunk_prep(w, a, b)
+    y = torch.empty_like(v)
+    sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device) if save else None
+    hs = torch.empty(B, H, T // CHUNK_T, C, C, dtype=torch.float32, device=w.device) if save else None
+    with torch.cuda.device_of(w), _timed("wkv7c_fwd", w):
+        rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_" + sfx)(
+            B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(tinv), _p(y),
+            None if sa is None else _p(sa), None if hs is None else _p(hs), _stream(w))
+    _lib.check(rc, "wkv7_chunk_forward")
+    return (y, tinv, sa, hs) if save else y
+
+
+def debug_mma32(X, Y):
+    """GPU unit-test hook: D = X Y^T for X,Y fp32 [32,64] through the bf16-split MFMA primitive; returns (D, DT)."""
+    D = torch.empty(32, 32, device=X.device)
+    DT = torch.empty(32, 32, device=X.device)
+    rc = _lib.lib().rwkv7_debug_mma32(_p(X.contiguous()), _p(Y.contiguous()), _p(D), _p(DT), _stream(X))
+    _lib.check(rc, "debug_mma32")
+    return D, DT

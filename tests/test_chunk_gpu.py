@@ -1,0 +1,61 @@
+"""GPU (-m gpu): the chunked (MFMA) WKV7 kernels against the scalar oracle.
+
+Tolerance: operands are split into two bf16 pieces (about 16 mantissa bits), accumulation is fp32; the CPU
+prototype (tools/chunked_proto.py) measures 5e-6..2e-5 relative error for this scheme, so fp32-I/O results must be
+within 1e-4 * max|oracle| and bf16-I/O results within 1 bf16 ulp (2 for gradients), like the scalar kernels."""
+import pytest
+import torch
+
+from rwkvtts_amd import ops
+from rwkvtts_amd.synthetic import make_wkv_inputs
+from test_wkv7_gpu import _assert_bf16_close, _assert_f32_close, NAMES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_mfma_fragment_layout_and_transposed_writeback():
+    """Asymmetric operands: catches swapped rows/cols in the fragment maps (cdna_hip_programming.md rule 16)."""
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(32, 64, generator=g)
+    Y = torch.randn(32, 64, generator=g) * torch.linspace(0.5, 2.0, 32)[:, None]
+    D, DT = ops.debug_mma32(X.to(DEV), Y.to(DEV))
+    want = X.double() @ Y.double().t()
+    assert (D.cpu().double() - want).abs().max().item() < 2e-4 * want.abs().max().item()
+    assert (DT.cpu().double() - want.t()).abs().max().item() < 2e-4 * want.abs().max().item()
+
+
+def test_prep_inverse_matches_torch():
+    B, T, H = 2, 64, 3
+    w, q, k, v, a, b = make_wkv_inputs(B, T, H, 3, torch.float32)
+    tinv = ops.wkv7_chunk_prep(w.to(DEV), a.to(DEV), b.to(DEV)).cpu()
+    lw = -torch.exp(w.double())
+    for bi in range(B):
+        for hi in range(H):
+            for c in range(T // 32):
+                sl = slice(32 * c, 32 * c + 32)
+                G = torch.cumsum(lw[bi, sl, hi], 0)
+                At = a[bi, sl, hi].double() * torch.exp(G - lw[bi, sl, hi])
+                Bh = b[bi, sl, hi].double() * torch.exp(-G)
+                A = torch.tril(At @ Bh.t(), -1)
+                want = torch.linalg.inv(torch.eye(32, dtype=torch.float64) - A)
+                err = (tinv[bi, hi, c].double() - want).abs().max().item()
+                assert err < 2e-4 * want.abs().max().item(), (bi, hi, c, err)
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chunk_forward_vs_oracle(c_oracle, B, T, H, seed, dtype):
+    ins = make_wkv_inputs(B, T, H, seed, dtype)
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*[t.to(DEV) for t in ins])
+    torch.cuda.synchronize()
+    if dtype == torch.bfloat16:
+        _assert_bf16_close(y, y_o, "y")
+    else:
+        _assert_f32_close(y, y_o, "y", 1e-4)
+    _assert_f32_close(sa, sa_o, "sa", 2e-4 if dtype == torch.float32 else 2e-3)
+    # hs[c] = state at the start of chunk c = oracle checkpoint after step 32c-1 (stored transposed [j][i])
+    for c in range(1, T // 32):
+        _assert_f32_close(hs[:, :, c], s_o[:, :, 2 * c - 1].transpose(-1, -2), f"hs[{c}]", 2e-4 if dtype == torch.float32 else 2e-3)
+    assert hs[:, :, 0].abs().max().item() == 0.0

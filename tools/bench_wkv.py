@@ -56,8 +56,19 @@ def main():
     f3 = lambda t: t.view(B, T, H * 64)
     yy = torch.empty(B, T, H * 64, device=dev, dtype=dt)
     sfw = lambda: torch.ops.rwkv7_state_fwd_fp16.forward(B, T, H * 64, H, st, f3(q), f3(w), f3(k), f3(v), f3(aa), f3(b), yy)
+    prep = lambda: ops.wkv7_chunk_prep(w, aa, b)
+    tinv = prep()
+    sa2 = torch.empty(B, T, H, 64, device=dev)
+    hs = torch.empty(B, H, T // 32, 64, 64, device=dev)
+    import ctypes
+    from rwkvtts_amd import _lib
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st_ = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sfx = "bf16" if a.dtype == "bf16" else "f32"
+    cf = lambda: getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_" + sfx)(B, T, H, P(w), P(q), P(k), P(v), P(aa), P(b), P(tinv), P(y), P(sa2), P(hs), st_)
     for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz), ("wkv7_bwd", bwd, 13 * 64 * esz),
-                                ("wkv7_state_fwd", sfw, 7 * 64 * esz)):
+                                ("wkv7_state_fwd", sfw, 7 * 64 * esz), ("wkv7c_prep (T inverse)", prep, 3 * 64 * esz),
+                                ("wkv7c_fwd (chunked, save)", cf, 7 * 64 * esz)):
         med, best = timeit(fn, a.iters)
         gbs = th * bytes_per / (med * 1e-3) / 1e9
         print(f"{name:22s} B={B} T={T} H={H} {a.dtype}: median {med:8.3f} ms  best {best:8.3f} ms  "
