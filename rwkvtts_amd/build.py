@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "librwkv7_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only", "-fgpu-flush-denormals-to-zero",
          "-Wno-unused-result", "-Wno-pass-failed"]
 
 
@@ -64,7 +64,10 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--resource-usage", action="store_true", help="print VGPR/LDS/occupancy per kernel")
+    ap.add_argument("--timing", action="store_true", help="profiling build: per-phase s_memtime counters in the chunked kernels")
     a = ap.parse_args()
     extra = ["-Rpass-analysis=kernel-resource-usage"] if a.resource_usage else []
-    print(build(force=a.force or a.resource_usage, verbose=a.verbose, extra=extra))
+    if a.timing:
+        extra.append("-DWKV7C_TIMING")
+    print(build(force=a.force or a.resource_usage or a.timing, verbose=a.verbose, extra=extra))
     sys.exit(0)

@@ -26,10 +26,23 @@ using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
 constexpr int kC = 32;        // chunk length
 constexpr int kPad = 8;       // plane row padding (elements)
 
-__device__ __forceinline__ uint16_t bf_hi(float x) { return f2bf(x); }
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair (low half = a), round-to-nearest-even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+    const f2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t));
+}
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi), for a pair: 2 cvt_pk + shift + and + 2 sub
+__device__ __forceinline__ void split_pk(float a, float b, uint32_t &hi, uint32_t &lo) {
+    hi = cvt_pk(a, b);
+    lo = cvt_pk(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
 __device__ __forceinline__ void split2(float x, uint16_t &hi, uint16_t &lo) {
-    hi = f2bf(x);
-    lo = f2bf(x - bf2f(hi));
+    uint32_t h, l;
+    split_pk(x, 0.f, h, l);
+    hi = (uint16_t)h;
+    lo = (uint16_t)l;
 }
 
 // acc += X[m0 + (0..31)][0..K) . Y[n0 + (0..31)][0..K)^T     (single planes)
@@ -44,27 +57,66 @@ __device__ __forceinline__ void mma_tile(f32x16 &acc, const uint16_t *X, int ldx
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
     }
 }
-// both operands split: Xh Yh + Xh Yl + Xl Yh
+// both operands split: Xh Yh + Xh Yl + Xl Yh.  All fragments are fetched first, then the MFMAs issue back to back
+// (hipcc otherwise interleaves each ds_read pair with its dependent MFMA and the lone wave eats the LDS latency
+// K/16 * 3 times per product).
 template <int K>
 __device__ __forceinline__ void mma_tile3(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx,
                                           const uint16_t *Yh, const uint16_t *Yl, int ldy, int lane) {
-    mma_tile<K>(acc, Xh, ldx, Yh, ldy, lane);
-    mma_tile<K>(acc, Xh, ldx, Yl, ldy, lane);
-    mma_tile<K>(acc, Xl, ldx, Yh, ldy, lane);
+    constexpr int NK = K / 16;
+    const int xo = (lane & 31) * ldx + (lane >> 5) * 8, yo = (lane & 31) * ldy + (lane >> 5) * 8;
+    bf16x8 xh[NK], xl[NK], yh[NK], yl[NK];
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        xh[i] = *reinterpret_cast<const bf16x8 *>(Xh + xo + 16 * i);
+        yh[i] = *reinterpret_cast<const bf16x8 *>(Yh + yo + 16 * i);
+        xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
+        yl[i] = *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0);
+    }
 }
 // Y exact in bf16 (raw v / dy): Xh Y + Xl Y
 template <int K>
 __device__ __forceinline__ void mma_tile2x(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx,
                                            const uint16_t *Y, int ldy, int lane) {
-    mma_tile<K>(acc, Xh, ldx, Y, ldy, lane);
-    mma_tile<K>(acc, Xl, ldx, Y, ldy, lane);
+    constexpr int NK = K / 16;
+    const int xo = (lane & 31) * ldx + (lane >> 5) * 8, yo = (lane & 31) * ldy + (lane >> 5) * 8;
+    bf16x8 xh[NK], xl[NK], y[NK];
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        xh[i] = *reinterpret_cast<const bf16x8 *>(Xh + xo + 16 * i);
+        y[i] = *reinterpret_cast<const bf16x8 *>(Y + yo + 16 * i);
+        xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc, 0, 0, 0);
+    }
 }
 // X exact in bf16: X Yh + X Yl
 template <int K>
 __device__ __forceinline__ void mma_tile2y(f32x16 &acc, const uint16_t *X, int ldx, const uint16_t *Yh,
                                            const uint16_t *Yl, int ldy, int lane) {
-    mma_tile<K>(acc, X, ldx, Yh, ldy, lane);
-    mma_tile<K>(acc, X, ldx, Yl, ldy, lane);
+    constexpr int NK = K / 16;
+    const int xo = (lane & 31) * ldx + (lane >> 5) * 8, yo = (lane & 31) * ldy + (lane >> 5) * 8;
+    bf16x8 x[NK], yh[NK], yl[NK];
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        x[i] = *reinterpret_cast<const bf16x8 *>(X + xo + 16 * i);
+        yh[i] = *reinterpret_cast<const bf16x8 *>(Yh + yo + 16 * i);
+        yl[i] = *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], yh[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], yl[i], acc, 0, 0, 0);
+    }
 }
 
 // row index of accumulator register r for this lane
@@ -75,12 +127,12 @@ __device__ __forceinline__ void store_T_split(const f32x16 &acc, uint16_t *Oh, u
     const int n = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        uint16_t hi[4], lo[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) split2(acc[4 * j + i], hi[i], lo[i]);
+        uint32_t h0, l0, h1, l1;
+        split_pk(acc[4 * j + 0], acc[4 * j + 1], h0, l0);
+        split_pk(acc[4 * j + 2], acc[4 * j + 3], h1, l1);
         const int off = n * ld + 8 * j + 4 * h;
-        *reinterpret_cast<uint2 *>(Oh + off) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-        *reinterpret_cast<uint2 *>(Ol + off) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+        *reinterpret_cast<uint2 *>(Oh + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(Ol + off) = make_uint2(l0, l1);
     }
 }
 
@@ -96,6 +148,12 @@ __device__ __forceinline__ void mask_lower_T(f32x16 &acc, int lane) {
         acc[r] = keep ? acc[r] : 0.f;
     }
 }
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) and joins the barrier,
+// but does NOT drain the vector-memory queue.  __syncthreads() carries a workgroup fence that also waits for
+// outstanding global stores (gfx950: one vmcnt for loads and stores), which put ~1-2 us of HBM write latency on
+// every barrier that followed the sa/y/hs stores of a chunk.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;

@@ -18,6 +18,19 @@
 
 namespace rwkv7 {
 
+#ifdef WKV7C_TIMING
+// profiling build only (python -m rwkvtts_amd.build --timing): per-phase cycle totals of block 0, per wave
+__device__ long long g_chunk_timing[4 * 16];
+#define TSTAMP(i)                                                                  \
+    do {                                                                           \
+        const long long now_ = __builtin_readcyclecounter();                       \
+        if (blockIdx.x == 0 && lane == 0) g_chunk_timing[wave * 16 + (i)] += now_ - tprev_; \
+        tprev_ = now_;                                                             \
+    } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
 template <typename T>
 __device__ __forceinline__ float ld_scalar(const T *p);
 template <>
@@ -141,9 +154,12 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
     const long tstride = (long)H * kN;
     const long head_base = ((long)bb * T_ * H + hh) * kN;
 
-    // phase-1/2 roles: one time step x 8 channels per thread
-    const int pt = tid >> 3, pk = (tid & 7) * 8;
-    const int pv = (tid & 7) * 4;  // 4 value columns of this workgroup's half
+    // phase-1/2 roles: one time step x 8 channels per thread.  The time step is the FAST lane index so that the
+    // channel-major (transposed) plane stores of a wave land on consecutive 2-byte addresses (conflict-free);
+    // with the channel group fastest, the 8 groups alias onto one bank (any 16-B-aligned row stride x 8 rows is
+    // a multiple of 128 B).
+    const int pt = tid & 31, pk = (tid >> 5) * 8;
+    const int pv = (tid >> 5) * 4;  // 4 value columns of this workgroup's half
 
     // zero the state planes (chunk 0 starts from S = 0)
     for (int i = tid; i < 2 * VH * LDK; i += 256) sm[L::Sh + i] = 0;
@@ -164,9 +180,13 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         rv = ld4<T>(v_ + off + vh * VH + pv, true);
     };
     issue(0);
-    __syncthreads();
+    lds_barrier();
 
+#ifdef WKV7C_TIMING
+    long long tprev_ = __builtin_readcyclecounter();
+#endif
     for (int c = 0; c < nc; c++) {
+        TSTAMP(0);
         // ---- phase 1: log-decay and its cumulative sum over the chunk ---------------------------------------
         float lw[8], qv[8], kv[8], av[8], bv[8], vv[4];
         {
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         }
         *reinterpret_cast<float4 *>(&sh_G[pt * kN + pk]) = make_float4(lw[0], lw[1], lw[2], lw[3]);
         *reinterpret_cast<float4 *>(&sh_G[pt * kN + pk + 4]) = make_float4(lw[4], lw[5], lw[6], lw[7]);
-        __syncthreads();
+        lds_barrier();
         {
             // thread (channel = tid & 63, segment = wave): inclusive cumsum over its 8 steps, segment total aside
             const int ch = tid & 63;
@@ -196,7 +216,8 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             }
             sh_seg[wave * kN + ch] = run;
         }
-        __syncthreads();
+        lds_barrier();
+        TSTAMP(1);
         if (c + 1 < nc) issue(c + 1);  // next chunk's raw inputs fly during phases 2-6
         // ---- phase 2: scaled operands into bf16 hi/lo planes ------------------------------------------------
         {
@@ -211,20 +232,25 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
                     for (int j = 0; j < 8; j++) G[j] += sh_seg[s * kN + pk + j];
                 }
             }
-            uint16_t qh[8], ql[8], ah[8], al[8], kh[8], kl[8], bhh[8], bl[8];
+            float qs[8], as_[8], ks[8], bs[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const float gam = fast_exp(G[j]), gprev = fast_exp(G[j] - lw[j]), ig = fast_exp(-G[j]);
-                split2(qv[j] * gam, qh[j], ql[j]);
-                split2(av[j] * gprev, ah[j], al[j]);
-                split2(kv[j] * ig, kh[j], kl[j]);
-                split2(bv[j] * ig, bhh[j], bl[j]);
+                qs[j] = qv[j] * gam;
+                as_[j] = av[j] * gprev;
+                ks[j] = kv[j] * ig;
+                bs[j] = bv[j] * ig;
                 if (pt == kC - 1) sh_gC[pk + j] = gam;
             }
-            auto pack = [](const uint16_t (&x)[8]) {
-                return make_uint4((uint32_t)x[0] | ((uint32_t)x[1] << 16), (uint32_t)x[2] | ((uint32_t)x[3] << 16),
-                                  (uint32_t)x[4] | ((uint32_t)x[5] << 16), (uint32_t)x[6] | ((uint32_t)x[7] << 16));
-            };
+            uint32_t qh[4], ql[4], ah[4], al[4], kh[4], kl[4], bhh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                split_pk(qs[2 * j], qs[2 * j + 1], qh[j], ql[j]);
+                split_pk(as_[2 * j], as_[2 * j + 1], ah[j], al[j]);
+                split_pk(ks[2 * j], ks[2 * j + 1], kh[j], kl[j]);
+                split_pk(bs[2 * j], bs[2 * j + 1], bhh[j], bl[j]);
+            }
+            auto pack = [](const uint32_t (&x)[4]) { return make_uint4(x[0], x[1], x[2], x[3]); };
             const int o = pt * LDK + pk;
             *reinterpret_cast<uint4 *>(&sm[L::QTh + o]) = pack(qh);
             *reinterpret_cast<uint4 *>(&sm[L::QTl + o]) = pack(ql);
@@ -238,20 +264,27 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int ot = (pk + j) * LDC + pt;
-                sm[L::KTh + ot] = kh[j];
-                sm[L::KTl + ot] = kl[j];
-                sm[L::BTh + ot] = bhh[j];
-                sm[L::BTl + ot] = bl[j];
+                const int sh = (j & 1) * 16;
+                sm[L::KTh + ot] = (uint16_t)(kh[j >> 1] >> sh);
+                sm[L::KTl + ot] = (uint16_t)(kl[j >> 1] >> sh);
+                sm[L::BTh + ot] = (uint16_t)(bhh[j >> 1] >> sh);
+                sm[L::BTl + ot] = (uint16_t)(bl[j >> 1] >> sh);
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint16_t vhi, vlo;
-                split2(vv[j], vhi, vlo);
-                sm[L::Vt + (pv + j) * LDC + pt] = vhi;
-                if (!VEXACT) sm[L::Vtl + (pv + j) * LDC + pt] = vlo;  // bf16 inputs: v is exact, no low plane
+            for (int j = 0; j < 4; j += 2) {
+                uint32_t vhi, vlo;
+                split_pk(vv[j], vv[j + 1], vhi, vlo);
+                sm[L::Vt + (pv + j) * LDC + pt] = (uint16_t)vhi;
+                sm[L::Vt + (pv + j + 1) * LDC + pt] = (uint16_t)(vhi >> 16);
+                if (!VEXACT) {  // bf16 inputs: v is exact, no low plane
+                    sm[L::Vtl + (pv + j) * LDC + pt] = (uint16_t)vlo;
+                    sm[L::Vtl + (pv + j + 1) * LDC + pt] = (uint16_t)(vlo >> 16);
+                }
             }
         }
-        __syncthreads();
+        TSTAMP(2);
+        lds_barrier();
+        TSTAMP(3);
         // ---- phase 3: intra-chunk matrices (one per wave) ---------------------------------------------------
         if (wave == 0) {
             f32x16 acc = zero16();  // D[m = s][n = t] = k^_s . a~_t = A_ak[t][s]
@@ -272,27 +305,23 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             // T = (I - A_ab)^-1 of this chunk (wkv7c_prep_kernel), fp32 [32][32] -> planes Tm[t][r]
             const float *tp = tinv_ + ((long)bh * nc + c) * kC * kC;
             const int tr = lane >> 1, tc = (lane & 1) * 16;
-            uint16_t hi[16], lo[16];
+            uint32_t hi[8], lo[8];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float4 x = *reinterpret_cast<const float4 *>(tp + tr * kC + tc + 4 * j);
-                split2(x.x, hi[4 * j + 0], lo[4 * j + 0]);
-                split2(x.y, hi[4 * j + 1], lo[4 * j + 1]);
-                split2(x.z, hi[4 * j + 2], lo[4 * j + 2]);
-                split2(x.w, hi[4 * j + 3], lo[4 * j + 3]);
+                split_pk(x.x, x.y, hi[2 * j], lo[2 * j]);
+                split_pk(x.z, x.w, hi[2 * j + 1], lo[2 * j + 1]);
             }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int o = tr * LDC + tc + 8 * j;
-                *reinterpret_cast<uint4 *>(&sm[L::TMh + o]) =
-                    make_uint4((uint32_t)hi[8 * j] | ((uint32_t)hi[8 * j + 1] << 16), (uint32_t)hi[8 * j + 2] | ((uint32_t)hi[8 * j + 3] << 16),
-                               (uint32_t)hi[8 * j + 4] | ((uint32_t)hi[8 * j + 5] << 16), (uint32_t)hi[8 * j + 6] | ((uint32_t)hi[8 * j + 7] << 16));
-                *reinterpret_cast<uint4 *>(&sm[L::TMl + o]) =
-                    make_uint4((uint32_t)lo[8 * j] | ((uint32_t)lo[8 * j + 1] << 16), (uint32_t)lo[8 * j + 2] | ((uint32_t)lo[8 * j + 3] << 16),
-                               (uint32_t)lo[8 * j + 4] | ((uint32_t)lo[8 * j + 5] << 16), (uint32_t)lo[8 * j + 6] | ((uint32_t)lo[8 * j + 7] << 16));
+                *reinterpret_cast<uint4 *>(&sm[L::TMh + o]) = make_uint4(hi[4 * j], hi[4 * j + 1], hi[4 * j + 2], hi[4 * j + 3]);
+                *reinterpret_cast<uint4 *>(&sm[L::TMl + o]) = make_uint4(lo[4 * j], lo[4 * j + 1], lo[4 * j + 2], lo[4 * j + 3]);
             }
         }
-        __syncthreads();
+        TSTAMP(4);
+        lds_barrier();
+        TSTAMP(5);
         // ---- phase 4: R = A~ H0 + A_ak V   (D[t][v]) ---------------------------------------------------------
         if (wave == 0) {
             f32x16 acc = zero16();
@@ -300,7 +329,9 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             mma_xv(acc, sm + L::AKh, sm + L::AKl, lane);
             store_T_split(acc, sm + L::Rh, sm + L::Rl, LDC, lane);
         }
-        __syncthreads();
+        TSTAMP(6);
+        lds_barrier();
+        TSTAMP(7);
         // ---- phase 5: U = T R ----------------------------------------------------------------------------------
         if (wave == 0) {
             f32x16 acc = zero16();
@@ -312,7 +343,9 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
                     sa_[head_base + (long)(c * kC + d_row(r, lane)) * tstride + vh * VH + (lane & 31)] = acc[r];
             }
         }
-        __syncthreads();
+        TSTAMP(8);
+        lds_barrier();
+        TSTAMP(9);
         // ---- phase 6: Y (wave 0) and the state update (waves 1,2) ---------------------------------------------
         if (wave == 0) {
             f32x16 acc = zero16();
@@ -342,7 +375,9 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
 #pragma unroll
             for (int r = 0; r < 16; r++) Smaster[r] = sh_gC[kt * 32 + d_row(r, lane)] * (Smaster[r] + acc[r]);
         }
-        __syncthreads();
+        TSTAMP(10);
+        lds_barrier();
+        TSTAMP(11);
         // ---- phase 7: publish the new state planes S[v][k] ---------------------------------------------------
         if (wave == 1 || wave == 2) store_T_split(Smaster, sm + L::Sh + (wave - 1) * 32, sm + L::Sl + (wave - 1) * 32, LDK, lane);
         // (ordered against phase 4 of the next chunk by that chunk's phase-1/2/3 barriers)
@@ -416,6 +451,16 @@ int chunk_fwd_f32(int B, int T_, int H, const void *w, const void *q, const void
     return (sa && hs) ? launch_fwd_t<float, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, st)
                       : launch_fwd_t<float, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, st);
 }
+#ifdef WKV7C_TIMING
+extern "C" int rwkv7_debug_chunk_timing(long long *out, int reset) {
+    if (reset) {
+        long long z[64] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_chunk_timing), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chunk_timing), sizeof(long long) * 64);
+}
+#endif
+
 int chunk_debug_mma(const float *X, const float *Y, float *D, float *DT, hipStream_t st) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(chunk_debug_mma_kernel, dim3(1), dim3(64), 0, st, X, Y, D, DT);

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift; rocprofv3 --pmc "$@" -d $REPO/$OUT/$name -o $name --output-format csv -- python $REPO/tools/bench_wkv.py --iters 2 $EXTRA > $REPO/$OUT/$name.log 2>&1 || echo "pass $name failed"; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU
 run sq2 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES
+run sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_TRANS SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_WAVE32_LDS
 run tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
 run tcc2 WRITE_SIZE GRBM_GUI_ACTIVE
 cd $REPO
