@@ -84,10 +84,11 @@ int rwkv7_mix_fwd_bf16(int B, int T, int D, int nmix, const void *x, const void 
                        const void *params, void *out, int nblocks, rwkv7_stream_t stream);
 int rwkv7_mix_fwd_f32(int B, int T, int D, int nmix, const void *x, const void *x_prev, const void *mask,
                       const void *params, void *out, int nblocks, rwkv7_stream_t stream);
-int rwkv7_mix_bwd_bf16(int B, int T, int D, int nmix, const void *grad_out, const void *x, const void *x_prev,
+/* grad_outs: HOST array of nmix device pointers, one [rows][D] gradient per output of the forward */
+int rwkv7_mix_bwd_bf16(int B, int T, int D, int nmix, const void *const *grad_outs, const void *x, const void *x_prev,
                        const void *mask, const void *params, void *dx, float *dparams_partial, int nblocks,
                        rwkv7_stream_t stream);
-int rwkv7_mix_bwd_f32(int B, int T, int D, int nmix, const void *grad_out, const void *x, const void *x_prev,
+int rwkv7_mix_bwd_f32(int B, int T, int D, int nmix, const void *const *grad_outs, const void *x, const void *x_prev,
                       const void *mask, const void *params, void *dx, float *dparams_partial, int nblocks,
                       rwkv7_stream_t stream);
 

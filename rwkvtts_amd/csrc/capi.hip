@@ -26,7 +26,7 @@ int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 struct bf16_t;
 template <typename T> int mix_fwd(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, hipStream_t);
-template <typename T> int mix_bwd(int, int, int, int, const void *, const void *, const void *, const void *, const void *, void *, float *, int, hipStream_t);
+template <typename T> int mix_bwd(int, int, int, int, const void *const *, const void *, const void *, const void *, const void *, void *, float *, int, hipStream_t);
 template <typename T> int tmix_prepare_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, int, hipStream_t);
 template <typename T> int tmix_prepare_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
 template <typename T> int tmix_post_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, int, hipStream_t);
@@ -105,11 +105,13 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
         if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
         return rwkv7::mix_fwd<TY>(B, T, D, nmix, x, x_prev, mask, params, out, nblocks, (hipStream_t)stream);         \
     }                                                                                                                 \
-    int rwkv7_mix_bwd_##SFX(int B, int T, int D, int nmix, const void *g, const void *x, const void *x_prev,          \
+    int rwkv7_mix_bwd_##SFX(int B, int T, int D, int nmix, const void *const *g, const void *x, const void *x_prev,   \
                             const void *mask, const void *params, void *dx, float *dpart, int nblocks,                \
                             rwkv7_stream_t stream) {                                                                  \
         if (B <= 0 || T <= 0 || nblocks <= 0 || any_null({g, x, params, dx, dpart})) return RWKV7_EINVAL;             \
         if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
+        for (int i = 0; i < nmix; i++)                                                                                \
+            if (!g[i]) return RWKV7_EINVAL;                                                                           \
         return rwkv7::mix_bwd<TY>(B, T, D, nmix, g, x, x_prev, mask, params, dx, dpart, nblocks, (hipStream_t)stream); \
     }                                                                                                                 \
     int rwkv7_tmix_prepare_fwd_##SFX(long rows, int D, const void *w_pre, const void *k, const void *v,               \

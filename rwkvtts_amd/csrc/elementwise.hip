@@ -96,63 +96,79 @@ __global__ void mix_fwd_kernel(int B, int T_, int D, const T *__restrict__ x, co
 }
 
 // dxm[t] = sum_i g_i[t] (1 - p_i) + sum_i g_i[t+1] p_i ; dx = dxm * mask ; dp_i = sum_rows g_i[t] (xm[t-1] - xm[t])
+// Each workgroup walks a CONTIGUOUS range of rows downwards, so g_i[t+1] and xm[t-1] are carried in registers from
+// one row to the next (7 row loads per row instead of 14).  The nmix gradients are separate tensors (one per
+// output of the forward), passed as an array of pointers: no stacking copy on the autograd side.
+template <int NMIX>
+struct MixGrads {
+    const void *g[NMIX];
+};
+
 template <typename T, int NMIX>
-__global__ void mix_bwd_kernel(int B, int T_, int D, const T *__restrict__ g, const T *__restrict__ x,
+__global__ void mix_bwd_kernel(int B, int T_, int D, MixGrads<NMIX> gs, const T *__restrict__ x,
                                const T *__restrict__ x_prev, const T *__restrict__ mask, const T *__restrict__ params,
                                T *__restrict__ dx, float *__restrict__ dpart) {
     const int c = threadIdx.x * 8;
     const long rows = (long)B * T_;
-    float p[NMIX][8], dp[NMIX][8];
+    const long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long r_lo = (long)blockIdx.x * per;
+    const long r_hi = r_lo + per < rows ? r_lo + per : rows;
+    float p[NMIX][8], dp[NMIX][8], gn[NMIX][8];
 #pragma unroll
     for (int i = 0; i < NMIX; i++) {
         V8<T>::ld(params + (long)i * D + c, p[i]);
 #pragma unroll
-        for (int j = 0; j < 8; j++) dp[i][j] = 0.f;
+        for (int j = 0; j < 8; j++) dp[i][j] = gn[i][j] = 0.f;
     }
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int t = (int)(row % T_);
-        float xc[8], xp[8], acc[8];
-        V8<T>::ld(x + row * D + c, xc);
-        float m = 1.f;
+    auto load_xm = [&](long row, float (&o)[8]) {  // xm[row], or the carried state / zeros in front of a sequence
+        V8<T>::ld(x + row * D + c, o);
         if (mask) {
-            m = V8<T>::ld1(mask + row);
+            const float m = V8<T>::ld1(mask + row);
 #pragma unroll
-            for (int j = 0; j < 8; j++) xc[j] *= m;
+            for (int j = 0; j < 8; j++) o[j] *= m;
         }
-        if (t > 0) {
-            V8<T>::ld(x + (row - 1) * D + c, xp);
-            if (mask) {
-                const float mp = V8<T>::ld1(mask + row - 1);
+    };
+    if (r_lo < r_hi) {
+        // prime the carried values with row r_hi (the row after this range), if it belongs to the same sequence
+        if (r_hi < rows && (r_hi % T_) != 0) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) xp[j] *= mp;
+            for (int i = 0; i < NMIX; i++) V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + r_hi * D + c, gn[i]);
+        }
+        float xc[8];
+        load_xm(r_hi - 1, xc);
+        for (long row = r_hi - 1; row >= r_lo; row--) {
+            const int t = (int)(row % T_);
+            float xp[8], acc[8];
+            if (t > 0) {
+                load_xm(row - 1, xp);
+            } else if (x_prev) {
+                V8<T>::ld(x_prev + (row / T_) * D + c, xp);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) xp[j] = 0.f;
             }
-        } else if (x_prev) {
-            V8<T>::ld(x_prev + (row / T_) * D + c, xp);
-        } else {
+            const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
 #pragma unroll
-            for (int j = 0; j < 8; j++) xp[j] = 0.f;
-        }
+            for (int j = 0; j < 8; j++) acc[j] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = 0.f;
+            for (int i = 0; i < NMIX; i++) {
+                float gc[8];
+                V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + row * D + c, gc);
 #pragma unroll
-        for (int i = 0; i < NMIX; i++) {
-            float gc[8];
-            V8<T>::ld(g + ((long)i * rows + row) * D + c, gc);
+                for (int j = 0; j < 8; j++) {
+                    acc[j] = fmaf(gc[j], 1.f - p[i][j], acc[j]);
+                    acc[j] = fmaf(gn[i][j], p[i][j], acc[j]);  // g_i[t+1] (zero past the end of the sequence)
+                    dp[i][j] = fmaf(gc[j], xp[j] - xc[j], dp[i][j]);
+                    gn[i][j] = t > 0 ? gc[j] : 0.f;             // row-1 is the last row of the previous sequence if t == 0
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                acc[j] = fmaf(gc[j], 1.f - p[i][j], acc[j]);
-                dp[i][j] = fmaf(gc[j], xp[j] - xc[j], dp[i][j]);
+                acc[j] *= m;
+                xc[j] = xp[j];
             }
-            if (t + 1 < T_) {
-                float gn[8];
-                V8<T>::ld(g + ((long)i * rows + row + 1) * D + c, gn);
-#pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] = fmaf(gn[j], p[i][j], acc[j]);
-            }
+            V8<T>::st(dx + row * D + c, acc);
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] *= m;
-        V8<T>::st(dx + row * D + c, acc);
     }
 #pragma unroll
     for (int i = 0; i < NMIX; i++) V8<float>::st(dpart + ((long)blockIdx.x * NMIX + i) * D + c, dp[i]);
@@ -480,16 +496,21 @@ int mix_fwd(int B, int T_, int D, int nmix, const void *x, const void *x_prev, c
     return finish();
 }
 template <typename T>
-int mix_bwd(int B, int T_, int D, int nmix, const void *g, const void *x, const void *x_prev, const void *mask,
+int mix_bwd(int B, int T_, int D, int nmix, const void *const *g, const void *x, const void *x_prev, const void *mask,
             const void *params, void *dx, float *dpart, int nblocks, hipStream_t st) {
     (void)hipGetLastError();
     const dim3 grid(nblocks), block(D / 8);
-    if (nmix == 6)
-        hipLaunchKernelGGL((mix_bwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, (const T *)g, (const T *)x,
-                           (const T *)x_prev, (const T *)mask, (const T *)params, (T *)dx, dpart);
-    else
-        hipLaunchKernelGGL((mix_bwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, (const T *)g, (const T *)x,
-                           (const T *)x_prev, (const T *)mask, (const T *)params, (T *)dx, dpart);
+    if (nmix == 6) {
+        MixGrads<6> gs;
+        for (int i = 0; i < 6; i++) gs.g[i] = g[i];
+        hipLaunchKernelGGL((mix_bwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, gs, (const T *)x, (const T *)x_prev,
+                           (const T *)mask, (const T *)params, (T *)dx, dpart);
+    } else {
+        MixGrads<1> gs;
+        gs.g[0] = g[0];
+        hipLaunchKernelGGL((mix_bwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, gs, (const T *)x, (const T *)x_prev,
+                           (const T *)mask, (const T *)params, (T *)dx, dpart);
+    }
     return finish();
 }
 template <typename T>
@@ -557,8 +578,8 @@ int relusq_bwd(long n, const void *x, const void *dy, void *dx, hipStream_t st) 
 #define INSTANTIATE(T)                                                                                              \
     template int mix_fwd<T>(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, \
                             hipStream_t);                                                                           \
-    template int mix_bwd<T>(int, int, int, int, const void *, const void *, const void *, const void *, const void *, \
-                            void *, float *, int, hipStream_t);                                                     \
+    template int mix_bwd<T>(int, int, int, int, const void *const *, const void *, const void *, const void *,       \
+                            const void *, void *, float *, int, hipStream_t);                                                     \
     template int tmix_prepare_fwd<T>(long, int, const void *, const void *, const void *, const void *, const void *, \
                                      const void *, const void *, const void *, const void *, void *, void *, void *, \
                                      void *, void *, int, hipStream_t);                                             \

@@ -52,6 +52,9 @@ def _mask_rows(mask, like):
 
 
 class _Mix(torch.autograd.Function):
+    """nmix outputs are separate autograd outputs (slices of one buffer), so backward receives nmix separate
+    gradients and hands their pointers to the kernel -- no torch.stack of 6 x [B,T,D] on the way back."""
+
     @staticmethod
     def forward(ctx, x, x_prev, mask, params):
         B, T, D = x.shape
@@ -61,18 +64,19 @@ class _Mix(torch.autograd.Function):
         xp = None if x_prev is None else _c(x_prev.to(x.dtype))
         _call("mix_fwd", x, B, T, D, nmix, _p(x), _p(xp), _p(mask), _p(params), _p(out), min(B * T, _FWD_BLOCKS))
         ctx.save_for_backward(x, xp, mask, params)
-        return out
+        return tuple(out[i] for i in range(nmix))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         x, xp, mask, params = ctx.saved_tensors
         B, T, D = x.shape
         nmix = params.shape[0]
-        g = _c(g)
+        gs = [torch.zeros_like(x) if g is None else _c(g) for g in gs]
         nb = min(B * T, _BWD_BLOCKS)
         dx = torch.empty_like(x)
         part = torch.empty(nb, nmix, D, dtype=torch.float32, device=x.device)
-        _call("mix_bwd", x, B, T, D, nmix, _p(g), _p(x), _p(xp), _p(mask), _p(params), _p(dx), _p(part), nb)
+        ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])
+        _call("mix_bwd", x, B, T, D, nmix, ptrs, _p(x), _p(xp), _p(mask), _p(params), _p(dx), _p(part), nb)
         return dx, None, None, part.sum(0).to(params.dtype)
 
 
@@ -80,7 +84,7 @@ def token_shift_mix6(x, x_prev, x_r, x_w, x_k, x_v, x_a, x_g, mask=None):
     """xm = x*mask ; xx = shift(xm) - xm ; returns xm + xx*x_? for ? in r,w,k,v,a,g  (6 tensors [B,T,D])."""
     D = x.shape[-1]
     params = torch.cat([p.reshape(1, D) for p in (x_r, x_w, x_k, x_v, x_a, x_g)], 0).to(x.dtype)
-    return _Mix.apply(x, x_prev, _mask_rows(mask, x), params).unbind(0)
+    return _Mix.apply(x, x_prev, _mask_rows(mask, x), params)
 
 
 def token_shift_mix1(x, x_prev, x_k, mask=None):
