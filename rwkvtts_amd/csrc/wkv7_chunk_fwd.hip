@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
                     for (int j = 0; j < 8; j++) G[j] += sh_seg[s * kN + pk + j];
                 }
             }
+            TSTAMP(12);
             float qs[8], as_[8], ks[8], bs[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
                 split_pk(ks[2 * j], ks[2 * j + 1], kh[j], kl[j]);
                 split_pk(bs[2 * j], bs[2 * j + 1], bhh[j], bl[j]);
             }
+            TSTAMP(13);
             auto pack = [](const uint32_t (&x)[4]) { return make_uint4(x[0], x[1], x[2], x[3]); };
             const int o = pt * LDK + pk;
             *reinterpret_cast<uint4 *>(&sm[L::QTh + o]) = pack(qh);
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             *reinterpret_cast<uint4 *>(&sm[L::KHl + o]) = pack(kl);
             *reinterpret_cast<uint4 *>(&sm[L::BHh + o]) = pack(bhh);
             *reinterpret_cast<uint4 *>(&sm[L::BHl + o]) = pack(bl);
+            TSTAMP(14);
             // channel-major copies of k^, b^ (the state update contracts over time) and of v
 #pragma unroll
             for (int j = 0; j < 8; j++) {

@@ -16,3 +16,4 @@ nc = T // 32
 for w in range(4):
     tot = sum(buf[w * 16 + i] for i in range(12))
     print(f"wave {w}: total {tot / nc:8.0f} cyc/chunk | " + " ".join(f"{names[i]}={buf[w * 16 + i] / nc:6.0f}" for i in range(12)))
+    print("        ph2 detail: G+seg=%d exps+mul+split=%d b128 stores=%d (rest of ph2 = b16 transposed stores + v)" % tuple(buf[w * 16 + i] / nc for i in (12, 13, 14)))
