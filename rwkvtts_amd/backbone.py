@@ -207,7 +207,8 @@ class RWKV7Attention(nn.Module):
         else:
             y = ops.RWKV7_BATCH_OP(state.att_kv, r.contiguous(), w, k2, v2, a_in, b_in)
             last = x[:, -1].detach()
-            state.att_x_prev = (last * mask[:, -1] if mask is not None else last).clone()
+            # in place: the state tensors keep their addresses (hipGraph-captured decode steps replay on them)
+            state.att_x_prev.copy_(last * mask[:, -1] if mask is not None else last)
         y = fused.tmix_post(y, r, k2, v2, g, self.g_norm.weight, self.g_norm.bias, self.r_k, H, self.g_norm.eps)
         return self.o_proj(y), v_first
 
@@ -226,7 +227,7 @@ class RWKV7FeedForward(nn.Module):
         kx = fused.token_shift_mix1(x, x_prev, self.x_k, mask)
         if state is not None:
             last = x[:, -1].detach()
-            state.ffn_x_prev = (last * mask[:, -1] if mask is not None else last).clone()
+            state.ffn_x_prev.copy_(last * mask[:, -1] if mask is not None else last)
         return self.value(fused.relu_sq(self.key(kx)))
 
 

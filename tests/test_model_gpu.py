@@ -195,3 +195,20 @@ def test_packed_cu_seqlens_equals_per_sequence_forward():
     assert (got - torch.cat(singles)).abs().max().item() < 1e-4
     assert (got - torch.cat(oracle)).abs().max().item() < 1e-3
     assert torch.isfinite(out.loss)
+
+
+def test_graph_decoder_matches_eager_generate():
+    """config 5 machinery: hipGraph-replayed persistent-state decode == the eager generate loop, id for id."""
+    from rwkvtts_amd.decode import GraphDecoder
+    model, p, rcfg = _spark_pair(seed=13)
+    B, P, NEW = 4, 9, 20
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, P, 128, generator=g) * 0.5).to(DEV)
+    mask = torch.ones(B, P, dtype=torch.long, device=DEV)
+    mask[2, :3] = 0
+    x = x * mask.unsqueeze(-1)
+    want = model.generate(inputs_embeds=x, attention_mask=mask, max_new_tokens=NEW, do_sample=False,
+                          suppress_tokens=[256])
+    got = GraphDecoder(model, B).generate(inputs_embeds=x, attention_mask=mask, max_new_tokens=NEW,
+                                          suppress_tokens=[256])
+    assert torch.equal(got, want)
