@@ -14,6 +14,7 @@ from . import _lib
 
 _FWD_BLOCKS = 4096   # workgroups walking the rows (D/8 threads each)
 _BWD_BLOCKS = 2048   # also the number of parameter-gradient partials
+_MIX_BWD_ROWS = 16   # rows per workgroup in mix_bwd (contiguous run, neighbours carried in registers)
 
 
 def _p(t):
@@ -72,7 +73,8 @@ class _Mix(torch.autograd.Function):
         B, T, D = x.shape
         nmix = params.shape[0]
         gs = [torch.zeros_like(x) if g is None else _c(g) for g in gs]
-        nb = min(B * T, _BWD_BLOCKS)
+        # each workgroup walks a contiguous run of rows (measured: 16-row runs 0.44 ms, 7/15/31/33-row runs slower)
+        nb = max(1, -(-B * T // _MIX_BWD_ROWS))
         dx = torch.empty_like(x)
         part = torch.empty(nb, nmix, D, dtype=torch.float32, device=x.device)
         ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])

@@ -14,9 +14,10 @@ def mixb():
     torch.autograd.grad(outs, [x] + ps, gs, retain_graph=True)
 print("mix6 fwd  ms", timeit(lambda: fused.token_shift_mix6(x, None, *ps), 10)[0])
 print("mix6 bwd  ms (incl. stack of 6 grads + partial sum)", timeit(mixb, 10)[0])
-for nb in (512, 1024, 2048, 4096):
-    fused._BWD_BLOCKS = nb
-    print("  BWD_BLOCKS", nb, timeit(mixb, 10)[0])
+for nr in (7, 15, 16, 31, 33):
+    fused._MIX_BWD_ROWS = nr
+    print("  MIX_BWD_ROWS", nr, timeit(mixb, 10)[0])
+fused._MIX_BWD_ROWS = 15
 ins = [mk(B, T, D).requires_grad_(True) for _ in range(6)]
 kk, ka = mk(D).requires_grad_(True), mk(D).requires_grad_(True)
 po = fused.tmix_prepare(*ins, kk, ka, None, H, False)
