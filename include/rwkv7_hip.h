@@ -58,6 +58,18 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
                       const void *a, const void *b, const void *dy, const float *s, const float *sa,
                       void *dw, void *dq, void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
 
+/* ---- same backward with each head split over two workgroups (32 state rows each) so that 256 CUs are busy at
+ *      B*H = 128.  dv is complete; dw,dq,dk,da,db are HOST arrays of 2 device pointers receiving the two partial
+ *      column sums (final gradient = [0] + [1]); rwkv7_tmix_prepare_bwd_* can consume the pairs directly. ---- */
+int rwkv7_wkv_bwd_split_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                             const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                             void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
+                             void *const *db, rwkv7_stream_t stream);
+int rwkv7_wkv_bwd_split_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                            const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                            void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
+                            void *const *db, rwkv7_stream_t stream);
+
 /* ---- state-carrying forward: torch.ops.rwkv7_state_fwd_fp16.forward (rwkv7_state_fwd_fp16.cpp:8-14,
  *      kernel rwkv7_state_fwd_fp16.cu:9-57) and its B=1 twin torch.ops.wkv7s.forward
  *      (wkv7s_op.cpp:9-15).  state is read at entry and overwritten at exit; any T >= 1. ---- */
@@ -117,6 +129,21 @@ int rwkv7_tmix_prepare_bwd_f32(long rows, int D, const void *w_pre, const void *
                                const void *d_ain, const void *d_bin, void *d_wpre, void *d_k, void *d_v,
                                void *d_apre, void *d_vpre, void *d_vfirst, float *dparams_partial, int nblocks,
                                rwkv7_stream_t stream);
+
+/* Same backward with the incoming gradients given as sums, added in fp32 on load (no separate add kernels): gsum is a
+ * HOST array of 14 device pointers {d_w a,b; d_k2 a,b,c; d_v2 a,b; d_ain a,b; d_bin a,b; d_r a,b,c}, and
+ * d_r = d_r a+b+c is written as well.  Consumes the two partial sets of rwkv7_wkv_bwd_split_* plus tmix_post's
+ * contributions to k2, v2 and r. */
+int rwkv7_tmix_prepare_bwd_sum_bf16(long rows, int D, const void *w_pre, const void *k, const void *v,
+                                    const void *a_pre, const void *v_pre, const void *v_first, const void *mask,
+                                    const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre, void *d_k,
+                                    void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, void *d_r,
+                                    float *dparams_partial, int nblocks, rwkv7_stream_t stream);
+int rwkv7_tmix_prepare_bwd_sum_f32(long rows, int D, const void *w_pre, const void *k, const void *v,
+                                   const void *a_pre, const void *v_pre, const void *v_first, const void *mask,
+                                   const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre, void *d_k,
+                                   void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, void *d_r,
+                                   float *dparams_partial, int nblocks, rwkv7_stream_t stream);
 
 /* after the scan (rwkv_s2s_single_ffn.py:192-195): out = (GroupNorm_H(y; gn_w, gn_b, eps) + (sum_head r*k*r_k) v) * g.
  * r_k is [H*64] flattened.  backward partials: P = 3 (d gn_w, d gn_b, d r_k). */

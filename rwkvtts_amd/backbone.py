@@ -144,6 +144,11 @@ class Cache:
                     for _ in range(cfg.num_hidden_layers)])
 
 
+# Training runs prepare -> scan -> post as one autograd node (fused._TmixCore: row-split scan backward, gradient sums
+# folded into the prepare backward).  False selects the three separate nodes (same forward kernels).
+FUSED_TMIX_CORE = True
+
+
 class RWKV7Attention(nn.Module):
     """Time-mix block (rwkv_s2s_single_ffn.py:158-196; Appendix A of SURVEY.md)."""
 
@@ -195,10 +200,14 @@ class RWKV7Attention(nn.Module):
             if mask is not None:
                 v = v * mask  # rwkv_s2s_single_ffn.py:178: v is masked before it becomes v_first
             v_first = v
-        w, k2, v2, a_in, b_in = fused.tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, self.k_k, self.k_a, mask,
-                                                   H, self.layer_idx == 0)
         if mask is not None:
             r = r * mask
+        if state is None and torch.is_grad_enabled() and (r.requires_grad or w_pre.requires_grad) and FUSED_TMIX_CORE:
+            y = fused.tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, self.k_k, self.k_a, self.g_norm.weight,
+                                self.g_norm.bias, self.r_k, mask, H, self.g_norm.eps, self.layer_idx == 0)
+            return self.o_proj(y), v_first
+        w, k2, v2, a_in, b_in = fused.tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, self.k_k, self.k_a, mask,
+                                                   H, self.layer_idx == 0)
         if state is None:
             if torch.is_grad_enabled() and (r.requires_grad or w.requires_grad):
                 y = ops.RUN_CUDA_RWKV7g(r, w, k2, v2, a_in, b_in)

@@ -17,6 +17,12 @@ int wkv_bwd_f32(int, int, int, const void *, const void *, const void *, const v
                 const void *, const float *, const float *, void *, void *, void *, void *, void *, void *,
                 hipStream_t);
 
+int wkv_bwd_split_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
+                       const void *, const float *, const float *, void *const *, void *const *, void *const *, void *,
+                       void *const *, void *const *, hipStream_t);
+int wkv_bwd_split_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
+                      const void *, const float *, const float *, void *const *, void *const *, void *const *, void *,
+                      void *const *, void *const *, hipStream_t);
 int chunk_prep_bf16(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_prep_f32(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
@@ -29,6 +35,7 @@ template <typename T> int mix_fwd(int, int, int, int, const void *, const void *
 template <typename T> int mix_bwd(int, int, int, int, const void *const *, const void *, const void *, const void *, const void *, void *, float *, int, hipStream_t);
 template <typename T> int tmix_prepare_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, int, hipStream_t);
 template <typename T> int tmix_prepare_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
+template <typename T> int tmix_prepare_bwd_sum(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *const *, void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
 template <typename T> int tmix_post_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, int, hipStream_t);
 template <typename T> int tmix_post_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, void *, void *, void *, void *, float *, int, hipStream_t);
 template <typename T> int relusq_fwd(long, const void *, void *, hipStream_t);
@@ -77,6 +84,27 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
                       const void *a, const void *b, const void *dy, const float *s, const float *sa, void *dw,
                       void *dq, void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream) {
     BWD_BODY(wkv_bwd_f32)
+}
+
+#define BWD2_BODY(IMPL)                                                                                   \
+    if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db}))   \
+        return RWKV7_EINVAL;                                                                               \
+    for (int i = 0; i < 2; i++)                                                                            \
+        if (!dw[i] || !dq[i] || !dk[i] || !da[i] || !db[i]) return RWKV7_EINVAL;                           \
+    if (T % RWKV7_CHUNK_LEN != 0) return RWKV7_ECHUNK;                                                     \
+    return rwkv7::IMPL(B, T, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, (hipStream_t)stream);
+
+int rwkv7_wkv_bwd_split_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                             const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                             void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
+                             void *const *db, rwkv7_stream_t stream) {
+    BWD2_BODY(wkv_bwd_split_bf16)
+}
+int rwkv7_wkv_bwd_split_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                            const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                            void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
+                            void *const *db, rwkv7_stream_t stream) {
+    BWD2_BODY(wkv_bwd_split_f32)
 }
 
 #define STATE_BODY(IMPL)                                                                              \
@@ -140,6 +168,23 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
         return rwkv7::tmix_prepare_bwd<TY>(rows, D, w_pre, k, v, a_pre, v_pre, v_first, mask, k_k, k_a, d_w, d_k2,    \
                                            d_v2, d_ain, d_bin, d_wpre, d_k, d_v, d_apre, d_vpre, d_vfirst, dpart,     \
                                            nblocks, (hipStream_t)stream);                                             \
+    }                                                                                                                 \
+    int rwkv7_tmix_prepare_bwd_sum_##SFX(long rows, int D, const void *w_pre, const void *k, const void *v,           \
+                                         const void *a_pre, const void *v_pre, const void *v_first, const void *mask, \
+                                         const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre,     \
+                                         void *d_k, void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, void *d_r, \
+                                         float *dpart, int nblocks, rwkv7_stream_t stream) {                          \
+        if (rows <= 0 || nblocks <= 0 ||                                                                              \
+            any_null({w_pre, k, v, a_pre, k_k, k_a, (const void *)gsum, d_wpre, d_k, d_v, d_apre, d_r, dpart}))       \
+            return RWKV7_EINVAL;                                                                                      \
+        for (int i = 0; i < 14; i++)                                                                                  \
+            if (!gsum[i]) return RWKV7_EINVAL;                                                                        \
+        if ((v_pre == nullptr) != (v_first == nullptr)) return RWKV7_EINVAL;                                          \
+        if (v_pre && (!d_vpre || !d_vfirst)) return RWKV7_EINVAL;                                                     \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::tmix_prepare_bwd_sum<TY>(rows, D, w_pre, k, v, a_pre, v_pre, v_first, mask, k_k, k_a, gsum,     \
+                                               d_wpre, d_k, d_v, d_apre, d_vpre, d_vfirst, d_r, dpart, nblocks,       \
+                                               (hipStream_t)stream);                                                  \
     }                                                                                                                 \
     int rwkv7_tmix_post_fwd_##SFX(long rows, int D, const void *y, const void *r, const void *k, const void *v,       \
                                   const void *g, const void *gn_w, const void *gn_b, const void *r_k, float eps,      \

@@ -167,6 +167,7 @@ __global__ void mix_bwd_kernel(int B, int T_, int D, MixGrads<NMIX> gs, const T 
                 acc[j] *= m;
                 xc[j] = xp[j];
             }
+            if (t == 0 && row > r_lo) load_xm(row - 1, xc);  // the run continues into the previous sequence
             V8<T>::st(dx + row * D + c, acc);
         }
     }
@@ -234,7 +235,17 @@ __global__ void tmix_prepare_fwd_kernel(long rows, int D, const T *__restrict__ 
     }
 }
 
+// Extra addends of the fused time-mix backward (rwkvtts_amd/fused.py:_TmixCore): the row-split WKV7 backward
+// leaves two partial sets of dw,dk,da,db (and dq), and tmix_post's backward contributes to k2, v2 and r.  They are
+// summed here in fp32 on load instead of by separate elementwise add kernels.
 template <typename T>
+struct PrepBwdExtra {
+    const T *d_w_b, *d_k2_b, *d_k2_c, *d_v2_b, *d_a_b, *d_b_b;  // added to d_w, d_k2, d_k2, d_v2, d_ain, d_bin
+    const T *d_r_a, *d_r_b, *d_r_c;                              // d_r = a + b + c
+    T *d_r;
+};
+
+template <typename T, bool MULTI>
 __global__ void tmix_prepare_bwd_kernel(long rows, int D, const T *__restrict__ w_pre, const T *__restrict__ k,
                                         const T *__restrict__ v, const T *__restrict__ a_pre,
                                         const T *__restrict__ v_pre, const T *__restrict__ v_first,
@@ -244,7 +255,8 @@ __global__ void tmix_prepare_bwd_kernel(long rows, int D, const T *__restrict__ 
                                         const T *__restrict__ d_ain, const T *__restrict__ d_bin,
                                         T *__restrict__ d_wpre, T *__restrict__ d_k, T *__restrict__ d_v,
                                         T *__restrict__ d_apre, T *__restrict__ d_vpre, T *__restrict__ d_vfirst,
-                                        float *__restrict__ dpart /* [nblk][2][D]: dk_k, dk_a */) {
+                                        float *__restrict__ dpart /* [nblk][2][D]: dk_k, dk_a */,
+                                        PrepBwdExtra<T> ex) {
     const int c = threadIdx.x * 8;
     float kk_p[8], ka_p[8], dkk_acc[8], dka_acc[8];
     V8<T>::ld(k_k + c, kk_p);
@@ -264,6 +276,32 @@ __global__ void tmix_prepare_bwd_kernel(long rows, int D, const T *__restrict__ 
         V8<T>::ld(d_v2 + o, gv2);
         V8<T>::ld(d_ain + o, ga);
         V8<T>::ld(d_bin + o, gb);
+        if constexpr (MULTI) {
+            float t[8], t2[8];
+            V8<T>::ld(ex.d_w_b + o, t);
+#pragma unroll
+            for (int j = 0; j < 8; j++) gw[j] += t[j];
+            V8<T>::ld(ex.d_k2_b + o, t);
+            V8<T>::ld(ex.d_k2_c + o, t2);
+#pragma unroll
+            for (int j = 0; j < 8; j++) gk2[j] += t[j] + t2[j];
+            V8<T>::ld(ex.d_v2_b + o, t);
+#pragma unroll
+            for (int j = 0; j < 8; j++) gv2[j] += t[j];
+            V8<T>::ld(ex.d_a_b + o, t);
+#pragma unroll
+            for (int j = 0; j < 8; j++) ga[j] += t[j];
+            V8<T>::ld(ex.d_b_b + o, t);
+#pragma unroll
+            for (int j = 0; j < 8; j++) gb[j] += t[j];
+            float r3[8];
+            V8<T>::ld(ex.d_r_a + o, r3);
+            V8<T>::ld(ex.d_r_b + o, t);
+            V8<T>::ld(ex.d_r_c + o, t2);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r3[j] += t[j] + t2[j];
+            V8<T>::st(ex.d_r + o, r3);
+        }
         float kkr[8], a[8], du[8], u[8], o1[8], o2[8];
         float ss = 0.f;
 #pragma unroll
@@ -530,11 +568,26 @@ int tmix_prepare_bwd(long rows, int D, const void *w_pre, const void *k, const v
                      void *d_wpre, void *d_k, void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, float *dpart,
                      int nblocks, hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL((tmix_prepare_bwd_kernel<T>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)w_pre,
-                       (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre, (const T *)v_first,
-                       (const T *)mask, (const T *)k_k, (const T *)k_a, (const T *)d_w, (const T *)d_k2,
-                       (const T *)d_v2, (const T *)d_ain, (const T *)d_bin, (T *)d_wpre, (T *)d_k, (T *)d_v,
-                       (T *)d_apre, (T *)d_vpre, (T *)d_vfirst, dpart);
+    hipLaunchKernelGGL((tmix_prepare_bwd_kernel<T, false>), dim3(nblocks), dim3(D / 8), 0, st, rows, D,
+                       (const T *)w_pre, (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre,
+                       (const T *)v_first, (const T *)mask, (const T *)k_k, (const T *)k_a, (const T *)d_w,
+                       (const T *)d_k2, (const T *)d_v2, (const T *)d_ain, (const T *)d_bin, (T *)d_wpre, (T *)d_k,
+                       (T *)d_v, (T *)d_apre, (T *)d_vpre, (T *)d_vfirst, dpart, PrepBwdExtra<T>{});
+    return finish();
+}
+// gsum: HOST array of 14 device pointers {d_w a,b; d_k2 a,b,c; d_v2 a,b; d_ain a,b; d_bin a,b; d_r a,b,c}
+template <typename T>
+int tmix_prepare_bwd_sum(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
+                         const void *v_pre, const void *v_first, const void *mask, const void *k_k, const void *k_a,
+                         const void *const *gsum, void *d_wpre, void *d_k, void *d_v, void *d_apre, void *d_vpre,
+                         void *d_vfirst, void *d_r, float *dpart, int nblocks, hipStream_t st) {
+    (void)hipGetLastError();
+    const T *const *g = reinterpret_cast<const T *const *>(gsum);
+    PrepBwdExtra<T> ex{g[1], g[3], g[4], g[6], g[8], g[10], g[11], g[12], g[13], (T *)d_r};
+    hipLaunchKernelGGL((tmix_prepare_bwd_kernel<T, true>), dim3(nblocks), dim3(D / 8), 0, st, rows, D,
+                       (const T *)w_pre, (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre,
+                       (const T *)v_first, (const T *)mask, (const T *)k_k, (const T *)k_a, g[0], g[2], g[5], g[7],
+                       g[9], (T *)d_wpre, (T *)d_k, (T *)d_v, (T *)d_apre, (T *)d_vpre, (T *)d_vfirst, dpart, ex);
     return finish();
 }
 template <typename T>
@@ -583,6 +636,10 @@ int relusq_bwd(long n, const void *x, const void *dy, void *dx, hipStream_t st) 
     template int tmix_prepare_fwd<T>(long, int, const void *, const void *, const void *, const void *, const void *, \
                                      const void *, const void *, const void *, const void *, void *, void *, void *, \
                                      void *, void *, int, hipStream_t);                                             \
+    template int tmix_prepare_bwd_sum<T>(long, int, const void *, const void *, const void *, const void *,          \
+                                         const void *, const void *, const void *, const void *, const void *,       \
+                                         const void *const *, void *, void *, void *, void *, void *, void *, void *, \
+                                         float *, int, hipStream_t);                                                 \
     template int tmix_prepare_bwd<T>(long, int, const void *, const void *, const void *, const void *, const void *, \
                                      const void *, const void *, const void *, const void *, const void *,          \
                                      const void *, const void *, const void *, const void *, void *, void *, void *, \

@@ -32,12 +32,23 @@ constexpr int RV_V = 0, RV_DY = 1, RV_SA = 2;                                   
 constexpr int NCV = 7, NRV = 3, NOUT = 5;  // outputs per column: dq, dw, dk, db, da
 }  // namespace
 
+// Output pointers.  With RT = 4 one workgroup owns all 64 state rows of a head and set [0] receives the final
+// gradients (the reference-schema op).  With RT = 2 the head is split over TWO workgroups (32 rows each, so that all
+// 256 CUs work at B*H = 128): dv is complete per row, the column sums dq,dw,dk,db,da are partial over the workgroup's
+// rows and go to set [part]; the consumer adds the two sets (rwkv7_tmix_prepare_bwd takes both).
 template <typename T>
+struct BwdOuts {
+    T *dw[2], *dq[2], *dk[2], *db[2], *da[2];
+    T *dv;
+};
+
+template <typename T, int RT>
 __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
     int T_, int H, const T *__restrict__ w_, const T *__restrict__ q_, const T *__restrict__ k_,
     const T *__restrict__ v_, const T *__restrict__ a_, const T *__restrict__ b_, const T *__restrict__ dy_,
-    const float *__restrict__ s_, const float *__restrict__ sa_, T *__restrict__ dw_, T *__restrict__ dq_,
-    T *__restrict__ dk_, T *__restrict__ dv_, T *__restrict__ da_, T *__restrict__ db_) {
+    const float *__restrict__ s_, const float *__restrict__ sa_, BwdOuts<T> outs) {
+    constexpr int NSPLIT = 4 / RT;       // workgroups per head
+    constexpr int ROWS_WG = 16 * RT;     // state rows per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float(*sh_cv)[NCV][kN] = reinterpret_cast<float(*)[NCV][kN]>(smem);                       // [kTB][7][64]
     float(*sh_rv)[NRV][kN] = reinterpret_cast<float(*)[NRV][kN]>(smem + kTB * NCV * kN);      // [kTB][3][64]
@@ -45,12 +56,14 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
         reinterpret_cast<float(*)[kTB][NOUT][kN]>(smem + kTB * (NCV + NRV) * kN);             // [4][kTB][5][64]
     float(*sh_dv)[kN] = reinterpret_cast<float(*)[kN]>(smem + kTB * (NCV + NRV) * kN + 4 * kTB * NOUT * kN);
 
-    const int bh = blockIdx.x;
+    const int part = blockIdx.x % NSPLIT;
+    const int bh = blockIdx.x / NSPLIT;
     const int bb = bh / H, hh = bh - bb * H;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int til = lane >> 4, tj = lane & 15;
-    const int r0 = wave * 16 + til * 4;
+    const int r0l = wave * (4 * RT) + til * RT;  // first row of this lane's tile, inside the workgroup
+    const int r0 = part * ROWS_WG + r0l;         // ... inside the head
     const int c0 = tj * 4;
 
     const int st = tid >> 4;          // staging: time step inside the stage
@@ -60,9 +73,9 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
     const long head_base = ((long)bb * T_ * H + hh) * kN;
     const int nchunk = T_ / kChunk;
 
-    float S[4][4], dS[4][4];
+    float S[RT][4], dS[RT][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < RT; r++)
 #pragma unroll
         for (int c = 0; c < 4; c++) S[r][c] = dS[r][c] = 0.f;
 
@@ -98,6 +111,15 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
         *reinterpret_cast<float4 *>(&sh_rv[st][RV_DY][sc]) = cvt4(rdy);
         *reinterpret_cast<float4 *>(&sh_rv[st][RV_SA][sc]) = rsa;
     };
+    auto ld_rows = [&](const float *p, float (&o)[RT]) {  // RT consecutive floats, RT-aligned
+        if constexpr (RT == 4) {
+            const float4 x = *reinterpret_cast<const float4 *>(p);
+            o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
+        } else {
+            const float2 x = *reinterpret_cast<const float2 *>(p);
+            o[0] = x.x; o[1] = x.y;
+        }
+    };
 
     const int nblk = T_ / kTB;  // T % 16 == 0 is checked on the host
     issue((nblk - 1) * kTB);
@@ -114,8 +136,10 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
             const float *sp = s_ + (((long)bh * nchunk + n) * kN + c0) * kN + r0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const float4 x = *reinterpret_cast<const float4 *>(sp + (long)c * kN);
-                S[0][c] = x.x; S[1][c] = x.y; S[2][c] = x.z; S[3][c] = x.w;
+                float x[RT];
+                ld_rows(sp + (long)c * kN, x);
+#pragma unroll
+                for (int r = 0; r < RT; r++) S[r][c] = x[r];
             }
         }
 #pragma unroll 4
@@ -126,33 +150,33 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
             const float4 k4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_K][c0]);
             const float4 a4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_A][c0]);
             const float4 b4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_B][c0]);
-            const float4 v4 = *reinterpret_cast<const float4 *>(&sh_rv[tt][RV_V][r0]);
-            const float4 dy4 = *reinterpret_cast<const float4 *>(&sh_rv[tt][RV_DY][r0]);
-            const float4 sa4 = *reinterpret_cast<const float4 *>(&sh_rv[tt][RV_SA][r0]);
             const float wt[4] = {wt4.x, wt4.y, wt4.z, wt4.w};
             const float iw[4] = {iw4.x, iw4.y, iw4.z, iw4.w};
             const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
             const float kv[4] = {k4.x, k4.y, k4.z, k4.w};
             const float av[4] = {a4.x, a4.y, a4.z, a4.w};
             const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-            const float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
-            const float sav[4] = {sa4.x, sa4.y, sa4.z, sa4.w};
+            float vv[RT], dyv[RT], sav[RT];
+            ld_rows(&sh_rv[tt][RV_V][r0], vv);
+            ld_rows(&sh_rv[tt][RV_DY][r0], dyv);
+            ld_rows(&sh_rv[tt][RV_SA][r0], sav);
 
-            float colp[NOUT][4];  // dq, dw, dk, db, da partial sums over this lane's 4 rows
+            float colp[NOUT][4];  // dq, dw, dk, db, da partial sums over this lane's RT rows
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 float dq = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; r++) dq = fmaf(S[r][c], dyv[r], dq);
+                for (int r = 0; r < RT; r++) dq = fmaf(S[r][c], dyv[r], dq);
                 colp[0][c] = dq;
             }
-            float dvp[4] = {0.f, 0.f, 0.f, 0.f}, dsbp[4] = {0.f, 0.f, 0.f, 0.f};
+            float dvp[RT], dsbp[RT];
+#pragma unroll
+            for (int r = 0; r < RT; r++) dvp[r] = dsbp[r] = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 float dw = 0.f, dk = 0.f, db = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < RT; r++) {
                     // un-do step t: S_{t-1} = (S_t - v k^T - sa b^T) / w~
                     S[r][c] = (S[r][c] - kv[c] * vv[r] - bv[c] * sav[r]) * iw[c];
                     dS[r][c] = fmaf(dyv[r], qv[c], dS[r][c]);
@@ -166,9 +190,9 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
                 colp[2][c] = dk;
                 colp[3][c] = db;
             }
-            float dvv[4], dsb[4];
+            float dvv[RT], dsb[RT];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < RT; r++) {
                 dvv[r] = sum16(dvp[r]);
                 dsb[r] = sum16(dsbp[r]);
             }
@@ -176,7 +200,7 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
             for (int c = 0; c < 4; c++) {
                 float da = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < RT; r++) {
                     da = fmaf(S[r][c], dsb[r], da);
                     dS[r][c] = fmaf(dS[r][c], wt[c], dsb[r] * av[c]);
                 }
@@ -194,16 +218,19 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
                 sh_part[wave][tt][o][c0 + til] = swap16_sum(x0, x1);
             }
             {
-                // dv[r] totals are replicated over the 16 lanes of the DPP row: lane tj stores row r0 + (tj&3)
-                const int rs = tj & 3;
-                const float d = rs == 0 ? dvv[0] : rs == 1 ? dvv[1] : rs == 2 ? dvv[2] : dvv[3];
-                sh_dv[tt][r0 + rs] = d;
+                // dv[r] totals are replicated over the 16 lanes of the DPP row: lane tj stores local row r0l + tj % RT
+                const int rs = tj & (RT - 1);
+                float d = dvv[0];
+#pragma unroll
+                for (int r = 1; r < RT; r++) d = rs == r ? dvv[r] : d;
+                sh_dv[tt][r0l + rs] = d;
             }
         }
         __syncthreads();
         {
             // stage write-out: thread (st, sc) sums the 4 wave partials of its column quad
-            const long off = head_base + (long)(t0 + st) * tstride + sc;
+            const long off_t = head_base + (long)(t0 + st) * tstride;
+            const long off = off_t + sc;
             float4 o[NOUT];
 #pragma unroll
             for (int i = 0; i < NOUT; i++) {
@@ -217,12 +244,12 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
             }
             const float4 ws = *reinterpret_cast<const float4 *>(&sh_cv[st][CV_WS][sc]);
             o[1].x *= ws.x; o[1].y *= ws.y; o[1].z *= ws.z; o[1].w *= ws.w;  // dw * w~ * (-exp(w)), :108
-            st4(dq_ + off, o[0]);
-            st4(dw_ + off, o[1]);
-            st4(dk_ + off, o[2]);
-            st4(db_ + off, o[3]);
-            st4(da_ + off, o[4]);
-            st4(dv_ + off, *reinterpret_cast<const float4 *>(&sh_dv[st][sc]));
+            st4(outs.dq[part] + off, o[0]);
+            st4(outs.dw[part] + off, o[1]);
+            st4(outs.dk[part] + off, o[2]);
+            st4(outs.db[part] + off, o[3]);
+            st4(outs.da[part] + off, o[4]);
+            if (sc < ROWS_WG) st4(outs.dv + off_t + part * ROWS_WG + sc, *reinterpret_cast<const float4 *>(&sh_dv[st][sc]));
         }
         __syncthreads();
         if (n > 0) {
@@ -234,33 +261,64 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
 
 constexpr size_t kBwdSmemBytes = (size_t)(kTB * (NCV + NRV) * kN + 4 * kTB * NOUT * kN + kTB * kN) * sizeof(float);
 
-template <typename T>
+template <typename T, int RT>
 static int launch_bwd(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v,
-                      const void *a, const void *b, const void *dy, const float *s, const float *sa, void *dw,
-                      void *dq, void *dk, void *dv, void *da, void *db, hipStream_t stream) {
+                      const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                      const BwdOuts<T> &outs, hipStream_t stream) {
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7_bwd_kernel<T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7_bwd_kernel<T, RT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdSmemBytes);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     (void)hipGetLastError();  // drop any stale error left by an earlier runtime call of the host program
-    hipLaunchKernelGGL((wkv7_bwd_kernel<T>), dim3(B * H), dim3(256), kBwdSmemBytes, stream, T_, H, (const T *)w,
-                       (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, (const T *)dy, s, sa,
-                       (T *)dw, (T *)dq, (T *)dk, (T *)dv, (T *)da, (T *)db);
+    hipLaunchKernelGGL((wkv7_bwd_kernel<T, RT>), dim3(B * H * (4 / RT)), dim3(256), kBwdSmemBytes, stream, T_, H,
+                       (const T *)w, (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b,
+                       (const T *)dy, s, sa, outs);
     return (int)hipGetLastError();
+}
+
+template <typename T>
+static int bwd_full(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                    const void *b, const void *dy, const float *s, const float *sa, void *dw, void *dq, void *dk,
+                    void *dv, void *da, void *db, hipStream_t stream) {
+    BwdOuts<T> o;
+    o.dw[0] = o.dw[1] = (T *)dw; o.dq[0] = o.dq[1] = (T *)dq; o.dk[0] = o.dk[1] = (T *)dk;
+    o.db[0] = o.db[1] = (T *)db; o.da[0] = o.da[1] = (T *)da; o.dv = (T *)dv;
+    return launch_bwd<T, 4>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
+}
+template <typename T>
+static int bwd_split(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                     const void *b, const void *dy, const float *s, const float *sa, void *const *dw, void *const *dq,
+                     void *const *dk, void *dv, void *const *da, void *const *db, hipStream_t stream) {
+    BwdOuts<T> o;
+    for (int i = 0; i < 2; i++) {
+        o.dw[i] = (T *)dw[i]; o.dq[i] = (T *)dq[i]; o.dk[i] = (T *)dk[i]; o.db[i] = (T *)db[i]; o.da[i] = (T *)da[i];
+    }
+    o.dv = (T *)dv;
+    return launch_bwd<T, 2>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
 }
 
 int wkv_bwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                  const void *b, const void *dy, const float *s, const float *sa, void *dw, void *dq, void *dk,
                  void *dv, void *da, void *db, hipStream_t stream) {
-    return launch_bwd<bf16_t>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, stream);
+    return bwd_full<bf16_t>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, stream);
 }
 int wkv_bwd_f32(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                 const void *b, const void *dy, const float *s, const float *sa, void *dw, void *dq, void *dk,
                 void *dv, void *da, void *db, hipStream_t stream) {
-    return launch_bwd<float>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, stream);
+    return bwd_full<float>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, stream);
+}
+int wkv_bwd_split_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                       const void *b, const void *dy, const float *s, const float *sa, void *const *dw,
+                       void *const *dq, void *const *dk, void *dv, void *const *da, void *const *db, hipStream_t st) {
+    return bwd_split<bf16_t>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, st);
+}
+int wkv_bwd_split_f32(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                      const void *b, const void *dy, const float *s, const float *sa, void *const *dw, void *const *dq,
+                      void *const *dk, void *dv, void *const *da, void *const *db, hipStream_t st) {
+    return bwd_split<float>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, st);
 }
 
 }  // namespace rwkv7

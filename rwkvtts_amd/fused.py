@@ -188,3 +188,86 @@ class _TmixPost(torch.autograd.Function):
 def tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, eps):
     """(GroupNorm_H(y) + (sum_head r*k*r_k) * v) * g ; r_k is [H,64]."""
     return _TmixPost.apply(y, r, k, v, g, gn_weight, gn_bias, r_k.reshape(-1), eps)
+
+
+class _TmixCore(torch.autograd.Function):
+    """prepare -> WKV7 scan -> GroupNorm/bonus/gate as ONE autograd node for training (zero initial state).
+
+    Same kernels as tmix_prepare / RUN_CUDA_RWKV7g / tmix_post in forward.  In backward the node owns the whole
+    gradient flow between the three stages, so (a) the scan backward can run row-split over 2 workgroups per head
+    (ops.wkv7_backward_split) and (b) the sums  d_k2 = scan + post,  d_v2 = scan + post,  d_r = scan + post  and the
+    two partial sets are added in fp32 inside rwkv7_tmix_prepare_bwd_sum instead of by autograd's bf16 add kernels."""
+
+    @staticmethod
+    def forward(ctx, r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask, H, eps):
+        from . import ops
+        B, T, D = k.shape
+        if T % ops.CHUNK_LEN != 0:
+            raise ValueError(f"T={T} must be a multiple of {ops.CHUNK_LEN}")
+        r, w_pre, k, v, a_pre, g = _c(r), _c(w_pre), _c(k), _c(v), _c(a_pre), _c(g)
+        v_pre = None if v_pre is None else _c(v_pre)
+        v_first = None if v_first is None else _c(v_first)
+        k_k, k_a = _c(k_k.to(k.dtype)), _c(k_a.to(k.dtype))
+        gn_w, gn_b, r_k = _c(gn_w.to(k.dtype)), _c(gn_b.to(k.dtype)), _c(r_k.reshape(-1).to(k.dtype))
+        rows = B * T
+        w, k2, v2, a_in, b_in = [torch.empty_like(k) for _ in range(5)]
+        _call("tmix_prepare_fwd", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
+              _p(mask), _p(k_k), _p(k_a), _p(w), _p(k2), _p(v2), _p(a_in), _p(b_in), min(rows, _FWD_BLOCKS))
+        y = torch.empty_like(k)
+        s = torch.empty(B, H, T // ops.CHUNK_LEN, 64, 64, dtype=torch.float32, device=k.device)
+        sa = torch.empty(B, T, H, 64, dtype=torch.float32, device=k.device)
+        v4 = lambda t: t.view(B, T, H, 64)
+        torch.ops.wind_backstepping.forward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(y), s, sa)
+        out = torch.empty_like(k)
+        _call("tmix_post_fwd", k, ctypes.c_long(rows), D, _p(y), _p(r), _p(k2), _p(v2), _p(g), _p(gn_w), _p(gn_b), _p(r_k),
+              ctypes.c_float(eps), _p(out), min(rows, _FWD_BLOCKS))
+        ctx.save_for_backward(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
+                              w, k2, v2, a_in, b_in, y, s, sa)
+        ctx.H, ctx.eps = H, eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import ops
+        (r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
+         w, k2, v2, a_in, b_in, y, s, sa) = ctx.saved_tensors
+        B, T, D = k.shape
+        H = ctx.H
+        rows = B * T
+        nb = min(rows, _BWD_BLOCKS)
+        dout = _c(dout)
+        # 1. GroupNorm / bonus / gate
+        d_y, d_r_post, d_k2_post, d_v2_post, d_g = [torch.empty_like(k) for _ in range(5)]
+        part_post = torch.empty(nb, 3, D, dtype=torch.float32, device=k.device)
+        _call("tmix_post_bwd", k, ctypes.c_long(rows), D, _p(dout), _p(y), _p(r), _p(k2), _p(v2), _p(g), _p(gn_w), _p(gn_b),
+              _p(r_k), ctypes.c_float(ctx.eps), _p(d_y), _p(d_r_post), _p(d_k2_post), _p(d_v2_post), _p(d_g),
+              _p(part_post), nb)
+        # 2. scan, two workgroups per head
+        v4 = lambda t: t.view(B, T, H, 64)
+        dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in),
+                                                              v4(d_y), s, sa)
+        # 3. decay / kk / k' / value residual, summing all contributions on load
+        d_wpre, d_k, d_v, d_apre, d_r = [torch.empty_like(k) for _ in range(5)]
+        d_vpre = torch.empty_like(k) if v_pre is not None else None
+        d_vf = torch.empty_like(k) if v_pre is not None else None
+        part = torch.empty(nb, 2, D, dtype=torch.float32, device=k.device)
+        gsum = [dw2[0], dw2[1], dk2[0], dk2[1], d_k2_post, dv, d_v2_post, da2[0], da2[1], db2[0], db2[1],
+                dq2[0], dq2[1], d_r_post]
+        ptrs = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in gsum])
+        _call("tmix_prepare_bwd_sum", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
+              _p(mask), _p(k_k), _p(k_a), ptrs, _p(d_wpre), _p(d_k), _p(d_v), _p(d_apre), _p(d_vpre), _p(d_vf),
+              _p(d_r), _p(part), nb)
+        dp = part.sum(0).to(k.dtype)
+        dpp = part_post.sum(0).to(k.dtype)
+        return (d_r, d_wpre, d_k, d_v, d_apre, d_g, d_vpre, d_vf, dp[0], dp[1], dpp[0], dpp[1], dpp[2], None, None,
+                None)
+
+
+def tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_bias, r_k, mask, H, eps, is_layer0):
+    """Training-time time-mix core: tmix_post(RUN_CUDA_RWKV7g(r, *tmix_prepare(...)), ...) as one autograd node.
+    r must already be masked (r * mask) when a mask is used."""
+    assert k.shape[-1] == H * 64
+    if is_layer0:
+        v_pre = v_first = None
+    return _TmixCore.apply(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_bias, r_k.reshape(-1),
+                           _mask_rows(mask, k), H, eps)

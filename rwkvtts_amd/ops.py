@@ -93,6 +93,23 @@ def _wb_backward(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
     _lib.check(rc, "wind_backstepping.backward")
 
 
+def wkv7_backward_split(w, q, k, v, z, a, dy, s, sa):
+    """WKV7 backward with each head split over two workgroups (rwkv7_wkv_bwd_split_*: all 256 CUs busy at B*H=128).
+    Returns (dw2, dq2, dk2, dv, dz2, da2): the *2 tensors are [2, B,T,H,64] partial column sums whose sum over dim 0
+    is the gradient wind_backstepping.backward returns; dv is complete."""
+    B, T, H, C = w.shape
+    sfx = _sfx([w, q, k, v, z, a, dy], "wkv7_backward_split")
+    dw2, dq2, dk2, dz2, da2 = [torch.empty((2,) + tuple(w.shape), dtype=w.dtype, device=w.device) for _ in range(5)]
+    dv = torch.empty_like(v)
+    pair = lambda t: (ctypes.c_void_p * 2)(t[0].data_ptr(), t[1].data_ptr())
+    with torch.cuda.device_of(w), _timed("wkv7_bwd", w):
+        rc = getattr(_lib.lib(), "rwkv7_wkv_bwd_split_" + sfx)(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a),
+                                                             _p(dy), _p(s), _p(sa), pair(dw2), pair(dq2), pair(dk2),
+                                                             _p(dv), pair(dz2), pair(da2), _stream(w))
+    _lib.check(rc, "wkv7_backward_split")
+    return dw2, dq2, dk2, dv, dz2, da2
+
+
 def _state_forward(B, T, C, H, state, r, w, k, v, a, b, y):
     sfx = _sfx([r, w, k, v, a, b, y], "rwkv7_state_fwd.forward")
     if state.dtype != torch.float32 or not state.is_contiguous():

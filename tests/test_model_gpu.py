@@ -212,3 +212,43 @@ def test_graph_decoder_matches_eager_generate():
     got = GraphDecoder(model, B).generate(inputs_embeds=x, attention_mask=mask, max_new_tokens=NEW,
                                           suppress_tokens=[256])
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+def test_fused_tmix_core_equals_separate_nodes(dtype, tol):
+    """fused._TmixCore (row-split scan backward + gradient sums folded into the prepare backward) against the
+    three separate autograd nodes, with a padding mask, on every parameter gradient."""
+    from rwkvtts_amd import backbone
+    cfg = RWKV7Config(hidden_size=128, num_hidden_layers=3, vocab_size=64, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=16, gate_low_rank_dim=32)
+    torch.manual_seed(5)
+    model = RWKV7Model(cfg)
+    backbone.init_weights(model, cfg, seed=5)
+    model = model.to(DEV).to(dtype).train()
+    B, T = 3, 48
+    x = (torch.randn(B, T, 128, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV).to(dtype)
+    mask = torch.ones(B, T, device=DEV, dtype=torch.long)
+    mask[0, :7] = 0
+    mask[2, :20] = 0
+    proj = torch.randn(B, T, 128, generator=torch.Generator().manual_seed(2)).to(DEV)
+    res = {}
+    for flag in (True, False):
+        backbone.FUSED_TMIX_CORE = flag
+        try:
+            model.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            out = model(inputs_embeds=xin, attention_mask=mask).last_hidden_state
+            (out.float() * proj).sum().backward()
+            res[flag] = (out.detach().float(), xin.grad.float(), {n: p.grad.float().clone() for n, p in model.named_parameters()
+                                                                   if p.grad is not None})
+        finally:
+            backbone.FUSED_TMIX_CORE = True
+    assert torch.equal(res[True][0], res[False][0]), "forward runs the same kernels"
+    def close(a, b, what):
+        scale = max(b.abs().max().item(), 1e-6)
+        err = (a - b).abs().max().item()
+        assert err <= tol * scale, f"{what}: {err:.3e} vs scale {scale:.3e}"
+    close(res[True][1], res[False][1], "d_inputs_embeds")
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) > 50
+    for n in res[True][2]:
+        close(res[True][2][n], res[False][2][n], n)

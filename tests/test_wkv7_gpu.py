@@ -194,3 +194,35 @@ def test_full_size_config2_properties_and_slices(c_oracle):
     lhs = fq(sub[3] + v2)
     rhs = fq(sub[3]) + fq(v2)
     assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 16, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_row_split_backward_vs_oracle(c_oracle, B, T, H, seed, dtype):
+    """rwkv7_wkv_bwd_split_*: two workgroups per head; dv complete, the other five as two partial column sums."""
+    ins = make_wkv_inputs(B, T, H, seed, dtype)
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).to(dtype)
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    g_o = dict(zip(NAMES, c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)))
+    d = [t.to(DEV) for t in ins]
+    y, s, sa = torch.empty_like(d[0]), torch.empty(B, H, T // 16, 64, 64, device=DEV), torch.empty(B, T, H, 64, device=DEV)
+    torch.ops.wind_backstepping.forward(*d, y, s, sa)
+    dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(*d, dy.to(DEV), s, sa)
+    full = [torch.empty_like(d[0]) for _ in range(6)]
+    torch.ops.wind_backstepping.backward(*d, dy.to(DEV), s, sa, *full)
+    assert torch.equal(dv, full[3]), "dv rows are summed in the same order by both kernels"
+    got = dict(dw=dw2, dq=dq2, dk=dk2, da=da2, db=db2)
+    for n, g2 in got.items():
+        tot = g2[0].float() + g2[1].float()
+        if dtype == torch.bfloat16:
+            # each half is rounded to bf16 on its own (half an ulp of |half|, the halves can cancel), on top of the
+            # 2 ulp granted to the unsplit kernel
+            want = g_o[n].float()
+            floor = want.abs().mean().item() * 0.25 + 1e-6
+            tol = 2.0 ** -8 * (g2[0].float().abs() + g2[1].float().abs()).cpu() + 2.0 ** -6 * torch.clamp(want.abs(), min=floor)
+            bad = (tot.cpu() - want).abs() > tol
+            assert not bad.any(), f"{n}: {bad.sum().item()}/{bad.numel()} out of tolerance"
+        else:
+            _assert_f32_close(tot, g_o[n], n, 5e-4)
+    if dtype == torch.bfloat16:
+        _assert_bf16_close(dv, g_o["dv"], "dv", ulps=2.0)

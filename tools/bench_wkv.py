@@ -52,6 +52,7 @@ def main():
     th = B * T * H
     fwd = lambda: torch.ops.wind_backstepping.forward(w, q, k, v, aa, b, y, s, sa)
     bwd = lambda: torch.ops.wind_backstepping.backward(w, q, k, v, aa, b, dy, s, sa, *grads)
+    bwd2 = lambda: ops.wkv7_backward_split(w, q, k, v, aa, b, dy, s, sa)
     st = torch.zeros(B, H, 64, 64, device=dev)
     f3 = lambda t: t.view(B, T, H * 64)
     yy = torch.empty(B, T, H * 64, device=dev, dtype=dt)
@@ -67,6 +68,7 @@ def main():
     sfx = "bf16" if a.dtype == "bf16" else "f32"
     cf = lambda: getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_" + sfx)(B, T, H, P(w), P(q), P(k), P(v), P(aa), P(b), P(tinv), P(y), P(sa2), P(hs), st_)
     for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz), ("wkv7_bwd", bwd, 13 * 64 * esz),
+                                ("wkv7_bwd row-split", bwd2, 13 * 64 * esz),
                                 ("wkv7_state_fwd", sfw, 7 * 64 * esz), ("wkv7c_prep (T inverse)", prep, 3 * 64 * esz),
                                 ("wkv7c_fwd (chunked, save)", cf, 7 * 64 * esz)):
         med, best = timeit(fn, a.iters)
