@@ -94,16 +94,32 @@ def config_1p5b(**kw):
                        v_low_rank_dim=64, gate_low_rank_dim=256, **kw)
 
 
+# bf16 low-rank branches through csrc/lora.hip.  Off by default: measured on MI355X (tools/bench_lora.py) the BLAS
+# library serves x @ w1^T at 24 us for every rank, the hand-written kernel needs 19 / 30 / 47 us at R = 32 / 64 / 128.
+FUSED_LORA = False
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose weight gradient is reduced over B*T in slabs
+    (fused.wgrad_splitk) when training in bf16."""
+
+    def forward(self, x):
+        return fused.linear(x, self.weight, self.bias)
+
+
 class LoRA(nn.Module):
     """rwkvfla LoRA: Linear(in,r,bias=False) -> act -> Linear(r,out,bias) ; keys lora.0.weight / lora.2.{weight,bias}."""
 
     def __init__(self, in_dim, out_dim, rank, activation: Optional[str], bias: bool):
         super().__init__()
         act = {None: nn.Identity(), "tanh": nn.Tanh(), "sigmoid": nn.Sigmoid()}[activation]
-        self.lora = nn.Sequential(nn.Linear(in_dim, rank, bias=False), act, nn.Linear(rank, out_dim, bias=bias))
+        self.lora = nn.Sequential(Linear(in_dim, rank, bias=False), act, Linear(rank, out_dim, bias=bias))
+        self.activation, self.rank = activation, rank
 
     def forward(self, x):
-        return self.lora(x)
+        if FUSED_LORA and fused.lora_supported(x, self.rank):
+            return fused.lora(x, self.lora[0].weight, self.lora[2].weight, self.lora[2].bias, self.activation)
+        return self.lora(x)  # fp32 models and decode-sized inputs: BLAS
 
 
 class LayerState:
@@ -161,10 +177,10 @@ class RWKV7Attention(nn.Module):
         self.k_k = nn.Parameter(torch.zeros(D))
         self.k_a = nn.Parameter(torch.zeros(D))
         self.r_k = nn.Parameter(torch.zeros(H, N))
-        self.r_proj = nn.Linear(D, D, bias=False)
-        self.k_proj = nn.Linear(D, D, bias=False)
-        self.v_proj = nn.Linear(D, D, bias=False)
-        self.o_proj = nn.Linear(D, D, bias=False)
+        self.r_proj = Linear(D, D, bias=False)
+        self.k_proj = Linear(D, D, bias=False)
+        self.v_proj = Linear(D, D, bias=False)
+        self.o_proj = Linear(D, D, bias=False)
         self.w_lora = LoRA(D, D, cfg.decay_low_rank_dim, "tanh", True)
         if layer_idx != 0:
             self.v_lora = LoRA(D, D, cfg.v_low_rank_dim, None, True)
@@ -228,8 +244,8 @@ class RWKV7FeedForward(nn.Module):
     def __init__(self, cfg: RWKV7Config, layer_idx: int):
         super().__init__()
         self.x_k = nn.Parameter(torch.zeros(cfg.hidden_size))
-        self.key = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
-        self.value = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+        self.key = Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.value = Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
 
     def forward(self, x, mask, state: Optional[LayerState] = None):
         x_prev = None if state is None else state.ffn_x_prev
