@@ -96,13 +96,15 @@ int rwkv7_mix_fwd_bf16(int B, int T, int D, int nmix, const void *x, const void 
                        const void *params, void *out, int nblocks, rwkv7_stream_t stream);
 int rwkv7_mix_fwd_f32(int B, int T, int D, int nmix, const void *x, const void *x_prev, const void *mask,
                       const void *params, void *out, int nblocks, rwkv7_stream_t stream);
-/* grad_outs: HOST array of nmix device pointers, one [rows][D] gradient per output of the forward */
+/* grad_outs: HOST array of nmix device pointers, one [rows][D] gradient per output of the forward.
+ * Workgroup b walks the runs of run_len consecutive rows number b, b + nblocks, b + 2 nblocks, ...;
+ * dparams_partial is [nblocks][nmix][D] fp32 (summed by the caller). */
 int rwkv7_mix_bwd_bf16(int B, int T, int D, int nmix, const void *const *grad_outs, const void *x, const void *x_prev,
                        const void *mask, const void *params, void *dx, float *dparams_partial, int nblocks,
-                       rwkv7_stream_t stream);
+                       int run_len, rwkv7_stream_t stream);
 int rwkv7_mix_bwd_f32(int B, int T, int D, int nmix, const void *const *grad_outs, const void *x, const void *x_prev,
                       const void *mask, const void *params, void *dx, float *dparams_partial, int nblocks,
-                      rwkv7_stream_t stream);
+                      int run_len, rwkv7_stream_t stream);
 
 /* everything between the projections and the scan (rwkv_s2s_single_ffn.py:172-190):
  *   w = (-softplus(-w_pre) - 0.5)*mask ; k,v *= mask ; v += (v_first - v)*sigmoid(v_pre) (v_pre != NULL)

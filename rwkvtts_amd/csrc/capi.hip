@@ -34,7 +34,7 @@ int lora_down_bf16(long, int, int, int, const void *, const void *, void *, hipS
 int lora_dgrad_up_bf16(long, int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 struct bf16_t;
 template <typename T> int mix_fwd(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, hipStream_t);
-template <typename T> int mix_bwd(int, int, int, int, const void *const *, const void *, const void *, const void *, const void *, void *, float *, int, hipStream_t);
+template <typename T> int mix_bwd(int, int, int, int, const void *const *, const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t);
 template <typename T> int tmix_prepare_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, int, hipStream_t);
 template <typename T> int tmix_prepare_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
 template <typename T> int tmix_prepare_bwd_sum(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *const *, void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
@@ -143,7 +143,7 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
 
 
 // ---- fused elementwise stages ----------------------------------------------------------------------------------
-#define SHAPE_OK(D) ((D) > 0 && (D) % 64 == 0 && (D) <= 8192)
+#define SHAPE_OK(D) ((D) > 0 && (D) % 64 == 0 && (D) <= 4096)  /* D/8 threads per row, kEwMaxThreads = 512 */
 #define EW_DEFINE(SFX, TY)                                                                                           \
     int rwkv7_mix_fwd_##SFX(int B, int T, int D, int nmix, const void *x, const void *x_prev, const void *mask,       \
                             const void *params, void *out, int nblocks, rwkv7_stream_t stream) {                      \
@@ -153,12 +153,14 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
     }                                                                                                                 \
     int rwkv7_mix_bwd_##SFX(int B, int T, int D, int nmix, const void *const *g, const void *x, const void *x_prev,   \
                             const void *mask, const void *params, void *dx, float *dpart, int nblocks,                \
-                            rwkv7_stream_t stream) {                                                                  \
-        if (B <= 0 || T <= 0 || nblocks <= 0 || any_null({g, x, params, dx, dpart})) return RWKV7_EINVAL;             \
+                            int run_len, rwkv7_stream_t stream) {                                                     \
+        if (B <= 0 || T <= 0 || nblocks <= 0 || run_len <= 0 || any_null({g, x, params, dx, dpart}))                  \
+            return RWKV7_EINVAL;                                                                                      \
         if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
         for (int i = 0; i < nmix; i++)                                                                                \
             if (!g[i]) return RWKV7_EINVAL;                                                                           \
-        return rwkv7::mix_bwd<TY>(B, T, D, nmix, g, x, x_prev, mask, params, dx, dpart, nblocks, (hipStream_t)stream); \
+        return rwkv7::mix_bwd<TY>(B, T, D, nmix, g, x, x_prev, mask, params, dx, dpart, nblocks, run_len,            \
+                                  (hipStream_t)stream); \
     }                                                                                                                 \
     int rwkv7_tmix_prepare_fwd_##SFX(long rows, int D, const void *w_pre, const void *k, const void *v,               \
                                      const void *a_pre, const void *v_pre, const void *v_first, const void *mask,     \

@@ -16,6 +16,11 @@
 
 namespace rwkv7 {
 
+// One thread per 8 columns of a row: D <= 4096.  Declaring the bound lets the register allocator use 256 VGPRs
+// (the default assumes 1024-thread blocks = 128 VGPRs, which made mix_bwd<6> spill 392 bytes of scratch per lane
+// and serialised its loads: 1.1 TB/s).
+constexpr int kEwMaxThreads = 512;
+
 template <typename T>
 struct V8;
 template <>
@@ -56,7 +61,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // mix: out_i[t] = xm[t] + (xm[t-1] - xm[t]) * p_i,   xm = x * mask,   xm[-1] = x_prev (or 0)
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int NMIX>
-__global__ void mix_fwd_kernel(int B, int T_, int D, const T *__restrict__ x, const T *__restrict__ x_prev,
+__global__ __launch_bounds__(kEwMaxThreads) void mix_fwd_kernel(int B, int T_, int D, const T *__restrict__ x, const T *__restrict__ x_prev,
                                const T *__restrict__ mask, const T *__restrict__ params, T *__restrict__ out) {
     const int c = threadIdx.x * 8;
     const long rows = (long)B * T_;
@@ -104,23 +109,24 @@ struct MixGrads {
     const void *g[NMIX];
 };
 
+// Rows are walked in short descending runs (RUN rows: the t+1 gradients and x[t-1] are carried in registers inside a
+// run), and run j of workgroup b is run b + j * gridDim: at any moment the workgroups together stream one contiguous
+// window of the 8 tensors.  (Giving each workgroup ONE long contiguous range instead -- 2048 ranges 32 KB apart --
+// measured 1.15 TB/s: thousands of concurrent 2 KB streams defeat the DRAM row buffers.)
 template <typename T, int NMIX>
-__global__ void mix_bwd_kernel(int B, int T_, int D, MixGrads<NMIX> gs, const T *__restrict__ x,
+__global__ __launch_bounds__(kEwMaxThreads) void mix_bwd_kernel(int B, int T_, int D, int run_len, MixGrads<NMIX> gs, const T *__restrict__ x,
                                const T *__restrict__ x_prev, const T *__restrict__ mask, const T *__restrict__ params,
                                T *__restrict__ dx, float *__restrict__ dpart) {
     const int c = threadIdx.x * 8;
     const long rows = (long)B * T_;
-    const long per = (rows + gridDim.x - 1) / gridDim.x;
-    const long r_lo = (long)blockIdx.x * per;
-    const long r_hi = r_lo + per < rows ? r_lo + per : rows;
     float p[NMIX][8], dp[NMIX][8], gn[NMIX][8];
 #pragma unroll
     for (int i = 0; i < NMIX; i++) {
         V8<T>::ld(params + (long)i * D + c, p[i]);
 #pragma unroll
-        for (int j = 0; j < 8; j++) dp[i][j] = gn[i][j] = 0.f;
+        for (int j = 0; j < 8; j++) dp[i][j] = 0.f;
     }
-    auto load_xm = [&](long row, float (&o)[8]) {  // xm[row], or the carried state / zeros in front of a sequence
+    auto load_xm = [&](long row, float (&o)[8]) {  // xm[row] = x[row] * mask[row]
         V8<T>::ld(x + row * D + c, o);
         if (mask) {
             const float m = V8<T>::ld1(mask + row);
@@ -128,11 +134,17 @@ __global__ void mix_bwd_kernel(int B, int T_, int D, MixGrads<NMIX> gs, const T 
             for (int j = 0; j < 8; j++) o[j] *= m;
         }
     };
-    if (r_lo < r_hi) {
-        // prime the carried values with row r_hi (the row after this range), if it belongs to the same sequence
+    for (long r_lo = (long)blockIdx.x * run_len; r_lo < rows; r_lo += (long)gridDim.x * run_len) {
+        const long r_hi = r_lo + run_len < rows ? r_lo + run_len : rows;
+        // prime the carried values with row r_hi (the row after this run), if it belongs to the same sequence
         if (r_hi < rows && (r_hi % T_) != 0) {
 #pragma unroll
             for (int i = 0; i < NMIX; i++) V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + r_hi * D + c, gn[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NMIX; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) gn[i][j] = 0.f;
         }
         float xc[8];
         load_xm(r_hi - 1, xc);
@@ -181,7 +193,7 @@ __global__ void mix_bwd_kernel(int B, int T_, int D, MixGrads<NMIX> gs, const T 
 __device__ __forceinline__ float softplus_(float u) { return u > 20.f ? u : log1pf(__expf(u)); }
 
 template <typename T>
-__global__ void tmix_prepare_fwd_kernel(long rows, int D, const T *__restrict__ w_pre, const T *__restrict__ k,
+__global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_fwd_kernel(long rows, int D, const T *__restrict__ w_pre, const T *__restrict__ k,
                                         const T *__restrict__ v, const T *__restrict__ a_pre,
                                         const T *__restrict__ v_pre, const T *__restrict__ v_first,
                                         const T *__restrict__ mask, const T *__restrict__ k_k,
@@ -246,7 +258,7 @@ struct PrepBwdExtra {
 };
 
 template <typename T, bool MULTI>
-__global__ void tmix_prepare_bwd_kernel(long rows, int D, const T *__restrict__ w_pre, const T *__restrict__ k,
+__global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long rows, int D, const T *__restrict__ w_pre, const T *__restrict__ k,
                                         const T *__restrict__ v, const T *__restrict__ a_pre,
                                         const T *__restrict__ v_pre, const T *__restrict__ v_first,
                                         const T *__restrict__ mask, const T *__restrict__ k_k,
@@ -370,7 +382,7 @@ __global__ void tmix_prepare_bwd_kernel(long rows, int D, const T *__restrict__ 
 // tmix_post (rwkv_s2s_single_ffn.py:192-195): out = (GroupNorm_head(y) + (sum_head r k r_k) v) * g
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void tmix_post_fwd_kernel(long rows, int D, const T *__restrict__ y, const T *__restrict__ r,
+__global__ __launch_bounds__(kEwMaxThreads) void tmix_post_fwd_kernel(long rows, int D, const T *__restrict__ y, const T *__restrict__ r,
                                      const T *__restrict__ k, const T *__restrict__ v, const T *__restrict__ g,
                                      const T *__restrict__ gn_w, const T *__restrict__ gn_b,
                                      const T *__restrict__ r_k, float eps, T *__restrict__ out) {
@@ -410,7 +422,7 @@ __global__ void tmix_post_fwd_kernel(long rows, int D, const T *__restrict__ y, 
 }
 
 template <typename T>
-__global__ void tmix_post_bwd_kernel(long rows, int D, const T *__restrict__ dout, const T *__restrict__ y,
+__global__ __launch_bounds__(kEwMaxThreads) void tmix_post_bwd_kernel(long rows, int D, const T *__restrict__ dout, const T *__restrict__ y,
                                      const T *__restrict__ r, const T *__restrict__ k, const T *__restrict__ v,
                                      const T *__restrict__ g, const T *__restrict__ gn_w, const T *__restrict__ gn_b,
                                      const T *__restrict__ r_k, float eps, T *__restrict__ d_y, T *__restrict__ d_r,
@@ -535,18 +547,20 @@ int mix_fwd(int B, int T_, int D, int nmix, const void *x, const void *x_prev, c
 }
 template <typename T>
 int mix_bwd(int B, int T_, int D, int nmix, const void *const *g, const void *x, const void *x_prev, const void *mask,
-            const void *params, void *dx, float *dpart, int nblocks, hipStream_t st) {
+            const void *params, void *dx, float *dpart, int nblocks, int run_len, hipStream_t st) {
     (void)hipGetLastError();
     const dim3 grid(nblocks), block(D / 8);
     if (nmix == 6) {
         MixGrads<6> gs;
         for (int i = 0; i < 6; i++) gs.g[i] = g[i];
-        hipLaunchKernelGGL((mix_bwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, gs, (const T *)x, (const T *)x_prev,
+        hipLaunchKernelGGL((mix_bwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, run_len, gs, (const T *)x,
+                           (const T *)x_prev,
                            (const T *)mask, (const T *)params, (T *)dx, dpart);
     } else {
         MixGrads<1> gs;
         gs.g[0] = g[0];
-        hipLaunchKernelGGL((mix_bwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, gs, (const T *)x, (const T *)x_prev,
+        hipLaunchKernelGGL((mix_bwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, run_len, gs, (const T *)x,
+                           (const T *)x_prev,
                            (const T *)mask, (const T *)params, (T *)dx, dpart);
     }
     return finish();
@@ -632,7 +646,7 @@ int relusq_bwd(long n, const void *x, const void *dy, void *dx, hipStream_t st) 
     template int mix_fwd<T>(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, \
                             hipStream_t);                                                                           \
     template int mix_bwd<T>(int, int, int, int, const void *const *, const void *, const void *, const void *,       \
-                            const void *, void *, float *, int, hipStream_t);                                                     \
+                            const void *, void *, float *, int, int, hipStream_t);                                                     \
     template int tmix_prepare_fwd<T>(long, int, const void *, const void *, const void *, const void *, const void *, \
                                      const void *, const void *, const void *, const void *, void *, void *, void *, \
                                      void *, void *, int, hipStream_t);                                             \

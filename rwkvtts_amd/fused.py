@@ -14,7 +14,8 @@ from . import _lib
 
 _FWD_BLOCKS = 4096   # workgroups walking the rows (D/8 threads each)
 _BWD_BLOCKS = 2048   # also the number of parameter-gradient partials
-_MIX_BWD_ROWS = 16   # rows per workgroup in mix_bwd (contiguous run, neighbours carried in registers)
+_MIX_BWD_ROWS = 4     # rows per run in mix_bwd (neighbours carried in registers inside a run)
+_MIX_BWD_BLOCKS = 1024
 
 
 def _p(t):
@@ -73,12 +74,12 @@ class _Mix(torch.autograd.Function):
         B, T, D = x.shape
         nmix = params.shape[0]
         gs = [torch.zeros_like(x) if g is None else _c(g) for g in gs]
-        # each workgroup walks a contiguous run of rows (measured: 16-row runs 0.44 ms, 7/15/31/33-row runs slower)
-        nb = max(1, -(-B * T // _MIX_BWD_ROWS))
+        # workgroup b walks the _MIX_BWD_ROWS-row runs b, b + nb, b + 2 nb, ... (see mix_bwd_kernel)
+        nb = max(1, min(-(-B * T // _MIX_BWD_ROWS), _MIX_BWD_BLOCKS))
         dx = torch.empty_like(x)
         part = torch.empty(nb, nmix, D, dtype=torch.float32, device=x.device)
         ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])
-        _call("mix_bwd", x, B, T, D, nmix, ptrs, _p(x), _p(xp), _p(mask), _p(params), _p(dx), _p(part), nb)
+        _call("mix_bwd", x, B, T, D, nmix, ptrs, _p(x), _p(xp), _p(mask), _p(params), _p(dx), _p(part), nb, _MIX_BWD_ROWS)
         return dx, None, None, part.sum(0).to(params.dtype)
 
 

@@ -14,10 +14,10 @@ def mixb():
     torch.autograd.grad(outs, [x] + ps, gs, retain_graph=True)
 print("mix6 fwd  ms", timeit(lambda: fused.token_shift_mix6(x, None, *ps), 10)[0])
 print("mix6 bwd  ms (incl. stack of 6 grads + partial sum)", timeit(mixb, 10)[0])
-for nr in (7, 15, 16, 31, 33):
-    fused._MIX_BWD_ROWS = nr
-    print("  MIX_BWD_ROWS", nr, timeit(mixb, 10)[0])
-fused._MIX_BWD_ROWS = 15
+for nr, nblk in ((1, 1024), (2, 1024), (4, 512), (4, 1024), (4, 2048), (8, 1024), (16, 1024), (16, 2048)):
+    fused._MIX_BWD_ROWS, fused._MIX_BWD_BLOCKS = nr, nblk
+    print("  MIX_BWD_ROWS", nr, "BLOCKS", nblk, timeit(mixb, 10)[0])
+fused._MIX_BWD_ROWS, fused._MIX_BWD_BLOCKS = 4, 1024
 ins = [mk(B, T, D).requires_grad_(True) for _ in range(6)]
 kk, ka = mk(D).requires_grad_(True), mk(D).requires_grad_(True)
 po = fused.tmix_prepare(*ins, kk, ka, None, H, False)
