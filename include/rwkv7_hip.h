@@ -147,6 +147,24 @@ int rwkv7_tmix_prepare_bwd_sum_f32(long rows, int D, const void *w_pre, const vo
                                    void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, void *d_r,
                                    float *dparams_partial, int nblocks, rwkv7_stream_t stream);
 
+/* ---- residual add + LayerNorm (block wiring of rwkv_s2s_single_ffn.py:262-276: x = x + att(ln1(x)); x = x + ffn(ln2(x));
+ *      rwkvfla RWKV7Block attn_norm / ffn_norm / pre_norm, model-level norm) ----
+ *   fwd: x_out = x + branch (rounded to the tensor type) ; h = LayerNorm(x_out; gamma, beta, eps) ; mean/rstd [rows] fp32.
+ *        branch NULL: plain LayerNorm of x (x_out unused).  beta NULL: no bias.
+ *   bwd: dx = d_resid + dLayerNorm(dh)   (d_resid NULL = 0) ; dparams_partial [nblocks][2][D] fp32 = dgamma, dbeta */
+int rwkv7_add_ln_fwd_bf16(long rows, int D, const void *x, const void *branch, const void *gamma, const void *beta,
+                          float eps, void *x_out, void *h, float *mean, float *rstd, int nblocks,
+                          rwkv7_stream_t stream);
+int rwkv7_add_ln_fwd_f32(long rows, int D, const void *x, const void *branch, const void *gamma, const void *beta,
+                         float eps, void *x_out, void *h, float *mean, float *rstd, int nblocks,
+                         rwkv7_stream_t stream);
+int rwkv7_add_ln_bwd_bf16(long rows, int D, const void *dh, const void *d_resid, const void *x1, const float *mean,
+                          const float *rstd, const void *gamma, void *dx, float *dparams_partial, int nblocks,
+                          rwkv7_stream_t stream);
+int rwkv7_add_ln_bwd_f32(long rows, int D, const void *dh, const void *d_resid, const void *x1, const float *mean,
+                         const float *rstd, const void *gamma, void *dx, float *dparams_partial, int nblocks,
+                         rwkv7_stream_t stream);
+
 /* ---- low-rank branches (rwkv_s2s_single_ffn.py:172-181: w0 + tanh(xw@w1)@w2, a0 + (xa@a1)@a2, v0 + (xv@v1)@v2,
  *      sigmoid(xg@g1)@g2; rwkvfla LoRA modules *.lora.0 / *.lora.2).  The two skinny products with a [M,K] operand
  *      and a [M,R] result, bf16, fp32 accumulate on MFMA.  R in {32,64,128}, K % 64 == 0, act 0 none / 1 tanh / 2 sigmoid.

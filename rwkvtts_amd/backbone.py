@@ -268,13 +268,22 @@ class RWKV7Block(nn.Module):
         self.ffn_norm = nn.LayerNorm(D, eps=cfg.norm_eps, bias=cfg.norm_bias)
         self.ffn = RWKV7FeedForward(cfg, layer_idx)
 
-    def forward(self, x, mask, v_first, state: Optional[LayerState] = None):
+    def forward(self, x, delta, mask, v_first, state: Optional[LayerState] = None):
+        """The block input is x + delta (delta = the previous block's channel-mix output, None for the first
+        block): every residual add is fused with the LayerNorm that follows it (fused.add_layer_norm), so this
+        block's own last add is left to the next block / the model's final norm.  Returns (x, delta, v_first)."""
         if self.layer_idx == 0:
-            x = self.pre_norm(x)
-        att, v_first = self.attn(self.attn_norm(x), mask, v_first, state)
-        x = x + att
-        x = x + self.ffn(self.ffn_norm(x), mask, state)
-        return x, v_first
+            if delta is not None:
+                x = x + delta
+                delta = None
+            x = fused.layer_norm(x, self.pre_norm)
+        if delta is None:
+            h = fused.layer_norm(x, self.attn_norm)
+        else:
+            x, h = fused.add_layer_norm(x, delta, self.attn_norm)
+        att, v_first = self.attn(h, mask, v_first, state)
+        x, h = fused.add_layer_norm(x, att, self.ffn_norm)
+        return x, self.ffn(h, mask, state), v_first
 
 
 class ModelOutput(dict):
@@ -330,14 +339,15 @@ class RWKV7Model(nn.Module):
             x = torch.cat([x.new_zeros(B, pad, D), x], 1)
             m = torch.ones(B, T, 1, dtype=x.dtype, device=x.device) if mask is None else mask
             mask = torch.cat([m.new_zeros(B, pad, 1), m], 1)
-        v_first = None
+        v_first = delta = None
         for i, layer in enumerate(self.layers):
             st = past_key_values[i] if stateful else None
             if self.gradient_checkpointing and self.training and not stateful:
-                x, v_first = torch.utils.checkpoint.checkpoint(layer, x, mask, v_first, None, use_reentrant=False)
+                x, delta, v_first = torch.utils.checkpoint.checkpoint(layer, x, delta, mask, v_first, None,
+                                                                      use_reentrant=False)
             else:
-                x, v_first = layer(x, mask, v_first, st)
-        x = self.norm(x)
+                x, delta, v_first = layer(x, delta, mask, v_first, st)
+        x = fused.add_layer_norm(x, delta, self.norm)[1] if delta is not None else fused.layer_norm(x, self.norm)
         if pad:
             x = x[:, pad:]
         if stateful:

@@ -40,6 +40,8 @@ template <typename T> int tmix_prepare_bwd(long, int, const void *, const void *
 template <typename T> int tmix_prepare_bwd_sum(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *const *, void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
 template <typename T> int tmix_post_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, int, hipStream_t);
 template <typename T> int tmix_post_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, void *, void *, void *, void *, float *, int, hipStream_t);
+template <typename T> int add_ln_fwd(long, int, const void *, const void *, const void *, const void *, float, void *, void *, float *, float *, int, hipStream_t);
+template <typename T> int add_ln_bwd(long, int, const void *, const void *, const void *, const float *, const float *, const void *, void *, float *, int, hipStream_t);
 template <typename T> int relusq_fwd(long, const void *, void *, hipStream_t);
 template <typename T> int relusq_bwd(long, const void *, const void *, void *, hipStream_t);
 }  // namespace rwkv7
@@ -205,6 +207,26 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
         return rwkv7::tmix_prepare_bwd_sum<TY>(rows, D, w_pre, k, v, a_pre, v_pre, v_first, mask, k_k, k_a, gsum,     \
                                                d_wpre, d_k, d_v, d_apre, d_vpre, d_vfirst, d_r, dpart, nblocks,       \
                                                (hipStream_t)stream);                                                  \
+    }                                                                                                                 \
+    int rwkv7_add_ln_fwd_##SFX(long rows, int D, const void *x, const void *branch, const void *gamma,                \
+                               const void *beta, float eps, void *x_out, void *h, float *mean, float *rstd,           \
+                               int nblocks, rwkv7_stream_t stream) {                                                  \
+        if (rows <= 0 || nblocks <= 0 || any_null({x, gamma, h, (const void *)mean, (const void *)rstd}))             \
+            return RWKV7_EINVAL;                                                                                      \
+        if (branch && !x_out) return RWKV7_EINVAL;                                                                    \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::add_ln_fwd<TY>(rows, D, x, branch, gamma, beta, eps, x_out, h, mean, rstd, nblocks,             \
+                                     (hipStream_t)stream);                                                            \
+    }                                                                                                                 \
+    int rwkv7_add_ln_bwd_##SFX(long rows, int D, const void *dh, const void *d_resid, const void *x1,                 \
+                               const float *mean, const float *rstd, const void *gamma, void *dx, float *dpart,       \
+                               int nblocks, rwkv7_stream_t stream) {                                                  \
+        if (rows <= 0 || nblocks <= 0 ||                                                                              \
+            any_null({dh, x1, (const void *)mean, (const void *)rstd, gamma, dx, (const void *)dpart}))               \
+            return RWKV7_EINVAL;                                                                                      \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::add_ln_bwd<TY>(rows, D, dh, d_resid, x1, mean, rstd, gamma, dx, dpart, nblocks,                 \
+                                     (hipStream_t)stream);                                                            \
     }                                                                                                                 \
     int rwkv7_tmix_post_fwd_##SFX(long rows, int D, const void *y, const void *r, const void *k, const void *v,       \
                                   const void *g, const void *gn_w, const void *gn_b, const void *r_k, float eps,      \

@@ -530,6 +530,142 @@ __global__ void relusq_bwd_kernel(long n8, const T *__restrict__ x, const T *__r
 // ------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------
+// residual add + LayerNorm (block structure of rwkv_s2s_single_ffn.py:262-276: x = x + att(ln1(x)); x = x + ffn(ln2(x)))
+//   forward : x1 = x + branch (rounded to T, as the separate add would) ; h = LN(x1) * gamma + beta
+//   backward: dx1 = d_resid + LN'(dh)          (d_resid = gradient arriving at x1 through the residual path)
+// One workgroup (D/8 threads) per row; row sums go through LDS (one slot per 8-lane group).
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float round_to(float v);
+template <>
+__device__ __forceinline__ float round_to<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <>
+__device__ __forceinline__ float round_to<float>(float v) { return v; }
+
+// sum of v over the D/8 threads of the workgroup; red has D/64 slots; every thread gets the total
+__device__ __forceinline__ float block_sum(float v, float *red, int ngroups) {
+    v = sum8(v);
+    if ((threadIdx.x & 7) == 0) red[threadIdx.x >> 3] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < ngroups; i++) t += red[i];
+    return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kEwMaxThreads) void add_ln_fwd_kernel(long rows, int D, const T *__restrict__ x,
+                                                                   const T *__restrict__ branch,
+                                                                   const T *__restrict__ gamma,
+                                                                   const T *__restrict__ beta, float eps,
+                                                                   T *__restrict__ x_out, T *__restrict__ h,
+                                                                   float *__restrict__ mean, float *__restrict__ rstd) {
+    __shared__ float red[2][kEwMaxThreads / 8];
+    const int c = threadIdx.x * 8, ng = D / 64;
+    const float inv_d = 1.0f / (float)D;
+    float gm[8], bt[8];
+    V8<T>::ld(gamma + c, gm);
+    if (beta) {
+        V8<T>::ld(beta + c, bt);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) bt[j] = 0.f;
+    }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long o = row * D + c;
+        float v[8];
+        V8<T>::ld(x + o, v);
+        if (branch) {
+            float b[8];
+            V8<T>::ld(branch + o, b);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = round_to<T>(v[j] + b[j]);
+            V8<T>::st(x_out + o, v);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[j];
+        const float mu = block_sum(s, red[0], ng) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            v[j] -= mu;
+            q = fmaf(v[j], v[j], q);
+        }
+        const float rs = rsqrtf(block_sum(q, red[1], ng) * inv_d + eps);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = fmaf(v[j] * rs, gm[j], bt[j]);
+        V8<T>::st(h + o, v);
+        if (threadIdx.x == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kEwMaxThreads) void add_ln_bwd_kernel(long rows, int D, const T *__restrict__ dh,
+                                                                   const T *__restrict__ d_resid,
+                                                                   const T *__restrict__ x1,
+                                                                   const float *__restrict__ mean,
+                                                                   const float *__restrict__ rstd,
+                                                                   const T *__restrict__ gamma, T *__restrict__ dx,
+                                                                   float *__restrict__ dpart /* [nblk][2][D] */) {
+    __shared__ float red[4][kEwMaxThreads / 8];
+    const int c = threadIdx.x * 8, ng = D / 64;
+    const float inv_d = 1.0f / (float)D;
+    float gm[8], dg[8], db[8];
+    V8<T>::ld(gamma + c, gm);
+#pragma unroll
+    for (int j = 0; j < 8; j++) dg[j] = db[j] = 0.f;
+    int ph = 0;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x, ph ^= 2) {
+        const long o = row * D + c;
+        float g[8], xh[8];
+        V8<T>::ld(dh + o, g);
+        V8<T>::ld(x1 + o, xh);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            xh[j] = (xh[j] - mu) * rs;
+            dg[j] = fmaf(g[j], xh[j], dg[j]);
+            db[j] += g[j];
+            g[j] *= gm[j];
+            s1 += g[j];
+            s2 = fmaf(g[j], xh[j], s2);
+        }
+        // two sums, one barrier (slots alternate between rows so that a fast wave cannot overwrite a slot a slow
+        // wave is still reading)
+        s1 = sum8(s1);
+        s2 = sum8(s2);
+        if ((threadIdx.x & 7) == 0) {
+            red[ph][threadIdx.x >> 3] = s1;
+            red[ph + 1][threadIdx.x >> 3] = s2;
+        }
+        __syncthreads();
+        float m1 = 0.f, m2 = 0.f;
+        for (int i = 0; i < ng; i++) {
+            m1 += red[ph][i];
+            m2 += red[ph + 1][i];
+        }
+        m1 *= inv_d;
+        m2 *= inv_d;
+        float r[8];
+        if (d_resid) {
+            V8<T>::ld(d_resid + o, r);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] += rs * (g[j] - m1 - xh[j] * m2);
+        V8<T>::st(dx + o, r);
+    }
+    V8<float>::st(dpart + ((long)blockIdx.x * 2 + 0) * D + c, dg);
+    V8<float>::st(dpart + ((long)blockIdx.x * 2 + 1) * D + c, db);
+}
+
 static inline int finish() { return (int)hipGetLastError(); }
 
 template <typename T>
@@ -626,6 +762,22 @@ int tmix_post_bwd(long rows, int D, const void *dout, const void *y, const void 
     return finish();
 }
 template <typename T>
+int add_ln_fwd(long rows, int D, const void *x, const void *branch, const void *gamma, const void *beta, float eps,
+               void *x_out, void *h, float *mean, float *rstd, int nblocks, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((add_ln_fwd_kernel<T>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)x,
+                       (const T *)branch, (const T *)gamma, (const T *)beta, eps, (T *)x_out, (T *)h, mean, rstd);
+    return finish();
+}
+template <typename T>
+int add_ln_bwd(long rows, int D, const void *dh, const void *d_resid, const void *x1, const float *mean,
+               const float *rstd, const void *gamma, void *dx, float *dpart, int nblocks, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((add_ln_bwd_kernel<T>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)dh,
+                       (const T *)d_resid, (const T *)x1, mean, rstd, (const T *)gamma, (T *)dx, dpart);
+    return finish();
+}
+template <typename T>
 int relusq_fwd(long n, const void *x, void *y, hipStream_t st) {
     (void)hipGetLastError();
     const long n8 = n / 8;
@@ -650,6 +802,10 @@ int relusq_bwd(long n, const void *x, const void *dy, void *dx, hipStream_t st) 
     template int tmix_prepare_fwd<T>(long, int, const void *, const void *, const void *, const void *, const void *, \
                                      const void *, const void *, const void *, const void *, void *, void *, void *, \
                                      void *, void *, int, hipStream_t);                                             \
+    template int add_ln_fwd<T>(long, int, const void *, const void *, const void *, const void *, float, void *, void *, \
+                               float *, float *, int, hipStream_t);                                                 \
+    template int add_ln_bwd<T>(long, int, const void *, const void *, const void *, const float *, const float *,    \
+                               const void *, void *, float *, int, hipStream_t);                                     \
     template int tmix_prepare_bwd_sum<T>(long, int, const void *, const void *, const void *, const void *,          \
                                          const void *, const void *, const void *, const void *, const void *,       \
                                          const void *const *, void *, void *, void *, void *, void *, void *, void *, \

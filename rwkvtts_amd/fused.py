@@ -373,3 +373,66 @@ def linear(x, weight, bias=None):
             and x.numel() // x.shape[-1] >= WGRAD_MIN_ROWS):
         return _Linear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------------
+# residual add + LayerNorm
+# ------------------------------------------------------------------------------------------------------
+class _AddLN(torch.autograd.Function):
+    """(x1, h) = (x + branch, LayerNorm(x + branch)); with branch None: h = LayerNorm(x) only.
+    backward folds the gradient arriving at x1 through the residual path into the LayerNorm backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, branch, gamma, beta, eps):
+        D = x.shape[-1]
+        x = _c(x)
+        rows = x.numel() // D
+        gamma_c = _c(gamma.to(x.dtype))
+        beta_c = None if beta is None else _c(beta.to(x.dtype))
+        h = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        if branch is not None:
+            branch = _c(branch)
+            x1 = torch.empty_like(x)
+        else:
+            x1 = None
+        _call("add_ln_fwd", x, ctypes.c_long(rows), D, _p(x), _p(branch), _p(gamma_c), _p(beta_c), ctypes.c_float(eps),
+              _p(x1), _p(h), _p(mean), _p(rstd), min(rows, _FWD_BLOCKS))
+        ctx.has_branch, ctx.has_beta = branch is not None, beta is not None
+        ctx.save_for_backward(x1 if branch is not None else x, mean, rstd, gamma_c)
+        if branch is None:
+            return h
+        return x1, h
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xs, mean, rstd, gamma = ctx.saved_tensors
+        D = xs.shape[-1]
+        rows = xs.numel() // D
+        if ctx.has_branch:
+            d_x1, dh = grads
+        else:
+            d_x1, dh = None, grads[0]
+        if dh is None:  # h unused downstream: only the residual path carries gradient
+            dx = d_x1
+            return dx, (dx if ctx.has_branch else None), None, None, None
+        dh = _c(dh)
+        d_x1 = None if d_x1 is None else _c(d_x1)
+        nb = min(rows, _BWD_BLOCKS)
+        dx = torch.empty_like(xs)
+        part = torch.empty(nb, 2, D, dtype=torch.float32, device=xs.device)
+        _call("add_ln_bwd", xs, ctypes.c_long(rows), D, _p(dh), _p(d_x1), _p(xs), _p(mean), _p(rstd), _p(gamma), _p(dx),
+              _p(part), nb)
+        dp = part.sum(0).to(xs.dtype)
+        return dx, (dx if ctx.has_branch else None), dp[0], (dp[1] if ctx.has_beta else None), None
+
+
+def layer_norm(x, norm):
+    """norm: nn.LayerNorm over the last dim."""
+    return _AddLN.apply(x, None, norm.weight, norm.bias, norm.eps)
+
+
+def add_layer_norm(x, branch, norm):
+    """returns (x + branch, norm(x + branch))."""
+    return _AddLN.apply(x, branch, norm.weight, norm.bias, norm.eps)

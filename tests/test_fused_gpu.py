@@ -240,3 +240,56 @@ def test_linear_split_wgrad_vs_fp32_reference(N, K):
     _cmp(wd.grad, wr.grad, 2.0 ** -8 + 1e-3, "dw")   # one bf16 rounding of the fp32 sum
     _cmp(xd.grad, xr.grad, 1e-2, "dx")
     _cmp(bd.grad, br.grad, 1e-2, "db")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D,with_branch,with_bias", [(128, True, True), (1024, True, True), (1024, False, True), (256, True, False)])
+def test_add_layer_norm(dtype, D, with_branch, with_bias):
+    """rwkv7_add_ln_{fwd,bwd}: x1 = x + branch, h = LayerNorm(x1) and the backward with the residual gradient folded
+    in, against torch (fp32 on CPU) on the same rounded inputs."""
+    rows = (3, 37)
+    g = torch.Generator().manual_seed(D)
+    x = (torch.randn(*rows, D, generator=g) * 1.5 + 0.3).to(dtype)
+    br = (torch.randn(*rows, D, generator=g)).to(dtype) if with_branch else None
+    norm = torch.nn.LayerNorm(D, eps=1e-5, bias=with_bias)
+    with torch.no_grad():
+        norm.weight.copy_((1 + 0.2 * torch.randn(D, generator=g)).to(dtype).float())
+        if with_bias:
+            norm.bias.copy_((0.1 * torch.randn(D, generator=g)).to(dtype).float())
+    dh = torch.randn(*rows, D, generator=g).to(dtype)
+    dx1 = torch.randn(*rows, D, generator=g).to(dtype)
+    # reference
+    xr = x.float().clone().requires_grad_(True)
+    brr = None if br is None else br.float().clone().requires_grad_(True)
+    x1r = xr if br is None else (xr + brr)
+    if dtype == torch.bfloat16 and br is not None:
+        x1r = x1r + (x1r.detach().bfloat16().float() - x1r.detach())   # the add is rounded to bf16, straight-through
+    hr = norm(x1r)
+    loss = (hr * dh.float()).sum() + ((x1r * dx1.float()).sum() if br is not None else 0)
+    loss.backward()
+    # HIP
+    import copy
+    nd = copy.deepcopy(norm).to(DEV).to(dtype)
+    xd = x.to(DEV).requires_grad_(True)
+    if br is None:
+        hd = fused.layer_norm(xd, nd)
+        (hd.float() * dh.to(DEV).float()).sum().backward()
+    else:
+        bd = br.to(DEV).requires_grad_(True)
+        x1d, hd = fused.add_layer_norm(xd, bd, nd)
+        ((hd.float() * dh.to(DEV).float()).sum() + (x1d.float() * dx1.to(DEV).float()).sum()).backward()
+        assert torch.equal(bd.grad, xd.grad)
+        if dtype == torch.bfloat16:
+            assert torch.equal(x1d.cpu(), (x.float() + br.float()).bfloat16())
+    if dtype == torch.float32:
+        _cmp(hd, hr, 2e-5, "h")
+        _cmp(xd.grad, xr.grad, 1e-4, "dx")
+        _cmp(nd.weight.grad, norm.weight.grad, 1e-4, "dgamma")
+        if with_bias:
+            _cmp(nd.bias.grad, norm.bias.grad, 1e-4, "dbeta")
+    else:
+        _cmp_bf16(hd, hr, "h")
+        _cmp_bf16(xd.grad, xr.grad, "dx")
+        _cmp(nd.weight.grad, norm.weight.grad, 1e-2, "dgamma")
+        if with_bias:
+            _cmp(nd.bias.grad, norm.bias.grad, 1e-2, "dbeta")
