@@ -24,6 +24,8 @@
 #ifndef RWKV7_HIP_H
 #define RWKV7_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -57,6 +59,15 @@ int rwkv7_wkv_bwd_bf16(int B, int T, int H, const void *w, const void *q, const 
 int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                       const void *a, const void *b, const void *dy, const float *s, const float *sa,
                       void *dw, void *dq, void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
+
+/* Sizes of the two caller-allocated scratch tensors of the training forward/backward pair (the reference allocates
+ * them in Python, rwkv_s2s_single_ffn.py:22-24): s = fp32 [B,H,T/16,64,64] state checkpoints, sa = fp32 [B,T,H,64]. */
+int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_bytes);
+
+/* measurement aid: force the forward kernel's shape (4 or 8 state columns per lane; 0 = automatic by B*H) */
+void rwkv7_debug_set_fwd_shape(int cols_per_lane);
+/* row-split backward: 0 = 256 threads, 2 state rows per lane tile (default); 1 = 512 threads, 1 row per lane tile */
+void rwkv7_debug_set_bwd_shape(int wide);
 
 /* ---- same backward with each head split over two workgroups (32 state rows each) so that 256 CUs are busy at
  *      B*H = 128.  dv is complete; dw,dq,dk,da,db are HOST arrays of 2 device pointers receiving the two partial

@@ -30,6 +30,8 @@ int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, cons
 int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                   const float *, void *, float *, float *, hipStream_t);
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
+void fwd_force_shape(int);
+void bwd_force_shape(int);
 int lora_down_bf16(long, int, int, int, const void *, const void *, void *, hipStream_t);
 int lora_dgrad_up_bf16(long, int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 struct bf16_t;
@@ -126,6 +128,16 @@ int rwkv7_lora_dgrad_up_bf16(long M, int K, int R, int act, const void *dz, cons
     if (!lora_shape_ok(M, K, R, act)) return RWKV7_ESHAPE;
     return rwkv7::lora_dgrad_up_bf16(M, K, R, act, dz, w2t, a, dy, (hipStream_t)stream);
 }
+
+int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_bytes) {
+    if (B <= 0 || T <= 0 || H <= 0 || !s_bytes || !sa_bytes) return RWKV7_EINVAL;
+    if (T % RWKV7_CHUNK_LEN != 0) return RWKV7_ECHUNK;
+    *s_bytes = (size_t)B * H * (T / RWKV7_CHUNK_LEN) * RWKV7_HEAD_SIZE * RWKV7_HEAD_SIZE * sizeof(float);
+    *sa_bytes = (size_t)B * T * H * RWKV7_HEAD_SIZE * sizeof(float);
+    return 0;
+}
+void rwkv7_debug_set_fwd_shape(int cols_per_lane) { rwkv7::fwd_force_shape(cols_per_lane); }
+void rwkv7_debug_set_bwd_shape(int wide) { rwkv7::bwd_force_shape(wide); }
 
 #define STATE_BODY(IMPL)                                                                              \
     if (B <= 0 || T <= 0 || H <= 0 || any_null({state, r, w, k, v, a, b, y})) return RWKV7_EINVAL;   \

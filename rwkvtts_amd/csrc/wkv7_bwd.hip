@@ -42,19 +42,27 @@ struct BwdOuts {
     T *dv;
 };
 
-template <typename T, int RT>
-__global__ __launch_bounds__(256) void wkv7_bwd_kernel(
+// RT = state rows per lane tile, NW = wavefronts per workgroup; a workgroup owns NW*4*RT rows of a head:
+//   <4,4> 64 rows, 256 threads: the whole head (reference-schema op)
+//   <2,4> 32 rows, 256 threads: two workgroups per head
+//   <1,8> 32 rows, 512 threads: two workgroups per head AND two waves per SIMD (measured slower, see g_bwd_split_wide)
+// The per-wave column partials are combined every FL = 64/NW steps (16 or 8), which keeps sh_part at 80 KB.
+template <typename T, int RT, int NW>
+__global__ __launch_bounds__(64 * NW) void wkv7_bwd_kernel(
     int T_, int H, const T *__restrict__ w_, const T *__restrict__ q_, const T *__restrict__ k_,
     const T *__restrict__ v_, const T *__restrict__ a_, const T *__restrict__ b_, const T *__restrict__ dy_,
     const float *__restrict__ s_, const float *__restrict__ sa_, BwdOuts<T> outs) {
-    constexpr int NSPLIT = 4 / RT;       // workgroups per head
-    constexpr int ROWS_WG = 16 * RT;     // state rows per workgroup
+    constexpr int ROWS_WG = NW * 4 * RT;  // state rows per workgroup
+    constexpr int NSPLIT = kN / ROWS_WG;  // workgroups per head
+    constexpr int FL = 64 / NW;           // steps between two write-outs
+    constexpr bool WIDE = NW == 8;        // 512 threads: staging and write-out work is split between the halves
+    static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float(*sh_cv)[NCV][kN] = reinterpret_cast<float(*)[NCV][kN]>(smem);                       // [kTB][7][64]
     float(*sh_rv)[NRV][kN] = reinterpret_cast<float(*)[NRV][kN]>(smem + kTB * NCV * kN);      // [kTB][3][64]
-    float(*sh_part)[kTB][NOUT][kN] =
-        reinterpret_cast<float(*)[kTB][NOUT][kN]>(smem + kTB * (NCV + NRV) * kN);             // [4][kTB][5][64]
-    float(*sh_dv)[kN] = reinterpret_cast<float(*)[kN]>(smem + kTB * (NCV + NRV) * kN + 4 * kTB * NOUT * kN);
+    float(*sh_part)[FL][NOUT][kN] =
+        reinterpret_cast<float(*)[FL][NOUT][kN]>(smem + kTB * (NCV + NRV) * kN);              // [NW][FL][5][64]
+    float(*sh_dv)[kN] = reinterpret_cast<float(*)[kN]>(smem + kTB * (NCV + NRV) * kN + NW * FL * NOUT * kN);
 
     const int part = blockIdx.x % NSPLIT;
     const int bh = blockIdx.x / NSPLIT;
@@ -66,8 +74,10 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
     const int r0 = part * ROWS_WG + r0l;         // ... inside the head
     const int c0 = tj * 4;
 
-    const int st = tid >> 4;          // staging: time step inside the stage
-    const int sc = (tid & 15) * 4;    // staging: element quad
+    // staging roles: 16 steps x 16 element quads; with 512 threads the lower half takes w,q,k,a and the upper b,v,dy,sa
+    const int st = (tid & 255) >> 4;
+    const int sc = (tid & 15) * 4;
+    const bool lo_half = !WIDE || tid < 256, hi_half = !WIDE || tid >= 256;
 
     const long tstride = (long)H * kN;
     const long head_base = ((long)bb * T_ * H + hh) * kN;
@@ -84,40 +94,169 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
 
     auto issue = [&](int t0) {
         const long off = head_base + (long)(t0 + st) * tstride + sc;
-        rw = ld4<T>(w_ + off, true);
-        rq = ld4<T>(q_ + off, true);
-        rk = ld4<T>(k_ + off, true);
-        ra = ld4<T>(a_ + off, true);
-        rb = ld4<T>(b_ + off, true);
-        rvv = ld4<T>(v_ + off, true);
-        rdy = ld4<T>(dy_ + off, true);
-        rsa = *reinterpret_cast<const float4 *>(sa_ + off);
+        if (lo_half) {
+            rw = ld4<T>(w_ + off, true);
+            rq = ld4<T>(q_ + off, true);
+            rk = ld4<T>(k_ + off, true);
+            ra = ld4<T>(a_ + off, true);
+        }
+        if (hi_half) {
+            rb = ld4<T>(b_ + off, true);
+            rvv = ld4<T>(v_ + off, true);
+            rdy = ld4<T>(dy_ + off, true);
+            rsa = *reinterpret_cast<const float4 *>(sa_ + off);
+        }
     };
     auto stage = [&]() {
-        const float4 wr = cvt4(rw);
-        float4 wf, wt, iw, ws;
-        wf.x = -fast_exp(wr.x); wf.y = -fast_exp(wr.y); wf.z = -fast_exp(wr.z); wf.w = -fast_exp(wr.w);
-        wt.x = fast_exp(wf.x); wt.y = fast_exp(wf.y); wt.z = fast_exp(wf.z); wt.w = fast_exp(wf.w);
-        iw.x = 1.0f / wt.x; iw.y = 1.0f / wt.y; iw.z = 1.0f / wt.z; iw.w = 1.0f / wt.w;
-        ws.x = wt.x * wf.x; ws.y = wt.y * wf.y; ws.z = wt.z * wf.z; ws.w = wt.w * wf.w;
-        *reinterpret_cast<float4 *>(&sh_cv[st][CV_W][sc]) = wt;
-        *reinterpret_cast<float4 *>(&sh_cv[st][CV_IW][sc]) = iw;
-        *reinterpret_cast<float4 *>(&sh_cv[st][CV_WS][sc]) = ws;
-        *reinterpret_cast<float4 *>(&sh_cv[st][CV_Q][sc]) = cvt4(rq);
-        *reinterpret_cast<float4 *>(&sh_cv[st][CV_K][sc]) = cvt4(rk);
-        *reinterpret_cast<float4 *>(&sh_cv[st][CV_A][sc]) = cvt4(ra);
-        *reinterpret_cast<float4 *>(&sh_cv[st][CV_B][sc]) = cvt4(rb);
-        *reinterpret_cast<float4 *>(&sh_rv[st][RV_V][sc]) = cvt4(rvv);
-        *reinterpret_cast<float4 *>(&sh_rv[st][RV_DY][sc]) = cvt4(rdy);
-        *reinterpret_cast<float4 *>(&sh_rv[st][RV_SA][sc]) = rsa;
+        if (lo_half) {
+            const float4 wr = cvt4(rw);
+            float4 wf, wt, iw, ws;
+            wf.x = -fast_exp(wr.x); wf.y = -fast_exp(wr.y); wf.z = -fast_exp(wr.z); wf.w = -fast_exp(wr.w);
+            wt.x = fast_exp(wf.x); wt.y = fast_exp(wf.y); wt.z = fast_exp(wf.z); wt.w = fast_exp(wf.w);
+            iw.x = 1.0f / wt.x; iw.y = 1.0f / wt.y; iw.z = 1.0f / wt.z; iw.w = 1.0f / wt.w;
+            ws.x = wt.x * wf.x; ws.y = wt.y * wf.y; ws.z = wt.z * wf.z; ws.w = wt.w * wf.w;
+            *reinterpret_cast<float4 *>(&sh_cv[st][CV_W][sc]) = wt;
+            *reinterpret_cast<float4 *>(&sh_cv[st][CV_IW][sc]) = iw;
+            *reinterpret_cast<float4 *>(&sh_cv[st][CV_WS][sc]) = ws;
+            *reinterpret_cast<float4 *>(&sh_cv[st][CV_Q][sc]) = cvt4(rq);
+            *reinterpret_cast<float4 *>(&sh_cv[st][CV_K][sc]) = cvt4(rk);
+            *reinterpret_cast<float4 *>(&sh_cv[st][CV_A][sc]) = cvt4(ra);
+        }
+        if (hi_half) {
+            *reinterpret_cast<float4 *>(&sh_cv[st][CV_B][sc]) = cvt4(rb);
+            *reinterpret_cast<float4 *>(&sh_rv[st][RV_V][sc]) = cvt4(rvv);
+            *reinterpret_cast<float4 *>(&sh_rv[st][RV_DY][sc]) = cvt4(rdy);
+            *reinterpret_cast<float4 *>(&sh_rv[st][RV_SA][sc]) = rsa;
+        }
     };
     auto ld_rows = [&](const float *p, float (&o)[RT]) {  // RT consecutive floats, RT-aligned
         if constexpr (RT == 4) {
             const float4 x = *reinterpret_cast<const float4 *>(p);
             o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
-        } else {
+        } else if constexpr (RT == 2) {
             const float2 x = *reinterpret_cast<const float2 *>(p);
             o[0] = x.x; o[1] = x.y;
+        } else {
+            o[0] = *p;
+        }
+    };
+
+    // one reverse time step; column partials go to slot `fs` of this wave's sh_part
+    auto step = [&](const int tt, const int fs) {
+        const float4 wt4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_W][c0]);
+        const float4 iw4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_IW][c0]);
+        const float4 q4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_Q][c0]);
+        const float4 k4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_K][c0]);
+        const float4 a4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_A][c0]);
+        const float4 b4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_B][c0]);
+        const float wt[4] = {wt4.x, wt4.y, wt4.z, wt4.w};
+        const float iw[4] = {iw4.x, iw4.y, iw4.z, iw4.w};
+        const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float kv[4] = {k4.x, k4.y, k4.z, k4.w};
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        float vv[RT], dyv[RT], sav[RT];
+        ld_rows(&sh_rv[tt][RV_V][r0], vv);
+        ld_rows(&sh_rv[tt][RV_DY][r0], dyv);
+        ld_rows(&sh_rv[tt][RV_SA][r0], sav);
+
+        float colp[NOUT][4];  // dq, dw, dk, db, da partial sums over this lane's RT rows
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float dq = 0.f;
+#pragma unroll
+            for (int r = 0; r < RT; r++) dq = fmaf(S[r][c], dyv[r], dq);
+            colp[0][c] = dq;
+        }
+        float dvp[RT], dsbp[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) dvp[r] = dsbp[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float dw = 0.f, dk = 0.f, db = 0.f;
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                // un-do step t: S_{t-1} = (S_t - v k^T - sa b^T) / w~
+                S[r][c] = (S[r][c] - kv[c] * vv[r] - bv[c] * sav[r]) * iw[c];
+                dS[r][c] = fmaf(dyv[r], qv[c], dS[r][c]);
+                dw = fmaf(dS[r][c], S[r][c], dw);
+                dk = fmaf(dS[r][c], vv[r], dk);
+                db = fmaf(dS[r][c], sav[r], db);
+                dvp[r] = fmaf(dS[r][c], kv[c], dvp[r]);
+                dsbp[r] = fmaf(dS[r][c], bv[c], dsbp[r]);
+            }
+            colp[1][c] = dw;
+            colp[2][c] = dk;
+            colp[3][c] = db;
+        }
+        float dvv[RT], dsb[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            dvv[r] = sum16(dvp[r]);
+            dsb[r] = sum16(dsbp[r]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float da = 0.f;
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                da = fmaf(S[r][c], dsb[r], da);
+                dS[r][c] = fmaf(dS[r][c], wt[c], dsb[r] * av[c]);
+            }
+            colp[4][c] = da;
+        }
+        // column partials -> wave totals, over the 4 row groups (til) of this wave.  Transposing
+        // butterfly: v_permlane32_swap pairs column c with c+2 (lanes <32 keep c, lanes >=32 keep c+2),
+        // v_permlane16_swap pairs c with c+1 (even DPP rows keep c, odd rows keep c+1): 15 swaps + 15
+        // adds for 20 values, and row `til` ends up owning column c0 + til of all 5 outputs -- every lane
+        // then stores its 5 totals (64 distinct consecutive addresses per output), no exec-masked store.
+#pragma unroll
+        for (int o = 0; o < NOUT; o++) {
+            const float x0 = swap32_sum(colp[o][0], colp[o][2]);
+            const float x1 = swap32_sum(colp[o][1], colp[o][3]);
+            sh_part[wave][fs][o][c0 + til] = swap16_sum(x0, x1);
+        }
+        {
+            // dv[r] totals are replicated over the 16 lanes of the DPP row: lane tj stores local row r0l + tj % RT
+            const int rs = tj & (RT - 1);
+            float d = dvv[0];
+#pragma unroll
+            for (int r = 1; r < RT; r++) d = rs == r ? dvv[r] : d;
+            sh_dv[fs][r0l + rs] = d;
+        }
+    };
+
+    // write-out of FL steps starting at stage step tb: sum the NW wave partials of a column quad.  256 threads take
+    // part; with FL = 8 they form two groups (outputs dq,dw,dk | db,da,dv), with FL = 16 every thread does all six.
+    auto write_out = [&](const int t0, const int tb) {
+        constexpr int NOG = 16 / FL;  // output groups
+        if (tid >= 256) return;
+        const int fs = (tid >> 4) % FL, og = (tid >> 4) / FL;
+        const int tt = tb + fs;
+        const long off_t = head_base + (long)(t0 + tt) * tstride;
+        const long off = off_t + sc;
+        auto total = [&](const int i) {
+            float4 acc = *reinterpret_cast<const float4 *>(&sh_part[0][fs][i][sc]);
+#pragma unroll
+            for (int wv = 1; wv < NW; wv++) {
+                const float4 p = *reinterpret_cast<const float4 *>(&sh_part[wv][fs][i][sc]);
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+            return acc;
+        };
+        if (NOG == 1 || og == 0) {
+            st4(outs.dq[part] + off, total(0));
+            float4 o1 = total(1);
+            const float4 ws = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_WS][sc]);
+            o1.x *= ws.x; o1.y *= ws.y; o1.z *= ws.z; o1.w *= ws.w;  // dw * w~ * (-exp(w)), wkv7_cuda.cu:108
+            st4(outs.dw[part] + off, o1);
+            st4(outs.dk[part] + off, total(2));
+        }
+        if (NOG == 1 || og == 1) {
+            st4(outs.db[part] + off, total(3));
+            st4(outs.da[part] + off, total(4));
+            if (sc < ROWS_WG)
+                st4(outs.dv + off_t + part * ROWS_WG + sc, *reinterpret_cast<const float4 *>(&sh_dv[fs][sc]));
         }
     };
 
@@ -142,116 +281,14 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
                 for (int r = 0; r < RT; r++) S[r][c] = x[r];
             }
         }
+#pragma unroll 1
+        for (int tb = kTB - FL; tb >= 0; tb -= FL) {
 #pragma unroll 4
-        for (int tt = kTB - 1; tt >= 0; tt--) {
-            const float4 wt4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_W][c0]);
-            const float4 iw4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_IW][c0]);
-            const float4 q4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_Q][c0]);
-            const float4 k4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_K][c0]);
-            const float4 a4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_A][c0]);
-            const float4 b4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_B][c0]);
-            const float wt[4] = {wt4.x, wt4.y, wt4.z, wt4.w};
-            const float iw[4] = {iw4.x, iw4.y, iw4.z, iw4.w};
-            const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
-            const float kv[4] = {k4.x, k4.y, k4.z, k4.w};
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-            float vv[RT], dyv[RT], sav[RT];
-            ld_rows(&sh_rv[tt][RV_V][r0], vv);
-            ld_rows(&sh_rv[tt][RV_DY][r0], dyv);
-            ld_rows(&sh_rv[tt][RV_SA][r0], sav);
-
-            float colp[NOUT][4];  // dq, dw, dk, db, da partial sums over this lane's RT rows
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float dq = 0.f;
-#pragma unroll
-                for (int r = 0; r < RT; r++) dq = fmaf(S[r][c], dyv[r], dq);
-                colp[0][c] = dq;
-            }
-            float dvp[RT], dsbp[RT];
-#pragma unroll
-            for (int r = 0; r < RT; r++) dvp[r] = dsbp[r] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float dw = 0.f, dk = 0.f, db = 0.f;
-#pragma unroll
-                for (int r = 0; r < RT; r++) {
-                    // un-do step t: S_{t-1} = (S_t - v k^T - sa b^T) / w~
-                    S[r][c] = (S[r][c] - kv[c] * vv[r] - bv[c] * sav[r]) * iw[c];
-                    dS[r][c] = fmaf(dyv[r], qv[c], dS[r][c]);
-                    dw = fmaf(dS[r][c], S[r][c], dw);
-                    dk = fmaf(dS[r][c], vv[r], dk);
-                    db = fmaf(dS[r][c], sav[r], db);
-                    dvp[r] = fmaf(dS[r][c], kv[c], dvp[r]);
-                    dsbp[r] = fmaf(dS[r][c], bv[c], dsbp[r]);
-                }
-                colp[1][c] = dw;
-                colp[2][c] = dk;
-                colp[3][c] = db;
-            }
-            float dvv[RT], dsb[RT];
-#pragma unroll
-            for (int r = 0; r < RT; r++) {
-                dvv[r] = sum16(dvp[r]);
-                dsb[r] = sum16(dsbp[r]);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float da = 0.f;
-#pragma unroll
-                for (int r = 0; r < RT; r++) {
-                    da = fmaf(S[r][c], dsb[r], da);
-                    dS[r][c] = fmaf(dS[r][c], wt[c], dsb[r] * av[c]);
-                }
-                colp[4][c] = da;
-            }
-            // column partials -> wave totals, over the 4 row groups (til) of this wave.  Transposing
-            // butterfly: v_permlane32_swap pairs column c with c+2 (lanes <32 keep c, lanes >=32 keep c+2),
-            // v_permlane16_swap pairs c with c+1 (even DPP rows keep c, odd rows keep c+1): 15 swaps + 15
-            // adds for 20 values, and row `til` ends up owning column c0 + til of all 5 outputs -- every lane
-            // then stores its 5 totals (64 distinct consecutive addresses per output), no exec-masked store.
-#pragma unroll
-            for (int o = 0; o < NOUT; o++) {
-                const float x0 = swap32_sum(colp[o][0], colp[o][2]);
-                const float x1 = swap32_sum(colp[o][1], colp[o][3]);
-                sh_part[wave][tt][o][c0 + til] = swap16_sum(x0, x1);
-            }
-            {
-                // dv[r] totals are replicated over the 16 lanes of the DPP row: lane tj stores local row r0l + tj % RT
-                const int rs = tj & (RT - 1);
-                float d = dvv[0];
-#pragma unroll
-                for (int r = 1; r < RT; r++) d = rs == r ? dvv[r] : d;
-                sh_dv[tt][r0l + rs] = d;
-            }
+            for (int fs = FL - 1; fs >= 0; fs--) step(tb + fs, fs);
+            __syncthreads();
+            write_out(t0, tb);
+            __syncthreads();
         }
-        __syncthreads();
-        {
-            // stage write-out: thread (st, sc) sums the 4 wave partials of its column quad
-            const long off_t = head_base + (long)(t0 + st) * tstride;
-            const long off = off_t + sc;
-            float4 o[NOUT];
-#pragma unroll
-            for (int i = 0; i < NOUT; i++) {
-                float4 acc = *reinterpret_cast<const float4 *>(&sh_part[0][st][i][sc]);
-#pragma unroll
-                for (int wv = 1; wv < 4; wv++) {
-                    const float4 p = *reinterpret_cast<const float4 *>(&sh_part[wv][st][i][sc]);
-                    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-                }
-                o[i] = acc;
-            }
-            const float4 ws = *reinterpret_cast<const float4 *>(&sh_cv[st][CV_WS][sc]);
-            o[1].x *= ws.x; o[1].y *= ws.y; o[1].z *= ws.z; o[1].w *= ws.w;  // dw * w~ * (-exp(w)), :108
-            st4(outs.dq[part] + off, o[0]);
-            st4(outs.dw[part] + off, o[1]);
-            st4(outs.dk[part] + off, o[2]);
-            st4(outs.db[part] + off, o[3]);
-            st4(outs.da[part] + off, o[4]);
-            if (sc < ROWS_WG) st4(outs.dv + off_t + part * ROWS_WG + sc, *reinterpret_cast<const float4 *>(&sh_dv[st][sc]));
-        }
-        __syncthreads();
         if (n > 0) {
             stage();
             __syncthreads();
@@ -259,25 +296,35 @@ __global__ __launch_bounds__(256) void wkv7_bwd_kernel(
     }
 }
 
-constexpr size_t kBwdSmemBytes = (size_t)(kTB * (NCV + NRV) * kN + 4 * kTB * NOUT * kN + kTB * kN) * sizeof(float);
+template <int NW>
+constexpr size_t bwd_smem_bytes() {
+    return (size_t)(kTB * (NCV + NRV) * kN + NW * (64 / NW) * NOUT * kN + (64 / NW) * kN) * sizeof(float);
+}
 
-template <typename T, int RT>
+template <typename T, int RT, int NW>
 static int launch_bwd(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v,
                       const void *a, const void *b, const void *dy, const float *s, const float *sa,
                       const BwdOuts<T> &outs, hipStream_t stream) {
+    constexpr size_t smem = bwd_smem_bytes<NW>();
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7_bwd_kernel<T, RT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdSmemBytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7_bwd_kernel<T, RT, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     (void)hipGetLastError();  // drop any stale error left by an earlier runtime call of the host program
-    hipLaunchKernelGGL((wkv7_bwd_kernel<T, RT>), dim3(B * H * (4 / RT)), dim3(256), kBwdSmemBytes, stream, T_, H,
-                       (const T *)w, (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b,
+    hipLaunchKernelGGL((wkv7_bwd_kernel<T, RT, NW>), dim3(B * H * (kN / (NW * 4 * RT))), dim3(64 * NW), smem, stream,
+                       T_, H, (const T *)w, (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b,
                        (const T *)dy, s, sa, outs);
     return (int)hipGetLastError();
 }
+
+// 0: <2,4> (256 threads, default), 1: <1,8> (512 threads); rwkv7_debug_set_bwd_shape.  Measured at B=8,T=4096,H=16:
+// <2,4> 2.11 ms, <1,8> 2.56 ms -- with 8 waves the 9 ds_read_b128 per wave and step saturate the LDS return path
+// (8 x ~60 cycles per step per CU), so the second wave per SIMD buys nothing.
+static int g_bwd_split_wide = 0;
+void bwd_force_shape(int wide) { g_bwd_split_wide = wide ? 1 : 0; }
 
 template <typename T>
 static int bwd_full(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
@@ -286,7 +333,7 @@ static int bwd_full(int B, int T_, int H, const void *w, const void *q, const vo
     BwdOuts<T> o;
     o.dw[0] = o.dw[1] = (T *)dw; o.dq[0] = o.dq[1] = (T *)dq; o.dk[0] = o.dk[1] = (T *)dk;
     o.db[0] = o.db[1] = (T *)db; o.da[0] = o.da[1] = (T *)da; o.dv = (T *)dv;
-    return launch_bwd<T, 4>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
+    return launch_bwd<T, 4, 4>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
 }
 template <typename T>
 static int bwd_split(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
@@ -297,7 +344,8 @@ static int bwd_split(int B, int T_, int H, const void *w, const void *q, const v
         o.dw[i] = (T *)dw[i]; o.dq[i] = (T *)dq[i]; o.dk[i] = (T *)dk[i]; o.db[i] = (T *)db[i]; o.da[i] = (T *)da[i];
     }
     o.dv = (T *)dv;
-    return launch_bwd<T, 2>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
+    if (g_bwd_split_wide) return launch_bwd<T, 1, 8>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
+    return launch_bwd<T, 2, 4>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
 }
 
 int wkv_bwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,

@@ -43,6 +43,21 @@ def test_argument_errors_do_not_launch(hip_lib):
     # H*64 != C -> RWKV7_EHEAD (reference: assert at rwkv7_state_fwd_fp16.cu:61)
     assert hip_lib.rwkv7_wkv_state_fwd_bf16(1, 1, 100, 2, one, one, one, one, one, one, one, one, None) == -3
     assert hip_lib.rwkv7_wkv_state_fwd_bf16(0, 1, 128, 2, one, one, one, one, one, one, one, one, None) == -1
+    # the row-split backward and the fused stages validate the same way
+    two = (ctypes.c_void_p * 2)(16, 16)
+    assert hip_lib.rwkv7_wkv_bwd_split_bf16(1, 24, 1, *([one] * 9), two, two, two, one, two, two, None) == -2
+    bad = (ctypes.c_void_p * 2)(16, None)
+    assert hip_lib.rwkv7_wkv_bwd_split_bf16(1, 16, 1, *([one] * 9), two, bad, two, one, two, two, None) == -1
+    assert hip_lib.rwkv7_add_ln_fwd_bf16(ctypes.c_long(4), 100, one, None, one, None, ctypes.c_float(1e-5), None, one, one,
+                                         one, 4, None) == -4          # D % 64 != 0 -> RWKV7_ESHAPE
+    assert hip_lib.rwkv7_lora_down_bf16(ctypes.c_long(64), 1024, 48, 0, one, one, one, None) == -4   # rank 48 unsupported
+
+
+def test_workspace_query(hip_lib):
+    s, sa = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip_lib.rwkv7_wkv_workspace_bytes(8, 4096, 16, ctypes.byref(s), ctypes.byref(sa)) == 0
+    assert s.value == 8 * 16 * 256 * 64 * 64 * 4 and sa.value == 8 * 4096 * 16 * 64 * 4   # 512 MiB / 128 MiB, SURVEY 8(a) a1
+    assert hip_lib.rwkv7_wkv_workspace_bytes(8, 4097, 16, ctypes.byref(s), ctypes.byref(sa)) == -2
 
 
 def test_reference_op_namespaces_exist_and_refuse_cpu():

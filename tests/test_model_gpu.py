@@ -252,3 +252,21 @@ def test_fused_tmix_core_equals_separate_nodes(dtype, tol):
     assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) > 50
     for n in res[True][2]:
         close(res[True][2][n], res[False][2][n], n)
+
+
+def test_cfg4_width_block_matches_oracle():
+    """BASELINE configs[3] (XY 1.5B) dimensions -- D = 2048, H = 32, LoRA ranks 96/96/64/256 -- on one block pair, fp32,
+    against the oracle: the fused stages run 256 threads per row here instead of 128."""
+    dims = dict(hidden_size=2048, num_hidden_layers=2, decay_low_rank_dim=96, a_low_rank_dim=96, v_low_rank_dim=64,
+                gate_low_rank_dim=256)
+    rcfg = R.RefConfig(vocab_size=32, **dims)
+    p = R.init_params(rcfg, seed=4)
+    model = RWKV7Model(RWKV7Config(vocab_size=32, **dims))
+    model.load_state_dict({k[len("model."):]: v for k, v in p.items() if k.startswith("model.")}, strict=True)
+    model = model.to(DEV).eval()
+    B, T = 2, 32
+    x = torch.randn(B, T, 2048, generator=torch.Generator().manual_seed(8)) * 0.5
+    with torch.no_grad():
+        h = model(inputs_embeds=x.to(DEV)).last_hidden_state.cpu()
+        h_o, _ = R.backbone(p, rcfg, x, None)
+    assert (h - h_o).abs().max().item() < 1e-3 * max(1.0, h_o.abs().max().item())

@@ -196,10 +196,19 @@ def test_full_size_config2_properties_and_slices(c_oracle):
     assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
 
 
+@pytest.fixture(params=[1, 0], ids=["512thr", "256thr"])
+def bwd_shape(request):
+    from rwkvtts_amd import _lib
+    _lib.lib().rwkv7_debug_set_bwd_shape(request.param)
+    yield request.param
+    _lib.lib().rwkv7_debug_set_bwd_shape(0)
+
+
 @pytest.mark.parametrize("B,T,H,seed", [(1, 16, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_row_split_backward_vs_oracle(c_oracle, B, T, H, seed, dtype):
-    """rwkv7_wkv_bwd_split_*: two workgroups per head; dv complete, the other five as two partial column sums."""
+def test_row_split_backward_vs_oracle(c_oracle, bwd_shape, B, T, H, seed, dtype):
+    """rwkv7_wkv_bwd_split_*: two workgroups per head (512 threads x 1 row per lane tile, or 256 threads x 2 rows);
+    dv complete, the other five as two partial column sums."""
     ins = make_wkv_inputs(B, T, H, seed, dtype)
     dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).to(dtype)
     y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
@@ -226,3 +235,40 @@ def test_row_split_backward_vs_oracle(c_oracle, B, T, H, seed, dtype):
             _assert_f32_close(tot, g_o[n], n, 5e-4)
     if dtype == torch.bfloat16:
         _assert_bf16_close(dv, g_o["dv"], "dv", ulps=2.0)
+
+
+@pytest.mark.parametrize("cw", [4, 8])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_forward_both_lane_shapes_vs_oracle(c_oracle, cw, dtype):
+    """The launcher picks 4 or 8 state columns per lane from B*H; force each and check forward + saved tensors +
+    carried state against the oracle."""
+    from rwkvtts_amd import _lib
+    B, T, H = 2, 64, 3
+    ins = make_wkv_inputs(B, T, H, 11, dtype)
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    d = [t.to(DEV) for t in ins]
+    y, s, sa = torch.empty_like(d[0]), torch.empty(B, H, T // 16, 64, 64, device=DEV), torch.empty(B, T, H, 64, device=DEV)
+    st0 = torch.randn(B, H, 64, 64, generator=torch.Generator().manual_seed(5)) * 0.1
+    w, q, k, v, a, b = ins
+    st_o = st0.clone()
+    y2_o = c_oracle.wkv7_state_fwd(st_o, *[t.reshape(B, T, H * 64) for t in (q, w, k, v, a, b)])
+    st = st0.to(DEV).clone()
+    y2 = torch.empty_like(d[0])
+    f3 = lambda t: t.view(B, T, H * 64)
+    _lib.lib().rwkv7_debug_set_fwd_shape(cw)
+    try:
+        torch.ops.wind_backstepping.forward(*d, y, s, sa)
+        torch.ops.rwkv7_state_fwd_fp16.forward(B, T, H * 64, H, st, f3(d[1]), f3(d[0]), f3(d[2]), f3(d[3]), f3(d[4]),
+                                                f3(d[5]), f3(y2))
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().rwkv7_debug_set_fwd_shape(0)
+    if dtype == torch.bfloat16:
+        _assert_bf16_close(y, y_o, "y")
+        _assert_bf16_close(y2, y2_o.view(B, T, H, 64), "y(state)")
+    else:
+        _assert_f32_close(y, y_o, "y", 2e-5)
+        _assert_f32_close(y2, y2_o.view(B, T, H, 64), "y(state)", 2e-5)
+    _assert_f32_close(s, s_o, "s", 2e-5)
+    _assert_f32_close(sa, sa_o, "sa", 2e-5)
+    _assert_f32_close(st, st_o, "state", 2e-5)

@@ -67,8 +67,19 @@ def main():
     st_ = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     sfx = "bf16" if a.dtype == "bf16" else "f32"
     cf = lambda: getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_" + sfx)(B, T, H, P(w), P(q), P(k), P(v), P(aa), P(b), P(tinv), P(y), P(sa2), P(hs), st_)
-    for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz), ("wkv7_bwd", bwd, 13 * 64 * esz),
-                                ("wkv7_bwd row-split", bwd2, 13 * 64 * esz),
+    def shaped(cw, fn):
+        def g():
+            _lib.lib().rwkv7_debug_set_fwd_shape(cw)
+            fn()
+            _lib.lib().rwkv7_debug_set_fwd_shape(0)
+        return g
+    for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz),
+                                ("wkv7_fwd 8 col/lane", shaped(8, fwd), 7 * 64 * esz),
+                                ("wkv7_fwd 4 col/lane", shaped(4, fwd), 7 * 64 * esz),
+                                ("wkv7_state_fwd 8 col/lane", shaped(8, sfw), 7 * 64 * esz),
+                                ("wkv7_state_fwd 4 col/lane", shaped(4, sfw), 7 * 64 * esz), ("wkv7_bwd", bwd, 13 * 64 * esz),
+                                ("wkv7_bwd row-split 256 thr", bwd2, 13 * 64 * esz),
+                                ("wkv7_bwd row-split 512 thr", lambda: (_lib.lib().rwkv7_debug_set_bwd_shape(1), bwd2(), _lib.lib().rwkv7_debug_set_bwd_shape(0)), 13 * 64 * esz),
                                 ("wkv7_state_fwd", sfw, 7 * 64 * esz), ("wkv7c_prep (T inverse)", prep, 3 * 64 * esz),
                                 ("wkv7c_fwd (chunked, save)", cf, 7 * 64 * esz)):
         med, best = timeit(fn, a.iters)
