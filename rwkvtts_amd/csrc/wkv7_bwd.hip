@@ -26,6 +26,8 @@
 
 namespace rwkv7 {
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
 namespace {
 constexpr int CV_W = 0, CV_IW = 1, CV_WS = 2, CV_Q = 3, CV_K = 4, CV_A = 5, CV_B = 6;  // per-column streams
 constexpr int RV_V = 0, RV_DY = 1, RV_SA = 2;                                          // per-row streams
@@ -141,7 +143,10 @@ __global__ __launch_bounds__(64 * NW) void wkv7_bwd_kernel(
         }
     };
 
-    // one reverse time step; column partials go to slot `fs` of this wave's sh_part
+    // one reverse time step; column partials go to slot `fs` of this wave's sh_part.
+    // The 4 columns of the lane tile are handled as two float pairs so that the whole state arithmetic is
+    // v_pk_fma_f32 / v_pk_mul_f32 (2 fp32 lanes per instruction; the row scalars v, dy, sa, dSb are broadcast
+    // through op_sel): 13 packed instructions per row and column pair instead of ~20 scalar ones.
     auto step = [&](const int tt, const int fs) {
         const float4 wt4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_W][c0]);
         const float4 iw4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_IW][c0]);
@@ -149,61 +154,60 @@ __global__ __launch_bounds__(64 * NW) void wkv7_bwd_kernel(
         const float4 k4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_K][c0]);
         const float4 a4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_A][c0]);
         const float4 b4 = *reinterpret_cast<const float4 *>(&sh_cv[tt][CV_B][c0]);
-        const float wt[4] = {wt4.x, wt4.y, wt4.z, wt4.w};
-        const float iw[4] = {iw4.x, iw4.y, iw4.z, iw4.w};
-        const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float kv[4] = {k4.x, k4.y, k4.z, k4.w};
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        const f2_t wt[2] = {{wt4.x, wt4.y}, {wt4.z, wt4.w}};
+        const f2_t iw[2] = {{iw4.x, iw4.y}, {iw4.z, iw4.w}};
+        const f2_t qv[2] = {{q4.x, q4.y}, {q4.z, q4.w}};
+        const f2_t kv[2] = {{k4.x, k4.y}, {k4.z, k4.w}};
+        const f2_t av[2] = {{a4.x, a4.y}, {a4.z, a4.w}};
+        const f2_t bv[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
         float vv[RT], dyv[RT], sav[RT];
         ld_rows(&sh_rv[tt][RV_V][r0], vv);
         ld_rows(&sh_rv[tt][RV_DY][r0], dyv);
         ld_rows(&sh_rv[tt][RV_SA][r0], sav);
 
-        float colp[NOUT][4];  // dq, dw, dk, db, da partial sums over this lane's RT rows
+        f2_t colp[NOUT][2];  // dq, dw, dk, db, da partial sums over this lane's RT rows, per column pair
+        f2_t dvp[RT], dsbp[RT];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float dq = 0.f;
+        for (int r = 0; r < RT; r++) dvp[r] = dsbp[r] = f2_t{0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < RT; r++) dq = fmaf(S[r][c], dyv[r], dq);
-            colp[0][c] = dq;
-        }
-        float dvp[RT], dsbp[RT];
-#pragma unroll
-        for (int r = 0; r < RT; r++) dvp[r] = dsbp[r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float dw = 0.f, dk = 0.f, db = 0.f;
+        for (int cp = 0; cp < 2; cp++) {
+            f2_t dq = {0.f, 0.f}, dw = {0.f, 0.f}, dk = {0.f, 0.f}, db = {0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < RT; r++) {
+                f2_t &Sx = *reinterpret_cast<f2_t *>(&S[r][2 * cp]);
+                f2_t &dSx = *reinterpret_cast<f2_t *>(&dS[r][2 * cp]);
+                dq = Sx * dyv[r] + dq;
                 // un-do step t: S_{t-1} = (S_t - v k^T - sa b^T) / w~
-                S[r][c] = (S[r][c] - kv[c] * vv[r] - bv[c] * sav[r]) * iw[c];
-                dS[r][c] = fmaf(dyv[r], qv[c], dS[r][c]);
-                dw = fmaf(dS[r][c], S[r][c], dw);
-                dk = fmaf(dS[r][c], vv[r], dk);
-                db = fmaf(dS[r][c], sav[r], db);
-                dvp[r] = fmaf(dS[r][c], kv[c], dvp[r]);
-                dsbp[r] = fmaf(dS[r][c], bv[c], dsbp[r]);
+                Sx = (Sx - kv[cp] * vv[r] - bv[cp] * sav[r]) * iw[cp];
+                dSx = qv[cp] * dyv[r] + dSx;
+                dw = dSx * Sx + dw;
+                dk = dSx * vv[r] + dk;
+                db = dSx * sav[r] + db;
+                dvp[r] = dSx * kv[cp] + dvp[r];
+                dsbp[r] = dSx * bv[cp] + dsbp[r];
             }
-            colp[1][c] = dw;
-            colp[2][c] = dk;
-            colp[3][c] = db;
+            colp[0][cp] = dq;
+            colp[1][cp] = dw;
+            colp[2][cp] = dk;
+            colp[3][cp] = db;
         }
         float dvv[RT], dsb[RT];
 #pragma unroll
         for (int r = 0; r < RT; r++) {
-            dvv[r] = sum16(dvp[r]);
-            dsb[r] = sum16(dsbp[r]);
+            dvv[r] = sum16(dvp[r].x + dvp[r].y);
+            dsb[r] = sum16(dsbp[r].x + dsbp[r].y);
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float da = 0.f;
+        for (int cp = 0; cp < 2; cp++) {
+            f2_t da = {0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < RT; r++) {
-                da = fmaf(S[r][c], dsb[r], da);
-                dS[r][c] = fmaf(dS[r][c], wt[c], dsb[r] * av[c]);
+                f2_t &Sx = *reinterpret_cast<f2_t *>(&S[r][2 * cp]);
+                f2_t &dSx = *reinterpret_cast<f2_t *>(&dS[r][2 * cp]);
+                da = Sx * dsb[r] + da;
+                dSx = dSx * wt[cp] + av[cp] * dsb[r];
             }
-            colp[4][c] = da;
+            colp[4][cp] = da;
         }
         // column partials -> wave totals, over the 4 row groups (til) of this wave.  Transposing
         // butterfly: v_permlane32_swap pairs column c with c+2 (lanes <32 keep c, lanes >=32 keep c+2),
@@ -212,8 +216,8 @@ __global__ __launch_bounds__(64 * NW) void wkv7_bwd_kernel(
         // then stores its 5 totals (64 distinct consecutive addresses per output), no exec-masked store.
 #pragma unroll
         for (int o = 0; o < NOUT; o++) {
-            const float x0 = swap32_sum(colp[o][0], colp[o][2]);
-            const float x1 = swap32_sum(colp[o][1], colp[o][3]);
+            const float x0 = swap32_sum(colp[o][0].x, colp[o][1].x);
+            const float x1 = swap32_sum(colp[o][0].y, colp[o][1].y);
             sh_part[wave][fs][o][c0 + til] = swap16_sum(x0, x1);
         }
         {

@@ -219,7 +219,11 @@ def test_row_split_backward_vs_oracle(c_oracle, bwd_shape, B, T, H, seed, dtype)
     dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(*d, dy.to(DEV), s, sa)
     full = [torch.empty_like(d[0]) for _ in range(6)]
     torch.ops.wind_backstepping.backward(*d, dy.to(DEV), s, sa, *full)
-    assert torch.equal(dv, full[3]), "dv rows are summed in the same order by both kernels"
+    # dv is a complete row sum in every shape; the instantiations may associate the fp32 terms differently
+    if dtype == torch.bfloat16:
+        _assert_bf16_close(dv, full[3].float().cpu(), "dv vs unsplit kernel", ulps=1.0)
+    else:
+        _assert_f32_close(dv, full[3].cpu(), "dv vs unsplit kernel", 1e-5)
     got = dict(dw=dw2, dq=dq2, dk=dk2, da=da2, db=db2)
     for n, g2 in got.items():
         tot = g2[0].float() + g2[1].float()
