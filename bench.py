@@ -158,7 +158,7 @@ def main():
                        "grad_allreduce": "bucketed RCCL AVG, bf16, overlapped with backward" if world > 1 else "none"},
             "loss": round(loss_val, 4),
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
-            "roofline": {"kernel": "wkv7_bwd_kernel<bf16>", "bound": "hbm",
+            "roofline": {"kernel": "wkv7_bwd_kernel<bf16,2,4> (row-split WKV7 backward, 24 launches/step)", "bound": "hbm",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 4) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": th * WKV_BWD_BYTES_PER_TOKEN_HEAD,
