@@ -231,6 +231,16 @@ int rwkv7_wkv_chunk_fwd_bf16(int B, int T, int H, const void *w, const void *q, 
 int rwkv7_wkv_chunk_fwd_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                             const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
                             rwkv7_stream_t stream);
+/* ---- chunked backward, bf16 (csrc/wkv7_chunk_bwd.hip).  With H = S^T and the chunk quantities above, the adjoint state
+ *      obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
+ *   bwd_pre : parallel over chunks.  mt  = M_c^T as bf16 hi/lo planes, uint16 [B*H*T/32][2][64][64];
+ *                                    np  = N'_c, fp32 [B*H*T/32][4 tiles][64 lanes][16] (MFMA accumulator layout)
+ *   state   : sequential over chunks (reverse).  e_vk[b,h,c][v][k], e_kv[b,h,c][k][v] = E_{c+1} (fp32), what chunk c
+ *             receives from its future. ---- */
+int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
+                                 const void *dy, const float *tinv, void *mt, float *np, rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_vk, float *e_kv,
+                               rwkv7_stream_t stream);
 /* unit-test hook for the MFMA fragment layouts: D[32][32] = X[32][64] Y[32][64]^T (fp32 in, bf16-split MFMA),
  * DT = the same tile after the transposed LDS write-back (hi+lo planes re-joined). */
 int rwkv7_debug_mma32(const float *X, const float *Y, float *D, float *DT, rwkv7_stream_t stream);

@@ -30,6 +30,9 @@ int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, cons
 int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                   const float *, void *, float *, float *, hipStream_t);
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
+int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
+                       float *, hipStream_t);
+int chunk_state_bf16(int, int, const void *, const float *, float *, float *, hipStream_t);
 void fwd_force_shape(int);
 void bwd_force_shape(int);
 int lora_down_bf16(long, int, int, int, const void *, const void *, void *, hipStream_t);
@@ -293,6 +296,18 @@ EW_DEFINE(f32, float)
 CHUNK_DEFINE(bf16)
 CHUNK_DEFINE(f32)
 
+// chunked backward (bf16): see csrc/wkv7_chunk_bwd.hip
+int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
+                                 const void *dy, const float *tinv, void *mt, float *np, rwkv7_stream_t stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, a, b, dy, (const void *)tinv, mt, (const void *)np})) return RWKV7_EINVAL;
+    if (T % 32 != 0) return RWKV7_ECHUNK;
+    return rwkv7::chunk_bwd_pre_bf16(B, T, H, w, q, a, b, dy, tinv, mt, np, (hipStream_t)stream);
+}
+int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_vk, float *e_kv,
+                               rwkv7_stream_t stream) {
+    if (BH <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk, (const void *)e_kv})) return RWKV7_EINVAL;
+    return rwkv7::chunk_state_bf16(BH, nchunks, mt, np, e_vk, e_kv, (hipStream_t)stream);
+}
 int rwkv7_debug_mma32(const float *X, const float *Y, float *D, float *DT, rwkv7_stream_t stream) {
     if (any_null({X, Y, D, DT})) return RWKV7_EINVAL;
     return rwkv7::chunk_debug_mma(X, Y, D, DT, (hipStream_t)stream);

@@ -263,6 +263,32 @@ def wkv7_chunk_forward(w, q, k, v, a, b, save=True):
     return (y, tinv, sa, hs) if save else y
 
 
+def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv):
+    """First two stages of the chunked backward (bf16): per-chunk M^T / N' (parallel) and the adjoint-state recurrence
+    E_c = M_c^T E_{c+1} + N'_c (sequential over chunks).  Returns (mt, np, e_vk, e_kv): e_*[b,h,c] = E_{c+1} in the two
+    orientations [v][k] and [k][v]."""
+    B, T, H, C = w.shape
+    if w.dtype != torch.bfloat16:
+        raise TypeError("the chunked backward is bf16 only")
+    if T % CHUNK_T != 0:
+        raise ValueError(f"chunked WKV7 needs T % {CHUNK_T} == 0, got T={T}")
+    nc = T // CHUNK_T
+    dev = w.device
+    mt = torch.empty(B, H, nc, 2, C, C, dtype=torch.int16, device=dev)
+    np_ = torch.empty(B, H, nc, 4, 64, 16, dtype=torch.float32, device=dev)
+    e_vk = torch.empty(B, H, nc, C, C, dtype=torch.float32, device=dev)
+    e_kv = torch.empty(B, H, nc, C, C, dtype=torch.float32, device=dev)
+    with torch.cuda.device_of(w):
+        with _timed("wkv7c_bwd_pre", w):
+            rc = _lib.lib().rwkv7_wkv_chunk_bwd_pre_bf16(B, T, H, _p(w), _p(q), _p(a), _p(b), _p(dy), _p(tinv), _p(mt), _p(np_),
+                                                         _stream(w))
+        _lib.check(rc, "wkv7_chunk_bwd_pre")
+        with _timed("wkv7c_state", w):
+            rc = _lib.lib().rwkv7_wkv_chunk_state_bf16(B * H, nc, _p(mt), _p(np_), _p(e_vk), _p(e_kv), _stream(w))
+        _lib.check(rc, "wkv7_chunk_state")
+    return mt, np_, e_vk, e_kv
+
+
 def debug_mma32(X, Y):
     """GPU unit-test hook: D = X Y^T for X,Y fp32 [32,64] through the bf16-split MFMA primitive; returns (D, DT)."""
     D = torch.empty(32, 32, device=X.device)

@@ -59,3 +59,53 @@ def test_chunk_forward_vs_oracle(c_oracle, B, T, H, seed, dtype):
     for c in range(1, T // 32):
         _assert_f32_close(hs[:, :, c], s_o[:, :, 2 * c - 1].transpose(-1, -2), f"hs[{c}]", 2e-4 if dtype == torch.float32 else 2e-3)
     assert hs[:, :, 0].abs().max().item() == 0.0
+
+
+def _untile(np_tiles):
+    """[4 tiles][64 lanes][16 regs] (MFMA accumulator layout, tile = 2*mt + nt) -> [64 (m)][64 (n)]."""
+    out = torch.zeros(64, 64)
+    for tile in range(4):
+        mt, nt = tile >> 1, tile & 1
+        for lane in range(64):
+            for r in range(16):
+                m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                out[mt * 32 + m, nt * 32 + (lane & 31)] = np_tiles[tile, lane, r]
+    return out
+
+
+def test_chunked_backward_state_recurrence_vs_prototype():
+    """wkv7c_bwd_pre + wkv7c_state: M_c^T, N'_c and the adjoint states E against the CPU prototype of the same algebra
+    (tools/chunked_proto2.py, fp32), which itself is checked against the scalar oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import chunked_proto2 as P2
+    B, T, H = 1, 128, 2
+    ins = make_wkv_inputs(B, T, H, 21, torch.bfloat16)
+    dy = torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(3)).bfloat16()
+    d = [t.to(DEV) for t in ins]
+    w, q, k, v, a, b = d
+    tinv = ops.wkv7_chunk_prep(w, a, b)
+    mt, np_, e_vk, e_kv = ops.wkv7_chunk_bwd_state(w, q, a, b, dy.to(DEV), tinv)
+    torch.cuda.synchronize()
+    mt = mt.cpu().view(torch.bfloat16).float()
+    mt = mt[:, :, :, 0] + mt[:, :, :, 1]            # hi + lo
+    nc = T // 32
+    for h in range(H):
+        one = [t[0, :, h].float() for t in ins]
+        y, U, hs, L, Ms = P2.fwd3(*one, 32, torch.float32, 0)
+        dyh = dy[0, :, h].float()
+        S = lambda x: x
+        Np = [l["Qt"].T @ dyh[c * 32:c * 32 + 32] + l["W"].T @ (l["A_qb"].T @ dyh[c * 32:c * 32 + 32]) for c, l in enumerate(L)]
+        E = torch.zeros(64, 64)
+        Es = [None] * nc
+        for c in range(nc - 1, -1, -1):
+            Es[c] = E
+            E = Ms[c].T @ E + Np[c]
+        for c in range(nc):
+            ref = Ms[c].T
+            assert (mt[0, h, c] - ref).abs().max() <= 2e-5 * ref.abs().max(), ("M^T", h, c)
+            got = _untile(np_[0, h, c].cpu())
+            assert (got - Np[c]).abs().max() <= 2e-5 * Np[c].abs().max() + 1e-6, ("N'", h, c)
+            scale = max(Es[c].abs().max().item(), 1e-3)
+            assert (e_kv[0, h, c].cpu() - Es[c]).abs().max() <= 1e-4 * scale, ("E[k][v]", h, c)
+            assert (e_vk[0, h, c].cpu() - Es[c].T).abs().max() <= 1e-4 * scale, ("E[v][k]", h, c)
