@@ -347,6 +347,384 @@ __global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// out: all six gradients of one chunk from (H_c, E_{c+1}, U, dY) -- tools/chunked_proto2.py:bwd3, third loop
+//   G1 = A_qb^T dY + B^ (g_C E)          Z  = T^T G1                                  (Z_t = dL/du_t)
+//   dV = A_qk^T dY + A_ak^T Z + K^ (g_C E)
+//   dK = (P_vy Q~ + P_vz A~ + V (g_C E)^T) / gamma      dB = (P_uy Q~ + P_uz A~ + U (g_C E)^T) / gamma
+//   dQ = (dY H0^T + P_vy^T K^ + P_uy^T B^) gamma        dA = (Z H0^T + P_vz^T K^ + P_uz^T B^) gamma_prev
+//   P_vy = triu(V dY^T)  P_vz = triu(V Z^T, 1)  P_uy = triu(U dY^T)  P_uz = triu(U Z^T, 1)
+//   dlw_t = sum_{s >= t} (q dQ - k dK - b dB)_s + sum_{s > t} (a dA)_s + rowsum(E * H_C) ;  dw = dlw * lw
+// 35 tile products in 7 barrier-separated phases; the LDS map below is a union over the phases (160 KB exactly).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct OutSmem {  // offsets in uint16 units
+    static constexpr int TM1 = kC * LDK, CM1 = kN * LDC, SQ1 = kN * LDK, A1 = kC * LDC, ST = kC * kN * 2;
+    // fixed for the whole kernel
+    static constexpr int QTTh = 0, QTTl = QTTh + CM1, ATTh = QTTl + CM1, ATTl = ATTh + CM1;
+    static constexpr int KHTh = ATTl + CM1, KHTl = KHTh + CM1, BHTh = KHTl + CM1, BHTl = BHTh + CM1;
+    static constexpr int Vp = BHTl + CM1, DYp = Vp + TM1, Uh = DYp + TM1, Ul = Uh + TM1, Zh = Ul + TM1, Zl = Zh + TM1;
+    static constexpr int STG = Zl + TM1;                    // fp32 [32][64] staging tiles: dK, dB, dQ, dA
+    static constexpr int sK = STG, sB = STG + ST, sQ = STG + 2 * ST, sA = STG + 3 * ST;
+    static constexpr int gC = STG + 4 * ST, dterm = gC + 2 * kN;  // 64 floats each
+    static constexpr int S = dterm + 2 * kN;                // phase scratch
+    // phases A-D inside S
+    static constexpr int KHh = S, KHl = KHh + TM1, BHh = KHl + TM1, BHl = BHh + TM1;
+    static constexpr int QTh = BHl + TM1, QTl = QTh + TM1, ATh = QTl + TM1, ATl = ATh + TM1;   // dead after phase A
+    static constexpr int G1Th = QTh, G1Tl = G1Th + CM1, sV = G1Tl + CM1;                       // laid over QT/AT
+    static constexpr int EGh = ATl + TM1, EGl = EGh + SQ1;                                     // (g_C E)[v][k]
+    static constexpr int DYT = EGl + SQ1;
+    static constexpr int endAD = DYT + CM1;
+    // phases A-D inside the (still unused) staging area
+    static constexpr int TMTh = STG, TMTl = TMTh + A1, QBTh = TMTl + A1, QBTl = QBTh + A1, QKTh = QBTl + A1, QKTl = QKTh + A1;
+    static constexpr int AKTh = QKTl + A1, AKTl = AKTh + A1, ZTh = AKTl + A1, ZTl = ZTh + CM1;
+    static constexpr int scratch = ZTh;                     // prologue cumsum scratch (4608 u16)
+    // phases E-F inside S
+    static constexpr int XTh = S, XTl = XTh + SQ1;          // (g_C E)^T [k][v], later H0^T [k][v]
+    static constexpr int P0 = EGh;                          // 4 pairs of [32][LDC] planes over the dead EG / DYT area
+    static constexpr int aDA = sV;                          // epilogue: fp32 [32][64] a*dA
+    static constexpr int end16 = endAD;
+    static constexpr size_t bytes = (size_t)end16 * 2;
+};
+static_assert(OutSmem::sV + OutSmem::ST <= OutSmem::EGh, "dV staging must end before the E planes");
+static_assert(OutSmem::ZTl + OutSmem::CM1 <= OutSmem::gC, "phase A-D planes must fit in the staging area");
+static_assert(OutSmem::P0 + 8 * OutSmem::A1 <= OutSmem::endAD, "P planes");
+static_assert(OutSmem::XTl + OutSmem::SQ1 <= OutSmem::sV, "E^T / H0^T planes must not reach the dV staging tile");
+static_assert(OutSmem::bytes <= 160 * 1024, "LDS budget");
+static_assert(OutSmem::S % 8 == 0 && OutSmem::EGh % 8 == 0 && OutSmem::DYT % 8 == 0 && OutSmem::STG % 8 == 0, "alignment");
+
+// X exact (single plane), Y exact
+template <int K>
+__device__ __forceinline__ void mma_ee(f32x16 &acc, const uint16_t *X, int ldx, const uint16_t *Y, int ldy, int lane) {
+    mma_tile<K>(acc, X, ldx, Y, ldy, lane);
+}
+// D tile -> fp32 staging [32][64], columns [32 ct, 32 ct + 32)
+__device__ __forceinline__ void stage_tile(const f32x16 &acc, float *stg, int ct, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) stg[d_row(r, lane) * kN + ct * 32 + (lane & 31)] = acc[r];
+}
+__device__ __forceinline__ void ld_stage8(const float *stg, int pt, int pk, float (&x)[8]) {
+    const float4 a = *reinterpret_cast<const float4 *>(stg + pt * kN + pk), b = *reinterpret_cast<const float4 *>(stg + pt * kN + pk + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+__device__ __forceinline__ void st_bf16x8(bf16_t *p, const float (&x)[8]) {
+    uint4 o;
+    o.x = cvt_pk(x[0], x[1]); o.y = cvt_pk(x[2], x[3]); o.z = cvt_pk(x[4], x[5]); o.w = cvt_pk(x[6], x[7]);
+    *reinterpret_cast<uint4 *>(p) = o;
+}
+// 4 consecutive fp32 of row `row` -> hi/lo planes [..][LDK]
+__device__ __forceinline__ void put4(uint16_t *Ph, uint16_t *Pl, int row, int c4, float4 x, float scale_x, float scale_y,
+                                     float scale_z, float scale_w) {
+    uint32_t h0, l0, h1, l1;
+    split_pk(x.x * scale_x, x.y * scale_y, h0, l0);
+    split_pk(x.z * scale_z, x.w * scale_w, h1, l1);
+    *reinterpret_cast<uint2 *>(Ph + row * LDK + c4) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(Pl + row * LDK + c4) = make_uint2(l0, l1);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
+    int T_, int H, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
+    const bf16_t *__restrict__ v_, const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_, const bf16_t *__restrict__ dy_,
+    const float *__restrict__ s_, const float *__restrict__ sa_, const float *__restrict__ tinv_, const float *__restrict__ e_vk,
+    const float *__restrict__ e_kv, bf16_t *__restrict__ dw_, bf16_t *__restrict__ dq_, bf16_t *__restrict__ dk_,
+    bf16_t *__restrict__ dv_, bf16_t *__restrict__ da_, bf16_t *__restrict__ db_) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
+    using L = OutSmem;
+    float *sh_gC = reinterpret_cast<float *>(sm + L::gC), *sh_dterm = reinterpret_cast<float *>(sm + L::dterm);
+    const int nc = T_ / kC;
+    const int bh = blockIdx.x / nc, c = blockIdx.x - bh * nc;
+    const int bb = bh / H, hh = bh - bb * H;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int pt = tid & 31, pk = (tid >> 5) * 8;
+    const long tstride = (long)H * kN;
+    const long off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + pt) * tstride + pk;
+
+    // ---- global loads ---------------------------------------------------------------------------------------------------
+    const Raw8 rw = ld8(w_ + off), rq = ld8(q_ + off), rk = ld8(k_ + off), ra = ld8(a_ + off), rb = ld8(b_ + off);
+    const Raw8 rv = ld8(v_ + off), rdy = ld8(dy_ + off);
+    const float4 ru0 = *reinterpret_cast<const float4 *>(sa_ + off), ru1 = *reinterpret_cast<const float4 *>(sa_ + off + 4);
+    // 64x64 fp32 matrices: piece p = tid + 256 i covers row p >> 4, columns 4 (p & 15) .. +4
+    const float *evk = e_vk + (long)blockIdx.x * kN * kN, *ekv = e_kv + (long)blockIdx.x * kN * kN;
+    const long nck = T_ / kChunk;  // scalar-forward checkpoints (every 16 steps), s[b,h,n][k][v]
+    const float *h0p = s_ + ((long)bh * nck + (2 * c - 1)) * kN * kN, *hcp = s_ + ((long)bh * nck + (2 * c + 1)) * kN * kN;
+    float4 rekv[4], rh0[4];
+    {
+        float part[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int p = tid + 256 * i;
+            rekv[i] = *reinterpret_cast<const float4 *>(ekv + p * 4);
+            rh0[i] = c > 0 ? *reinterpret_cast<const float4 *>(h0p + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 hc = *reinterpret_cast<const float4 *>(hcp + p * 4);
+            part[i] = rekv[i].x * hc.x + rekv[i].y * hc.y + rekv[i].z * hc.z + rekv[i].w * hc.w;
+        }
+        // rowsum(E * H_C): the 16 lanes tid & 15 share a row
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float t = sum16(part[i]);
+            if ((tid & 15) == 0) sh_dterm[(tid + 256 * i) >> 4] = t;
+        }
+    }
+    load_tm<true>(tinv_ + (long)blockIdx.x * kC * kC, sm + L::TMTh, sm + L::TMTl, tid);
+
+    // ---- prologue: decay, scaled operands ----------------------------------------------------------------------------------
+    float lw[8], G[8], qv[8], kv[8], av[8], bv[8], gam[8], gprev[8], igam[8];
+    cvt8(rw, lw);
+#pragma unroll
+    for (int j = 0; j < 8; j++) lw[j] = -fast_exp(lw[j]);
+    {
+        float *sh_G = reinterpret_cast<float *>(sm + L::scratch);
+        chunk_cumsum(lw, G, sh_G, sh_G + kC * kN, tid, pt, pk);
+    }
+    cvt8(rq, qv); cvt8(rk, kv); cvt8(ra, av); cvt8(rb, bv);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        gam[j] = fast_exp(G[j]);
+        gprev[j] = fast_exp(G[j] - lw[j]);
+        igam[j] = fast_exp(-G[j]);
+    }
+    if (pt == kC - 1) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) sh_gC[pk + j] = gam[j];
+    }
+    {
+        float x[8];
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = qv[j] * gam[j];
+        put_row8(sm + L::QTh, sm + L::QTl, pt * LDK + pk, x, hi, lo);
+        put_col8(sm + L::QTTh, sm + L::QTTl, LDC, pk, pt, hi, lo);
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = av[j] * gprev[j];
+        put_row8(sm + L::ATh, sm + L::ATl, pt * LDK + pk, x, hi, lo);
+        put_col8(sm + L::ATTh, sm + L::ATTl, LDC, pk, pt, hi, lo);
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = kv[j] * igam[j];
+        put_row8(sm + L::KHh, sm + L::KHl, pt * LDK + pk, x, hi, lo);
+        put_col8(sm + L::KHTh, sm + L::KHTl, LDC, pk, pt, hi, lo);
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = bv[j] * igam[j];
+        put_row8(sm + L::BHh, sm + L::BHl, pt * LDK + pk, x, hi, lo);
+        put_col8(sm + L::BHTh, sm + L::BHTl, LDC, pk, pt, hi, lo);
+        const float u[8] = {ru0.x, ru0.y, ru0.z, ru0.w, ru1.x, ru1.y, ru1.z, ru1.w};
+        put_row8(sm + L::Uh, sm + L::Ul, pt * LDK + pk, u, hi, lo);
+        *reinterpret_cast<uint4 *>(sm + L::Vp + pt * LDK + pk) = rv.r;     // bf16 inputs are exact: single planes
+        *reinterpret_cast<uint4 *>(sm + L::DYp + pt * LDK + pk) = rdy.r;
+        const uint32_t dyr[4] = {rdy.r.x, rdy.r.y, rdy.r.z, rdy.r.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) sm[L::DYT + (pk + j) * LDC + pt] = (uint16_t)(dyr[j >> 1] >> ((j & 1) * 16));
+    }
+    lds_barrier();  // sh_gC visible
+    {
+        // (g_C E)[v][k] planes: row v, scale per column k
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
+            const float4 e = *reinterpret_cast<const float4 *>(evk + p * 4);
+            put4(sm + L::EGh, sm + L::EGl, row, c4, e, sh_gC[c4], sh_gC[c4 + 1], sh_gC[c4 + 2], sh_gC[c4 + 3]);
+        }
+    }
+    lds_barrier();
+    // ---- phase A: A_qb^T, A_qk^T, A_ak^T ------------------------------------------------------------------------------------
+    if (wave == 0) {
+        f32x16 acc = zero16();  // D[t][s] = q~_t . b^_s, t >= s -> QBT[s][t]
+        mma_tile3<kN>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::BHh, sm + L::BHl, LDK, lane);
+        mask_upper_T<false>(acc, lane);
+        store_T_split(acc, sm + L::QBTh, sm + L::QBTl, LDC, lane);
+    } else if (wave == 1) {
+        f32x16 acc = zero16();  // q~_t . k^_s, t >= s -> QKT[s][t]
+        mma_tile3<kN>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::KHh, sm + L::KHl, LDK, lane);
+        mask_upper_T<false>(acc, lane);
+        store_T_split(acc, sm + L::QKTh, sm + L::QKTl, LDC, lane);
+    } else if (wave == 2) {
+        f32x16 acc = zero16();  // a~_t . k^_s, t > s -> AKT[s][t]
+        mma_tile3<kN>(acc, sm + L::ATh, sm + L::ATl, LDK, sm + L::KHh, sm + L::KHl, LDK, lane);
+        mask_upper_T<true>(acc, lane);
+        store_T_split(acc, sm + L::AKTh, sm + L::AKTl, LDC, lane);
+    }
+    lds_barrier();
+    // ---- phase B: G1[s][v] = sum_t A_qb[t][s] dY[t][v] + sum_k b^[s][k] (g_C E)[k][v]  -> G1T[v][s] ---------------------------
+    if (wave <= 1) {
+        const int vt = wave;
+        f32x16 acc = zero16();
+        mma_xs_ye<kC>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
+        mma_tile3<kN>(acc, sm + L::BHh, sm + L::BHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
+        store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
+    }
+    lds_barrier();
+    // ---- phase C: Z = T^T G1 in both orientations ---------------------------------------------------------------------------------
+    if (wave <= 1) {
+        const int vt = wave;
+        f32x16 acc = zero16();  // D[t][v] = sum_s T[s][t] G1[s][v] -> ZT[v][t]
+        mma_tile3<kC>(acc, sm + L::TMTh, sm + L::TMTl, LDC, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
+        store_T_split(acc, sm + L::ZTh + vt * 32 * LDC, sm + L::ZTl + vt * 32 * LDC, LDC, lane);
+    } else {
+        const int vt = wave - 2;
+        f32x16 acc = zero16();  // D[v][t] -> Z[t][v]
+        mma_tile3<kC>(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, sm + L::TMTh, sm + L::TMTl, LDC, lane);
+        store_T_split(acc, sm + L::Zh + vt * 32, sm + L::Zl + vt * 32, LDK, lane);
+    }
+    lds_barrier();
+    // ---- phase D: dV[s][v] = sum_t A_qk[t][s] dY[t][v] + A_ak[t][s] Z[t][v] + sum_k k^[s][k] (g_C E)[k][v] -----------------------
+    if (wave <= 1) {
+        const int vt = wave;
+        f32x16 acc = zero16();
+        mma_xs_ye<kC>(acc, sm + L::QKTh, sm + L::QKTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
+        mma_tile3<kC>(acc, sm + L::AKTh, sm + L::AKTl, LDC, sm + L::ZTh + vt * 32 * LDC, sm + L::ZTl + vt * 32 * LDC, LDC, lane);
+        mma_tile3<kN>(acc, sm + L::KHh, sm + L::KHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
+        stage_tile(acc, reinterpret_cast<float *>(sm + L::sV), vt, lane);
+    }
+    lds_barrier();
+    // ---- phase E1: dV out; (g_C E)^T planes; the four P matrices of dK / dB --------------------------------------------------------
+    {
+        float x[8];
+        ld_stage8(reinterpret_cast<const float *>(sm + L::sV), pt, pk, x);
+        st_bf16x8(dv_ + off, x);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
+            const float g = sh_gC[row];
+            put4(sm + L::XTh, sm + L::XTl, row, c4, rekv[i], g, g, g, g);
+        }
+        uint16_t *Ph = sm + L::P0 + wave * 2 * L::A1, *Pl = Ph + L::A1;
+        f32x16 acc = zero16();  // D[m = s][n = t], kept for s >= t (P_vy, P_uy) or s > t (P_vz, P_uz); stored [t][s]
+        if (wave == 0) {
+            mma_ee<kN>(acc, sm + L::DYp, LDK, sm + L::Vp, LDK, lane);                       // dy_s . v_t
+            mask_upper_T<false>(acc, lane);
+        } else if (wave == 1) {
+            mma_xs_ye<kN>(acc, sm + L::Zh, sm + L::Zl, LDK, sm + L::Vp, LDK, lane);         // z_s . v_t
+            mask_upper_T<true>(acc, lane);
+        } else if (wave == 2) {
+            mma_tile2y<kN>(acc, sm + L::DYp, LDK, sm + L::Uh, sm + L::Ul, LDK, lane);       // dy_s . u_t
+            mask_upper_T<false>(acc, lane);
+        } else {
+            mma_tile3<kN>(acc, sm + L::Zh, sm + L::Zl, LDK, sm + L::Uh, sm + L::Ul, LDK, lane);  // z_s . u_t
+            mask_upper_T<true>(acc, lane);
+        }
+        store_T_split(acc, Ph, Pl, LDC, lane);
+    }
+    lds_barrier();
+    // ---- phase F1: dK (waves 0,1) and dB (waves 2,3), unscaled, to staging ---------------------------------------------------------
+    {
+        const int kt = wave & 1;
+        const uint16_t *P1h = sm + L::P0 + (wave < 2 ? 0 : 2) * 2 * L::A1, *P1l = P1h + L::A1, *P2h = P1h + 2 * L::A1, *P2l = P2h + L::A1;
+        f32x16 acc = zero16();  // D[m = t][n = k]
+        mma_tile3<kC>(acc, P1h, P1l, LDC, sm + L::QTTh + kt * 32 * LDC, sm + L::QTTl + kt * 32 * LDC, LDC, lane);
+        mma_tile3<kC>(acc, P2h, P2l, LDC, sm + L::ATTh + kt * 32 * LDC, sm + L::ATTl + kt * 32 * LDC, LDC, lane);
+        if (wave < 2) {
+            mma_tile2y<kN>(acc, sm + L::Vp, LDK, sm + L::XTh + kt * 32 * LDK, sm + L::XTl + kt * 32 * LDK, LDK, lane);
+            stage_tile(acc, reinterpret_cast<float *>(sm + L::sK), kt, lane);
+        } else {
+            mma_tile3<kN>(acc, sm + L::Uh, sm + L::Ul, LDK, sm + L::XTh + kt * 32 * LDK, sm + L::XTl + kt * 32 * LDK, LDK, lane);
+            stage_tile(acc, reinterpret_cast<float *>(sm + L::sB), kt, lane);
+        }
+    }
+    lds_barrier();
+    // ---- phase E2: H0^T planes over (g_C E)^T; the four transposed P matrices of dQ / dA -------------------------------------------
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
+            put4(sm + L::XTh, sm + L::XTl, row, c4, rh0[i], 1.f, 1.f, 1.f, 1.f);
+        }
+        uint16_t *Ph = sm + L::P0 + wave * 2 * L::A1, *Pl = Ph + L::A1;
+        f32x16 acc = zero16();  // D[m = s][n = t'], kept for s <= t' (vy, uy) or s < t' (vz, uz); stored [t'][s]
+        if (wave == 0) {
+            mma_ee<kN>(acc, sm + L::Vp, LDK, sm + L::DYp, LDK, lane);                       // v_s . dy_t'
+            mask_lower_T<false>(acc, lane);
+        } else if (wave == 1) {
+            mma_xs_ye<kN>(acc, sm + L::Uh, sm + L::Ul, LDK, sm + L::DYp, LDK, lane);        // u_s . dy_t'
+            mask_lower_T<false>(acc, lane);
+        } else if (wave == 2) {
+            mma_tile2y<kN>(acc, sm + L::Vp, LDK, sm + L::Zh, sm + L::Zl, LDK, lane);        // v_s . z_t'
+            mask_lower_T<true>(acc, lane);
+        } else {
+            mma_tile3<kN>(acc, sm + L::Uh, sm + L::Ul, LDK, sm + L::Zh, sm + L::Zl, LDK, lane);  // u_s . z_t'
+            mask_lower_T<true>(acc, lane);
+        }
+        store_T_split(acc, Ph, Pl, LDC, lane);
+    }
+    lds_barrier();
+    // ---- phase F2: dQ (waves 0,1) and dA (waves 2,3), unscaled, to staging ---------------------------------------------------------
+    {
+        const int kt = wave & 1;
+        // dQ uses P planes 0 (vy) and 1 (uy); dA uses 2 (vz) and 3 (uz)
+        const uint16_t *P1h = sm + L::P0 + (wave < 2 ? 0 : 2) * 2 * L::A1, *P1l = P1h + L::A1, *P2h = P1h + 2 * L::A1, *P2l = P2h + L::A1;
+        f32x16 acc = zero16();  // D[m = t'][n = k]
+        mma_tile3<kC>(acc, P1h, P1l, LDC, sm + L::KHTh + kt * 32 * LDC, sm + L::KHTl + kt * 32 * LDC, LDC, lane);
+        mma_tile3<kC>(acc, P2h, P2l, LDC, sm + L::BHTh + kt * 32 * LDC, sm + L::BHTl + kt * 32 * LDC, LDC, lane);
+        if (wave < 2) {
+            mma_tile2y<kN>(acc, sm + L::DYp, LDK, sm + L::XTh + kt * 32 * LDK, sm + L::XTl + kt * 32 * LDK, LDK, lane);
+            stage_tile(acc, reinterpret_cast<float *>(sm + L::sQ), kt, lane);
+        } else {
+            mma_tile3<kN>(acc, sm + L::Zh, sm + L::Zl, LDK, sm + L::XTh + kt * 32 * LDK, sm + L::XTl + kt * 32 * LDK, LDK, lane);
+            stage_tile(acc, reinterpret_cast<float *>(sm + L::sA), kt, lane);
+        }
+    }
+    lds_barrier();
+    // ---- epilogue: decay scaling, decay gradient, stores ----------------------------------------------------------------------------
+    float dQ[8], dK[8], dB[8], dA[8], e[8];
+    ld_stage8(reinterpret_cast<const float *>(sm + L::sQ), pt, pk, dQ);
+    ld_stage8(reinterpret_cast<const float *>(sm + L::sK), pt, pk, dK);
+    ld_stage8(reinterpret_cast<const float *>(sm + L::sB), pt, pk, dB);
+    ld_stage8(reinterpret_cast<const float *>(sm + L::sA), pt, pk, dA);
+    float *sh_ada = reinterpret_cast<float *>(sm + L::aDA);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        dQ[j] *= gam[j];
+        dK[j] *= igam[j];
+        dB[j] *= igam[j];
+        dA[j] *= gprev[j];
+        e[j] = qv[j] * dQ[j] - kv[j] * dK[j] - bv[j] * dB[j];
+    }
+    {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = av[j] * dA[j];
+        *reinterpret_cast<float4 *>(&sh_ada[pt * kN + pk]) = make_float4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<float4 *>(&sh_ada[pt * kN + pk + 4]) = make_float4(t[4], t[5], t[6], t[7]);
+    }
+    st_bf16x8(dq_ + off, dQ);
+    st_bf16x8(dk_ + off, dK);
+    st_bf16x8(db_ + off, dB);
+    st_bf16x8(da_ + off, dA);
+    lds_barrier();
+    if (pt < kC - 1) {
+        const float4 n0 = *reinterpret_cast<const float4 *>(&sh_ada[(pt + 1) * kN + pk]);
+        const float4 n1 = *reinterpret_cast<const float4 *>(&sh_ada[(pt + 1) * kN + pk + 4]);
+        e[0] += n0.x; e[1] += n0.y; e[2] += n0.z; e[3] += n0.w; e[4] += n1.x; e[5] += n1.y; e[6] += n1.z; e[7] += n1.w;
+    }
+    {
+        // suffix sums over the 32 steps (staging area is free now): dlw_t = sum_{s >= t} e_s + dterm
+        float *sh_E = reinterpret_cast<float *>(sm + L::sK), *sh_seg = reinterpret_cast<float *>(sm + L::sQ);
+        *reinterpret_cast<float4 *>(&sh_E[pt * kN + pk]) = make_float4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<float4 *>(&sh_E[pt * kN + pk + 4]) = make_float4(e[4], e[5], e[6], e[7]);
+        lds_barrier();
+        {
+            const int ch = tid & 63, seg = tid >> 6;
+            float run = 0.f;
+#pragma unroll
+            for (int i = 7; i >= 0; i--) {
+                run += sh_E[(seg * 8 + i) * kN + ch];
+                sh_E[(seg * 8 + i) * kN + ch] = run;
+            }
+            sh_seg[seg * kN + ch] = run;
+        }
+        lds_barrier();
+        float dG[8];
+        const float4 g0 = *reinterpret_cast<const float4 *>(&sh_E[pt * kN + pk]), g1 = *reinterpret_cast<const float4 *>(&sh_E[pt * kN + pk + 4]);
+        dG[0] = g0.x; dG[1] = g0.y; dG[2] = g0.z; dG[3] = g0.w; dG[4] = g1.x; dG[5] = g1.y; dG[6] = g1.z; dG[7] = g1.w;
+        for (int sgi = (pt >> 3) + 1; sgi < 4; sgi++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) dG[j] += sh_seg[sgi * kN + pk + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) dG[j] = (dG[j] + sh_dterm[pk + j]) * lw[j];
+        st_bf16x8(dw_ + off, dG);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 int chunk_bwd_pre_bf16(int B, int T_, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
@@ -374,6 +752,24 @@ int chunk_state_bf16(int BH, int nc, const void *mt, const float *np, float *e_v
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL(wkv7c_state_kernel, dim3(BH), dim3(256), StateSmem::bytes, st, nc, (const uint16_t *)mt, np, e_vk, e_kv);
+    return (int)hipGetLastError();
+}
+
+int chunk_bwd_out_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                       const void *b, const void *dy, const float *s, const float *sa, const float *tinv, const float *e_vk,
+                       const float *e_kv, void *dw, void *dq, void *dk, void *dv, void *da, void *db, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_bwd_out_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)OutSmem::bytes);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(wkv7c_bwd_out_kernel, dim3(B * H * (T_ / kC)), dim3(256), OutSmem::bytes, st, T_, H, (const bf16_t *)w,
+                       (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a, (const bf16_t *)b,
+                       (const bf16_t *)dy, s, sa, tinv, e_vk, e_kv, (bf16_t *)dw, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
+                       (bf16_t *)da, (bf16_t *)db);
     return (int)hipGetLastError();
 }
 
