@@ -136,12 +136,20 @@ def main():
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items() if v}
         th = B * T * H
         bwd_ms = kern.get("wkv7_bwd")
+        bwd_name = "wkv7_bwd_kernel<bf16,2,4> (row-split scalar WKV7 backward, 24 launches/step)"
+        pmc_key = "wkv7_bwd"
+        chunk_parts = ["wkv7c_prep", "wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bwd_out"]
+        if bwd_ms is None and all(k in kern for k in chunk_parts):
+            # chunked MFMA backward: four launches per layer form the WKV7 backward; report them as one unit
+            bwd_ms = sum(kern[k] for k in chunk_parts)
+            bwd_name = "WKV7 backward, chunked MFMA (wkv7c_prep + wkv7c_bwd_pre + wkv7c_state + wkv7c_bwd_out, 24x per step)"
+            pmc_key = "wkv7c_bwd"
         achieved = th * WKV_BWD_BYTES_PER_TOKEN_HEAD / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_wkv7.json")
         if os.path.exists(pmc):
             try:
-                d = json.load(open(pmc))["wkv7_bwd"]
+                d = json.load(open(pmc))[pmc_key]
                 if d.get("B") == B and d.get("T") == T and d.get("H") == H:
                     traffic = int((2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024)
             except Exception:
@@ -158,7 +166,7 @@ def main():
                        "grad_allreduce": "bucketed RCCL AVG, bf16, overlapped with backward" if world > 1 else "none"},
             "loss": round(loss_val, 4),
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
-            "roofline": {"kernel": "wkv7_bwd_kernel<bf16,2,4> (row-split WKV7 backward, 24 launches/step)", "bound": "hbm",
+            "roofline": {"kernel": bwd_name, "bound": "hbm",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 4) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": th * WKV_BWD_BYTES_PER_TOKEN_HEAD,

@@ -146,7 +146,8 @@ int rwkv7_tmix_prepare_bwd_f32(long rows, int D, const void *w_pre, const void *
 /* Same backward with the incoming gradients given as sums, added in fp32 on load (no separate add kernels): gsum is a
  * HOST array of 14 device pointers {d_w a,b; d_k2 a,b,c; d_v2 a,b; d_ain a,b; d_bin a,b; d_r a,b,c}, and
  * d_r = d_r a+b+c is written as well.  Consumes the two partial sets of rwkv7_wkv_bwd_split_* plus tmix_post's
- * contributions to k2, v2 and r. */
+ * contributions to k2, v2 and r.  The second partials (d_w b, d_k2 b, d_ain b, d_bin b, d_r b) may be NULL: complete
+ * gradients, as the chunked backward produces them. */
 int rwkv7_tmix_prepare_bwd_sum_bf16(long rows, int D, const void *w_pre, const void *k, const void *v,
                                     const void *a_pre, const void *v_pre, const void *v_first, const void *mask,
                                     const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre, void *d_k,

@@ -217,8 +217,8 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
         if (rows <= 0 || nblocks <= 0 ||                                                                              \
             any_null({w_pre, k, v, a_pre, k_k, k_a, (const void *)gsum, d_wpre, d_k, d_v, d_apre, d_r, dpart}))       \
             return RWKV7_EINVAL;                                                                                      \
-        for (int i = 0; i < 14; i++)                                                                                  \
-            if (!gsum[i]) return RWKV7_EINVAL;                                                                        \
+        for (int i = 0; i < 14; i++) /* the second partials {1,3,8,10,12} may be NULL */                              \
+            if (!gsum[i] && i != 1 && i != 3 && i != 8 && i != 10 && i != 12) return RWKV7_EINVAL;                    \
         if ((v_pre == nullptr) != (v_first == nullptr)) return RWKV7_EINVAL;                                          \
         if (v_pre && (!d_vpre || !d_vfirst)) return RWKV7_EINVAL;                                                     \
         if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \

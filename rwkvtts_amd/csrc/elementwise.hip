@@ -289,29 +289,25 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
         V8<T>::ld(d_ain + o, ga);
         V8<T>::ld(d_bin + o, gb);
         if constexpr (MULTI) {
-            float t[8], t2[8];
-            V8<T>::ld(ex.d_w_b + o, t);
+            // second partial set: present after the row-split scan backward, absent (NULL) after the chunked one
+            auto add = [&](const T *p, float (&acc)[8]) {
+                if (p) {
+                    float t[8];
+                    V8<T>::ld(p + o, t);
 #pragma unroll
-            for (int j = 0; j < 8; j++) gw[j] += t[j];
-            V8<T>::ld(ex.d_k2_b + o, t);
-            V8<T>::ld(ex.d_k2_c + o, t2);
-#pragma unroll
-            for (int j = 0; j < 8; j++) gk2[j] += t[j] + t2[j];
-            V8<T>::ld(ex.d_v2_b + o, t);
-#pragma unroll
-            for (int j = 0; j < 8; j++) gv2[j] += t[j];
-            V8<T>::ld(ex.d_a_b + o, t);
-#pragma unroll
-            for (int j = 0; j < 8; j++) ga[j] += t[j];
-            V8<T>::ld(ex.d_b_b + o, t);
-#pragma unroll
-            for (int j = 0; j < 8; j++) gb[j] += t[j];
+                    for (int j = 0; j < 8; j++) acc[j] += t[j];
+                }
+            };
+            add(ex.d_w_b, gw);
+            add(ex.d_k2_b, gk2);
+            add(ex.d_k2_c, gk2);
+            add(ex.d_v2_b, gv2);
+            add(ex.d_a_b, ga);
+            add(ex.d_b_b, gb);
             float r3[8];
             V8<T>::ld(ex.d_r_a + o, r3);
-            V8<T>::ld(ex.d_r_b + o, t);
-            V8<T>::ld(ex.d_r_c + o, t2);
-#pragma unroll
-            for (int j = 0; j < 8; j++) r3[j] += t[j] + t2[j];
+            add(ex.d_r_b, r3);
+            add(ex.d_r_c, r3);
             V8<T>::st(ex.d_r + o, r3);
         }
         float kkr[8], a[8], du[8], u[8], o1[8], o2[8];

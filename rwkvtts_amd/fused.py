@@ -191,6 +191,9 @@ def tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, eps):
     return _TmixPost.apply(y, r, k, v, g, gn_weight, gn_bias, r_k.reshape(-1), eps)
 
 
+CHUNKED_WKV_BWD = True   # bf16 training: scan backward on the matrix cores (csrc/wkv7_chunk_bwd.hip)
+
+
 class _TmixCore(torch.autograd.Function):
     """prepare -> WKV7 scan -> GroupNorm/bonus/gate as ONE autograd node for training (zero initial state).
 
@@ -243,10 +246,14 @@ class _TmixCore(torch.autograd.Function):
         _call("tmix_post_bwd", k, ctypes.c_long(rows), D, _p(dout), _p(y), _p(r), _p(k2), _p(v2), _p(g), _p(gn_w), _p(gn_b),
               _p(r_k), ctypes.c_float(ctx.eps), _p(d_y), _p(d_r_post), _p(d_k2_post), _p(d_v2_post), _p(d_g),
               _p(part_post), nb)
-        # 2. scan, two workgroups per head
+        # 2. scan: chunked MFMA backward (bf16, T % 32 == 0) or the scalar kernel with two workgroups per head
         v4 = lambda t: t.view(B, T, H, 64)
-        dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in),
-                                                              v4(d_y), s, sa)
+        if CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0:
+            dw, dq, dk, dv, da, db = ops.wkv7_chunk_backward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(d_y), s, sa)
+            dw2, dq2, dk2, da2, db2 = [(g, None) for g in (dw, dq, dk, da, db)]
+        else:
+            dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in),
+                                                                  v4(d_y), s, sa)
         # 3. decay / kk / k' / value residual, summing all contributions on load
         d_wpre, d_k, d_v, d_apre, d_r = [torch.empty_like(k) for _ in range(5)]
         d_vpre = torch.empty_like(k) if v_pre is not None else None
@@ -254,7 +261,7 @@ class _TmixCore(torch.autograd.Function):
         part = torch.empty(nb, 2, D, dtype=torch.float32, device=k.device)
         gsum = [dw2[0], dw2[1], dk2[0], dk2[1], d_k2_post, dv, d_v2_post, da2[0], da2[1], db2[0], db2[1],
                 dq2[0], dq2[1], d_r_post]
-        ptrs = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in gsum])
+        ptrs = (ctypes.c_void_p * 14)(*[None if t is None else t.data_ptr() for t in gsum])
         _call("tmix_prepare_bwd_sum", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
               _p(mask), _p(k_k), _p(k_a), ptrs, _p(d_wpre), _p(d_k), _p(d_v), _p(d_apre), _p(d_vpre), _p(d_vf),
               _p(d_r), _p(part), nb)

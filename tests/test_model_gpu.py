@@ -214,8 +214,9 @@ def test_graph_decoder_matches_eager_generate():
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("T", [48, 64])   # 64: the bf16 run takes the chunked MFMA backward (T % 32 == 0)
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
-def test_fused_tmix_core_equals_separate_nodes(dtype, tol):
+def test_fused_tmix_core_equals_separate_nodes(dtype, tol, T):
     """fused._TmixCore (row-split scan backward + gradient sums folded into the prepare backward) against the
     three separate autograd nodes, with a padding mask, on every parameter gradient."""
     from rwkvtts_amd import backbone
@@ -225,7 +226,7 @@ def test_fused_tmix_core_equals_separate_nodes(dtype, tol):
     model = RWKV7Model(cfg)
     backbone.init_weights(model, cfg, seed=5)
     model = model.to(DEV).to(dtype).train()
-    B, T = 3, 48
+    B = 3
     x = (torch.randn(B, T, 128, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV).to(dtype)
     mask = torch.ones(B, T, device=DEV, dtype=torch.long)
     mask[0, :7] = 0

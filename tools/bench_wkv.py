@@ -73,6 +73,8 @@ def main():
             fn()
             _lib.lib().rwkv7_debug_set_fwd_shape(0)
         return g
+    cb = (lambda: ops.wkv7_chunk_backward(w, q, k, v, aa, b, dy, s, sa)) if a.dtype == "bf16" else None
+    cb_state = (lambda: ops.wkv7_chunk_bwd_state(w, q, aa, b, dy, tinv)) if a.dtype == "bf16" else None
     for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz),
                                 ("wkv7_fwd 8 col/lane", shaped(8, fwd), 7 * 64 * esz),
                                 ("wkv7_fwd 4 col/lane", shaped(4, fwd), 7 * 64 * esz),
@@ -81,7 +83,11 @@ def main():
                                 ("wkv7_bwd row-split 256 thr", bwd2, 13 * 64 * esz),
                                 ("wkv7_bwd row-split 512 thr", lambda: (_lib.lib().rwkv7_debug_set_bwd_shape(1), bwd2(), _lib.lib().rwkv7_debug_set_bwd_shape(0)), 13 * 64 * esz),
                                 ("wkv7_state_fwd", sfw, 7 * 64 * esz), ("wkv7c_prep (T inverse)", prep, 3 * 64 * esz),
-                                ("wkv7c_fwd (chunked, save)", cf, 7 * 64 * esz)):
+                                ("wkv7c_fwd (chunked, save)", cf, 7 * 64 * esz),
+                                ("wkv7c bwd pre+state", cb_state, 13 * 64 * esz),
+                                ("wkv7c bwd total (4 launches)", cb, 13 * 64 * esz)):
+        if fn is None:
+            continue
         med, best = timeit(fn, a.iters)
         gbs = th * bytes_per / (med * 1e-3) / 1e9
         print(f"{name:22s} B={B} T={T} H={H} {a.dtype}: median {med:8.3f} ms  best {best:8.3f} ms  "
