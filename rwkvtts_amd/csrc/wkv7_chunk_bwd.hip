@@ -15,6 +15,21 @@
 
 namespace rwkv7 {
 
+#ifdef WKV7C_TIMING
+// profiling build only (python -m rwkvtts_amd.build --timing): per-phase cycle totals of workgroup 0, per wave
+__device__ long long g_cbwd_timing[4 * 32];
+#define BSTAMP(i)                                                                  \
+    do {                                                                           \
+        const long long now_ = __builtin_readcyclecounter();                       \
+        if (blockIdx.x == 0 && lane == 0) g_cbwd_timing[wave * 32 + (i)] += now_ - tprev_; \
+        tprev_ = now_;                                                             \
+    } while (0)
+#define BSTAMP_INIT long long tprev_ = __builtin_readcyclecounter()
+#else
+#define BSTAMP(i) do { } while (0)
+#define BSTAMP_INIT do { } while (0)
+#endif
+
 namespace {
 constexpr int LDK = kN + kPad;  // planes with 64 contiguous elements per row
 constexpr int LDC = kC + kPad;  // planes with 32 contiguous elements per row
@@ -112,11 +127,10 @@ __device__ __forceinline__ void chunk_cumsum(const float (&lw)[8], float (&G)[8]
     }
 }
 
-// T (or T^T) of the chunk, fp32 [32][32] in global memory -> bf16 hi/lo planes [32][LDC]
+// T (or T^T) of the chunk, fp32 [32][32] in global memory -> bf16 hi/lo planes [32][LDC]; thread tid holds T[tid>>3][4(tid&7)..]
 template <bool TRANSPOSE>
-__device__ __forceinline__ void load_tm(const float *tp, uint16_t *Th, uint16_t *Tl, int tid) {
+__device__ __forceinline__ void put_tm(const float4 x, uint16_t *Th, uint16_t *Tl, int tid) {
     const int tr = tid >> 3, tc = (tid & 7) * 4;
-    const float4 x = *reinterpret_cast<const float4 *>(tp + tr * kC + tc);
     if (!TRANSPOSE) {
         uint32_t h0, l0, h1, l1;
         split_pk(x.x, x.y, h0, l0);
@@ -130,13 +144,16 @@ __device__ __forceinline__ void load_tm(const float *tp, uint16_t *Th, uint16_t 
     }
 }
 
+constexpr int kChunksPerWG = 4;  // the parallel kernels walk this many consecutive chunks, prefetching the next one's inputs
+
 struct PreSmem {  // offsets in uint16 units
-    // time-major planes, dead after phase 1; G1T (phase 2+) is laid over them
+    // phase-1 inputs, contiguous: dead after phase 1 and overlaid by G1T and the M^T planes
     static constexpr int QTh = 0, QTl = QTh + kC * LDK, BHh = QTl + kC * LDK, BHl = BHh + kC * LDK;
-    static constexpr int G1Th = QTh, G1Tl = G1Th + kN * LDC;  // 2 * 2560 <= 4 * 2304
-    static constexpr int ATTh = BHl + kC * LDK, ATTl = ATTh + kN * LDC, QTTh = ATTl + kN * LDC, QTTl = QTTh + kN * LDC;
-    static constexpr int BCTh = QTTl + kN * LDC, BCTl = BCTh + kN * LDC, DYT = BCTl + kN * LDC;
-    static constexpr int TMh = DYT + kN * LDC, TMl = TMh + kC * LDC, QBTh = TMl + kC * LDC, QBTl = QBTh + kC * LDC;
+    static constexpr int ATTh = BHl + kC * LDK, ATTl = ATTh + kN * LDC, TMh = ATTl + kN * LDC, TMl = TMh + kC * LDC;
+    static constexpr int end1 = TMl + kC * LDC;
+    static constexpr int G1Th = 0, G1Tl = G1Th + kN * LDC, MPh = G1Tl + kN * LDC, MPl = MPh + kN * LDK;   // M^T[k][k'] planes
+    static constexpr int QTTh = end1, QTTl = QTTh + kN * LDC, BCTh = QTTl + kN * LDC, BCTl = BCTh + kN * LDC;
+    static constexpr int DYT = BCTl + kN * LDC, QBTh = DYT + kN * LDC, QBTl = QBTh + kC * LDC;
     // W^T planes; the fp32 cumsum scratch of the prologue (sh_G 2048 + sh_seg 256 floats = 4608 u16) lies over them
     static constexpr int WTh = QBTl + kC * LDC, WTl = WTh + kN * LDC;
     static constexpr int scratch = WTh;
@@ -144,15 +161,18 @@ struct PreSmem {  // offsets in uint16 units
     static constexpr int end16 = gC + 2 * kN;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
+static_assert(PreSmem::MPl + kN * LDK <= PreSmem::end1, "G1T + M^T planes must fit over the phase-1 inputs");
 static_assert(2 * kN * LDC >= (kC * kN + 4 * kN) * 2, "cumsum scratch must fit under the W^T planes");
-static_assert(PreSmem::QTh % 8 == 0 && PreSmem::ATTh % 8 == 0 && PreSmem::WTh % 8 == 0 && PreSmem::gC % 8 == 0, "16-byte alignment");
+static_assert(PreSmem::ATTh % 8 == 0 && PreSmem::QTTh % 8 == 0 && PreSmem::WTh % 8 == 0 && PreSmem::gC % 8 == 0 &&
+                  PreSmem::MPh % 8 == 0, "16-byte alignment");
+static_assert(PreSmem::bytes <= 80 * 1024, "two workgroups per CU");
 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// pre: M_c^T planes and N'_c
+// pre: M_c^T (bf16 hi/lo, in MFMA A-fragment order: [chunk][k-tile][plane][k-step][lane][8]) and N'_c
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, const bf16_t *__restrict__ w_,
+__global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int nchunks_total, const bf16_t *__restrict__ w_,
                                                             const bf16_t *__restrict__ q_, const bf16_t *__restrict__ a_,
                                                             const bf16_t *__restrict__ b_, const bf16_t *__restrict__ dy_,
                                                             const float *__restrict__ tinv_, uint16_t *__restrict__ mt_,
@@ -162,116 +182,136 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, const
     float *sh_G = reinterpret_cast<float *>(sm + L::scratch), *sh_seg = sh_G + kC * kN;
     float *sh_gC = reinterpret_cast<float *>(sm + L::gC);
     const int nc = T_ / kC;
-    const int bh = blockIdx.x / nc, c = blockIdx.x - bh * nc;
-    const int bb = bh / H, hh = bh - bb * H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int pt = tid & 31, pk = (tid >> 5) * 8;
     const long tstride = (long)H * kN;
-    const long off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + pt) * tstride + pk;
 
-    // ---- prologue ---------------------------------------------------------------------------------------------------
-    const Raw8 rw = ld8(w_ + off), rq = ld8(q_ + off), ra = ld8(a_ + off), rb = ld8(b_ + off), rdy = ld8(dy_ + off);
-    load_tm<false>(tinv_ + (long)blockIdx.x * kC * kC, sm + L::TMh, sm + L::TMl, tid);
-    float lw[8], G[8];
-    cvt8(rw, lw);
+    struct In {
+        Raw8 w, q, a, b, dy;
+        float4 tm;
+    };
+    auto load = [&](int chunk) {
+        const int bh = chunk / nc, c = chunk - bh * nc;
+        const int bb = bh / H, hh = bh - bb * H;
+        const long off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + pt) * tstride + pk;
+        In r;
+        r.w = ld8(w_ + off); r.q = ld8(q_ + off); r.a = ld8(a_ + off); r.b = ld8(b_ + off); r.dy = ld8(dy_ + off);
+        r.tm = *reinterpret_cast<const float4 *>(tinv_ + (long)chunk * kC * kC + tid * 4);
+        return r;
+    };
+    const int chunk0 = blockIdx.x * kChunksPerWG;
+    In cur = load(chunk0);
+    for (int ci = 0; ci < kChunksPerWG; ci++) {
+        const int chunk = chunk0 + ci;
+        if (chunk >= nchunks_total) break;
+        In nxt = cur;
+        if (ci + 1 < kChunksPerWG && chunk + 1 < nchunks_total) nxt = load(chunk + 1);
+        // ---- prologue -----------------------------------------------------------------------------------------------
+        put_tm<false>(cur.tm, sm + L::TMh, sm + L::TMl, tid);
+        float lw[8], G[8];
+        cvt8(cur.w, lw);
 #pragma unroll
-    for (int j = 0; j < 8; j++) lw[j] = -fast_exp(lw[j]);
-    chunk_cumsum(lw, G, sh_G, sh_seg, tid, pt, pk);
-    if (pt == kC - 1) {
+        for (int j = 0; j < 8; j++) lw[j] = -fast_exp(lw[j]);
+        chunk_cumsum(lw, G, sh_G, sh_seg, tid, pt, pk);
+        if (pt == kC - 1) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) sh_gC[pk + j] = fast_exp(G[j]);
-    }
-    lds_barrier();  // sh_gC complete; cumsum scratch free (W^T planes are written in phase 1)
-    {
-        float qv[8], av[8], bv[8], x[8];
-        cvt8(rq, qv); cvt8(ra, av); cvt8(rb, bv);
-        uint32_t hi[4], lo[4];
+            for (int j = 0; j < 8; j++) sh_gC[pk + j] = fast_exp(G[j]);
+        }
+        lds_barrier();  // sh_gC complete; cumsum scratch free (W^T planes are written in phase 1)
+        {
+            float qv[8], av[8], bv[8], x[8];
+            cvt8(cur.q, qv); cvt8(cur.a, av); cvt8(cur.b, bv);
+            uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = qv[j] * fast_exp(G[j]);                 // q~ = q gamma_t
-        put_row8(sm + L::QTh, sm + L::QTl, pt * LDK + pk, x, hi, lo);
-        put_col8(sm + L::QTTh, sm + L::QTTl, LDC, pk, pt, hi, lo);
+            for (int j = 0; j < 8; j++) x[j] = qv[j] * fast_exp(G[j]);                 // q~ = q gamma_t
+            put_row8(sm + L::QTh, sm + L::QTl, pt * LDK + pk, x, hi, lo);
+            put_col8(sm + L::QTTh, sm + L::QTTl, LDC, pk, pt, hi, lo);
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = bv[j] * fast_exp(-G[j]);                // b^ = b / gamma_t
-        put_row8(sm + L::BHh, sm + L::BHl, pt * LDK + pk, x, hi, lo);
+            for (int j = 0; j < 8; j++) x[j] = bv[j] * fast_exp(-G[j]);                // b^ = b / gamma_t
+            put_row8(sm + L::BHh, sm + L::BHl, pt * LDK + pk, x, hi, lo);
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] *= sh_gC[pk + j];                          // b^ g_C (bounded by |b|)
+            for (int j = 0; j < 8; j++) x[j] *= sh_gC[pk + j];                          // b^ g_C (bounded by |b|)
 #pragma unroll
-        for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], hi[j], lo[j]);
-        put_col8(sm + L::BCTh, sm + L::BCTl, LDC, pk, pt, hi, lo);
+            for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], hi[j], lo[j]);
+            put_col8(sm + L::BCTh, sm + L::BCTl, LDC, pk, pt, hi, lo);
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = av[j] * fast_exp(G[j] - lw[j]);         // a~ = a gamma_{t-1}
+            for (int j = 0; j < 8; j++) x[j] = av[j] * fast_exp(G[j] - lw[j]);         // a~ = a gamma_{t-1}
 #pragma unroll
-        for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], hi[j], lo[j]);
-        put_col8(sm + L::ATTh, sm + L::ATTl, LDC, pk, pt, hi, lo);
-        const uint32_t dyr[4] = {rdy.r.x, rdy.r.y, rdy.r.z, rdy.r.w};            // dY is bf16: exact, one plane
+            for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], hi[j], lo[j]);
+            put_col8(sm + L::ATTh, sm + L::ATTl, LDC, pk, pt, hi, lo);
+            const uint32_t dyr[4] = {cur.dy.r.x, cur.dy.r.y, cur.dy.r.z, cur.dy.r.w};  // dY is bf16: exact, one plane
 #pragma unroll
-        for (int j = 0; j < 8; j++) sm[L::DYT + (pk + j) * LDC + pt] = (uint16_t)(dyr[j >> 1] >> ((j & 1) * 16));
-    }
-    lds_barrier();
-    // ---- phase 1: A_qb^T (wave 0), W = T A~ (waves 1, 2) ---------------------------------------------------------------
-    if (wave == 0) {
-        f32x16 acc = zero16();  // D[m = t][n = s] = q~_t . b^_s, kept for t >= s; stored as QBT[s][t]
-        mma_tile3<kN>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::BHh, sm + L::BHl, LDK, lane);
-        mask_upper_T<false>(acc, lane);
-        store_T_split(acc, sm + L::QBTh, sm + L::QBTl, LDC, lane);
-    } else if (wave <= 2) {
-        const int kt = wave - 1;
-        f32x16 acc = zero16();  // D[m = t][n = k] = sum_s T[t][s] a~[s][k]; stored as WT[k][t]
-        mma_tile3<kC>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::ATTh + kt * 32 * LDC, sm + L::ATTl + kt * 32 * LDC, LDC, lane);
-        store_T_split(acc, sm + L::WTh + kt * 32 * LDC, sm + L::WTl + kt * 32 * LDC, LDC, lane);
-    }
-    lds_barrier();
-    // ---- phase 2: G1 = A_qb^T dY (waves 0, 1); M^T = diag(g_C) + W^T (B^ g_C) (waves 2, 3) ---------------------------
-    if (wave <= 1) {
-        const int vt = wave;
-        f32x16 acc = zero16();  // D[m = s][n = v] = sum_t QBT[s][t] dY[t][v]; stored as G1T[v][s]
-        mma_xs_ye<kC>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
-        store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
-    } else {
-        const int mt = wave - 2;  // rows k of M^T
-        uint16_t *outh = mt_ + (long)blockIdx.x * 2 * kN * kN, *outl = outh + kN * kN;
+            for (int j = 0; j < 8; j++) sm[L::DYT + (pk + j) * LDC + pt] = (uint16_t)(dyr[j >> 1] >> ((j & 1) * 16));
+        }
+        lds_barrier();
+        // ---- phase 1: A_qb^T (wave 0), W = T A~ (waves 1, 2) -----------------------------------------------------------
+        if (wave == 0) {
+            f32x16 acc = zero16();  // D[m = t][n = s] = q~_t . b^_s, kept for t >= s; stored as QBT[s][t]
+            mma_tile3<kN>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::BHh, sm + L::BHl, LDK, lane);
+            mask_upper_T<false>(acc, lane);
+            store_T_split(acc, sm + L::QBTh, sm + L::QBTl, LDC, lane);
+        } else if (wave <= 2) {
+            const int kt = wave - 1;
+            f32x16 acc = zero16();  // D[m = t][n = k] = sum_s T[t][s] a~[s][k]; stored as WT[k][t]
+            mma_tile3<kC>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::ATTh + kt * 32 * LDC, sm + L::ATTl + kt * 32 * LDC, LDC, lane);
+            store_T_split(acc, sm + L::WTh + kt * 32 * LDC, sm + L::WTl + kt * 32 * LDC, LDC, lane);
+        }
+        lds_barrier();
+        // ---- phase 2: G1 = A_qb^T dY (waves 0, 1); M^T = diag(g_C) + W^T (B^ g_C) (waves 2, 3) -----------------------
+        if (wave <= 1) {
+            const int vt = wave;
+            f32x16 acc = zero16();  // D[m = s][n = v] = sum_t QBT[s][t] dY[t][v]; stored as G1T[v][s]
+            mma_xs_ye<kC>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
+            store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
+        } else {
+            const int mt = wave - 2;  // rows k' of the product below
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            f32x16 acc = zero16();  // D[m = k][n = k'] = sum_t W[t][k] (b^ g_C)[t][k'] = (M^T - diag)[k][k']
-            mma_tile3<kC>(acc, sm + L::WTh + mt * 32 * LDC, sm + L::WTl + mt * 32 * LDC, LDC, sm + L::BCTh + nt * 32 * LDC,
-                          sm + L::BCTl + nt * 32 * LDC, LDC, lane);
-            const int n = lane & 31;
+            for (int nt = 0; nt < 2; nt++) {
+                f32x16 acc = zero16();  // D[m = k'][n = k] = sum_t (b^ g_C)[t][k'] W[t][k]; stored as M^T[k][k']
+                mma_tile3<kC>(acc, sm + L::BCTh + mt * 32 * LDC, sm + L::BCTl + mt * 32 * LDC, LDC, sm + L::WTh + nt * 32 * LDC,
+                              sm + L::WTl + nt * 32 * LDC, LDC, lane);
+                if (mt == nt) {
+                    const int n = lane & 31;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = d_row(r, lane);
-                float x = acc[r];
-                if (mt == nt && m == n) x += sh_gC[mt * 32 + m];
-                uint16_t xh, xl;
-                split2(x, xh, xl);
-                const int o = (mt * 32 + m) * kN + nt * 32 + n;
-                outh[o] = xh;
-                outl[o] = xl;
+                    for (int r = 0; r < 16; r++)
+                        if (d_row(r, lane) == n) acc[r] += sh_gC[mt * 32 + n];
+                }
+                store_T_split(acc, sm + L::MPh + nt * 32 * LDK + mt * 32, sm + L::MPl + nt * 32 * LDK + mt * 32, LDK, lane);
             }
         }
-    }
-    lds_barrier();
-    // ---- phase 3: N' = Q~^T dY + W^T G1  (one 32x32 tile per wave, stored in MFMA register layout) ----------------------
-    {
-        const int mt = wave >> 1, nt = wave & 1;
-        f32x16 acc = zero16();  // D[m = k][n = v]
-        mma_xs_ye<kC>(acc, sm + L::QTTh + mt * 32 * LDC, sm + L::QTTl + mt * 32 * LDC, LDC, sm + L::DYT + nt * 32 * LDC, LDC, lane);
-        mma_tile3<kC>(acc, sm + L::WTh + mt * 32 * LDC, sm + L::WTl + mt * 32 * LDC, LDC, sm + L::G1Th + nt * 32 * LDC,
-                      sm + L::G1Tl + nt * 32 * LDC, LDC, lane);
-        float *o = np_ + (((long)blockIdx.x * 4 + wave) * 64 + lane) * 16;
+        lds_barrier();
+        // ---- phase 3: N' = Q~^T dY + W^T G1 (one tile per wave, MFMA register layout); M^T planes -> fragment order ---------
+        {
+            const int mt = wave >> 1, nt = wave & 1;
+            f32x16 acc = zero16();  // D[m = k][n = v]
+            mma_xs_ye<kC>(acc, sm + L::QTTh + mt * 32 * LDC, sm + L::QTTl + mt * 32 * LDC, LDC, sm + L::DYT + nt * 32 * LDC, LDC, lane);
+            mma_tile3<kC>(acc, sm + L::WTh + mt * 32 * LDC, sm + L::WTl + mt * 32 * LDC, LDC, sm + L::G1Th + nt * 32 * LDC,
+                          sm + L::G1Tl + nt * 32 * LDC, LDC, lane);
+            float *o = np_ + (((long)chunk * 4 + wave) * 64 + lane) * 16;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            *reinterpret_cast<float4 *>(o + 4 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            for (int j = 0; j < 4; j++)
+                *reinterpret_cast<float4 *>(o + 4 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            // wave = (k-tile mt, plane): the four 16-byte A fragments of its 32 rows of M^T
+            const uint16_t *pl = sm + ((wave & 1) ? L::MPl : L::MPh) + (mt * 32 + (lane & 31)) * LDK + (lane >> 5) * 8;
+            uint16_t *mo = mt_ + ((long)chunk * 4 + wave) * 4 * 512 + lane * 8;
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<uint4 *>(mo + i * 512) = *reinterpret_cast<const uint4 *>(pl + 16 * i);
+        }
+        lds_barrier();  // the next chunk's prologue overwrites what phase 3 reads
+        cur = nxt;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // state: E_c = M_c^T E_{c+1} + N'_c, c = nc-1 .. 0; writes E_{c+1} (the adjoint state chunk c sees at its end) for every c
-// in both orientations: e_vk[b,h,c][v][k] and e_kv[b,h,c][k][v]
+// in both orientations: e_vk[b,h,c][v][k] and e_kv[b,h,c][k][v].  M^T arrives in A-fragment order and N' in accumulator
+// order, so both go from global memory straight into MFMA operands / accumulators; only E itself passes through LDS
+// (accumulator layout -> B-operand planes).  The chain is one 64x64x64 product per chunk; inputs are prefetched three
+// chunks ahead in registers so that the ~2 us HBM latency is off the critical path.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
 struct StateSmem {
-    static constexpr int M0h = 0, M0l = M0h + kN * LDK, M1h = M0l + kN * LDK, M1l = M1h + kN * LDK;
-    static constexpr int E0h = M1l + kN * LDK, E0l = E0h + kN * LDK, E1h = E0l + kN * LDK, E1l = E1h + kN * LDK;
+    static constexpr int E0h = 0, E0l = E0h + kN * LDK, E1h = E0l + kN * LDK, E1l = E1h + kN * LDK;
     static constexpr int end16 = E1l + kN * LDK;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
@@ -285,36 +325,29 @@ __global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int mt = wave >> 1, nt = wave & 1;
 
-    uint4 rm[4];
-    float4 rn[4];
-    auto issue = [&](int c) {
-        const uint16_t *mp = mt_ + ((long)bh * nc + c) * 2 * kN * kN;
-#pragma unroll
-        for (int i = 0; i < 4; i++) rm[i] = *reinterpret_cast<const uint4 *>(mp + (tid + 256 * i) * 8);  // 1024 pieces of 8 u16
-        const float *np = np_ + ((((long)bh * nc + c) * 4 + wave) * 64 + lane) * 16;
-#pragma unroll
-        for (int j = 0; j < 4; j++) rn[j] = *reinterpret_cast<const float4 *>(np + 4 * j);
+    struct In {
+        bf16x8 mh[4], ml[4];
+        float4 n[4];
     };
-    auto commit = [&](int buf) {
-        uint16_t *base = sm + (buf ? L::M1h : L::M0h);
+    auto load = [&](int c) {
+        In r;
+        if (c >= 0) {
+            const uint16_t *mp = mt_ + (((long)bh * nc + c) * 4 + mt * 2) * 4 * 512 + lane * 8;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int p = tid + 256 * i;            // piece p: plane p >> 9, row (p >> 3) & 63, column 8 (p & 7)
-            const int plane = p >> 9, row = (p >> 3) & 63, col = (p & 7) * 8;
-            *reinterpret_cast<uint4 *>(base + plane * kN * LDK + row * LDK + col) = rm[i];
+            for (int i = 0; i < 4; i++) {
+                r.mh[i] = *reinterpret_cast<const bf16x8 *>(mp + i * 512);
+                r.ml[i] = *reinterpret_cast<const bf16x8 *>(mp + 4 * 512 + i * 512);
+            }
+            const float *np = np_ + ((((long)bh * nc + c) * 4 + wave) * 64 + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < 4; j++) r.n[j] = *reinterpret_cast<const float4 *>(np + 4 * j);
         }
+        return r;
     };
     for (int i = tid; i < 2 * kN * LDK; i += 256) sm[L::E0h + i] = 0;  // E_{nc} = 0
-    issue(nc - 1);
-    commit((nc - 1) & 1);
-    f32x16 E = zero16();  // this wave's tile of the current E, D layout [m = k][n = v]
-    float4 rn_cur[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) rn_cur[j] = rn[j];
-    lds_barrier();
+    f32x16 E = zero16();  // this wave's tile of the current E, accumulator layout [m = k][n = v]
     int cur = 0;
-    for (int c = nc - 1; c >= 0; c--) {
-        if (c > 0) issue(c - 1);
+    auto step = [&](int c, const In &in) {
         {
             // E_{c+1}: what chunk c receives from the future
             float *pv = e_vk + (((long)bh * nc + c) * kN + nt * 32 + (lane & 31)) * kN + mt * 32 + 4 * (lane >> 5);
@@ -325,24 +358,43 @@ __global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t
 #pragma unroll
             for (int r = 0; r < 16; r++) pk[(long)(mt * 32 + d_row(r, lane)) * kN] = E[r];
         }
-        const uint16_t *Mh = sm + ((c & 1) ? L::M1h : L::M0h), *Ml = Mh + kN * LDK;
-        const uint16_t *Eh = sm + (cur ? L::E1h : L::E0h), *El = Eh + kN * LDK;
-        f32x16 acc = zero16();  // D[m = k][n = v] = sum_k' M^T[k][k'] E[k'][v]
-        mma_tile3<kN>(acc, Mh + mt * 32 * LDK, Ml + mt * 32 * LDK, LDK, Eh + nt * 32 * LDK, El + nt * 32 * LDK, LDK, lane);
+        const uint16_t *Eh = sm + (cur ? L::E1h : L::E0h) + (nt * 32 + (lane & 31)) * LDK + (lane >> 5) * 8, *El = Eh + kN * LDK;
+        f32x16 acc;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            acc[4 * j] += rn_cur[j].x; acc[4 * j + 1] += rn_cur[j].y; acc[4 * j + 2] += rn_cur[j].z; acc[4 * j + 3] += rn_cur[j].w;
+            acc[4 * j] = in.n[j].x; acc[4 * j + 1] = in.n[j].y; acc[4 * j + 2] = in.n[j].z; acc[4 * j + 3] = in.n[j].w;
+        }
+        bf16x8 eh[4], el[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            eh[i] = *reinterpret_cast<const bf16x8 *>(Eh + 16 * i);
+            el[i] = *reinterpret_cast<const bf16x8 *>(El + 16 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {  // D[m = k][n = v] += sum_k' M^T[k][k'] E[k'][v]
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.mh[i], eh[i], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.mh[i], el[i], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.ml[i], eh[i], acc, 0, 0, 0);
         }
         E = acc;
         uint16_t *Oh = sm + (cur ? L::E0h : L::E1h), *Ol = Oh + kN * LDK;
         store_T_split(E, Oh + nt * 32 * LDK + mt * 32, Ol + nt * 32 * LDK + mt * 32, LDK, lane);  // planes [v][k]
-        if (c > 0) {
-            commit((c - 1) & 1);
-#pragma unroll
-            for (int j = 0; j < 4; j++) rn_cur[j] = rn[j];
-        }
         lds_barrier();
         cur ^= 1;
+    };
+    In r0 = load(nc - 1), r1 = load(nc - 2), r2 = load(nc - 3);
+    lds_barrier();
+    for (int c = nc - 1; c >= 0; c -= 3) {
+        step(c, r0);
+        r0 = load(c - 3);
+        if (c - 1 >= 0) {
+            step(c - 1, r1);
+            r1 = load(c - 4);
+        }
+        if (c - 2 >= 0) {
+            step(c - 2, r2);
+            r2 = load(c - 5);
+        }
     }
 }
 
@@ -423,7 +475,7 @@ __device__ __forceinline__ void put4(uint16_t *Ph, uint16_t *Pl, int row, int c4
 }  // namespace
 
 __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
-    int T_, int H, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
+    int T_, int H, int nchunks_total, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
     const bf16_t *__restrict__ v_, const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_, const bf16_t *__restrict__ dy_,
     const float *__restrict__ s_, const float *__restrict__ sa_, const float *__restrict__ tinv_, const float *__restrict__ e_vk,
     const float *__restrict__ e_kv, bf16_t *__restrict__ dw_, bf16_t *__restrict__ dq_, bf16_t *__restrict__ dk_,
@@ -432,41 +484,71 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     using L = OutSmem;
     float *sh_gC = reinterpret_cast<float *>(sm + L::gC), *sh_dterm = reinterpret_cast<float *>(sm + L::dterm);
     const int nc = T_ / kC;
-    const int bh = blockIdx.x / nc, c = blockIdx.x - bh * nc;
-    const int bb = bh / H, hh = bh - bb * H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int pt = tid & 31, pk = (tid >> 5) * 8;
     const long tstride = (long)H * kN;
-    const long off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + pt) * tstride + pk;
-
-    // ---- global loads ---------------------------------------------------------------------------------------------------
-    const Raw8 rw = ld8(w_ + off), rq = ld8(q_ + off), rk = ld8(k_ + off), ra = ld8(a_ + off), rb = ld8(b_ + off);
-    const Raw8 rv = ld8(v_ + off), rdy = ld8(dy_ + off);
-    const float4 ru0 = *reinterpret_cast<const float4 *>(sa_ + off), ru1 = *reinterpret_cast<const float4 *>(sa_ + off + 4);
-    // 64x64 fp32 matrices: piece p = tid + 256 i covers row p >> 4, columns 4 (p & 15) .. +4
-    const float *evk = e_vk + (long)blockIdx.x * kN * kN, *ekv = e_kv + (long)blockIdx.x * kN * kN;
     const long nck = T_ / kChunk;  // scalar-forward checkpoints (every 16 steps), s[b,h,n][k][v]
-    const float *h0p = s_ + ((long)bh * nck + (2 * c - 1)) * kN * kN, *hcp = s_ + ((long)bh * nck + (2 * c + 1)) * kN * kN;
-    float4 rekv[4], rh0[4];
-    {
-        float part[4];
+
+    // everything a chunk reads from global memory, held in registers one chunk ahead
+    struct In {
+        Raw8 w, q, k, a, b, v, dy;
+        float4 u0, u1, tm;
+        float4 evk[4], ekv[4], h0[4], hc[4];  // 64x64 fp32: piece p = tid + 256 i = row p >> 4, columns 4 (p & 15) .. +4
+        long off;
+    };
+    // first: load H0 as well; otherwise H0 of this chunk is H_C of the previous one (same head), already in registers
+    auto load = [&](int chunk, bool first) {
+        const int bh = chunk / nc, c = chunk - bh * nc;
+        const int bb = bh / H, hh = bh - bb * H;
+        In r;
+        r.off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + pt) * tstride + pk;
+        r.w = ld8(w_ + r.off); r.q = ld8(q_ + r.off); r.k = ld8(k_ + r.off); r.a = ld8(a_ + r.off); r.b = ld8(b_ + r.off);
+        r.v = ld8(v_ + r.off); r.dy = ld8(dy_ + r.off);
+        r.u0 = *reinterpret_cast<const float4 *>(sa_ + r.off);
+        r.u1 = *reinterpret_cast<const float4 *>(sa_ + r.off + 4);
+        r.tm = *reinterpret_cast<const float4 *>(tinv_ + (long)chunk * kC * kC + tid * 4);
+        const float *evk = e_vk + (long)chunk * kN * kN, *ekv = e_kv + (long)chunk * kN * kN;
+        const float *h0p = s_ + ((long)bh * nck + (2 * c - 1)) * kN * kN, *hcp = s_ + ((long)bh * nck + (2 * c + 1)) * kN * kN;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i;
-            rekv[i] = *reinterpret_cast<const float4 *>(ekv + p * 4);
-            rh0[i] = c > 0 ? *reinterpret_cast<const float4 *>(h0p + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 hc = *reinterpret_cast<const float4 *>(hcp + p * 4);
-            part[i] = rekv[i].x * hc.x + rekv[i].y * hc.y + rekv[i].z * hc.z + rekv[i].w * hc.w;
+            r.evk[i] = *reinterpret_cast<const float4 *>(evk + p * 4);
+            r.ekv[i] = *reinterpret_cast<const float4 *>(ekv + p * 4);
+            if (first || c == 0) r.h0[i] = c > 0 ? *reinterpret_cast<const float4 *>(h0p + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.hc[i] = *reinterpret_cast<const float4 *>(hcp + p * 4);
         }
-        // rowsum(E * H_C): the 16 lanes tid & 15 share a row
+        return r;
+    };
+    const int chunk0 = blockIdx.x * kChunksPerWG;
+    In cur = load(chunk0, true);
+    for (int ci = 0; ci < kChunksPerWG; ci++) {
+    const int chunk = chunk0 + ci;
+    if (chunk >= nchunks_total) break;
+    In nxt = cur;
+    if (ci + 1 < kChunksPerWG && chunk + 1 < nchunks_total) {
+        nxt = load(chunk + 1, false);
+        if ((chunk + 1) % nc != 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float t = sum16(part[i]);
-            if ((tid & 15) == 0) sh_dterm[(tid + 256 * i) >> 4] = t;
+            for (int i = 0; i < 4; i++) nxt.h0[i] = cur.hc[i];
         }
     }
-    load_tm<true>(tinv_ + (long)blockIdx.x * kC * kC, sm + L::TMTh, sm + L::TMTl, tid);
+    BSTAMP_INIT;
+    const long off = cur.off;
+    const Raw8 rw = cur.w, rq = cur.q, rk = cur.k, ra = cur.a, rb = cur.b, rv = cur.v, rdy = cur.dy;
+    const float4 ru0 = cur.u0, ru1 = cur.u1;
+    float4 rekv[4], rh0[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        rekv[i] = cur.ekv[i];
+        rh0[i] = cur.h0[i];
+        // rowsum(E * H_C): the 16 lanes tid & 15 share a row
+        const float part = rekv[i].x * cur.hc[i].x + rekv[i].y * cur.hc[i].y + rekv[i].z * cur.hc[i].z + rekv[i].w * cur.hc[i].w;
+        const float t = sum16(part);
+        if ((tid & 15) == 0) sh_dterm[(tid + 256 * i) >> 4] = t;
+    }
+    put_tm<true>(cur.tm, sm + L::TMTh, sm + L::TMTl, tid);
 
+    BSTAMP(0);
     // ---- prologue: decay, scaled operands ----------------------------------------------------------------------------------
     float lw[8], G[8], qv[8], kv[8], av[8], bv[8], gam[8], gprev[8], igam[8];
     cvt8(rw, lw);
@@ -514,17 +596,18 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
 #pragma unroll
         for (int j = 0; j < 8; j++) sm[L::DYT + (pk + j) * LDC + pt] = (uint16_t)(dyr[j >> 1] >> ((j & 1) * 16));
     }
+    BSTAMP(1);
     lds_barrier();  // sh_gC visible
     {
         // (g_C E)[v][k] planes: row v, scale per column k
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
-            const float4 e = *reinterpret_cast<const float4 *>(evk + p * 4);
-            put4(sm + L::EGh, sm + L::EGl, row, c4, e, sh_gC[c4], sh_gC[c4 + 1], sh_gC[c4 + 2], sh_gC[c4 + 3]);
+            put4(sm + L::EGh, sm + L::EGl, row, c4, cur.evk[i], sh_gC[c4], sh_gC[c4 + 1], sh_gC[c4 + 2], sh_gC[c4 + 3]);
         }
     }
     lds_barrier();
+    BSTAMP(2);
     // ---- phase A: A_qb^T, A_qk^T, A_ak^T ------------------------------------------------------------------------------------
     if (wave == 0) {
         f32x16 acc = zero16();  // D[t][s] = q~_t . b^_s, t >= s -> QBT[s][t]
@@ -543,6 +626,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         store_T_split(acc, sm + L::AKTh, sm + L::AKTl, LDC, lane);
     }
     lds_barrier();
+    BSTAMP(3);
     // ---- phase B: G1[s][v] = sum_t A_qb[t][s] dY[t][v] + sum_k b^[s][k] (g_C E)[k][v]  -> G1T[v][s] ---------------------------
     if (wave <= 1) {
         const int vt = wave;
@@ -552,6 +636,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
     }
     lds_barrier();
+    BSTAMP(4);
     // ---- phase C: Z = T^T G1 in both orientations ---------------------------------------------------------------------------------
     if (wave <= 1) {
         const int vt = wave;
@@ -565,6 +650,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         store_T_split(acc, sm + L::Zh + vt * 32, sm + L::Zl + vt * 32, LDK, lane);
     }
     lds_barrier();
+    BSTAMP(5);
     // ---- phase D: dV[s][v] = sum_t A_qk[t][s] dY[t][v] + A_ak[t][s] Z[t][v] + sum_k k^[s][k] (g_C E)[k][v] -----------------------
     if (wave <= 1) {
         const int vt = wave;
@@ -575,6 +661,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         stage_tile(acc, reinterpret_cast<float *>(sm + L::sV), vt, lane);
     }
     lds_barrier();
+    BSTAMP(6);
     // ---- phase E1: dV out; (g_C E)^T planes; the four P matrices of dK / dB --------------------------------------------------------
     {
         float x[8];
@@ -604,6 +691,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         store_T_split(acc, Ph, Pl, LDC, lane);
     }
     lds_barrier();
+    BSTAMP(7);
     // ---- phase F1: dK (waves 0,1) and dB (waves 2,3), unscaled, to staging ---------------------------------------------------------
     {
         const int kt = wave & 1;
@@ -620,6 +708,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         }
     }
     lds_barrier();
+    BSTAMP(8);
     // ---- phase E2: H0^T planes over (g_C E)^T; the four transposed P matrices of dQ / dA -------------------------------------------
     {
 #pragma unroll
@@ -645,6 +734,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         store_T_split(acc, Ph, Pl, LDC, lane);
     }
     lds_barrier();
+    BSTAMP(9);
     // ---- phase F2: dQ (waves 0,1) and dA (waves 2,3), unscaled, to staging ---------------------------------------------------------
     {
         const int kt = wave & 1;
@@ -662,6 +752,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         }
     }
     lds_barrier();
+    BSTAMP(10);
     // ---- epilogue: decay scaling, decay gradient, stores ----------------------------------------------------------------------------
     float dQ[8], dK[8], dB[8], dA[8], e[8];
     ld_stage8(reinterpret_cast<const float *>(sm + L::sQ), pt, pk, dQ);
@@ -722,6 +813,10 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         for (int j = 0; j < 8; j++) dG[j] = (dG[j] + sh_dterm[pk + j]) * lw[j];
         st_bf16x8(dw_ + off, dG);
     }
+    BSTAMP(11);
+    lds_barrier();  // the next chunk's prologue overwrites what the epilogue reads
+    cur = nxt;
+    }  // chunk loop
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -737,8 +832,10 @@ int chunk_bwd_pre_bf16(int B, int T_, int H, const void *w, const void *q, const
         attr = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(wkv7c_bwd_pre_kernel, dim3(B * H * (T_ / kC)), dim3(256), PreSmem::bytes, st, T_, H, (const bf16_t *)w,
-                       (const bf16_t *)q, (const bf16_t *)a, (const bf16_t *)b, (const bf16_t *)dy, tinv, (uint16_t *)mt, np);
+    const int total = B * H * (T_ / kC);
+    hipLaunchKernelGGL(wkv7c_bwd_pre_kernel, dim3((total + kChunksPerWG - 1) / kChunksPerWG), dim3(256), PreSmem::bytes, st, T_, H,
+                       total, (const bf16_t *)w, (const bf16_t *)q, (const bf16_t *)a, (const bf16_t *)b, (const bf16_t *)dy, tinv,
+                       (uint16_t *)mt, np);
     return (int)hipGetLastError();
 }
 
@@ -766,11 +863,23 @@ int chunk_bwd_out_bf16(int B, int T_, int H, const void *w, const void *q, const
         attr = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(wkv7c_bwd_out_kernel, dim3(B * H * (T_ / kC)), dim3(256), OutSmem::bytes, st, T_, H, (const bf16_t *)w,
+    const int total = B * H * (T_ / kC);
+    hipLaunchKernelGGL(wkv7c_bwd_out_kernel, dim3((total + kChunksPerWG - 1) / kChunksPerWG), dim3(256), OutSmem::bytes, st, T_, H,
+                       total, (const bf16_t *)w,
                        (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a, (const bf16_t *)b,
                        (const bf16_t *)dy, s, sa, tinv, e_vk, e_kv, (bf16_t *)dw, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
                        (bf16_t *)da, (bf16_t *)db);
     return (int)hipGetLastError();
 }
+
+#ifdef WKV7C_TIMING
+extern "C" int rwkv7_debug_cbwd_timing(long long *out, int reset) {
+    if (reset) {
+        long long z[128] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cbwd_timing), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cbwd_timing), sizeof(long long) * 128);
+}
+#endif
 
 }  // namespace rwkv7

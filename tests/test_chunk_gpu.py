@@ -87,8 +87,15 @@ def test_chunked_backward_state_recurrence_vs_prototype():
     tinv = ops.wkv7_chunk_prep(w, a, b)
     mt, np_, e_vk, e_kv = ops.wkv7_chunk_bwd_state(w, q, a, b, dy.to(DEV), tinv)
     torch.cuda.synchronize()
-    mt = mt.cpu().view(torch.bfloat16).float()
-    mt = mt[:, :, :, 0] + mt[:, :, :, 1]            # hi + lo
+    # M^T is stored in MFMA A-fragment order [k-tile][plane][k-step][lane][8]: row = 32*tile + lane%32, col = 16*step + 8*(lane//32) + j
+    frag = mt.cpu().view(torch.bfloat16).float().reshape(B, H, T // 32, 2, 2, 4, 64, 8)
+    frag = frag[:, :, :, :, 0] + frag[:, :, :, :, 1]                      # hi + lo -> [B,H,nc,tile,step,lane,8]
+    mt = torch.zeros(B, H, T // 32, 64, 64)
+    for tile in range(2):
+        for step in range(4):
+            for half in range(2):
+                mt[:, :, :, tile * 32:(tile + 1) * 32, 16 * step + 8 * half:16 * step + 8 * half + 8] = \
+                    frag[:, :, :, tile, step, 32 * half:32 * half + 32, :]
     nc = T // 32
     for h in range(H):
         one = [t[0, :, h].float() for t in ins]
