@@ -73,7 +73,11 @@ def main():
     ap.add_argument("--model", default="0.4b", choices=["0.1b", "0.4b", "1.5b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-checkpoint", action="store_true")
+    ap.add_argument("--scalar-wkv-bwd", action="store_true", help="A/B: row-split scalar WKV7 backward instead of the chunked MFMA one")
     a = ap.parse_args()
+    if a.scalar_wkv_bwd:
+        from rwkvtts_amd import fused as _fused
+        _fused.CHUNKED_WKV_BWD = False
 
     from rwkvtts_amd import build
     build.build()  # no-op when the prebuilt .so is current

@@ -100,31 +100,34 @@ __device__ __forceinline__ void put_col8(uint16_t *Ph, uint16_t *Pl, int ld, int
     }
 }
 
-// inclusive cumulative sum of lw over the 32 steps of the chunk, per channel.  Thread (pt, pk) owns 8 channels of one
-// step; returns G[j] = sum_{s <= pt} lw_s[pk + j].  sh_G [32][64] and sh_seg [4][64] are fp32 scratch.
-__device__ __forceinline__ void chunk_cumsum(const float (&lw)[8], float (&G)[8], float *sh_G, float *sh_seg, int tid, int pt,
-                                             int pk) {
-    *reinterpret_cast<float4 *>(&sh_G[pt * kN + pk]) = make_float4(lw[0], lw[1], lw[2], lw[3]);
-    *reinterpret_cast<float4 *>(&sh_G[pt * kN + pk + 4]) = make_float4(lw[4], lw[5], lw[6], lw[7]);
-    lds_barrier();
-    {
-        const int ch = tid & 63, seg = tid >> 6;
-        float run = 0.f;
+// ---- scans along the time axis.  Thread (pt = lane & 31, ...) holds step pt, so the 32 steps of a chunk are the 32
+// consecutive lanes of a half-wave: prefix sums are DPP row shifts (no LDS, no barrier).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp0(float x) {  // lanes without a source (or outside ROW_MASK) get 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, BOUND));
+}
+// inclusive prefix sum over lanes [0,32) and [32,64) separately
+__device__ __forceinline__ float scan32(float x) {
+    x += dpp0<0x111, 0xf, true>(x);   // row_shr:1
+    x += dpp0<0x112, 0xf, true>(x);   // row_shr:2
+    x += dpp0<0x114, 0xf, true>(x);   // row_shr:4
+    x += dpp0<0x118, 0xf, true>(x);   // row_shr:8
+    x += dpp0<0x142, 0xa, false>(x);  // row_bcast:15 into rows 1 and 3: lane 15 / 47 carries the first 16 steps
+    return x;
+}
+// value of lane 31 (63) for every lane of the half-wave
+__device__ __forceinline__ float last32(float x, int lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) << 2, __float_as_int(x)));
+}
+// value of the next lane (next time step); 0 for the last step of the chunk
+__device__ __forceinline__ float next32(float x, int lane) {
+    const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __float_as_int(x)));
+    return (lane & 31) == 31 ? 0.f : y;
+}
+// G[j] = sum_{s <= pt} lw_s[pk + j]
+__device__ __forceinline__ void chunk_cumsum(const float (&lw)[8], float (&G)[8]) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            run += sh_G[(seg * 8 + i) * kN + ch];
-            sh_G[(seg * 8 + i) * kN + ch] = run;
-        }
-        sh_seg[seg * kN + ch] = run;
-    }
-    lds_barrier();
-    const float4 g0 = *reinterpret_cast<const float4 *>(&sh_G[pt * kN + pk]);
-    const float4 g1 = *reinterpret_cast<const float4 *>(&sh_G[pt * kN + pk + 4]);
-    G[0] = g0.x; G[1] = g0.y; G[2] = g0.z; G[3] = g0.w; G[4] = g1.x; G[5] = g1.y; G[6] = g1.z; G[7] = g1.w;
-    for (int s = 0; s < (pt >> 3); s++) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) G[j] += sh_seg[s * kN + pk + j];
-    }
+    for (int j = 0; j < 8; j++) G[j] = scan32(lw[j]);
 }
 
 // T (or T^T) of the chunk, fp32 [32][32] in global memory -> bf16 hi/lo planes [32][LDC]; thread tid holds T[tid>>3][4(tid&7)..]
@@ -179,7 +182,6 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
                                                             float *__restrict__ np_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = PreSmem;
-    float *sh_G = reinterpret_cast<float *>(sm + L::scratch), *sh_seg = sh_G + kC * kN;
     float *sh_gC = reinterpret_cast<float *>(sm + L::gC);
     const int nc = T_ / kC;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -212,12 +214,12 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
         cvt8(cur.w, lw);
 #pragma unroll
         for (int j = 0; j < 8; j++) lw[j] = -fast_exp(lw[j]);
-        chunk_cumsum(lw, G, sh_G, sh_seg, tid, pt, pk);
+        chunk_cumsum(lw, G);
         if (pt == kC - 1) {
 #pragma unroll
             for (int j = 0; j < 8; j++) sh_gC[pk + j] = fast_exp(G[j]);
         }
-        lds_barrier();  // sh_gC complete; cumsum scratch free (W^T planes are written in phase 1)
+        lds_barrier();  // sh_gC complete
         {
             float qv[8], av[8], bv[8], x[8];
             cvt8(cur.q, qv); cvt8(cur.a, av); cvt8(cur.b, bv);
@@ -554,10 +556,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     cvt8(rw, lw);
 #pragma unroll
     for (int j = 0; j < 8; j++) lw[j] = -fast_exp(lw[j]);
-    {
-        float *sh_G = reinterpret_cast<float *>(sm + L::scratch);
-        chunk_cumsum(lw, G, sh_G, sh_G + kC * kN, tid, pt, pk);
-    }
+    chunk_cumsum(lw, G);
     cvt8(rq, qv); cvt8(rk, kv); cvt8(ra, av); cvt8(rb, bv);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -759,58 +758,27 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     ld_stage8(reinterpret_cast<const float *>(sm + L::sK), pt, pk, dK);
     ld_stage8(reinterpret_cast<const float *>(sm + L::sB), pt, pk, dB);
     ld_stage8(reinterpret_cast<const float *>(sm + L::sA), pt, pk, dA);
-    float *sh_ada = reinterpret_cast<float *>(sm + L::aDA);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         dQ[j] *= gam[j];
         dK[j] *= igam[j];
         dB[j] *= igam[j];
         dA[j] *= gprev[j];
-        e[j] = qv[j] * dQ[j] - kv[j] * dK[j] - bv[j] * dB[j];
-    }
-    {
-        float t[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) t[j] = av[j] * dA[j];
-        *reinterpret_cast<float4 *>(&sh_ada[pt * kN + pk]) = make_float4(t[0], t[1], t[2], t[3]);
-        *reinterpret_cast<float4 *>(&sh_ada[pt * kN + pk + 4]) = make_float4(t[4], t[5], t[6], t[7]);
+        // e_t = (q dQ - k dK - b dB)_t + (a dA)_{t+1}
+        e[j] = qv[j] * dQ[j] - kv[j] * dK[j] - bv[j] * dB[j] + next32(av[j] * dA[j], lane);
     }
     st_bf16x8(dq_ + off, dQ);
     st_bf16x8(dk_ + off, dK);
     st_bf16x8(db_ + off, dB);
     st_bf16x8(da_ + off, dA);
-    lds_barrier();
-    if (pt < kC - 1) {
-        const float4 n0 = *reinterpret_cast<const float4 *>(&sh_ada[(pt + 1) * kN + pk]);
-        const float4 n1 = *reinterpret_cast<const float4 *>(&sh_ada[(pt + 1) * kN + pk + 4]);
-        e[0] += n0.x; e[1] += n0.y; e[2] += n0.z; e[3] += n0.w; e[4] += n1.x; e[5] += n1.y; e[6] += n1.z; e[7] += n1.w;
-    }
     {
-        // suffix sums over the 32 steps (staging area is free now): dlw_t = sum_{s >= t} e_s + dterm
-        float *sh_E = reinterpret_cast<float *>(sm + L::sK), *sh_seg = reinterpret_cast<float *>(sm + L::sQ);
-        *reinterpret_cast<float4 *>(&sh_E[pt * kN + pk]) = make_float4(e[0], e[1], e[2], e[3]);
-        *reinterpret_cast<float4 *>(&sh_E[pt * kN + pk + 4]) = make_float4(e[4], e[5], e[6], e[7]);
-        lds_barrier();
-        {
-            const int ch = tid & 63, seg = tid >> 6;
-            float run = 0.f;
-#pragma unroll
-            for (int i = 7; i >= 0; i--) {
-                run += sh_E[(seg * 8 + i) * kN + ch];
-                sh_E[(seg * 8 + i) * kN + ch] = run;
-            }
-            sh_seg[seg * kN + ch] = run;
-        }
-        lds_barrier();
+        // dlw_t = sum_{s >= t} e_s + rowsum(E * H_C) = total - (inclusive prefix - e_t) + dterm ;  dw = dlw * lw
         float dG[8];
-        const float4 g0 = *reinterpret_cast<const float4 *>(&sh_E[pt * kN + pk]), g1 = *reinterpret_cast<const float4 *>(&sh_E[pt * kN + pk + 4]);
-        dG[0] = g0.x; dG[1] = g0.y; dG[2] = g0.z; dG[3] = g0.w; dG[4] = g1.x; dG[5] = g1.y; dG[6] = g1.z; dG[7] = g1.w;
-        for (int sgi = (pt >> 3) + 1; sgi < 4; sgi++) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) dG[j] += sh_seg[sgi * kN + pk + j];
+        for (int j = 0; j < 8; j++) {
+            const float pre = scan32(e[j]);
+            dG[j] = (last32(pre, lane) - pre + e[j] + sh_dterm[pk + j]) * lw[j];
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++) dG[j] = (dG[j] + sh_dterm[pk + j]) * lw[j];
         st_bf16x8(dw_ + off, dG);
     }
     BSTAMP(11);
