@@ -73,11 +73,15 @@ def main():
     ap.add_argument("--model", default="0.4b", choices=["0.1b", "0.4b", "1.5b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-checkpoint", action="store_true")
+    ap.add_argument("--scalar-wkv-fwd", action="store_true", help="A/B: scalar WKV7 forward instead of the chunked MFMA one")
     ap.add_argument("--scalar-wkv-bwd", action="store_true", help="A/B: row-split scalar WKV7 backward instead of the chunked MFMA one")
     a = ap.parse_args()
     if a.scalar_wkv_bwd:
         from rwkvtts_amd import fused as _fused
         _fused.CHUNKED_WKV_BWD = False
+    if a.scalar_wkv_fwd:
+        from rwkvtts_amd import fused as _fused
+        _fused.CHUNKED_WKV_FWD = False
 
     from rwkvtts_amd import build
     build.build()  # no-op when the prebuilt .so is current
@@ -142,11 +146,14 @@ def main():
         bwd_ms = kern.get("wkv7_bwd")
         bwd_name = "wkv7_bwd_kernel<bf16,2,4> (row-split scalar WKV7 backward, 24 launches/step)"
         pmc_key = "wkv7_bwd"
-        chunk_parts = ["wkv7c_prep", "wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bwd_out"]
+        chunk_parts = ["wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bwd_out"]
+        fwd_ms, fwd_name = kern.get("wkv7_fwd"), "wkv7_fwd_kernel (scalar)"
+        if "wkv7c_fwd" in kern:   # chunked forward: T^-1 (wkv7c_prep, reused by the backward) + the chunk kernel
+            fwd_ms, fwd_name = kern["wkv7c_fwd"] + kern.get("wkv7c_prep", 0.0), "wkv7c_prep + wkv7c_fwd (chunked MFMA)"
         if bwd_ms is None and all(k in kern for k in chunk_parts):
-            # chunked MFMA backward: four launches per layer form the WKV7 backward; report them as one unit
-            bwd_ms = sum(kern[k] for k in chunk_parts)
-            bwd_name = "WKV7 backward, chunked MFMA (wkv7c_prep + wkv7c_bwd_pre + wkv7c_state + wkv7c_bwd_out, 24x per step)"
+            # chunked MFMA backward: three launches per layer (four when the forward was scalar and T^-1 is computed here)
+            bwd_ms = sum(kern[k] for k in chunk_parts) + (0.0 if "wkv7c_fwd" in kern else kern.get("wkv7c_prep", 0.0))
+            bwd_name = "WKV7 backward, chunked MFMA (wkv7c_bwd_pre + wkv7c_state + wkv7c_bwd_out, 24x per step)"
             pmc_key = "wkv7c_bwd"
         achieved = th * WKV_BWD_BYTES_PER_TOKEN_HEAD / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         traffic = None
@@ -175,9 +182,9 @@ def main():
                          "frac": round(achieved * 1e9 / HBM_PEAK, 4) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": th * WKV_BWD_BYTES_PER_TOKEN_HEAD,
                          "launch_ms": round(bwd_ms, 4) if bwd_ms else None,
-                         "fwd": {"launch_ms": round(kern["wkv7_fwd"], 4),
-                                 "achieved": round(th * WKV_FWD_BYTES_PER_TOKEN_HEAD / (kern["wkv7_fwd"] * 1e-3) / 1e9, 1)}
-                         if "wkv7_fwd" in kern else None},
+                         "fwd": {"kernel": fwd_name, "launch_ms": round(fwd_ms, 4),
+                                 "achieved": round(th * WKV_FWD_BYTES_PER_TOKEN_HEAD / (fwd_ms * 1e-3) / 1e9, 1)}
+                         if fwd_ms else None},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

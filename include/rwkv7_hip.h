@@ -242,12 +242,14 @@ int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void 
                                  const void *dy, const float *tinv, void *mt, float *np, rwkv7_stream_t stream);
 int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_vk, float *e_kv,
                                rwkv7_stream_t stream);
-/*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from the saved tensors
- *             of rwkv7_wkv_fwd_bf16 (s = fp32 checkpoints every 16 steps, sa), tinv and the adjoint states of `state`. */
+/*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from the forward's saved
+ *             tensors, tinv and the adjoint states of `state`.  ck_mode 0: s, sa as saved by rwkv7_wkv_fwd_bf16 (fp32
+ *             checkpoints every 16 steps); ck_mode 1: s = hs of rwkv7_wkv_chunk_fwd_bf16 (state at the start of every
+ *             32-step chunk, [k][v]). */
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,
-                                 const float *tinv, const float *e_vk, const float *e_kv, void *dw, void *dq, void *dk,
-                                 void *dv, void *da, void *db, rwkv7_stream_t stream);
+                                 const float *tinv, const float *e_vk, const float *e_kv, int ck_mode, void *dw, void *dq,
+                                 void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
 /* unit-test hook for the MFMA fragment layouts: D[32][32] = X[32][64] Y[32][64]^T (fp32 in, bf16-split MFMA),
  * DT = the same tile after the transposed LDS write-back (hi+lo planes re-joined). */
 int rwkv7_debug_mma32(const float *X, const float *Y, float *D, float *DT, rwkv7_stream_t stream);

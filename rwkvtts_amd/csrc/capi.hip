@@ -33,7 +33,7 @@ int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t)
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
 int chunk_state_bf16(int, int, const void *, const float *, float *, float *, hipStream_t);
-int chunk_bwd_out_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
+int chunk_bwd_out_bf16(int, int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                        const float *, const float *, const float *, const float *, const float *, void *, void *, void *, void *,
                        void *, void *, hipStream_t);
 void fwd_force_shape(int);
@@ -313,14 +313,14 @@ int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float 
 }
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,
-                                 const float *tinv, const float *e_vk, const float *e_kv, void *dw, void *dq, void *dk,
-                                 void *dv, void *da, void *db, rwkv7_stream_t stream) {
-    if (B <= 0 || T <= 0 || H <= 0 ||
+                                 const float *tinv, const float *e_vk, const float *e_kv, int ck_mode, void *dw, void *dq,
+                                 void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || ck_mode < 0 || ck_mode > 1 ||
         any_null({w, q, k, v, a, b, dy, (const void *)s, (const void *)sa, (const void *)tinv, (const void *)e_vk,
                   (const void *)e_kv, dw, dq, dk, dv, da, db}))
         return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
-    return rwkv7::chunk_bwd_out_bf16(B, T, H, w, q, k, v, a, b, dy, s, sa, tinv, e_vk, e_kv, dw, dq, dk, dv, da, db,
+    return rwkv7::chunk_bwd_out_bf16(B, T, H, ck_mode, w, q, k, v, a, b, dy, s, sa, tinv, e_vk, e_kv, dw, dq, dk, dv, da, db,
                                      (hipStream_t)stream);
 }
 int rwkv7_debug_mma32(const float *X, const float *Y, float *D, float *DT, rwkv7_stream_t stream) {

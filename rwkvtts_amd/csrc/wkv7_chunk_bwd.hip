@@ -476,8 +476,10 @@ __device__ __forceinline__ void put4(uint16_t *Ph, uint16_t *Pl, int row, int c4
 }
 }  // namespace
 
+// ck_mode 0: s_ = checkpoints of wkv7_fwd.hip (every 16 steps: H at the start of chunk c is entry 2c-1, at its end 2c+1);
+// ck_mode 1: s_ = hs of wkv7_chunk_fwd.hip (state at the START of every 32-step chunk: entries c and c+1).  [k][v] both.
 __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
-    int T_, int H, int nchunks_total, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
+    int T_, int H, int nchunks_total, int ck_mode, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
     const bf16_t *__restrict__ v_, const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_, const bf16_t *__restrict__ dy_,
     const float *__restrict__ s_, const float *__restrict__ sa_, const float *__restrict__ tinv_, const float *__restrict__ e_vk,
     const float *__restrict__ e_kv, bf16_t *__restrict__ dw_, bf16_t *__restrict__ dq_, bf16_t *__restrict__ dk_,
@@ -510,14 +512,17 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         r.u1 = *reinterpret_cast<const float4 *>(sa_ + r.off + 4);
         r.tm = *reinterpret_cast<const float4 *>(tinv_ + (long)chunk * kC * kC + tid * 4);
         const float *evk = e_vk + (long)chunk * kN * kN, *ekv = e_kv + (long)chunk * kN * kN;
-        const float *h0p = s_ + ((long)bh * nck + (2 * c - 1)) * kN * kN, *hcp = s_ + ((long)bh * nck + (2 * c + 1)) * kN * kN;
+        const long n_ck = ck_mode ? nc : nck;
+        const int i0 = ck_mode ? c : 2 * c - 1, iC = ck_mode ? c + 1 : 2 * c + 1;
+        const bool has0 = ck_mode ? true : c > 0, hasC = ck_mode ? c + 1 < nc : true;  // E = 0 after the last chunk: H_C unused
+        const float *h0p = s_ + ((long)bh * n_ck + i0) * kN * kN, *hcp = s_ + ((long)bh * n_ck + iC) * kN * kN;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i;
             r.evk[i] = *reinterpret_cast<const float4 *>(evk + p * 4);
             r.ekv[i] = *reinterpret_cast<const float4 *>(ekv + p * 4);
-            if (first || c == 0) r.h0[i] = c > 0 ? *reinterpret_cast<const float4 *>(h0p + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            r.hc[i] = *reinterpret_cast<const float4 *>(hcp + p * 4);
+            if (first || c == 0) r.h0[i] = has0 ? *reinterpret_cast<const float4 *>(h0p + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.hc[i] = hasC ? *reinterpret_cast<const float4 *>(hcp + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         return r;
     };
@@ -820,7 +825,7 @@ int chunk_state_bf16(int BH, int nc, const void *mt, const float *np, float *e_v
     return (int)hipGetLastError();
 }
 
-int chunk_bwd_out_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+int chunk_bwd_out_bf16(int B, int T_, int H, int ck_mode, const void *w, const void *q, const void *k, const void *v, const void *a,
                        const void *b, const void *dy, const float *s, const float *sa, const float *tinv, const float *e_vk,
                        const float *e_kv, void *dw, void *dq, void *dk, void *dv, void *da, void *db, hipStream_t st) {
     static bool attr = false;
@@ -833,7 +838,7 @@ int chunk_bwd_out_bf16(int B, int T_, int H, const void *w, const void *q, const
     (void)hipGetLastError();
     const int total = B * H * (T_ / kC);
     hipLaunchKernelGGL(wkv7c_bwd_out_kernel, dim3((total + kChunksPerWG - 1) / kChunksPerWG), dim3(256), OutSmem::bytes, st, T_, H,
-                       total, (const bf16_t *)w,
+                       total, ck_mode, (const bf16_t *)w,
                        (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a, (const bf16_t *)b,
                        (const bf16_t *)dy, s, sa, tinv, e_vk, e_kv, (bf16_t *)dw, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
                        (bf16_t *)da, (bf16_t *)db);

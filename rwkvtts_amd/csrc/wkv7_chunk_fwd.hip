@@ -13,7 +13,7 @@
 //                       interact in the forward), 4 waves; per chunk: decay cumsum + operand scaling into bf16
 //                       hi/lo planes -> A_ak, A_qb, A_qk (3 waves) + T planes (4th) -> R -> U -> Y | state update.
 // Saved for backward: U (= the scalar kernel's `sa`, fp32 [B,T,H,64]) and the state at the START of every chunk,
-// hs fp32 [B,H,T/32,64(v),64(k)].
+// hs fp32 [B,H,T/32,64(k),64(v)].
 #include "chunk_common.h"
 
 namespace rwkv7 {
@@ -365,12 +365,11 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         } else if (wave <= 2) {
             const int kt = wave - 1;  // rows (key channels) [32 kt, 32 kt + 32)
             if (SAVE) {
-                // state at the START of chunk c, hs[b,h,c][v][k]: lane = v, registers = k
-                float *hp = hs_ + (((long)bh * nc + c) * kN + vh * VH + (lane & 31)) * kN + kt * 32 + 4 * (lane >> 5);
+                // state at the START of chunk c, hs[b,h,c][k][v] (the orientation of the scalar kernel's checkpoints):
+                // lane = v, registers = k -> 32 consecutive lanes write 128 contiguous bytes
+                float *hp = hs_ + ((long)bh * nc + c) * kN * kN + vh * VH + (lane & 31);
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    *reinterpret_cast<float4 *>(hp + 8 * j) =
-                        make_float4(Smaster[4 * j], Smaster[4 * j + 1], Smaster[4 * j + 2], Smaster[4 * j + 3]);
+                for (int r = 0; r < 16; r++) hp[(long)(kt * 32 + d_row(r, lane)) * kN] = Smaster[r];
             }
             f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
             mma_tile3<kC>(acc, sm + L::BTh + kt * 32 * LDC, sm + L::BTl + kt * 32 * LDC, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);

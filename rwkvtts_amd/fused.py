@@ -192,6 +192,7 @@ def tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, eps):
 
 
 CHUNKED_WKV_BWD = True   # bf16 training: scan backward on the matrix cores (csrc/wkv7_chunk_bwd.hip)
+CHUNKED_WKV_FWD = True   # ... and the forward too (csrc/wkv7_chunk_fwd.hip); needs CHUNKED_WKV_BWD
 
 
 class _TmixCore(torch.autograd.Function):
@@ -217,24 +218,31 @@ class _TmixCore(torch.autograd.Function):
         w, k2, v2, a_in, b_in = [torch.empty_like(k) for _ in range(5)]
         _call("tmix_prepare_fwd", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
               _p(mask), _p(k_k), _p(k_a), _p(w), _p(k2), _p(v2), _p(a_in), _p(b_in), min(rows, _FWD_BLOCKS))
-        y = torch.empty_like(k)
-        s = torch.empty(B, H, T // ops.CHUNK_LEN, 64, 64, dtype=torch.float32, device=k.device)
-        sa = torch.empty(B, T, H, 64, dtype=torch.float32, device=k.device)
         v4 = lambda t: t.view(B, T, H, 64)
-        torch.ops.wind_backstepping.forward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(y), s, sa)
+        chunked = CHUNKED_WKV_FWD and CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0
+        if chunked:
+            # all-MFMA pair: saves T^-1, sa and the state at the start of every 32-step chunk (half the checkpoint bytes)
+            y4, tinv, sa, s = ops.wkv7_chunk_forward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in))
+            y = y4.view(B, T, D)
+        else:
+            tinv = None
+            y = torch.empty_like(k)
+            s = torch.empty(B, H, T // ops.CHUNK_LEN, 64, 64, dtype=torch.float32, device=k.device)
+            sa = torch.empty(B, T, H, 64, dtype=torch.float32, device=k.device)
+            torch.ops.wind_backstepping.forward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(y), s, sa)
         out = torch.empty_like(k)
         _call("tmix_post_fwd", k, ctypes.c_long(rows), D, _p(y), _p(r), _p(k2), _p(v2), _p(g), _p(gn_w), _p(gn_b), _p(r_k),
               ctypes.c_float(eps), _p(out), min(rows, _FWD_BLOCKS))
         ctx.save_for_backward(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
-                              w, k2, v2, a_in, b_in, y, s, sa)
-        ctx.H, ctx.eps = H, eps
+                              w, k2, v2, a_in, b_in, y, s, sa, tinv)
+        ctx.H, ctx.eps, ctx.chunked_fwd = H, eps, chunked
         return out
 
     @staticmethod
     def backward(ctx, dout):
         from . import ops
         (r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
-         w, k2, v2, a_in, b_in, y, s, sa) = ctx.saved_tensors
+         w, k2, v2, a_in, b_in, y, s, sa, tinv) = ctx.saved_tensors
         B, T, D = k.shape
         H = ctx.H
         rows = B * T
@@ -248,8 +256,9 @@ class _TmixCore(torch.autograd.Function):
               _p(part_post), nb)
         # 2. scan: chunked MFMA backward (bf16, T % 32 == 0) or the scalar kernel with two workgroups per head
         v4 = lambda t: t.view(B, T, H, 64)
-        if CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0:
-            dw, dq, dk, dv, da, db = ops.wkv7_chunk_backward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(d_y), s, sa)
+        if ctx.chunked_fwd or (CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0):
+            dw, dq, dk, dv, da, db = ops.wkv7_chunk_backward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(d_y), s, sa,
+                                                             tinv=tinv, ck_mode=1 if ctx.chunked_fwd else 0)
             dw2, dq2, dk2, da2, db2 = [(g, None) for g in (dw, dq, dk, da, db)]
         else:
             dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in),

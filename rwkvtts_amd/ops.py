@@ -289,18 +289,19 @@ def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv):
     return mt, np_, e_vk, e_kv
 
 
-def wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa):
-    """Chunked (MFMA) WKV7 backward, bf16: same inputs and outputs as torch.ops.wind_backstepping.backward
-    (s, sa = what wind_backstepping.forward saved), T % 32 == 0.  Four launches: T inverse, M^T/N', adjoint-state
-    recurrence, per-chunk gradients.  Returns (dw, dq, dk, dv, da, db)."""
+def wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa, tinv=None, ck_mode=0):
+    """Chunked (MFMA) WKV7 backward, bf16: same inputs and outputs as torch.ops.wind_backstepping.backward, T % 32 == 0.
+    ck_mode 0: s, sa = what wind_backstepping.forward saved; ck_mode 1: s = hs, sa, tinv = what wkv7_chunk_forward saved.
+    Launches: (T inverse,) M^T/N', adjoint-state recurrence, per-chunk gradients.  Returns (dw, dq, dk, dv, da, db)."""
     B, T, H, C = w.shape
-    tinv = wkv7_chunk_prep(w, a, b)
+    if tinv is None:
+        tinv = wkv7_chunk_prep(w, a, b)
     mt, np_, e_vk, e_kv = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv)
     del mt, np_
     grads = [torch.empty_like(w) for _ in range(6)]
     with torch.cuda.device_of(w), _timed("wkv7c_bwd_out", w):
         rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(s), _p(sa),
-                                                     _p(tinv), _p(e_vk), _p(e_kv), *[_p(g) for g in grads], _stream(w))
+                                                     _p(tinv), _p(e_vk), _p(e_kv), ck_mode, *[_p(g) for g in grads], _stream(w))
     _lib.check(rc, "wkv7_chunk_bwd_out")
     return tuple(grads)
 

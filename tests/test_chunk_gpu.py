@@ -55,9 +55,9 @@ def test_chunk_forward_vs_oracle(c_oracle, B, T, H, seed, dtype):
     else:
         _assert_f32_close(y, y_o, "y", 1e-4)
     _assert_f32_close(sa, sa_o, "sa", 2e-4 if dtype == torch.float32 else 2e-3)
-    # hs[c] = state at the start of chunk c = oracle checkpoint after step 32c-1 (stored transposed [j][i])
+    # hs[c] = state at the start of chunk c = oracle checkpoint after step 32c-1 (both [key][value])
     for c in range(1, T // 32):
-        _assert_f32_close(hs[:, :, c], s_o[:, :, 2 * c - 1].transpose(-1, -2), f"hs[{c}]", 2e-4 if dtype == torch.float32 else 2e-3)
+        _assert_f32_close(hs[:, :, c], s_o[:, :, 2 * c - 1], f"hs[{c}]", 2e-4 if dtype == torch.float32 else 2e-3)
     assert hs[:, :, 0].abs().max().item() == 0.0
 
 
@@ -131,5 +131,21 @@ def test_chunked_backward_vs_oracle(c_oracle, B, T, H, seed):
     torch.ops.wind_backstepping.forward(*d, y, s, sa)
     grads = ops.wkv7_chunk_backward(*d, dy.to(DEV), s, sa)
     torch.cuda.synchronize()
+    for n, g, go in zip(NAMES, grads, g_o):
+        _assert_bf16_close(g, go, n, ulps=2.0)
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2)])
+def test_chunked_forward_plus_backward_vs_oracle(c_oracle, B, T, H, seed):
+    """The all-MFMA training pair: chunked forward (saves tinv, sa, hs) feeding the chunked backward (ck_mode 1)."""
+    ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).bfloat16()
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    g_o = c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)
+    d = [t.to(DEV) for t in ins]
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
+    grads = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv=tinv, ck_mode=1)
+    torch.cuda.synchronize()
+    _assert_bf16_close(y, y_o, "y")
     for n, g, go in zip(NAMES, grads, g_o):
         _assert_bf16_close(g, go, n, ulps=2.0)

@@ -244,7 +244,12 @@ def test_fused_tmix_core_equals_separate_nodes(dtype, tol, T):
                                                                    if p.grad is not None})
         finally:
             backbone.FUSED_TMIX_CORE = True
-    assert torch.equal(res[True][0], res[False][0]), "forward runs the same kernels"
+    if dtype == torch.bfloat16 and T % 32 == 0:
+        # the fused node runs the chunked MFMA scan here, the separate nodes the scalar one: equal up to bf16 rounding
+        d = (res[True][0] - res[False][0]).abs().max().item()
+        assert d <= 4e-2 * res[False][0].abs().max().item(), d
+    else:
+        assert torch.equal(res[True][0], res[False][0]), "forward runs the same kernels"
     def close(a, b, what):
         scale = max(b.abs().max().item(), 1e-6)
         err = (a - b).abs().max().item()
