@@ -100,30 +100,6 @@ __device__ __forceinline__ void put_col8(uint16_t *Ph, uint16_t *Pl, int ld, int
     }
 }
 
-// ---- scans along the time axis.  Thread (pt = lane & 31, ...) holds step pt, so the 32 steps of a chunk are the 32
-// consecutive lanes of a half-wave: prefix sums are DPP row shifts (no LDS, no barrier).
-template <int CTRL, int ROW_MASK, bool BOUND>
-__device__ __forceinline__ float dpp0(float x) {  // lanes without a source (or outside ROW_MASK) get 0
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, BOUND));
-}
-// inclusive prefix sum over lanes [0,32) and [32,64) separately
-__device__ __forceinline__ float scan32(float x) {
-    x += dpp0<0x111, 0xf, true>(x);   // row_shr:1
-    x += dpp0<0x112, 0xf, true>(x);   // row_shr:2
-    x += dpp0<0x114, 0xf, true>(x);   // row_shr:4
-    x += dpp0<0x118, 0xf, true>(x);   // row_shr:8
-    x += dpp0<0x142, 0xa, false>(x);  // row_bcast:15 into rows 1 and 3: lane 15 / 47 carries the first 16 steps
-    return x;
-}
-// value of lane 31 (63) for every lane of the half-wave
-__device__ __forceinline__ float last32(float x, int lane) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) << 2, __float_as_int(x)));
-}
-// value of the next lane (next time step); 0 for the last step of the chunk
-__device__ __forceinline__ float next32(float x, int lane) {
-    const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __float_as_int(x)));
-    return (lane & 31) == 31 ? 0.f : y;
-}
 // G[j] = sum_{s <= pt} lw_s[pk + j]
 __device__ __forceinline__ void chunk_cumsum(const float (&lw)[8], float (&G)[8]) {
 #pragma unroll

@@ -202,36 +202,17 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
             vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w;
         }
-        *reinterpret_cast<float4 *>(&sh_G[pt * kN + pk]) = make_float4(lw[0], lw[1], lw[2], lw[3]);
-        *reinterpret_cast<float4 *>(&sh_G[pt * kN + pk + 4]) = make_float4(lw[4], lw[5], lw[6], lw[7]);
-        lds_barrier();
-        {
-            // thread (channel = tid & 63, segment = wave): inclusive cumsum over its 8 steps, segment total aside
-            const int ch = tid & 63;
-            float run = 0.f;
+        // inclusive cumulative log-decay over the chunk: DPP prefix sum across the 32 lanes that hold the 32 steps
+        float Gc[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                run += sh_G[(wave * 8 + i) * kN + ch];
-                sh_G[(wave * 8 + i) * kN + ch] = run;
-            }
-            sh_seg[wave * kN + ch] = run;
-        }
-        lds_barrier();
+        for (int j = 0; j < 8; j++) Gc[j] = scan32(lw[j]);
         TSTAMP(1);
         if (c + 1 < nc) issue(c + 1);  // next chunk's raw inputs fly during phases 2-6
         // ---- phase 2: scaled operands into bf16 hi/lo planes ------------------------------------------------
         {
-            const int seg = pt >> 3;
             float G[8];
-            {
-                const float4 g0 = *reinterpret_cast<const float4 *>(&sh_G[pt * kN + pk]);
-                const float4 g1 = *reinterpret_cast<const float4 *>(&sh_G[pt * kN + pk + 4]);
-                G[0] = g0.x; G[1] = g0.y; G[2] = g0.z; G[3] = g0.w; G[4] = g1.x; G[5] = g1.y; G[6] = g1.z; G[7] = g1.w;
-                for (int s = 0; s < seg; s++) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) G[j] += sh_seg[s * kN + pk + j];
-                }
-            }
+            for (int j = 0; j < 8; j++) G[j] = Gc[j];
             TSTAMP(12);
             float qs[8], as_[8], ks[8], bs[8];
 #pragma unroll
