@@ -149,3 +149,40 @@ def test_chunked_forward_plus_backward_vs_oracle(c_oracle, B, T, H, seed):
     _assert_bf16_close(y, y_o, "y")
     for n, g, go in zip(NAMES, grads, g_o):
         _assert_bf16_close(g, go, n, ulps=2.0)
+
+
+def test_full_size_config2_chunked_pair_vs_oracle_slices(c_oracle):
+    """BASELINE.json configs[1] (B=8, T=4096, H=16, bf16) through the chunked MFMA forward + backward that the training
+    step uses: (i) everything finite; (ii) three (batch, head) slices -- first, middle, last workgroups -- equal the
+    oracle run on exactly those slices (1 ulp on y, 2 ulp on the gradients); (iii) linearity of the backward in dy:
+    grads(dy1 + dy2) == grads(dy1) + grads(dy2) up to bf16 rounding (a size-independent property of the adjoint)."""
+    B, T, H = 8, 4096, 16
+    ins = make_wkv_inputs(B, T, H, 1234, torch.bfloat16)
+    d = [t.to(DEV) for t in ins]
+    g = torch.Generator().manual_seed(99)
+    dy1 = torch.randn(B, T, H, 64, generator=g).bfloat16()
+    dy2 = (torch.randn(B, T, H, 64, generator=g) * 0.5).bfloat16()
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
+    g1 = ops.wkv7_chunk_backward(*d, dy1.to(DEV), hs, sa, tinv=tinv, ck_mode=1)
+    g2 = ops.wkv7_chunk_backward(*d, dy2.to(DEV), hs, sa, tinv=tinv, ck_mode=1)
+    g12 = ops.wkv7_chunk_backward(*d, (dy1.float() + dy2.float()).bfloat16().to(DEV), hs, sa, tinv=tinv, ck_mode=1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    for n, ga in zip(NAMES, g1):
+        assert torch.isfinite(ga.float()).all(), n
+    for (bi, hi) in ((0, 0), (5, 11), (7, 15)):
+        sl = [t[bi:bi + 1, :, hi:hi + 1].contiguous() for t in ins]
+        y_o, s_o, sa_o = c_oracle.wkv7_fwd(*sl)
+        g_o = c_oracle.wkv7_bwd(*sl, dy1[bi:bi + 1, :, hi:hi + 1].contiguous(), s_o, sa_o)
+        _assert_bf16_close(y[bi:bi + 1, :, hi:hi + 1], y_o, f"y[{bi},{hi}]")
+        for n, ga, go in zip(NAMES, g1, g_o):
+            _assert_bf16_close(ga[bi:bi + 1, :, hi:hi + 1], go, f"{n}[{bi},{hi}]", ulps=2.0)
+    for n, a1, a2, a12 in zip(NAMES, g1, g2, g12):
+        want = a1.float() + a2.float()
+        err = (a12.float() - want).abs()
+        # three bf16 roundings, each relative to its own operand (a1 and a2 may cancel in the sum), + the rounding of
+        # dy1 + dy2 propagated through the adjoint
+        mag = a1.float().abs() + a2.float().abs()
+        tol = 2.0 ** -6 * torch.clamp(mag, min=mag.mean().item())
+        frac = (err > tol).float().mean().item()
+        assert frac < 1e-3, f"{n}: {frac:.2e} of the elements break linearity in dy"
