@@ -250,6 +250,9 @@ int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void 
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,
                                  const float *tinv, const float *e_vk, const float *e_kv, int ck_mode, void *dw, void *dq,
                                  void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
+/* probe of ds_read_b64_tr_b16 (LDS transpose read): in = 4096 u16 copied to LDS, addr[64] = element index each lane
+ * points at, out[64][4] = what each lane receives */
+int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream);
 /* unit-test hook for the MFMA fragment layouts: D[32][32] = X[32][64] Y[32][64]^T (fp32 in, bf16-split MFMA),
  * DT = the same tile after the transposed LDS write-back (hi+lo planes re-joined). */
 int rwkv7_debug_mma32(const float *X, const float *Y, float *D, float *DT, rwkv7_stream_t stream);

@@ -30,6 +30,7 @@ int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, cons
 int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                   const float *, void *, float *, float *, hipStream_t);
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
+int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
 int chunk_state_bf16(int, int, const void *, const float *, float *, float *, hipStream_t);
@@ -322,6 +323,10 @@ int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void 
     if (T % 32 != 0) return RWKV7_ECHUNK;
     return rwkv7::chunk_bwd_out_bf16(B, T, H, ck_mode, w, q, k, v, a, b, dy, s, sa, tinv, e_vk, e_kv, dw, dq, dk, dv, da, db,
                                      (hipStream_t)stream);
+}
+int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {
+    if (!in || !addr || !out) return RWKV7_EINVAL;
+    return rwkv7::chunk_debug_tr16((const uint16_t *)in, addr, (uint16_t *)out, (hipStream_t)stream);
 }
 int rwkv7_debug_mma32(const float *X, const float *Y, float *D, float *DT, rwkv7_stream_t stream) {
     if (any_null({X, Y, D, DT})) return RWKV7_EINVAL;

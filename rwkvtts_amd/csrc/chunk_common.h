@@ -119,6 +119,63 @@ __device__ __forceinline__ void mma_tile2y(f32x16 &acc, const uint16_t *X, int l
     }
 }
 
+// ---- operands whose contraction index is the ROW index of the stored plane (k-major, P[k][n]) ---------------------------
+// gfx950's LDS transpose read ds_read_b64_tr_b16 works on groups of 16 lanes: lane i passes the address of a row R_i of four
+// 16-bit elements and receives { R_{4j + (i >> 2)}[i & 3] : j = 0..3 } (probed on hardware, tools/tr16_probe.py).  Pointing
+// lane r of a group at P[k0 + (r >> 2)][n0 + 4 (r & 3) ..] therefore hands lane i the four values P[k0 .. k0+3][n0 + i]:
+// two such reads give the 8 consecutive k of one MFMA B fragment for column n -- no transposed copy of the plane needed.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8e_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 frag_tr(const uint16_t *P, int ld, int k0, int n_base, int lane) {
+    const int i16 = lane & 15;
+    const uint16_t *p = P + (k0 + 8 * (lane >> 5) + (i16 >> 2)) * ld + n_base + 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
+    using lds_ptr = bf16x4_t __attribute__((address_space(3))) *;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 4 * ld));
+    const bf16x8e_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// acc += X[m][0..K) . Y where Y is k-major: Y[k][n_base + n];  X split, Y split
+template <int K>
+__device__ __forceinline__ void mma_tile3_yK(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx, const uint16_t *Yh,
+                                             const uint16_t *Yl, int ldy, int n_base, int lane) {
+    constexpr int NK = K / 16;
+    const int xo = (lane & 31) * ldx + (lane >> 5) * 8;
+    bf16x8 xh[NK], xl[NK], yh[NK], yl[NK];
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        xh[i] = *reinterpret_cast<const bf16x8 *>(Xh + xo + 16 * i);
+        xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
+        yh[i] = frag_tr(Yh, ldy, 16 * i, n_base, lane);
+        yl[i] = frag_tr(Yl, ldy, 16 * i, n_base, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0);
+    }
+}
+// X split, Y exact (single plane), k-major
+template <int K>
+__device__ __forceinline__ void mma_xs_yeK(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx, const uint16_t *Y,
+                                           int ldy, int n_base, int lane) {
+    constexpr int NK = K / 16;
+    const int xo = (lane & 31) * ldx + (lane >> 5) * 8;
+    bf16x8 xh[NK], xl[NK], y[NK];
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        xh[i] = *reinterpret_cast<const bf16x8 *>(Xh + xo + 16 * i);
+        xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
+        y[i] = frag_tr(Y, ldy, 16 * i, n_base, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc, 0, 0, 0);
+    }
+}
+
 // row index of accumulator register r for this lane
 __device__ __forceinline__ int d_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

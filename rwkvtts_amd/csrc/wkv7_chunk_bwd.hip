@@ -389,38 +389,30 @@ __global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t
 namespace {
 struct OutSmem {  // offsets in uint16 units
     static constexpr int TM1 = kC * LDK, CM1 = kN * LDC, SQ1 = kN * LDK, A1 = kC * LDC, ST = kC * kN * 2;
-    // fixed for the whole kernel
-    static constexpr int QTTh = 0, QTTl = QTTh + CM1, ATTh = QTTl + CM1, ATTl = ATTh + CM1;
-    static constexpr int KHTh = ATTl + CM1, KHTl = KHTh + CM1, BHTh = KHTl + CM1, BHTl = BHTh + CM1;
-    static constexpr int Vp = BHTl + CM1, DYp = Vp + TM1, Uh = DYp + TM1, Ul = Uh + TM1, Zh = Ul + TM1, Zl = Zh + TM1;
+    // fixed for the whole kernel: the scaled operands and V, dY, U, Z, all TIME-major [t][.]; products that contract over
+    // time fetch them with LDS transpose reads (frag_tr), so no channel-major copies exist
+    static constexpr int QTh = 0, QTl = QTh + TM1, ATh = QTl + TM1, ATl = ATh + TM1;
+    static constexpr int KHh = ATl + TM1, KHl = KHh + TM1, BHh = KHl + TM1, BHl = BHh + TM1;
+    static constexpr int Vp = BHl + TM1, DYp = Vp + TM1, Uh = DYp + TM1, Ul = Uh + TM1, Zh = Ul + TM1, Zl = Zh + TM1;
     static constexpr int STG = Zl + TM1;                    // fp32 [32][64] staging tiles: dK, dB, dQ, dA
     static constexpr int sK = STG, sB = STG + ST, sQ = STG + 2 * ST, sA = STG + 3 * ST;
     static constexpr int gC = STG + 4 * ST, dterm = gC + 2 * kN;  // 64 floats each
     static constexpr int S = dterm + 2 * kN;                // phase scratch
     // phases A-D inside S
-    static constexpr int KHh = S, KHl = KHh + TM1, BHh = KHl + TM1, BHl = BHh + TM1;
-    static constexpr int QTh = BHl + TM1, QTl = QTh + TM1, ATh = QTl + TM1, ATl = ATh + TM1;   // dead after phase A
-    static constexpr int G1Th = QTh, G1Tl = G1Th + CM1, sV = G1Tl + CM1;                       // laid over QT/AT
-    static constexpr int EGh = ATl + TM1, EGl = EGh + SQ1;                                     // (g_C E)[v][k]
-    static constexpr int DYT = EGl + SQ1;
-    static constexpr int endAD = DYT + CM1;
+    static constexpr int G1Th = S, G1Tl = G1Th + CM1, sV = G1Tl + CM1;
+    static constexpr int EGh = sV + ST, EGl = EGh + SQ1;    // (g_C E)[v][k]
     // phases A-D inside the (still unused) staging area
     static constexpr int TMTh = STG, TMTl = TMTh + A1, QBTh = TMTl + A1, QBTl = QBTh + A1, QKTh = QBTl + A1, QKTl = QKTh + A1;
-    static constexpr int AKTh = QKTl + A1, AKTl = AKTh + A1, ZTh = AKTl + A1, ZTl = ZTh + CM1;
-    static constexpr int scratch = ZTh;                     // prologue cumsum scratch (4608 u16)
+    static constexpr int AKTh = QKTl + A1, AKTl = AKTh + A1;
     // phases E-F inside S
-    static constexpr int XTh = S, XTl = XTh + SQ1;          // (g_C E)^T [k][v], later H0^T [k][v]
-    static constexpr int P0 = EGh;                          // 4 pairs of [32][LDC] planes over the dead EG / DYT area
-    static constexpr int aDA = sV;                          // epilogue: fp32 [32][64] a*dA
-    static constexpr int end16 = endAD;
+    static constexpr int XTh = EGh, XTl = XTh + SQ1;        // (g_C E)^T [k][v], later H0^T [k][v]: over the dead E planes
+    static constexpr int P0 = EGl + SQ1;                    // 4 pairs of [32][LDC] planes
+    static constexpr int end16 = P0 + 8 * A1;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
-static_assert(OutSmem::sV + OutSmem::ST <= OutSmem::EGh, "dV staging must end before the E planes");
-static_assert(OutSmem::ZTl + OutSmem::CM1 <= OutSmem::gC, "phase A-D planes must fit in the staging area");
-static_assert(OutSmem::P0 + 8 * OutSmem::A1 <= OutSmem::endAD, "P planes");
-static_assert(OutSmem::XTl + OutSmem::SQ1 <= OutSmem::sV, "E^T / H0^T planes must not reach the dV staging tile");
+static_assert(OutSmem::AKTl + OutSmem::A1 <= OutSmem::gC, "phase A-D planes must fit in the staging area");
 static_assert(OutSmem::bytes <= 160 * 1024, "LDS budget");
-static_assert(OutSmem::S % 8 == 0 && OutSmem::EGh % 8 == 0 && OutSmem::DYT % 8 == 0 && OutSmem::STG % 8 == 0, "alignment");
+static_assert(OutSmem::S % 8 == 0 && OutSmem::EGh % 8 == 0 && OutSmem::P0 % 8 == 0 && OutSmem::STG % 8 == 0 && OutSmem::sV % 8 == 0, "alignment");
 
 // X exact (single plane), Y exact
 template <int K>
@@ -555,28 +547,20 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = qv[j] * gam[j];
         put_row8(sm + L::QTh, sm + L::QTl, pt * LDK + pk, x, hi, lo);
-        put_col8(sm + L::QTTh, sm + L::QTTl, LDC, pk, pt, hi, lo);
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = av[j] * gprev[j];
         put_row8(sm + L::ATh, sm + L::ATl, pt * LDK + pk, x, hi, lo);
-        put_col8(sm + L::ATTh, sm + L::ATTl, LDC, pk, pt, hi, lo);
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = kv[j] * igam[j];
         put_row8(sm + L::KHh, sm + L::KHl, pt * LDK + pk, x, hi, lo);
-        put_col8(sm + L::KHTh, sm + L::KHTl, LDC, pk, pt, hi, lo);
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = bv[j] * igam[j];
         put_row8(sm + L::BHh, sm + L::BHl, pt * LDK + pk, x, hi, lo);
-        put_col8(sm + L::BHTh, sm + L::BHTl, LDC, pk, pt, hi, lo);
         const float u[8] = {ru0.x, ru0.y, ru0.z, ru0.w, ru1.x, ru1.y, ru1.z, ru1.w};
         put_row8(sm + L::Uh, sm + L::Ul, pt * LDK + pk, u, hi, lo);
         *reinterpret_cast<uint4 *>(sm + L::Vp + pt * LDK + pk) = rv.r;     // bf16 inputs are exact: single planes
         *reinterpret_cast<uint4 *>(sm + L::DYp + pt * LDK + pk) = rdy.r;
-        const uint32_t dyr[4] = {rdy.r.x, rdy.r.y, rdy.r.z, rdy.r.w};
-#pragma unroll
-        for (int j = 0; j < 8; j++) sm[L::DYT + (pk + j) * LDC + pt] = (uint16_t)(dyr[j >> 1] >> ((j & 1) * 16));
     }
-    BSTAMP(1);
     lds_barrier();  // sh_gC visible
     {
         // (g_C E)[v][k] planes: row v, scale per column k
@@ -611,21 +595,16 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     if (wave <= 1) {
         const int vt = wave;
         f32x16 acc = zero16();
-        mma_xs_ye<kC>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
+        mma_xs_yeK<kC>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYp, LDK, vt * 32, lane);
         mma_tile3<kN>(acc, sm + L::BHh, sm + L::BHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
         store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
     }
     lds_barrier();
     BSTAMP(4);
-    // ---- phase C: Z = T^T G1 in both orientations ---------------------------------------------------------------------------------
+    // ---- phase C: Z[t][v] = sum_s T[s][t] G1[s][v] --------------------------------------------------------------------------------
     if (wave <= 1) {
         const int vt = wave;
-        f32x16 acc = zero16();  // D[t][v] = sum_s T[s][t] G1[s][v] -> ZT[v][t]
-        mma_tile3<kC>(acc, sm + L::TMTh, sm + L::TMTl, LDC, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
-        store_T_split(acc, sm + L::ZTh + vt * 32 * LDC, sm + L::ZTl + vt * 32 * LDC, LDC, lane);
-    } else {
-        const int vt = wave - 2;
-        f32x16 acc = zero16();  // D[v][t] -> Z[t][v]
+        f32x16 acc = zero16();  // D[m = v][n = t] -> stored as Z[t][v]
         mma_tile3<kC>(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, sm + L::TMTh, sm + L::TMTl, LDC, lane);
         store_T_split(acc, sm + L::Zh + vt * 32, sm + L::Zl + vt * 32, LDK, lane);
     }
@@ -635,8 +614,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     if (wave <= 1) {
         const int vt = wave;
         f32x16 acc = zero16();
-        mma_xs_ye<kC>(acc, sm + L::QKTh, sm + L::QKTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
-        mma_tile3<kC>(acc, sm + L::AKTh, sm + L::AKTl, LDC, sm + L::ZTh + vt * 32 * LDC, sm + L::ZTl + vt * 32 * LDC, LDC, lane);
+        mma_xs_yeK<kC>(acc, sm + L::QKTh, sm + L::QKTl, LDC, sm + L::DYp, LDK, vt * 32, lane);
+        mma_tile3_yK<kC>(acc, sm + L::AKTh, sm + L::AKTl, LDC, sm + L::Zh, sm + L::Zl, LDK, vt * 32, lane);
         mma_tile3<kN>(acc, sm + L::KHh, sm + L::KHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
         stage_tile(acc, reinterpret_cast<float *>(sm + L::sV), vt, lane);
     }
@@ -677,8 +656,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         const int kt = wave & 1;
         const uint16_t *P1h = sm + L::P0 + (wave < 2 ? 0 : 2) * 2 * L::A1, *P1l = P1h + L::A1, *P2h = P1h + 2 * L::A1, *P2l = P2h + L::A1;
         f32x16 acc = zero16();  // D[m = t][n = k]
-        mma_tile3<kC>(acc, P1h, P1l, LDC, sm + L::QTTh + kt * 32 * LDC, sm + L::QTTl + kt * 32 * LDC, LDC, lane);
-        mma_tile3<kC>(acc, P2h, P2l, LDC, sm + L::ATTh + kt * 32 * LDC, sm + L::ATTl + kt * 32 * LDC, LDC, lane);
+        mma_tile3_yK<kC>(acc, P1h, P1l, LDC, sm + L::QTh, sm + L::QTl, LDK, kt * 32, lane);
+        mma_tile3_yK<kC>(acc, P2h, P2l, LDC, sm + L::ATh, sm + L::ATl, LDK, kt * 32, lane);
         if (wave < 2) {
             mma_tile2y<kN>(acc, sm + L::Vp, LDK, sm + L::XTh + kt * 32 * LDK, sm + L::XTl + kt * 32 * LDK, LDK, lane);
             stage_tile(acc, reinterpret_cast<float *>(sm + L::sK), kt, lane);
@@ -721,8 +700,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         // dQ uses P planes 0 (vy) and 1 (uy); dA uses 2 (vz) and 3 (uz)
         const uint16_t *P1h = sm + L::P0 + (wave < 2 ? 0 : 2) * 2 * L::A1, *P1l = P1h + L::A1, *P2h = P1h + 2 * L::A1, *P2l = P2h + L::A1;
         f32x16 acc = zero16();  // D[m = t'][n = k]
-        mma_tile3<kC>(acc, P1h, P1l, LDC, sm + L::KHTh + kt * 32 * LDC, sm + L::KHTl + kt * 32 * LDC, LDC, lane);
-        mma_tile3<kC>(acc, P2h, P2l, LDC, sm + L::BHTh + kt * 32 * LDC, sm + L::BHTl + kt * 32 * LDC, LDC, lane);
+        mma_tile3_yK<kC>(acc, P1h, P1l, LDC, sm + L::KHh, sm + L::KHl, LDK, kt * 32, lane);
+        mma_tile3_yK<kC>(acc, P2h, P2l, LDC, sm + L::BHh, sm + L::BHl, LDK, kt * 32, lane);
         if (wave < 2) {
             mma_tile2y<kN>(acc, sm + L::DYp, LDK, sm + L::XTh + kt * 32 * LDK, sm + L::XTl + kt * 32 * LDK, LDK, lane);
             stage_tile(acc, reinterpret_cast<float *>(sm + L::sQ), kt, lane);

@@ -391,6 +391,25 @@ __global__ __launch_bounds__(64) void chunk_debug_mma_kernel(const float *__rest
     for (int i = lane; i < kC * kC; i += 64) DT[i] = bf2f(Oh[(i / kC) * LDC + i % kC]) + bf2f(Ol[(i / kC) * LDC + i % kC]);
 }
 
+// debug: semantics probe of ds_read_b64_tr_b16 (gfx950 LDS transpose read).  LDS is filled with in[0..4096); lane l
+// passes the address of element addr[l]; out[l][0..4) = the four 16-bit values the lane receives.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void tr16_probe_kernel(const uint16_t *__restrict__ in, const int *__restrict__ addr,
+                                                        uint16_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint16_t sm[4096];
+    for (int i = threadIdx.x; i < 4096; i += 64) sm[i] = in[i];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const v4s_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3))) *)(sm + addr[lane]));
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[lane * 4 + j] = (uint16_t)r[j];
+}
+int chunk_debug_tr16(const uint16_t *in, const int *addr, uint16_t *out, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tr16_probe_kernel, dim3(1), dim3(64), 0, st, in, addr, out);
+    return (int)hipGetLastError();
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------------------------------------------
