@@ -84,7 +84,8 @@ def main():
         _fused.CHUNKED_WKV_FWD = False
 
     from rwkvtts_amd import build
-    build.build()  # no-op when the prebuilt .so is current
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        build.build()  # no-op when the prebuilt .so is current; one rank per node, the others wait at the barrier below
     from rwkvtts_amd import backbone, ops, trainer
     from rwkvtts_amd.layouts import synthetic_spark_batch
     from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
@@ -93,6 +94,8 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.barrier()
 
     base = {"0.1b": backbone.config_0p1b, "0.4b": backbone.config_0p4b, "1.5b": backbone.config_1p5b}[a.model]()
     cfg = RWKV7SpeechConfig(**{k: v for k, v in base.to_dict().items() if k in backbone.RWKV7Config.__dataclass_fields__

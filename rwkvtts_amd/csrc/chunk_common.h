@@ -5,7 +5,7 @@
 //   A_ab[t,s] = a~_t.b^_s (s<t)  A_ak[t,s] = a~_t.k^_s (s<t)  A_qb[t,s] = q~_t.b^_s (s<=t)  A_qk[t,s] = q~_t.k^_s (s<=t)
 //   U = (I - A_ab)^-1 (A~ H0 + A_ak V)        (u_t = sa_t of the scalar kernel)
 //   Y = Q~ H0 + A_qb U + A_qk V               H_C = g_C * (H0 + B^^T U + K^^T V)
-// validated against the scalar oracle on CPU by tools/chunked_proto.py (fp32 rel. err 3e-7; with the 2-way bf16
+// validated against the scalar oracle on CPU by tests/chunked_proto.py (fp32 rel. err 3e-7; with the 2-way bf16
 // operand split used here 5e-6 -- three orders below the bf16 rounding of the outputs).
 //
 // Every matrix lives in LDS as bf16 "planes" [rows][K + 8] (K contiguous; +8 elements of padding make the 16-byte

@@ -4,7 +4,7 @@
 // With H = S^T in R^{K x V} and the per-chunk quantities of chunk_common.h (q~, a~, k^, b^, g_C, T = (I - A_ab)^-1,
 // W = T A~) the forward state obeys  H_{c+1} = M_c H_c + N_c  with  M_c = diag(g_C)(I + B^^T W), and the adjoint state
 //     E_c = M_c^T E_{c+1} + N'_c ,   N'_c = Q~^T dY + W^T (A_qb^T dY)              (E_c = dL/dH at the START of chunk c)
-// is the only sequential object of the backward pass (tools/chunked_proto2.py validates the algebra against the oracle).
+// is the only sequential object of the backward pass (tests/chunked_proto2.py validates the algebra against the oracle).
 // Three kernels:
 //   wkv7c_bwd_pre_kernel   grid B*H*(T/32), parallel: M_c^T (bf16 hi/lo planes) and N'_c (fp32, MFMA tile layout)
 //   wkv7c_state_kernel     grid B*H, sequential over chunks in reverse: E for every chunk (one 64x64x64 product each)
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// out: all six gradients of one chunk from (H_c, E_{c+1}, U, dY) -- tools/chunked_proto2.py:bwd3, third loop
+// out: all six gradients of one chunk from (H_c, E_{c+1}, U, dY) -- tests/chunked_proto2.py:bwd3, third loop
 //   G1 = A_qb^T dY + B^ (g_C E)          Z  = T^T G1                                  (Z_t = dL/du_t)
 //   dV = A_qk^T dY + A_ak^T Z + K^ (g_C E)
 //   dK = (P_vy Q~ + P_vz A~ + V (g_C E)^T) / gamma      dB = (P_uy Q~ + P_uz A~ + U (g_C E)^T) / gamma

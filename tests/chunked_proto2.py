@@ -12,9 +12,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import c_oracle  # noqa: E402
 from rwkvtts_amd.synthetic import make_wkv_inputs  # noqa: E402
-from tools.chunked_proto import bf16_split  # noqa: E402
+from chunked_proto import bf16_split  # noqa: E402
 
 
 def local(w, q, k, v, a, b, sl, dt, S):

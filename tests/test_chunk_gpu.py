@@ -1,7 +1,7 @@
 """GPU (-m gpu): the chunked (MFMA) WKV7 kernels against the scalar oracle.
 
 Tolerance: operands are split into two bf16 pieces (about 16 mantissa bits), accumulation is fp32; the CPU
-prototype (tools/chunked_proto.py) measures 5e-6..2e-5 relative error for this scheme, so fp32-I/O results must be
+prototype (tests/chunked_proto.py) measures 5e-6..2e-5 relative error for this scheme, so fp32-I/O results must be
 within 1e-4 * max|oracle| and bf16-I/O results within 1 bf16 ulp (2 for gradients), like the scalar kernels."""
 import pytest
 import torch
@@ -75,10 +75,8 @@ def _untile(np_tiles):
 
 def test_chunked_backward_state_recurrence_vs_prototype():
     """wkv7c_bwd_pre + wkv7c_state: M_c^T, N'_c and the adjoint states E against the CPU prototype of the same algebra
-    (tools/chunked_proto2.py, fp32), which itself is checked against the scalar oracle."""
-    import os, sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from tools import chunked_proto2 as P2
+    (tests/chunked_proto2.py, fp32), which itself is checked against the scalar oracle."""
+    import chunked_proto2 as P2
     B, T, H = 1, 128, 2
     ins = make_wkv_inputs(B, T, H, 21, torch.bfloat16)
     dy = torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(3)).bfloat16()
