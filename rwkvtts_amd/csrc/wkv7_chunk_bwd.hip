@@ -591,68 +591,71 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     }
     lds_barrier();
     BSTAMP(3);
-    // ---- phase B: G1[s][v] = sum_t A_qb[t][s] dY[t][v] + sum_k b^[s][k] (g_C E)[k][v]  -> G1T[v][s] ---------------------------
+    // ---- phase B: waves 0,1: G1[s][v] = sum_t A_qb[t][s] dY[t][v] + sum_k b^[s][k] (g_C E)[k][v]  -> G1T[v][s]
+    //               waves 2,3: the part of dV that does not need Z: sum_t A_qk[t][s] dY[t][v] + sum_k k^[s][k] (g_C E)[k][v] -------------
+    f32x16 accV = zero16();  // waves 2,3: dV tile D[m = s][n = v], finished in phase D
     if (wave <= 1) {
         const int vt = wave;
         f32x16 acc = zero16();
         mma_xs_yeK<kC>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYp, LDK, vt * 32, lane);
         mma_tile3<kN>(acc, sm + L::BHh, sm + L::BHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
         store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
+    } else {
+        const int vt = wave - 2;
+        mma_xs_yeK<kC>(accV, sm + L::QKTh, sm + L::QKTl, LDC, sm + L::DYp, LDK, vt * 32, lane);
+        mma_tile3<kN>(accV, sm + L::KHh, sm + L::KHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
     }
     lds_barrier();
     BSTAMP(4);
-    // ---- phase C: Z[t][v] = sum_s T[s][t] G1[s][v] --------------------------------------------------------------------------------
-    if (wave <= 1) {
-        const int vt = wave;
-        f32x16 acc = zero16();  // D[m = v][n = t] -> stored as Z[t][v]
-        mma_tile3<kC>(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, sm + L::TMTh, sm + L::TMTl, LDC, lane);
-        store_T_split(acc, sm + L::Zh + vt * 32, sm + L::Zl + vt * 32, LDK, lane);
-    }
-    lds_barrier();
-    BSTAMP(5);
-    // ---- phase D: dV[s][v] = sum_t A_qk[t][s] dY[t][v] + A_ak[t][s] Z[t][v] + sum_k k^[s][k] (g_C E)[k][v] -----------------------
-    if (wave <= 1) {
-        const int vt = wave;
-        f32x16 acc = zero16();
-        mma_xs_yeK<kC>(acc, sm + L::QKTh, sm + L::QKTl, LDC, sm + L::DYp, LDK, vt * 32, lane);
-        mma_tile3_yK<kC>(acc, sm + L::AKTh, sm + L::AKTl, LDC, sm + L::Zh, sm + L::Zl, LDK, vt * 32, lane);
-        mma_tile3<kN>(acc, sm + L::KHh, sm + L::KHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
-        stage_tile(acc, reinterpret_cast<float *>(sm + L::sV), vt, lane);
-    }
-    lds_barrier();
-    BSTAMP(6);
-    // ---- phase E1: dV out; (g_C E)^T planes; the four P matrices of dK / dB --------------------------------------------------------
+    // ---- phase C: waves 0,1: Z[t][v] = sum_s T[s][t] G1[s][v];  waves 2,3: P_vy, P_uy (need no Z);  all: (g_C E)^T planes ----------
     {
-        float x[8];
-        ld_stage8(reinterpret_cast<const float *>(sm + L::sV), pt, pk, x);
-        st_bf16x8(dv_ + off, x);
+        // P planes: index 0 = P_vy, 1 = P_vz (for dK), 2 = P_uy, 3 = P_uz (for dB); D[m = s][n = t] kept for s >= t (s > t), stored [t][s]
+        if (wave <= 1) {
+            const int vt = wave;
+            f32x16 acc = zero16();  // D[m = v][n = t] -> stored as Z[t][v]
+            mma_tile3<kC>(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, sm + L::TMTh, sm + L::TMTl, LDC, lane);
+            store_T_split(acc, sm + L::Zh + vt * 32, sm + L::Zl + vt * 32, LDK, lane);
+        } else {
+            f32x16 acc = zero16();
+            if (wave == 2) mma_ee<kN>(acc, sm + L::DYp, LDK, sm + L::Vp, LDK, lane);                    // dy_s . v_t
+            else mma_tile2y<kN>(acc, sm + L::DYp, LDK, sm + L::Uh, sm + L::Ul, LDK, lane);              // dy_s . u_t
+            mask_upper_T<false>(acc, lane);
+            uint16_t *Ph = sm + L::P0 + (wave == 2 ? 0 : 2) * 2 * L::A1;
+            store_T_split(acc, Ph, Ph + L::A1, LDC, lane);
+        }
+        // the E planes [v][k] were last read in phase B: their space becomes (g_C E)^T [k][v]
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
             const float g = sh_gC[row];
             put4(sm + L::XTh, sm + L::XTl, row, c4, rekv[i], g, g, g, g);
         }
-        uint16_t *Ph = sm + L::P0 + wave * 2 * L::A1, *Pl = Ph + L::A1;
-        f32x16 acc = zero16();  // D[m = s][n = t], kept for s >= t (P_vy, P_uy) or s > t (P_vz, P_uz); stored [t][s]
-        if (wave == 0) {
-            mma_ee<kN>(acc, sm + L::DYp, LDK, sm + L::Vp, LDK, lane);                       // dy_s . v_t
-            mask_upper_T<false>(acc, lane);
-        } else if (wave == 1) {
-            mma_xs_ye<kN>(acc, sm + L::Zh, sm + L::Zl, LDK, sm + L::Vp, LDK, lane);         // z_s . v_t
-            mask_upper_T<true>(acc, lane);
-        } else if (wave == 2) {
-            mma_tile2y<kN>(acc, sm + L::DYp, LDK, sm + L::Uh, sm + L::Ul, LDK, lane);       // dy_s . u_t
-            mask_upper_T<false>(acc, lane);
-        } else {
-            mma_tile3<kN>(acc, sm + L::Zh, sm + L::Zl, LDK, sm + L::Uh, sm + L::Ul, LDK, lane);  // z_s . u_t
-            mask_upper_T<true>(acc, lane);
-        }
-        store_T_split(acc, Ph, Pl, LDC, lane);
     }
     lds_barrier();
+    BSTAMP(5);
+    // ---- phase D: waves 2,3: dV += sum_t A_ak[t][s] Z[t][v] -> staging;  waves 0,1: P_vz, P_uz ------------------------------------
+    if (wave >= 2) {
+        const int vt = wave - 2;
+        mma_tile3_yK<kC>(accV, sm + L::AKTh, sm + L::AKTl, LDC, sm + L::Zh, sm + L::Zl, LDK, vt * 32, lane);
+        stage_tile(accV, reinterpret_cast<float *>(sm + L::sV), vt, lane);
+    } else {
+        f32x16 acc = zero16();
+        if (wave == 0) mma_xs_ye<kN>(acc, sm + L::Zh, sm + L::Zl, LDK, sm + L::Vp, LDK, lane);         // z_s . v_t
+        else mma_tile3<kN>(acc, sm + L::Zh, sm + L::Zl, LDK, sm + L::Uh, sm + L::Ul, LDK, lane);        // z_s . u_t
+        mask_upper_T<true>(acc, lane);
+        uint16_t *Ph = sm + L::P0 + (wave == 0 ? 1 : 3) * 2 * L::A1;
+        store_T_split(acc, Ph, Ph + L::A1, LDC, lane);
+    }
+    lds_barrier();
+    BSTAMP(6);
     BSTAMP(7);
-    // ---- phase F1: dK (waves 0,1) and dB (waves 2,3), unscaled, to staging ---------------------------------------------------------
+    // ---- phase F1: dV out; dK (waves 0,1) and dB (waves 2,3), unscaled, to staging -------------------------------------------------
     {
+        {
+            float x[8];
+            ld_stage8(reinterpret_cast<const float *>(sm + L::sV), pt, pk, x);
+            st_bf16x8(dv_ + off, x);
+        }
         const int kt = wave & 1;
         const uint16_t *P1h = sm + L::P0 + (wave < 2 ? 0 : 2) * 2 * L::A1, *P1l = P1h + L::A1, *P2h = P1h + 2 * L::A1, *P2l = P2h + L::A1;
         f32x16 acc = zero16();  // D[m = t][n = k]
@@ -668,28 +671,21 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     }
     lds_barrier();
     BSTAMP(8);
-    // ---- phase E2: H0^T planes over (g_C E)^T; the four transposed P matrices of dQ / dA -------------------------------------------
+    // ---- phase E2: the four transposed P matrices of dQ / dA; H0^T planes over (g_C E)^T --------------------------------------------
     {
+        uint16_t *Ph = sm + L::P0 + wave * 2 * L::A1, *Pl = Ph + L::A1;
+        f32x16 acc = zero16();  // D[m = s][n = t'], kept for s <= t' (vy, uy) or s < t' (vz, uz); stored [t'][s]
+        if (wave == 0) mma_ee<kN>(acc, sm + L::Vp, LDK, sm + L::DYp, LDK, lane);                        // v_s . dy_t'
+        else if (wave == 1) mma_xs_ye<kN>(acc, sm + L::Uh, sm + L::Ul, LDK, sm + L::DYp, LDK, lane);    // u_s . dy_t'
+        else if (wave == 2) mma_tile2y<kN>(acc, sm + L::Vp, LDK, sm + L::Zh, sm + L::Zl, LDK, lane);    // v_s . z_t'
+        else mma_tile3<kN>(acc, sm + L::Uh, sm + L::Ul, LDK, sm + L::Zh, sm + L::Zl, LDK, lane);        // u_s . z_t'
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
             put4(sm + L::XTh, sm + L::XTl, row, c4, rh0[i], 1.f, 1.f, 1.f, 1.f);
         }
-        uint16_t *Ph = sm + L::P0 + wave * 2 * L::A1, *Pl = Ph + L::A1;
-        f32x16 acc = zero16();  // D[m = s][n = t'], kept for s <= t' (vy, uy) or s < t' (vz, uz); stored [t'][s]
-        if (wave == 0) {
-            mma_ee<kN>(acc, sm + L::Vp, LDK, sm + L::DYp, LDK, lane);                       // v_s . dy_t'
-            mask_lower_T<false>(acc, lane);
-        } else if (wave == 1) {
-            mma_xs_ye<kN>(acc, sm + L::Uh, sm + L::Ul, LDK, sm + L::DYp, LDK, lane);        // u_s . dy_t'
-            mask_lower_T<false>(acc, lane);
-        } else if (wave == 2) {
-            mma_tile2y<kN>(acc, sm + L::Vp, LDK, sm + L::Zh, sm + L::Zl, LDK, lane);        // v_s . z_t'
-            mask_lower_T<true>(acc, lane);
-        } else {
-            mma_tile3<kN>(acc, sm + L::Uh, sm + L::Ul, LDK, sm + L::Zh, sm + L::Zl, LDK, lane);  // u_s . z_t'
-            mask_lower_T<true>(acc, lane);
-        }
+        if (wave <= 1) mask_lower_T<false>(acc, lane);
+        else mask_lower_T<true>(acc, lane);
         store_T_split(acc, Ph, Pl, LDC, lane);
     }
     lds_barrier();
