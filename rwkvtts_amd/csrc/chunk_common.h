@@ -176,6 +176,30 @@ __device__ __forceinline__ void mma_xs_yeK(f32x16 &acc, const uint16_t *Xh, cons
     }
 }
 
+// General tile product: acc[m][n] += sum_k X[m][k] Y[n][k] over K, where each operand is either row-major (free index = row,
+// k contiguous; `base` = first row) or k-major (k = row, free index contiguous; `base` = first column; fetched with
+// frag_tr), and either exact bf16 (one plane) or split hi/lo.  Terms: Xh Yh (+ Xl Yh) (+ Xh Yl).
+template <int K, bool XKM, bool XSPLIT, bool YKM, bool YSPLIT>
+__device__ __forceinline__ void mma_gen(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx, int xbase,
+                                        const uint16_t *Yh, const uint16_t *Yl, int ldy, int ybase, int lane) {
+    constexpr int NK = K / 16;
+    bf16x8 xh[NK], xl[NK], yh[NK], yl[NK];
+    const int xo = (xbase + (lane & 31)) * ldx + (lane >> 5) * 8, yo = (ybase + (lane & 31)) * ldy + (lane >> 5) * 8;
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        xh[i] = XKM ? frag_tr(Xh, ldx, 16 * i, xbase, lane) : *reinterpret_cast<const bf16x8 *>(Xh + xo + 16 * i);
+        yh[i] = YKM ? frag_tr(Yh, ldy, 16 * i, ybase, lane) : *reinterpret_cast<const bf16x8 *>(Yh + yo + 16 * i);
+        if (XSPLIT) xl[i] = XKM ? frag_tr(Xl, ldx, 16 * i, xbase, lane) : *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
+        if (YSPLIT) yl[i] = YKM ? frag_tr(Yl, ldy, 16 * i, ybase, lane) : *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
+        if (YSPLIT) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0);
+        if (XSPLIT) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0);
+    }
+}
+
 // row index of accumulator register r for this lane
 __device__ __forceinline__ int d_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

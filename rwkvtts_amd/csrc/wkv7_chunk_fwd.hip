@@ -115,8 +115,9 @@ constexpr int VH = 32;          // value columns per workgroup
 struct FwdSmem {  // all offsets in uint16 units; every plane 16-byte aligned
     static constexpr int QTh = 0, QTl = QTh + kC * LDK, ATh = QTl + kC * LDK, ATl = ATh + kC * LDK;
     static constexpr int KHh = ATl + kC * LDK, KHl = KHh + kC * LDK, BHh = KHl + kC * LDK, BHl = BHh + kC * LDK;
-    static constexpr int KTh = BHl + kC * LDK, KTl = KTh + kN * LDC, BTh = KTl + kN * LDC, BTl = BTh + kN * LDC;
-    static constexpr int Vt = BTl + kN * LDC, Vtl = Vt + VH * LDC;  // Vtl: low part, fp32 inputs only
+    // V[t][v] time-major like the other operands; products that contract over time read k^, b^, v with LDS transpose
+    // reads (frag_tr) instead of keeping channel-major copies
+    static constexpr int Vt = BHl + kC * LDK, Vtl = Vt + kC * LDC;  // Vtl: low part, fp32 inputs only
     static constexpr int Sh = Vtl + VH * LDC, Sl = Sh + VH * LDK;
     static constexpr int AKh = Sl + VH * LDK, AKl = AKh + kC * LDC, QBh = AKl + kC * LDC, QBl = QBh + kC * LDC;
     static constexpr int QKh = QBl + kC * LDC, QKl = QKh + kC * LDC, TMh = QKl + kC * LDC, TMl = TMh + kC * LDC;
@@ -141,9 +142,8 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
     using L = FwdSmem;
     constexpr bool VEXACT = sizeof(T) == 2;  // bf16 tensors: v needs no hi/lo split
     // acc += X V^T-plane product with X split; V exact (bf16 I/O) or split (fp32 I/O)
-    auto mma_xv = [&](f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int lane_) {
-        if (VEXACT) mma_tile2x<kC>(acc, Xh, Xl, LDC, sm + L::Vt, LDC, lane_);
-        else mma_tile3<kC>(acc, Xh, Xl, LDC, sm + L::Vt, sm + L::Vtl, LDC, lane_);
+    auto mma_xv = [&](f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int lane_) {  // X[t][s] . V[s][v]
+        mma_gen<kC, false, true, true, !VEXACT>(acc, Xh, Xl, LDC, 0, sm + L::Vt, sm + L::Vtl, LDC, 0, lane_);
     };
 
     const int vh = blockIdx.x & 1;
@@ -244,26 +244,12 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             *reinterpret_cast<uint4 *>(&sm[L::BHh + o]) = pack(bhh);
             *reinterpret_cast<uint4 *>(&sm[L::BHl + o]) = pack(bl);
             TSTAMP(14);
-            // channel-major copies of k^, b^ (the state update contracts over time) and of v
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int ot = (pk + j) * LDC + pt;
-                const int sh = (j & 1) * 16;
-                sm[L::KTh + ot] = (uint16_t)(kh[j >> 1] >> sh);
-                sm[L::KTl + ot] = (uint16_t)(kl[j >> 1] >> sh);
-                sm[L::BTh + ot] = (uint16_t)(bhh[j >> 1] >> sh);
-                sm[L::BTl + ot] = (uint16_t)(bl[j >> 1] >> sh);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                uint32_t vhi, vlo;
-                split_pk(vv[j], vv[j + 1], vhi, vlo);
-                sm[L::Vt + (pv + j) * LDC + pt] = (uint16_t)vhi;
-                sm[L::Vt + (pv + j + 1) * LDC + pt] = (uint16_t)(vhi >> 16);
-                if (!VEXACT) {  // bf16 inputs: v is exact, no low plane
-                    sm[L::Vtl + (pv + j) * LDC + pt] = (uint16_t)vlo;
-                    sm[L::Vtl + (pv + j + 1) * LDC + pt] = (uint16_t)(vlo >> 16);
-                }
+            {
+                uint32_t h0, l0, h1, l1;
+                split_pk(vv[0], vv[1], h0, l0);
+                split_pk(vv[2], vv[3], h1, l1);
+                *reinterpret_cast<uint2 *>(&sm[L::Vt + pt * LDC + pv]) = make_uint2(h0, h1);
+                if (!VEXACT) *reinterpret_cast<uint2 *>(&sm[L::Vtl + pt * LDC + pv]) = make_uint2(l0, l1);  // bf16 v is exact
             }
         }
         TSTAMP(2);
@@ -353,8 +339,8 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
                 for (int r = 0; r < 16; r++) hp[(long)(kt * 32 + d_row(r, lane)) * kN] = Smaster[r];
             }
             f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
-            mma_tile3<kC>(acc, sm + L::BTh + kt * 32 * LDC, sm + L::BTl + kt * 32 * LDC, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
-            mma_xv(acc, sm + L::KTh + kt * 32 * LDC, sm + L::KTl + kt * 32 * LDC, lane);
+            mma_gen<kC, true, true, false, true>(acc, sm + L::BHh, sm + L::BHl, LDK, kt * 32, sm + L::Uh, sm + L::Ul, LDC, 0, lane);
+            mma_gen<kC, true, true, true, !VEXACT>(acc, sm + L::KHh, sm + L::KHl, LDK, kt * 32, sm + L::Vt, sm + L::Vtl, LDC, 0, lane);
 #pragma unroll
             for (int r = 0; r < 16; r++) Smaster[r] = sh_gC[kt * 32 + d_row(r, lane)] * (Smaster[r] + acc[r]);
         }
