@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
                                                         float *__restrict__ sa_, float *__restrict__ hs_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     float *fm = reinterpret_cast<float *>(sm + FwdSmem::end16);
-    float *sh_G = fm + FwdSmem::fG, *sh_seg = fm + FwdSmem::fSeg, *sh_gC = fm + FwdSmem::fGC;
+    constexpr int kStageLD = 36;  // fp32 staging tiles [32][36]: conflict-free float4 reads with the step index across lanes
+    float *sh_U = fm + FwdSmem::fG, *sh_Y = sh_U + kC * kStageLD, *sh_gC = fm + FwdSmem::fGC;
+    static_assert(2 * kC * kStageLD <= kC * kN + 4 * kN, "staging tiles must fit in the former cumsum scratch");
     using L = FwdSmem;
     constexpr bool VEXACT = sizeof(T) == 2;  // bf16 tensors: v needs no hi/lo split
     // acc += X V^T-plane product with X split; V exact (bf16 I/O) or split (fp32 I/O)
@@ -307,10 +309,9 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             f32x16 acc = zero16();
             mma_tile3<kC>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::Rh, sm + L::Rl, LDC, lane);
             store_T_split(acc, sm + L::Uh, sm + L::Ul, LDC, lane);
-            if (SAVE) {
+            if (SAVE) {  // staged: written out by all threads after phase 6 with one 16-byte store each
 #pragma unroll
-                for (int r = 0; r < 16; r++)
-                    sa_[head_base + (long)(c * kC + d_row(r, lane)) * tstride + vh * VH + (lane & 31)] = acc[r];
+                for (int r = 0; r < 16; r++) sh_U[d_row(r, lane) * kStageLD + (lane & 31)] = acc[r];
             }
         }
         TSTAMP(8);
@@ -322,13 +323,8 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             mma_tile3<kN>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
             mma_tile3<kC>(acc, sm + L::QBh, sm + L::QBl, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
             mma_xv(acc, sm + L::QKh, sm + L::QKl, lane);
-            T *yp = y_ + head_base + (long)(c * kC) * tstride + vh * VH + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float val = acc[r];
-                if constexpr (sizeof(T) == 2) reinterpret_cast<uint16_t *>(yp)[(long)d_row(r, lane) * tstride] = f2bf(val);
-                else reinterpret_cast<float *>(yp)[(long)d_row(r, lane) * tstride] = val;
-            }
+            for (int r = 0; r < 16; r++) sh_Y[d_row(r, lane) * kStageLD + (lane & 31)] = acc[r];
         } else if (wave <= 2) {
             const int kt = wave - 1;  // rows (key channels) [32 kt, 32 kt + 32)
             if (SAVE) {
@@ -347,6 +343,18 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         TSTAMP(10);
         lds_barrier();
         TSTAMP(11);
+        {
+            // y (and sa) of this chunk: thread (pt, pv) owns 4 value columns of one step -> one 8/16-byte store per tensor
+            // (32 scalar stores per lane from the accumulator layout used to sit in front of the next chunk's loads)
+            const long o = head_base + (long)(c * kC + pt) * tstride + vh * VH + pv;
+            const float4 yv = *reinterpret_cast<const float4 *>(&sh_Y[pt * kStageLD + pv]);
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(y_) + o) = make_uint2(cvt_pk(yv.x, yv.y), cvt_pk(yv.z, yv.w));
+            } else {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y_) + o) = yv;
+            }
+            if (SAVE) *reinterpret_cast<float4 *>(sa_ + o) = *reinterpret_cast<const float4 *>(&sh_U[pt * kStageLD + pv]);
+        }
         // ---- phase 7: publish the new state planes S[v][k] ---------------------------------------------------
         if (wave == 1 || wave == 2) store_T_split(Smaster, sm + L::Sh + (wave - 1) * 32, sm + L::Sl + (wave - 1) * 32, LDK, lane);
         // (ordered against phase 4 of the next chunk by that chunk's phase-1/2/3 barriers)
