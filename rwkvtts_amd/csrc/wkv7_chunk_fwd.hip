@@ -295,11 +295,15 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         lds_barrier();
         TSTAMP(5);
         // ---- phase 4: R = A~ H0 + A_ak V   (D[t][v]) ---------------------------------------------------------
+        f32x16 accY = zero16();  // wave 3: the part of Y that does not need U (Q~ H0 + A_qk V), finished in phase 6
         if (wave == 0) {
             f32x16 acc = zero16();
             mma_tile3<kN>(acc, sm + L::ATh, sm + L::ATl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
             mma_xv(acc, sm + L::AKh, sm + L::AKl, lane);
             store_T_split(acc, sm + L::Rh, sm + L::Rl, LDC, lane);
+        } else if (wave == 3) {
+            mma_tile3<kN>(accY, sm + L::QTh, sm + L::QTl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
+            mma_xv(accY, sm + L::QKh, sm + L::QKl, lane);
         }
         TSTAMP(6);
         lds_barrier();
@@ -317,15 +321,12 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         TSTAMP(8);
         lds_barrier();
         TSTAMP(9);
-        // ---- phase 6: Y (wave 0) and the state update (waves 1,2) ---------------------------------------------
-        if (wave == 0) {
-            f32x16 acc = zero16();
-            mma_tile3<kN>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
-            mma_tile3<kC>(acc, sm + L::QBh, sm + L::QBl, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
-            mma_xv(acc, sm + L::QKh, sm + L::QKl, lane);
+        // ---- phase 6: Y += A_qb U (wave 3) and the state update (waves 1,2) -------------------------------------
+        if (wave == 3) {
+            mma_tile3<kC>(accY, sm + L::QBh, sm + L::QBl, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
 #pragma unroll
-            for (int r = 0; r < 16; r++) sh_Y[d_row(r, lane) * kStageLD + (lane & 31)] = acc[r];
-        } else if (wave <= 2) {
+            for (int r = 0; r < 16; r++) sh_Y[d_row(r, lane) * kStageLD + (lane & 31)] = accY[r];
+        } else if (wave == 1 || wave == 2) {
             const int kt = wave - 1;  // rows (key channels) [32 kt, 32 kt + 32)
             if (SAVE) {
                 // state at the START of chunk c, hs[b,h,c][k][v] (the orientation of the scalar kernel's checkpoints):
