@@ -288,20 +288,22 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
 // chunks ahead in registers so that the ~2 us HBM latency is off the critical path.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
-struct StateSmem {
-    static constexpr int E0h = 0, E0l = E0h + kN * LDK, E1h = E0l + kN * LDK, E1l = E1h + kN * LDK;
-    static constexpr int end16 = E1l + kN * LDK;
+struct StateSmem {  // E planes of one half of the value columns, [32 v][64 k], double buffered
+    static constexpr int E0h = 0, E0l = E0h + kC * LDK, E1h = E0l + kC * LDK, E1l = E1h + kC * LDK;
+    static constexpr int end16 = E1l + kC * LDK;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
 }  // namespace
 
-__global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t *__restrict__ mt_, const float *__restrict__ np_,
+__global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t *__restrict__ mt_, const float *__restrict__ np_,
                                                           float *__restrict__ e_vk, float *__restrict__ e_kv) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = StateSmem;
-    const int bh = blockIdx.x;
+    // the value columns of E never mix (E_c = M^T E + N' acts on columns): one workgroup per (head, half of the value
+    // columns), 2 waves = the two 32-row tiles of that half -> 2 B H workgroups keep all 256 CUs streaming
+    const int bh = blockIdx.x >> 1, nt = blockIdx.x & 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int mt = wave >> 1, nt = wave & 1;
+    const int mt = wave;
 
     struct In {
         bf16x8 mh[4], ml[4];
@@ -316,13 +318,13 @@ __global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t
                 r.mh[i] = *reinterpret_cast<const bf16x8 *>(mp + i * 512);
                 r.ml[i] = *reinterpret_cast<const bf16x8 *>(mp + 4 * 512 + i * 512);
             }
-            const float *np = np_ + ((((long)bh * nc + c) * 4 + wave) * 64 + lane) * 16;
+            const float *np = np_ + ((((long)bh * nc + c) * 4 + mt * 2 + nt) * 64 + lane) * 16;
 #pragma unroll
             for (int j = 0; j < 4; j++) r.n[j] = *reinterpret_cast<const float4 *>(np + 4 * j);
         }
         return r;
     };
-    for (int i = tid; i < 2 * kN * LDK; i += 256) sm[L::E0h + i] = 0;  // E_{nc} = 0
+    for (int i = tid; i < 2 * kC * LDK; i += 128) sm[L::E0h + i] = 0;  // E_{nc} = 0
     f32x16 E = zero16();  // this wave's tile of the current E, accumulator layout [m = k][n = v]
     int cur = 0;
     auto step = [&](int c, const In &in) {
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t
 #pragma unroll
             for (int r = 0; r < 16; r++) pk[(long)(mt * 32 + d_row(r, lane)) * kN] = E[r];
         }
-        const uint16_t *Eh = sm + (cur ? L::E1h : L::E0h) + (nt * 32 + (lane & 31)) * LDK + (lane >> 5) * 8, *El = Eh + kN * LDK;
+        const uint16_t *Eh = sm + (cur ? L::E1h : L::E0h) + (lane & 31) * LDK + (lane >> 5) * 8, *El = Eh + kC * LDK;
         f32x16 acc;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -355,8 +357,8 @@ __global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, const uint16_t
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.ml[i], eh[i], acc, 0, 0, 0);
         }
         E = acc;
-        uint16_t *Oh = sm + (cur ? L::E0h : L::E1h), *Ol = Oh + kN * LDK;
-        store_T_split(E, Oh + nt * 32 * LDK + mt * 32, Ol + nt * 32 * LDK + mt * 32, LDK, lane);  // planes [v][k]
+        uint16_t *Oh = sm + (cur ? L::E0h : L::E1h), *Ol = Oh + kC * LDK;
+        store_T_split(E, Oh + mt * 32, Ol + mt * 32, LDK, lane);  // planes [v (this half)][k]
         lds_barrier();
         cur ^= 1;
     };
@@ -772,7 +774,7 @@ int chunk_state_bf16(int BH, int nc, const void *mt, const float *np, float *e_v
         attr = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(wkv7c_state_kernel, dim3(BH), dim3(256), StateSmem::bytes, st, nc, (const uint16_t *)mt, np, e_vk, e_kv);
+    hipLaunchKernelGGL(wkv7c_state_kernel, dim3(BH * 2), dim3(128), StateSmem::bytes, st, nc, (const uint16_t *)mt, np, e_vk, e_kv);
     return (int)hipGetLastError();
 }
 
