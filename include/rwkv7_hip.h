@@ -236,20 +236,19 @@ int rwkv7_wkv_chunk_fwd_f32(int B, int T, int H, const void *w, const void *q, c
  *      obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
  *   bwd_pre : parallel over chunks.  mt  = M_c^T as bf16 hi/lo planes, uint16 [B*H*T/32][2][64][64];
  *                                    np  = N'_c, fp32 [B*H*T/32][4 tiles][64 lanes][16] (MFMA accumulator layout)
- *   state   : sequential over chunks (reverse).  e_vk[b,h,c][v][k], e_kv[b,h,c][k][v] = E_{c+1} (fp32), what chunk c
- *             receives from its future. ---- */
+ *   state   : sequential over chunks (reverse), one workgroup per (head, half of the value columns).
+ *             e_kv[b,h,c][k][v] = E_{c+1} (fp32), what chunk c receives from its future. ---- */
 int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
                                  const void *dy, const float *tinv, void *mt, float *np, rwkv7_stream_t stream);
-int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_vk, float *e_kv,
-                               rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_kv, rwkv7_stream_t stream);
 /*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from the forward's saved
  *             tensors, tinv and the adjoint states of `state`.  ck_mode 0: s, sa as saved by rwkv7_wkv_fwd_bf16 (fp32
  *             checkpoints every 16 steps); ck_mode 1: s = hs of rwkv7_wkv_chunk_fwd_bf16 (state at the start of every
  *             32-step chunk, [k][v]). */
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,
-                                 const float *tinv, const float *e_vk, const float *e_kv, int ck_mode, void *dw, void *dq,
-                                 void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
+                                 const float *tinv, const float *e_kv, int ck_mode, void *dw, void *dq, void *dk, void *dv,
+                                 void *da, void *db, rwkv7_stream_t stream);
 /* probe of ds_read_b64_tr_b16 (LDS transpose read): in = 4096 u16 copied to LDS, addr[64] = element index each lane
  * points at, out[64][4] = what each lane receives */
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream);

@@ -33,9 +33,9 @@ int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t)
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
-int chunk_state_bf16(int, int, const void *, const float *, float *, float *, hipStream_t);
+int chunk_state_bf16(int, int, const void *, const float *, float *, hipStream_t);
 int chunk_bwd_out_bf16(int, int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
-                       const float *, const float *, const float *, const float *, const float *, void *, void *, void *, void *,
+                       const float *, const float *, const float *, const float *, void *, void *, void *, void *,
                        void *, void *, hipStream_t);
 void fwd_force_shape(int);
 void bwd_force_shape(int);
@@ -307,21 +307,20 @@ int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void 
     if (T % 32 != 0) return RWKV7_ECHUNK;
     return rwkv7::chunk_bwd_pre_bf16(B, T, H, w, q, a, b, dy, tinv, mt, np, (hipStream_t)stream);
 }
-int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_vk, float *e_kv,
-                               rwkv7_stream_t stream) {
-    if (BH <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk, (const void *)e_kv})) return RWKV7_EINVAL;
-    return rwkv7::chunk_state_bf16(BH, nchunks, mt, np, e_vk, e_kv, (hipStream_t)stream);
+int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_kv, rwkv7_stream_t stream) {
+    if (BH <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_kv})) return RWKV7_EINVAL;
+    return rwkv7::chunk_state_bf16(BH, nchunks, mt, np, e_kv, (hipStream_t)stream);
 }
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,
-                                 const float *tinv, const float *e_vk, const float *e_kv, int ck_mode, void *dw, void *dq,
-                                 void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream) {
+                                 const float *tinv, const float *e_kv, int ck_mode, void *dw, void *dq, void *dk, void *dv,
+                                 void *da, void *db, rwkv7_stream_t stream) {
     if (B <= 0 || T <= 0 || H <= 0 || ck_mode < 0 || ck_mode > 1 ||
-        any_null({w, q, k, v, a, b, dy, (const void *)s, (const void *)sa, (const void *)tinv, (const void *)e_vk,
-                  (const void *)e_kv, dw, dq, dk, dv, da, db}))
+        any_null({w, q, k, v, a, b, dy, (const void *)s, (const void *)sa, (const void *)tinv, (const void *)e_kv, dw, dq, dk,
+                  dv, da, db}))
         return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
-    return rwkv7::chunk_bwd_out_bf16(B, T, H, ck_mode, w, q, k, v, a, b, dy, s, sa, tinv, e_vk, e_kv, dw, dq, dk, dv, da, db,
+    return rwkv7::chunk_bwd_out_bf16(B, T, H, ck_mode, w, q, k, v, a, b, dy, s, sa, tinv, e_kv, dw, dq, dk, dv, da, db,
                                      (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {

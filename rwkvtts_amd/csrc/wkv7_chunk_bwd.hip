@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
 
 // ------------------------------------------------------------------------------------------------------------------
 // state: E_c = M_c^T E_{c+1} + N'_c, c = nc-1 .. 0; writes E_{c+1} (the adjoint state chunk c sees at its end) for every c
-// in both orientations: e_vk[b,h,c][v][k] and e_kv[b,h,c][k][v].  M^T arrives in A-fragment order and N' in accumulator
+// as e_kv[b,h,c][k][v].  M^T arrives in A-fragment order and N' in accumulator
 // order, so both go from global memory straight into MFMA operands / accumulators; only E itself passes through LDS
 // (accumulator layout -> B-operand planes).  The chain is one 64x64x64 product per chunk; inputs are prefetched three
 // chunks ahead in registers so that the ~2 us HBM latency is off the critical path.
@@ -296,7 +296,7 @@ struct StateSmem {  // E planes of one half of the value columns, [32 v][64 k], 
 }  // namespace
 
 __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t *__restrict__ mt_, const float *__restrict__ np_,
-                                                          float *__restrict__ e_vk, float *__restrict__ e_kv) {
+                                                          float *__restrict__ e_kv) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = StateSmem;
     // the value columns of E never mix (E_c = M^T E + N' acts on columns): one workgroup per (head, half of the value
@@ -330,10 +330,6 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t
     auto step = [&](int c, const In &in) {
         {
             // E_{c+1}: what chunk c receives from the future
-            float *pv = e_vk + (((long)bh * nc + c) * kN + nt * 32 + (lane & 31)) * kN + mt * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                *reinterpret_cast<float4 *>(pv + 8 * j) = make_float4(E[4 * j], E[4 * j + 1], E[4 * j + 2], E[4 * j + 3]);
             float *pk = e_kv + ((long)bh * nc + c) * kN * kN + nt * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; r++) pk[(long)(mt * 32 + d_row(r, lane)) * kN] = E[r];
@@ -402,19 +398,18 @@ struct OutSmem {  // offsets in uint16 units
     static constexpr int S = dterm + 2 * kN;                // phase scratch
     // phases A-D inside S
     static constexpr int G1Th = S, G1Tl = G1Th + CM1, sV = G1Tl + CM1;
-    static constexpr int EGh = sV + ST, EGl = EGh + SQ1;    // (g_C E)[v][k]
+    static constexpr int XTh = sV + ST, XTl = XTh + SQ1;    // (g_C E)[k][v], after phase F1 H0^T [k][v]
     // phases A-D inside the (still unused) staging area
     static constexpr int TMTh = STG, TMTl = TMTh + A1, QBTh = TMTl + A1, QBTl = QBTh + A1, QKTh = QBTl + A1, QKTl = QKTh + A1;
     static constexpr int AKTh = QKTl + A1, AKTl = AKTh + A1;
     // phases E-F inside S
-    static constexpr int XTh = EGh, XTl = XTh + SQ1;        // (g_C E)^T [k][v], later H0^T [k][v]: over the dead E planes
-    static constexpr int P0 = EGl + SQ1;                    // 4 pairs of [32][LDC] planes
+    static constexpr int P0 = XTl + SQ1;                    // 4 pairs of [32][LDC] planes
     static constexpr int end16 = P0 + 8 * A1;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
 static_assert(OutSmem::AKTl + OutSmem::A1 <= OutSmem::gC, "phase A-D planes must fit in the staging area");
 static_assert(OutSmem::bytes <= 160 * 1024, "LDS budget");
-static_assert(OutSmem::S % 8 == 0 && OutSmem::EGh % 8 == 0 && OutSmem::P0 % 8 == 0 && OutSmem::STG % 8 == 0 && OutSmem::sV % 8 == 0, "alignment");
+static_assert(OutSmem::S % 8 == 0 && OutSmem::XTh % 8 == 0 && OutSmem::P0 % 8 == 0 && OutSmem::STG % 8 == 0 && OutSmem::sV % 8 == 0, "alignment");
 
 // X exact (single plane), Y exact
 template <int K>
@@ -451,8 +446,7 @@ __device__ __forceinline__ void put4(uint16_t *Ph, uint16_t *Pl, int row, int c4
 __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     int T_, int H, int nchunks_total, int ck_mode, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
     const bf16_t *__restrict__ v_, const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_, const bf16_t *__restrict__ dy_,
-    const float *__restrict__ s_, const float *__restrict__ sa_, const float *__restrict__ tinv_, const float *__restrict__ e_vk,
-    const float *__restrict__ e_kv, bf16_t *__restrict__ dw_, bf16_t *__restrict__ dq_, bf16_t *__restrict__ dk_,
+    const float *__restrict__ s_, const float *__restrict__ sa_, const float *__restrict__ tinv_, const float *__restrict__ e_kv, bf16_t *__restrict__ dw_, bf16_t *__restrict__ dq_, bf16_t *__restrict__ dk_,
     bf16_t *__restrict__ dv_, bf16_t *__restrict__ da_, bf16_t *__restrict__ db_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = OutSmem;
@@ -467,7 +461,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     struct In {
         Raw8 w, q, k, a, b, v, dy;
         float4 u0, u1, tm;
-        float4 evk[4], ekv[4], h0[4], hc[4];  // 64x64 fp32: piece p = tid + 256 i = row p >> 4, columns 4 (p & 15) .. +4
+        float4 ekv[4], h0[4], hc[4];  // 64x64 fp32: piece p = tid + 256 i = row p >> 4, columns 4 (p & 15) .. +4
         long off;
     };
     // first: load H0 as well; otherwise H0 of this chunk is H_C of the previous one (same head), already in registers
@@ -481,7 +475,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         r.u0 = *reinterpret_cast<const float4 *>(sa_ + r.off);
         r.u1 = *reinterpret_cast<const float4 *>(sa_ + r.off + 4);
         r.tm = *reinterpret_cast<const float4 *>(tinv_ + (long)chunk * kC * kC + tid * 4);
-        const float *evk = e_vk + (long)chunk * kN * kN, *ekv = e_kv + (long)chunk * kN * kN;
+        const float *ekv = e_kv + (long)chunk * kN * kN;
         const long n_ck = ck_mode ? nc : nck;
         const int i0 = ck_mode ? c : 2 * c - 1, iC = ck_mode ? c + 1 : 2 * c + 1;
         const bool has0 = ck_mode ? true : c > 0, hasC = ck_mode ? c + 1 < nc : true;  // E = 0 after the last chunk: H_C unused
@@ -489,7 +483,6 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i;
-            r.evk[i] = *reinterpret_cast<const float4 *>(evk + p * 4);
             r.ekv[i] = *reinterpret_cast<const float4 *>(ekv + p * 4);
             if (first || c == 0) r.h0[i] = has0 ? *reinterpret_cast<const float4 *>(h0p + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             r.hc[i] = hasC ? *reinterpret_cast<const float4 *>(hcp + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -565,11 +558,13 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     }
     lds_barrier();  // sh_gC visible
     {
-        // (g_C E)[v][k] planes: row v, scale per column k
+        // (g_C E)[k][v] planes (row k scaled by g_C[k]); both uses -- B^ (g_C E), K^ (g_C E) contracting over k and
+        // V (g_C E)^T, U (g_C E)^T contracting over v -- read this one orientation (k-major via frag_tr / row-major)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
-            put4(sm + L::EGh, sm + L::EGl, row, c4, cur.evk[i], sh_gC[c4], sh_gC[c4 + 1], sh_gC[c4 + 2], sh_gC[c4 + 3]);
+            const float g = sh_gC[row];
+            put4(sm + L::XTh, sm + L::XTl, row, c4, rekv[i], g, g, g, g);
         }
     }
     lds_barrier();
@@ -600,16 +595,16 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         const int vt = wave;
         f32x16 acc = zero16();
         mma_xs_yeK<kC>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYp, LDK, vt * 32, lane);
-        mma_tile3<kN>(acc, sm + L::BHh, sm + L::BHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
+        mma_gen<kN, false, true, true, true>(acc, sm + L::BHh, sm + L::BHl, LDK, 0, sm + L::XTh, sm + L::XTl, LDK, vt * 32, lane);
         store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
     } else {
         const int vt = wave - 2;
         mma_xs_yeK<kC>(accV, sm + L::QKTh, sm + L::QKTl, LDC, sm + L::DYp, LDK, vt * 32, lane);
-        mma_tile3<kN>(accV, sm + L::KHh, sm + L::KHl, LDK, sm + L::EGh + vt * 32 * LDK, sm + L::EGl + vt * 32 * LDK, LDK, lane);
+        mma_gen<kN, false, true, true, true>(accV, sm + L::KHh, sm + L::KHl, LDK, 0, sm + L::XTh, sm + L::XTl, LDK, vt * 32, lane);
     }
     lds_barrier();
     BSTAMP(4);
-    // ---- phase C: waves 0,1: Z[t][v] = sum_s T[s][t] G1[s][v];  waves 2,3: P_vy, P_uy (need no Z);  all: (g_C E)^T planes ----------
+    // ---- phase C: waves 0,1: Z[t][v] = sum_s T[s][t] G1[s][v];  waves 2,3: P_vy, P_uy (need no Z) ---------------------------------
     {
         // P planes: index 0 = P_vy, 1 = P_vz (for dK), 2 = P_uy, 3 = P_uz (for dB); D[m = s][n = t] kept for s >= t (s > t), stored [t][s]
         if (wave <= 1) {
@@ -624,13 +619,6 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
             mask_upper_T<false>(acc, lane);
             uint16_t *Ph = sm + L::P0 + (wave == 2 ? 0 : 2) * 2 * L::A1;
             store_T_split(acc, Ph, Ph + L::A1, LDC, lane);
-        }
-        // the E planes [v][k] were last read in phase B: their space becomes (g_C E)^T [k][v]
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
-            const float g = sh_gC[row];
-            put4(sm + L::XTh, sm + L::XTl, row, c4, rekv[i], g, g, g, g);
         }
     }
     lds_barrier();
@@ -765,7 +753,7 @@ int chunk_bwd_pre_bf16(int B, int T_, int H, const void *w, const void *q, const
     return (int)hipGetLastError();
 }
 
-int chunk_state_bf16(int BH, int nc, const void *mt, const float *np, float *e_vk, float *e_kv, hipStream_t st) {
+int chunk_state_bf16(int BH, int nc, const void *mt, const float *np, float *e_kv, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_state_kernel),
@@ -774,13 +762,12 @@ int chunk_state_bf16(int BH, int nc, const void *mt, const float *np, float *e_v
         attr = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(wkv7c_state_kernel, dim3(BH * 2), dim3(128), StateSmem::bytes, st, nc, (const uint16_t *)mt, np, e_vk, e_kv);
+    hipLaunchKernelGGL(wkv7c_state_kernel, dim3(BH * 2), dim3(128), StateSmem::bytes, st, nc, (const uint16_t *)mt, np, e_kv);
     return (int)hipGetLastError();
 }
 
 int chunk_bwd_out_bf16(int B, int T_, int H, int ck_mode, const void *w, const void *q, const void *k, const void *v, const void *a,
-                       const void *b, const void *dy, const float *s, const float *sa, const float *tinv, const float *e_vk,
-                       const float *e_kv, void *dw, void *dq, void *dk, void *dv, void *da, void *db, hipStream_t st) {
+                       const void *b, const void *dy, const float *s, const float *sa, const float *tinv, const float *e_kv, void *dw, void *dq, void *dk, void *dv, void *da, void *db, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_bwd_out_kernel),
@@ -793,7 +780,7 @@ int chunk_bwd_out_bf16(int B, int T_, int H, int ck_mode, const void *w, const v
     hipLaunchKernelGGL(wkv7c_bwd_out_kernel, dim3((total + kChunksPerWG - 1) / kChunksPerWG), dim3(256), OutSmem::bytes, st, T_, H,
                        total, ck_mode, (const bf16_t *)w,
                        (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a, (const bf16_t *)b,
-                       (const bf16_t *)dy, s, sa, tinv, e_vk, e_kv, (bf16_t *)dw, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
+                       (const bf16_t *)dy, s, sa, tinv, e_kv, (bf16_t *)dw, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
                        (bf16_t *)da, (bf16_t *)db);
     return (int)hipGetLastError();
 }

@@ -265,8 +265,7 @@ def wkv7_chunk_forward(w, q, k, v, a, b, save=True):
 
 def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv):
     """First two stages of the chunked backward (bf16): per-chunk M^T / N' (parallel) and the adjoint-state recurrence
-    E_c = M_c^T E_{c+1} + N'_c (sequential over chunks).  Returns (mt, np, e_vk, e_kv): e_*[b,h,c] = E_{c+1} in the two
-    orientations [v][k] and [k][v]."""
+    E_c = M_c^T E_{c+1} + N'_c (sequential over chunks).  Returns (mt, np, e_kv): e_kv[b,h,c][k][v] = E_{c+1}."""
     B, T, H, C = w.shape
     if w.dtype != torch.bfloat16:
         raise TypeError("the chunked backward is bf16 only")
@@ -276,7 +275,6 @@ def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv):
     dev = w.device
     mt = torch.empty(B, H, nc, 2, C, C, dtype=torch.int16, device=dev)
     np_ = torch.empty(B, H, nc, 4, 64, 16, dtype=torch.float32, device=dev)
-    e_vk = torch.empty(B, H, nc, C, C, dtype=torch.float32, device=dev)
     e_kv = torch.empty(B, H, nc, C, C, dtype=torch.float32, device=dev)
     with torch.cuda.device_of(w):
         with _timed("wkv7c_bwd_pre", w):
@@ -284,9 +282,9 @@ def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv):
                                                          _stream(w))
         _lib.check(rc, "wkv7_chunk_bwd_pre")
         with _timed("wkv7c_state", w):
-            rc = _lib.lib().rwkv7_wkv_chunk_state_bf16(B * H, nc, _p(mt), _p(np_), _p(e_vk), _p(e_kv), _stream(w))
+            rc = _lib.lib().rwkv7_wkv_chunk_state_bf16(B * H, nc, _p(mt), _p(np_), _p(e_kv), _stream(w))
         _lib.check(rc, "wkv7_chunk_state")
-    return mt, np_, e_vk, e_kv
+    return mt, np_, e_kv
 
 
 def wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa, tinv=None, ck_mode=0):
@@ -296,12 +294,12 @@ def wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa, tinv=None, ck_mode=0):
     B, T, H, C = w.shape
     if tinv is None:
         tinv = wkv7_chunk_prep(w, a, b)
-    mt, np_, e_vk, e_kv = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv)
+    mt, np_, e_kv = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv)
     del mt, np_
     grads = [torch.empty_like(w) for _ in range(6)]
     with torch.cuda.device_of(w), _timed("wkv7c_bwd_out", w):
         rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(s), _p(sa),
-                                                     _p(tinv), _p(e_vk), _p(e_kv), ck_mode, *[_p(g) for g in grads], _stream(w))
+                                                     _p(tinv), _p(e_kv), ck_mode, *[_p(g) for g in grads], _stream(w))
     _lib.check(rc, "wkv7_chunk_bwd_out")
     return tuple(grads)
 

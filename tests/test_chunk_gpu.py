@@ -83,7 +83,7 @@ def test_chunked_backward_state_recurrence_vs_prototype():
     d = [t.to(DEV) for t in ins]
     w, q, k, v, a, b = d
     tinv = ops.wkv7_chunk_prep(w, a, b)
-    mt, np_, e_vk, e_kv = ops.wkv7_chunk_bwd_state(w, q, a, b, dy.to(DEV), tinv)
+    mt, np_, e_kv = ops.wkv7_chunk_bwd_state(w, q, a, b, dy.to(DEV), tinv)
     torch.cuda.synchronize()
     # M^T is stored in MFMA A-fragment order [k-tile][plane][k-step][lane][8]: row = 32*tile + lane%32, col = 16*step + 8*(lane//32) + j
     frag = mt.cpu().view(torch.bfloat16).float().reshape(B, H, T // 32, 2, 2, 4, 64, 8)
@@ -113,7 +113,6 @@ def test_chunked_backward_state_recurrence_vs_prototype():
             assert (got - Np[c]).abs().max() <= 2e-5 * Np[c].abs().max() + 1e-6, ("N'", h, c)
             scale = max(Es[c].abs().max().item(), 1e-3)
             assert (e_kv[0, h, c].cpu() - Es[c]).abs().max() <= 1e-4 * scale, ("E[k][v]", h, c)
-            assert (e_vk[0, h, c].cpu() - Es[c].T).abs().max() <= 1e-4 * scale, ("E[v][k]", h, c)
 
 
 @pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2)])
