@@ -301,7 +301,17 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t
     using L = StateSmem;
     // the value columns of E never mix (E_c = M^T E + N' acts on columns): one workgroup per (head, half of the value
     // columns), 2 waves = the two 32-row tiles of that half -> 2 B H workgroups keep all 256 CUs streaming
-    const int bh = blockIdx.x >> 1, nt = blockIdx.x & 1;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the two halves of a head get block ids g and
+    // g + 8 so that they share an L2 and M_c^T is fetched from HBM once, not twice.
+    int bh, nt;
+    if ((gridDim.x & 15) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bh = (j >> 1) * 8 + xcd;
+        nt = j & 1;
+    } else {
+        bh = blockIdx.x >> 1;
+        nt = blockIdx.x & 1;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int mt = wave;
 

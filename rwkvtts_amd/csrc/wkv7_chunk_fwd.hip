@@ -148,8 +148,17 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         mma_gen<kC, false, true, true, !VEXACT>(acc, Xh, Xl, LDC, 0, sm + L::Vt, sm + L::Vtl, LDC, 0, lane_);
     };
 
-    const int vh = blockIdx.x & 1;
-    const int bh = blockIdx.x >> 1;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the two value halves of a head get block ids
+    // g and g + 8, so they run on the same XCD and the 5 shared input streams come from HBM once.
+    int vh, bh;
+    if ((gridDim.x & 15) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bh = (j >> 1) * 8 + xcd;
+        vh = j & 1;
+    } else {
+        vh = blockIdx.x & 1;
+        bh = blockIdx.x >> 1;
+    }
     const int bb = bh / H, hh = bh - bb * H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nc = T_ / kC;
