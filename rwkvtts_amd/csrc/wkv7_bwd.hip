@@ -66,8 +66,12 @@ __global__ __launch_bounds__(64 * NW) void wkv7_bwd_kernel(
         reinterpret_cast<float(*)[FL][NOUT][kN]>(smem + kTB * (NCV + NRV) * kN);              // [NW][FL][5][64]
     float(*sh_dv)[kN] = reinterpret_cast<float(*)[kN]>(smem + kTB * (NCV + NRV) * kN + NW * FL * NOUT * kN);
 
-    const int part = blockIdx.x % NSPLIT;
-    const int bh = blockIdx.x / NSPLIT;
+    int part = blockIdx.x % NSPLIT, bh = blockIdx.x / NSPLIT;
+    if (NSPLIT == 2 && (gridDim.x & 15) == 0) {  // both halves of a head on one XCD (shared L2): block ids g and g + 8
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bh = (j >> 1) * 8 + xcd;
+        part = j & 1;
+    }
     const int bb = bh / H, hh = bh - bb * H;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;

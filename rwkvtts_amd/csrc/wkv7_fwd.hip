@@ -41,8 +41,17 @@ __global__ __launch_bounds__(2048 / CW) void wkv7_fwd_kernel(int T_, int H, cons
     __shared__ __attribute__((aligned(16))) float sh_y[2][kTB][32];   // double-buffered: stored one stage late
     __shared__ __attribute__((aligned(16))) float sh_sa[2][kTB][32];
 
-    const int half = blockIdx.x & 1;  // which 32 rows of the head
-    const int bh = blockIdx.x >> 1;
+    // which 32 rows of which head.  Workgroups are dealt round-robin to the 8 XCDs; the two halves of a head get block ids
+    // g and g + 8 so that they share an L2 and the input streams are fetched from HBM once.
+    int half, bh;
+    if ((gridDim.x & 15) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bh = (j >> 1) * 8 + xcd;
+        half = j & 1;
+    } else {
+        half = blockIdx.x & 1;
+        bh = blockIdx.x >> 1;
+    }
     const int bb = bh / H, hh = bh - bb * H;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
