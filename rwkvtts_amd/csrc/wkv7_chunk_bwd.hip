@@ -396,7 +396,10 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
 struct OutSmem {  // offsets in uint16 units
-    static constexpr int TM1 = kC * LDK, CM1 = kN * LDC, SQ1 = kN * LDK, A1 = kC * LDC, ST = kC * kN * 2;
+    // staging tiles are fp32 [32][64 + 4]: with the step index across lanes (row stride 272 B) a thread's float4 read would
+    // otherwise hit the same 4 banks in all 32 lanes (measured: 46 % of the kernel's LDS cycles were bank conflicts)
+    static constexpr int kStLD = kN + 4;
+    static constexpr int TM1 = kC * LDK, CM1 = kN * LDC, SQ1 = kN * LDK, A1 = kC * LDC, ST = kC * kStLD * 2;
     // fixed for the whole kernel: the scaled operands and V, dY, U, Z, all TIME-major [t][.]; products that contract over
     // time fetch them with LDS transpose reads (frag_tr), so no channel-major copies exist
     static constexpr int QTh = 0, QTl = QTh + TM1, ATh = QTl + TM1, ATl = ATh + TM1;
@@ -429,10 +432,11 @@ __device__ __forceinline__ void mma_ee(f32x16 &acc, const uint16_t *X, int ldx, 
 // D tile -> fp32 staging [32][64], columns [32 ct, 32 ct + 32)
 __device__ __forceinline__ void stage_tile(const f32x16 &acc, float *stg, int ct, int lane) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) stg[d_row(r, lane) * kN + ct * 32 + (lane & 31)] = acc[r];
+    for (int r = 0; r < 16; r++) stg[d_row(r, lane) * OutSmem::kStLD + ct * 32 + (lane & 31)] = acc[r];
 }
 __device__ __forceinline__ void ld_stage8(const float *stg, int pt, int pk, float (&x)[8]) {
-    const float4 a = *reinterpret_cast<const float4 *>(stg + pt * kN + pk), b = *reinterpret_cast<const float4 *>(stg + pt * kN + pk + 4);
+    const float4 a = *reinterpret_cast<const float4 *>(stg + pt * OutSmem::kStLD + pk),
+                 b = *reinterpret_cast<const float4 *>(stg + pt * OutSmem::kStLD + pk + 4);
     x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
 }
 __device__ __forceinline__ void st_bf16x8(bf16_t *p, const float (&x)[8]) {
