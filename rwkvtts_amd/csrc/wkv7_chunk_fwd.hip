@@ -126,6 +126,11 @@ struct FwdSmem {  // all offsets in uint16 units; every plane 16-byte aligned
     // fp32 region (offsets in floats from the start of the fp32 area)
     static constexpr int fG = 0, fSeg = fG + kC * kN, fGC = fSeg + 4 * kN, fend = fGC + kN;
     static constexpr size_t bytes = (size_t)end16 * 2 + (size_t)fend * 4;
+    // + the raw input staging area (element type dependent)
+    template <typename T>
+    static constexpr size_t total() {
+        return bytes + (size_t)(5 * kC * (kN + 16 / sizeof(T)) + kC * (VH + 16 / sizeof(T))) * sizeof(T);
+    }
 };
 static_assert(FwdSmem::end16 % 8 == 0, "fp32 area must stay 16-byte aligned");
 }  // namespace
@@ -177,18 +182,47 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
 
     f32x16 Smaster = zero16();  // waves 1,2: D-layout tile [k-tile rows][v cols] of the fp32 state
 
-    Raw4<T> rw[2], rq[2], rk[2], ra[2], rb[2], rv;
+    // Global loads use a row-contiguous mapping (8 lanes cover the 64 channels of one step: every wave instruction touches
+    // 8 rows), the compute mapping has the step index across lanes (32 rows per instruction, which kept the address unit
+    // busy for ~2k cycles per chunk).  The raw rows pass through an LDS staging area to change mapping.
+    constexpr int RS = kN + 16 / (int)sizeof(T), RSV = VH + 16 / (int)sizeof(T);  // padded row strides (elements)
+    T *raw = reinterpret_cast<T *>(fm + FwdSmem::fend);                             // [5][32][RS] then [32][RSV]
+    const int lt = tid >> 3, lk = (tid & 7) * 8, lv = (tid & 7) * 4;
+    Raw4<T> gw[2], gq[2], gk[2], ga[2], gb[2], gv;
     auto issue = [&](int c) {
-        const long off = head_base + (long)(c * kC + pt) * tstride;
+        const long off = head_base + (long)(c * kC + lt) * tstride;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            rw[i] = ld4<T>(w_ + off + pk + 4 * i, true);
-            rq[i] = ld4<T>(q_ + off + pk + 4 * i, true);
-            rk[i] = ld4<T>(k_ + off + pk + 4 * i, true);
-            ra[i] = ld4<T>(a_ + off + pk + 4 * i, true);
-            rb[i] = ld4<T>(b_ + off + pk + 4 * i, true);
+            gw[i] = ld4<T>(w_ + off + lk + 4 * i, true);
+            gq[i] = ld4<T>(q_ + off + lk + 4 * i, true);
+            gk[i] = ld4<T>(k_ + off + lk + 4 * i, true);
+            ga[i] = ld4<T>(a_ + off + lk + 4 * i, true);
+            gb[i] = ld4<T>(b_ + off + lk + 4 * i, true);
         }
-        rv = ld4<T>(v_ + off + vh * VH + pv, true);
+        gv = ld4<T>(v_ + off + vh * VH + lv, true);
+    };
+    using RawVec = decltype(Raw4<T>::r);
+    Raw4<T> rw[2], rq[2], rk[2], ra[2], rb[2], rv;
+    auto restage = [&]() {  // load mapping -> LDS -> compute mapping (one barrier)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            *reinterpret_cast<RawVec *>(raw + (0 * kC + lt) * RS + lk + 4 * i) = gw[i].r;
+            *reinterpret_cast<RawVec *>(raw + (1 * kC + lt) * RS + lk + 4 * i) = gq[i].r;
+            *reinterpret_cast<RawVec *>(raw + (2 * kC + lt) * RS + lk + 4 * i) = gk[i].r;
+            *reinterpret_cast<RawVec *>(raw + (3 * kC + lt) * RS + lk + 4 * i) = ga[i].r;
+            *reinterpret_cast<RawVec *>(raw + (4 * kC + lt) * RS + lk + 4 * i) = gb[i].r;
+        }
+        *reinterpret_cast<RawVec *>(raw + 5 * kC * RS + lt * RSV + lv) = gv.r;
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            rw[i].r = *reinterpret_cast<const RawVec *>(raw + (0 * kC + pt) * RS + pk + 4 * i);
+            rq[i].r = *reinterpret_cast<const RawVec *>(raw + (1 * kC + pt) * RS + pk + 4 * i);
+            rk[i].r = *reinterpret_cast<const RawVec *>(raw + (2 * kC + pt) * RS + pk + 4 * i);
+            ra[i].r = *reinterpret_cast<const RawVec *>(raw + (3 * kC + pt) * RS + pk + 4 * i);
+            rb[i].r = *reinterpret_cast<const RawVec *>(raw + (4 * kC + pt) * RS + pk + 4 * i);
+        }
+        rv.r = *reinterpret_cast<const RawVec *>(raw + 5 * kC * RS + pt * RSV + pv);
     };
     issue(0);
     lds_barrier();
@@ -198,6 +232,8 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
 #endif
     for (int c = 0; c < nc; c++) {
         TSTAMP(0);
+        restage();
+        if (c + 1 < nc) issue(c + 1);  // next chunk's raw inputs fly during the whole chunk
         // ---- phase 1: log-decay and its cumulative sum over the chunk ---------------------------------------
         float lw[8], qv[8], kv[8], av[8], bv[8], vv[4];
         {
@@ -218,7 +254,6 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
 #pragma unroll
         for (int j = 0; j < 8; j++) Gc[j] = scan32(lw[j]);
         TSTAMP(1);
-        if (c + 1 < nc) issue(c + 1);  // next chunk's raw inputs fly during phases 2-6
         // ---- phase 2: scaled operands into bf16 hi/lo planes ------------------------------------------------
         {
             float G[8];
@@ -431,12 +466,12 @@ static int launch_fwd_t(int B, int T_, int H, const void *w, const void *q, cons
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_fwd_kernel<T, SAVE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FwdSmem::bytes);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FwdSmem::total<T>());
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((wkv7c_fwd_kernel<T, SAVE>), dim3(B * H * 2), dim3(256), FwdSmem::bytes, st, T_, H, (const T *)w,
+    hipLaunchKernelGGL((wkv7c_fwd_kernel<T, SAVE>), dim3(B * H * 2), dim3(256), FwdSmem::total<T>(), st, T_, H, (const T *)w,
                        (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, tinv, (T *)y, sa, hs);
     return (int)hipGetLastError();
 }
