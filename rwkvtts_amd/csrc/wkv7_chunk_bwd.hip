@@ -422,6 +422,8 @@ struct OutSmem {  // offsets in uint16 units
 };
 static_assert(OutSmem::AKTl + OutSmem::A1 <= OutSmem::gC, "phase A-D planes must fit in the staging area");
 static_assert(OutSmem::bytes <= 160 * 1024, "LDS budget");
+static_assert(OutSmem::S + 7 * kC * LDK + kC * OutSmem::kStLD * 2 <= OutSmem::end16, "raw-row restaging must fit in the phase scratch");
+static_assert(OutSmem::S + 6 * kC * LDK <= OutSmem::end16, "output restaging must fit in the phase scratch");
 static_assert(OutSmem::S % 8 == 0 && OutSmem::XTh % 8 == 0 && OutSmem::P0 % 8 == 0 && OutSmem::STG % 8 == 0 && OutSmem::sV % 8 == 0, "alignment");
 
 // X exact (single plane), Y exact
@@ -467,7 +469,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     float *sh_gC = reinterpret_cast<float *>(sm + L::gC), *sh_dterm = reinterpret_cast<float *>(sm + L::dterm);
     const int nc = T_ / kC;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int pt = tid & 31, pk = (tid >> 5) * 8;
+    const int pt = tid & 31, pk = (tid >> 5) * 8;   // compute mapping: step pt, channels pk .. pk+7
+    const int lt = tid >> 3, lk = (tid & 7) * 8;    // global-memory mapping: step lt, channels lk .. lk+7
     const long tstride = (long)H * kN;
     const long nck = T_ / kChunk;  // scalar-forward checkpoints (every 16 steps), s[b,h,n][k][v]
 
@@ -483,7 +486,9 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         const int bh = chunk / nc, c = chunk - bh * nc;
         const int bb = bh / H, hh = bh - bb * H;
         In r;
-        r.off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + pt) * tstride + pk;
+        // row-contiguous mapping for global memory (8 lanes = the 64 channels of one step); the compute mapping (step index
+        // across lanes) is reached through the LDS restaging below, and left the same way for the six outputs
+        r.off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + lt) * tstride + lk;
         r.w = ld8(w_ + r.off); r.q = ld8(q_ + r.off); r.k = ld8(k_ + r.off); r.a = ld8(a_ + r.off); r.b = ld8(b_ + r.off);
         r.v = ld8(v_ + r.off); r.dy = ld8(dy_ + r.off);
         r.u0 = *reinterpret_cast<const float4 *>(sa_ + r.off);
@@ -518,8 +523,33 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     }
     BSTAMP_INIT;
     const long off = cur.off;
-    const Raw8 rw = cur.w, rq = cur.q, rk = cur.k, ra = cur.a, rb = cur.b, rv = cur.v, rdy = cur.dy;
-    const float4 ru0 = cur.u0, ru1 = cur.u1;
+    Raw8 rw, rq, rk, ra, rb, rv, rdy;
+    float4 ru0, ru1;
+    {
+        // raw rows: global mapping -> LDS (phase scratch, free at this point) -> compute mapping
+        uint16_t *rs = sm + L::S;
+        float *rsu = reinterpret_cast<float *>(rs + 7 * kC * LDK);
+        const int wo = lt * LDK + lk, ro = pt * LDK + pk;
+        *reinterpret_cast<uint4 *>(rs + 0 * kC * LDK + wo) = cur.w.r;
+        *reinterpret_cast<uint4 *>(rs + 1 * kC * LDK + wo) = cur.q.r;
+        *reinterpret_cast<uint4 *>(rs + 2 * kC * LDK + wo) = cur.k.r;
+        *reinterpret_cast<uint4 *>(rs + 3 * kC * LDK + wo) = cur.a.r;
+        *reinterpret_cast<uint4 *>(rs + 4 * kC * LDK + wo) = cur.b.r;
+        *reinterpret_cast<uint4 *>(rs + 5 * kC * LDK + wo) = cur.v.r;
+        *reinterpret_cast<uint4 *>(rs + 6 * kC * LDK + wo) = cur.dy.r;
+        *reinterpret_cast<float4 *>(rsu + lt * L::kStLD + lk) = cur.u0;
+        *reinterpret_cast<float4 *>(rsu + lt * L::kStLD + lk + 4) = cur.u1;
+        lds_barrier();
+        rw.r = *reinterpret_cast<const uint4 *>(rs + 0 * kC * LDK + ro);
+        rq.r = *reinterpret_cast<const uint4 *>(rs + 1 * kC * LDK + ro);
+        rk.r = *reinterpret_cast<const uint4 *>(rs + 2 * kC * LDK + ro);
+        ra.r = *reinterpret_cast<const uint4 *>(rs + 3 * kC * LDK + ro);
+        rb.r = *reinterpret_cast<const uint4 *>(rs + 4 * kC * LDK + ro);
+        rv.r = *reinterpret_cast<const uint4 *>(rs + 5 * kC * LDK + ro);
+        rdy.r = *reinterpret_cast<const uint4 *>(rs + 6 * kC * LDK + ro);
+        ru0 = *reinterpret_cast<const float4 *>(rsu + pt * L::kStLD + pk);
+        ru1 = *reinterpret_cast<const float4 *>(rsu + pt * L::kStLD + pk + 4);
+    }
     float4 rekv[4], rh0[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -654,12 +684,9 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     BSTAMP(6);
     BSTAMP(7);
     // ---- phase F1: dV out; dK (waves 0,1) and dB (waves 2,3), unscaled, to staging -------------------------------------------------
+    float dVv[8];  // written out with the other gradients in the epilogue
     {
-        {
-            float x[8];
-            ld_stage8(reinterpret_cast<const float *>(sm + L::sV), pt, pk, x);
-            st_bf16x8(dv_ + off, x);
-        }
+        ld_stage8(reinterpret_cast<const float *>(sm + L::sV), pt, pk, dVv);
         const int kt = wave & 1;
         const uint16_t *P1h = sm + L::P0 + (wave < 2 ? 0 : 2) * 2 * L::A1, *P1l = P1h + L::A1, *P2h = P1h + 2 * L::A1, *P2l = P2h + L::A1;
         f32x16 acc = zero16();  // D[m = t][n = k]
@@ -727,19 +754,27 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         // e_t = (q dQ - k dK - b dB)_t + (a dA)_{t+1}
         e[j] = qv[j] * dQ[j] - kv[j] * dK[j] - bv[j] * dB[j] + next32(av[j] * dA[j], lane);
     }
-    st_bf16x8(dq_ + off, dQ);
-    st_bf16x8(dk_ + off, dK);
-    st_bf16x8(db_ + off, dB);
-    st_bf16x8(da_ + off, dA);
-    {
-        // dlw_t = sum_{s >= t} e_s + rowsum(E * H_C) = total - (inclusive prefix - e_t) + dterm ;  dw = dlw * lw
-        float dG[8];
+    float dG[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float pre = scan32(e[j]);
-            dG[j] = (last32(pre, lane) - pre + e[j] + sh_dterm[pk + j]) * lw[j];
-        }
-        st_bf16x8(dw_ + off, dG);
+    for (int j = 0; j < 8; j++) {
+        // dlw_t = sum_{s >= t} e_s + rowsum(E * H_C) = total - (inclusive prefix - e_t) + dterm ;  dw = dlw * lw
+        const float pre = scan32(e[j]);
+        dG[j] = (last32(pre, lane) - pre + e[j] + sh_dterm[pk + j]) * lw[j];
+    }
+    {
+        // the six gradients: compute mapping -> bf16 rows in LDS (phase scratch is free now) -> row-contiguous stores
+        uint16_t *os = sm + L::S;
+        auto put = [&](int i, const float (&x)[8]) {
+            uint4 o;
+            o.x = cvt_pk(x[0], x[1]); o.y = cvt_pk(x[2], x[3]); o.z = cvt_pk(x[4], x[5]); o.w = cvt_pk(x[6], x[7]);
+            *reinterpret_cast<uint4 *>(os + i * kC * LDK + pt * LDK + pk) = o;
+        };
+        put(0, dG); put(1, dQ); put(2, dK); put(3, dVv); put(4, dA); put(5, dB);
+        lds_barrier();
+        bf16_t *const outs[6] = {dw_, dq_, dk_, dv_, da_, db_};
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            *reinterpret_cast<uint4 *>(outs[i] + off) = *reinterpret_cast<const uint4 *>(os + i * kC * LDK + lt * LDK + lk);
     }
     BSTAMP(11);
     lds_barrier();  // the next chunk's prologue overwrites what the epilogue reads
