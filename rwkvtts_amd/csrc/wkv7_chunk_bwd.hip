@@ -133,15 +133,12 @@ struct PreSmem {  // offsets in uint16 units
     static constexpr int G1Th = 0, G1Tl = G1Th + kN * LDC, MPh = G1Tl + kN * LDC, MPl = MPh + kN * LDK;   // M^T[k][k'] planes
     static constexpr int QTTh = end1, QTTl = QTTh + kN * LDC, BCTh = QTTl + kN * LDC, BCTl = BCTh + kN * LDC;
     static constexpr int DYT = BCTl + kN * LDC, QBTh = DYT + kN * LDC, QBTl = QBTh + kC * LDC;
-    // W^T planes; the fp32 cumsum scratch of the prologue (sh_G 2048 + sh_seg 256 floats = 4608 u16) lies over them
-    static constexpr int WTh = QBTl + kC * LDC, WTl = WTh + kN * LDC;
-    static constexpr int scratch = WTh;
+    static constexpr int WTh = QBTl + kC * LDC, WTl = WTh + kN * LDC;   // W^T planes
     static constexpr int gC = WTl + kN * LDC;  // 64 floats
     static constexpr int end16 = gC + 2 * kN;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
 static_assert(PreSmem::MPl + kN * LDK <= PreSmem::end1, "G1T + M^T planes must fit over the phase-1 inputs");
-static_assert(2 * kN * LDC >= (kC * kN + 4 * kN) * 2, "cumsum scratch must fit under the W^T planes");
 static_assert(PreSmem::ATTh % 8 == 0 && PreSmem::QTTh % 8 == 0 && PreSmem::WTh % 8 == 0 && PreSmem::gC % 8 == 0 &&
                   PreSmem::MPh % 8 == 0, "16-byte alignment");
 static_assert(PreSmem::bytes <= 80 * 1024, "two workgroups per CU");
@@ -440,11 +437,6 @@ __device__ __forceinline__ void ld_stage8(const float *stg, int pt, int pk, floa
     const float4 a = *reinterpret_cast<const float4 *>(stg + pt * OutSmem::kStLD + pk),
                  b = *reinterpret_cast<const float4 *>(stg + pt * OutSmem::kStLD + pk + 4);
     x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
-}
-__device__ __forceinline__ void st_bf16x8(bf16_t *p, const float (&x)[8]) {
-    uint4 o;
-    o.x = cvt_pk(x[0], x[1]); o.y = cvt_pk(x[2], x[3]); o.z = cvt_pk(x[4], x[5]); o.w = cvt_pk(x[6], x[7]);
-    *reinterpret_cast<uint4 *>(p) = o;
 }
 // 4 consecutive fp32 of row `row` -> hi/lo planes [..][LDK]
 __device__ __forceinline__ void put4(uint16_t *Ph, uint16_t *Pl, int row, int c4, float4 x, float scale_x, float scale_y,

@@ -124,7 +124,7 @@ struct FwdSmem {  // all offsets in uint16 units; every plane 16-byte aligned
     static constexpr int Rh = TMl + kC * LDC, Rl = Rh + VH * LDC, Uh = Rl + VH * LDC, Ul = Uh + VH * LDC;
     static constexpr int end16 = Ul + VH * LDC;
     // fp32 region (offsets in floats from the start of the fp32 area)
-    static constexpr int fG = 0, fSeg = fG + kC * kN, fGC = fSeg + 4 * kN, fend = fGC + kN;
+    static constexpr int fStage = 0, fGC = fStage + 2 * kC * 36, fend = fGC + kN;   // U, Y staging tiles [32][36]; g_C
     static constexpr size_t bytes = (size_t)end16 * 2 + (size_t)fend * 4;
     // + the raw input staging area (element type dependent)
     template <typename T>
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     float *fm = reinterpret_cast<float *>(sm + FwdSmem::end16);
     constexpr int kStageLD = 36;  // fp32 staging tiles [32][36]: conflict-free float4 reads with the step index across lanes
-    float *sh_U = fm + FwdSmem::fG, *sh_Y = sh_U + kC * kStageLD, *sh_gC = fm + FwdSmem::fGC;
-    static_assert(2 * kC * kStageLD <= kC * kN + 4 * kN, "staging tiles must fit in the former cumsum scratch");
+    float *sh_U = fm + FwdSmem::fStage, *sh_Y = sh_U + kC * kStageLD, *sh_gC = fm + FwdSmem::fGC;
+    static_assert(2 * kC * kStageLD == FwdSmem::fGC - FwdSmem::fStage, "staging tiles");
     using L = FwdSmem;
     constexpr bool VEXACT = sizeof(T) == 2;  // bf16 tensors: v needs no hi/lo split
     // acc += X V^T-plane product with X split; V exact (bf16 I/O) or split (fp32 I/O)
