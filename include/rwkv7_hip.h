@@ -249,6 +249,11 @@ int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void 
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,
                                  const float *tinv, const float *e_kv, int ck_mode, void *dw, void *dq, void *dk, void *dv,
                                  void *da, void *db, rwkv7_stream_t stream);
+/* ---- decode-step linear layers: y[M,N] = x[M,K] @ w[N,K]^T (+ bias[N]), bf16, M <= 32 rows (one token per sequence and
+ *      step), K % 64 == 0.  Replaces the nn.Linear calls of the per-token path (rwkv_s2s_single_ffn.py:482-506,545-549)
+ *      for the decode batch; weight-streaming on MFMA, see csrc/gemv32.hip.  bias may be NULL. ---- */
+int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const void *bias, void *y, rwkv7_stream_t stream);
+
 /* probe of ds_read_b64_tr_b16 (LDS transpose read): in = 4096 u16 copied to LDS, addr[64] = element index each lane
  * points at, out[64][4] = what each lane receives */
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream);

@@ -31,6 +31,7 @@ int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const
                   const float *, void *, float *, float *, hipStream_t);
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
+int gemv32_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
 int chunk_state_bf16(int, int, const void *, const float *, float *, hipStream_t);
@@ -322,6 +323,11 @@ int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void 
     if (T % 32 != 0) return RWKV7_ECHUNK;
     return rwkv7::chunk_bwd_out_bf16(B, T, H, ck_mode, w, q, k, v, a, b, dy, s, sa, tinv, e_kv, dw, dq, dk, dv, da, db,
                                      (hipStream_t)stream);
+}
+int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const void *bias, void *y, rwkv7_stream_t stream) {
+    if (any_null({x, w, y})) return RWKV7_EINVAL;
+    if (M <= 0 || M > 32 || N <= 0 || K <= 0 || K % 64 != 0) return RWKV7_ESHAPE;
+    return rwkv7::gemv32_bf16(M, N, K, x, w, bias, y, (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {
     if (!in || !addr || !out) return RWKV7_EINVAL;

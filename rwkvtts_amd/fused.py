@@ -382,9 +382,24 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+GEMV_MAX_ROWS = 32   # decode batches: rwkv7_gemv32_bf16 instead of the BLAS library
+
+
 def linear(x, weight, bias=None):
-    """F.linear whose backward computes the weight gradient with wgrad_splitk (bf16 HIP tensors with many rows);
-    anything else goes to F.linear unchanged."""
+    """F.linear with two specialisations for bf16 HIP tensors: with many rows and autograd on, the backward computes the
+    weight gradient with wgrad_splitk; with at most 32 rows and autograd off (decode steps), the product runs on the
+    weight-streaming kernel rwkv7_gemv32_bf16.  Anything else goes to F.linear unchanged."""
+    rows = x.numel() // x.shape[-1]
+    if (GEMV_MAX_ROWS and x.is_cuda and x.dtype == torch.bfloat16 and rows <= GEMV_MAX_ROWS and x.shape[-1] % 64 == 0
+            and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) and weight.dtype == torch.bfloat16):
+        K, N = x.shape[-1], weight.shape[0]
+        x2, w2 = _c(x).view(rows, K), _c(weight)
+        b2 = None if bias is None else _c(bias.to(torch.bfloat16))
+        y = torch.empty(rows, N, dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = _lib.lib().rwkv7_gemv32_bf16(rows, N, K, _p(x2), _p(w2), _p(b2), _p(y), _stream(x))
+        _lib.check(rc, "gemv32")
+        return y.view(*x.shape[:-1], N)
     if (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and weight.requires_grad
             and x.numel() // x.shape[-1] >= WGRAD_MIN_ROWS):
         return _Linear.apply(x, weight, bias)

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .backbone import Cache, ModelOutput, RWKV7Config, RWKV7Model
+from .backbone import Cache, Linear, ModelOutput, RWKV7Config, RWKV7Model
 from .hf_api import HFModelMixin
 from .losses import fused_linear_cross_entropy
 
@@ -55,7 +55,7 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
         self.config = config
         self.model = RWKV7Model(config)
         self.vocab_size = config.vocab_size
-        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)  # 8192 + eos (spark_llm.py:26)
+        self.lm_head = Linear(config.hidden_size, config.vocab_size, bias=False)  # 8192 + eos (spark_llm.py:26)
         self.criterion = None
         self.text_embedder = nn.Embedding(config.text_vocab_size, config.hidden_size)
         self.global_embedder = nn.Embedding(config.audio_global_vocab_size, config.hidden_size)

@@ -293,3 +293,23 @@ def test_add_layer_norm(dtype, D, with_branch, with_bias):
         _cmp(nd.weight.grad, norm.weight.grad, 1e-2, "dgamma")
         if with_bias:
             _cmp(nd.bias.grad, norm.bias.grad, 1e-2, "dbeta")
+
+
+@pytest.mark.parametrize("M", [1, 7, 32])
+@pytest.mark.parametrize("K,N,with_bias", [(1024, 1024, False), (64, 1024, True), (1024, 64, False), (4096, 1024, False),
+                                          (1024, 8193, False), (256, 100, True)])
+def test_gemv32_decode_linear_vs_fp32_reference(M, K, N, with_bias):
+    """rwkv7_gemv32_bf16 (decode-step linear layers, <= 32 rows): fp32 accumulation on MFMA, one bf16 rounding."""
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    x = (torch.randn(M, K, generator=g)).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = (torch.randn(N, generator=g) * 0.1).bfloat16() if with_bias else None
+    ref = x.float() @ w.float().t() + (0 if b is None else b.float())
+    with torch.no_grad():
+        y = fused.linear(x.to(DEV).view(1, M, K), w.to(DEV), None if b is None else b.to(DEV))
+    assert y.shape == (1, M, N) and y.dtype == torch.bfloat16
+    _cmp_bf16(y.view(M, N), ref, "y")
+    # with autograd on (training) the same call must not take the decode kernel
+    xg = x.to(DEV).requires_grad_(True)
+    yg = fused.linear(xg, w.to(DEV), None if b is None else b.to(DEV))
+    assert yg.requires_grad
