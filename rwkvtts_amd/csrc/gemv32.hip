@@ -8,11 +8,13 @@
 //
 // Here one workgroup owns 32 output columns (32 rows of W); its 4 waves split K, each wave pulls its W and X fragments
 // straight from global memory into MFMA operand registers (all loads of a wave are issued before the first MFMA), the
-// four partial 32x32 tiles meet in LDS, and wave 0 adds the bias and stores bf16.  Measured (rocprofv3, 0.4B, B = 32): 9.9 us
-// average per call -- on par with the library, not the ~3 us the byte count suggests: every lane of a fragment load reads a
-// different 2 KB-strided row (32 lines per instruction) and each call still pays ~5 us of launch/drain even inside a
-// hipGraph.  The decode step went 4.4 -> 4.0 ms; the real lever is fewer, fused kernels per layer (655 launches per step).  X (64 KB at K = 1024) is re-read by
+// four partial 32x32 tiles meet in LDS, and wave 0 adds the bias and stores bf16.  X (64 KB at K = 1024) is re-read by
 // every workgroup from L2.  D[m][n]: m = output column inside the tile (A operand = W rows), n = batch row (B operand = X).
+//
+// Measured (rocprofv3, 0.4B, B = 32): 9.9 us average per call -- on par with the library, not the ~3 us the byte count
+// suggests: every lane of a fragment load reads a different 2 KB-strided row (32 lines per instruction) and each call
+// still pays ~5 us of launch/drain even inside a hipGraph.  The decode step went 4.4 -> 4.0 ms; the real lever is fewer,
+// fused kernels per layer (655 launches per step).
 #include "chunk_common.h"
 
 namespace rwkv7 {
