@@ -254,6 +254,11 @@ int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void 
  *      for the decode batch; weight-streaming on MFMA, see csrc/gemv32.hip.  bias may be NULL. ---- */
 int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const void *bias, void *y, rwkv7_stream_t stream);
 
+/* the low-rank pair of the decode step in one launch: y[M,N] = act(x[M,K] @ w1[R,K]^T) @ w2[N,R]^T (+ bias); M <= 32,
+ * K % 64 == 0, R in {32,64,128}, act 0 none / 1 tanh / 2 sigmoid (rwkv_s2s_single_ffn.py:497-500: w, a, v, g branches) */
+int rwkv7_lora32_bf16(int M, int N, int K, int R, int act, const void *x, const void *w1, const void *w2, const void *bias,
+                      void *y, rwkv7_stream_t stream);
+
 /* probe of ds_read_b64_tr_b16 (LDS transpose read): in = 4096 u16 copied to LDS, addr[64] = element index each lane
  * points at, out[64][4] = what each lane receives */
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream);

@@ -117,6 +117,8 @@ class LoRA(nn.Module):
         self.activation, self.rank = activation, rank
 
     def forward(self, x):
+        if fused.lora_decode_supported(x, self.rank) and self.lora[0].weight.dtype == torch.bfloat16:
+            return fused.lora_decode(x, self.lora[0].weight, self.lora[2].weight, self.lora[2].bias, self.activation)
         if FUSED_LORA and fused.lora_supported(x, self.rank):
             return fused.lora(x, self.lora[0].weight, self.lora[2].weight, self.lora[2].bias, self.activation)
         return self.lora(x)  # fp32 models and decode-sized inputs: BLAS
@@ -197,6 +199,17 @@ class RWKV7Attention(nn.Module):
                 state_dict[prefix + f"x_{n}"] = x_x[i].reshape(1, 1, -1)
         super()._load_from_state_dict(state_dict, prefix, *args, **kw)
 
+    def _stacked_mix(self, dtype):
+        """[6,D] stack of x_r..x_g for inference (no autograd through it), rebuilt when a parameter changes."""
+        if torch.is_grad_enabled():
+            return None
+        ps = (self.x_r, self.x_w, self.x_k, self.x_v, self.x_a, self.x_g)
+        key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (dtype,)
+        if getattr(self, "_mix_key", None) != key:
+            self._mix_cache = torch.cat([p.detach().reshape(1, -1) for p in ps], 0).to(dtype)
+            self._mix_key = key
+        return self._mix_cache
+
     def forward(self, x, mask, v_first, state: Optional[LayerState] = None):
         """x [B,T,D] (LayerNorm'ed), mask [B,T,1] or None.  Returns (out, v_first).
         With `state`, token shift and the WKV state are carried (and updated in place)."""
@@ -204,7 +217,7 @@ class RWKV7Attention(nn.Module):
         H, N = self.num_heads, self.head_dim
         x_prev = None if state is None else state.att_x_prev
         xr, xw, xk, xv, xa, xg = fused.token_shift_mix6(x, x_prev, self.x_r, self.x_w, self.x_k, self.x_v,
-                                                        self.x_a, self.x_g, mask)
+                                                        self.x_a, self.x_g, mask, self._stacked_mix(x.dtype))
         r = self.r_proj(xr)
         k = self.k_proj(xk)
         v = self.v_proj(xv)

@@ -32,6 +32,7 @@ int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int gemv32_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
+int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
 int chunk_state_bf16(int, int, const void *, const float *, float *, hipStream_t);
@@ -328,6 +329,13 @@ int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const v
     if (any_null({x, w, y})) return RWKV7_EINVAL;
     if (M <= 0 || M > 32 || N <= 0 || K <= 0 || K % 64 != 0) return RWKV7_ESHAPE;
     return rwkv7::gemv32_bf16(M, N, K, x, w, bias, y, (hipStream_t)stream);
+}
+int rwkv7_lora32_bf16(int M, int N, int K, int R, int act, const void *x, const void *w1, const void *w2, const void *bias,
+                      void *y, rwkv7_stream_t stream) {
+    if (any_null({x, w1, w2, y})) return RWKV7_EINVAL;
+    if (M <= 0 || M > 32 || N <= 0 || K <= 0 || K % 64 != 0 || (R != 32 && R != 64 && R != 128) || act < 0 || act > 2)
+        return RWKV7_ESHAPE;
+    return rwkv7::lora32_bf16(M, N, K, R, act, x, w1, w2, bias, y, (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {
     if (!in || !addr || !out) return RWKV7_EINVAL;

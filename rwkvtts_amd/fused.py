@@ -83,10 +83,11 @@ class _Mix(torch.autograd.Function):
         return dx, None, None, part.sum(0).to(params.dtype)
 
 
-def token_shift_mix6(x, x_prev, x_r, x_w, x_k, x_v, x_a, x_g, mask=None):
-    """xm = x*mask ; xx = shift(xm) - xm ; returns xm + xx*x_? for ? in r,w,k,v,a,g  (6 tensors [B,T,D])."""
+def token_shift_mix6(x, x_prev, x_r, x_w, x_k, x_v, x_a, x_g, mask=None, stacked=None):
+    """xm = x*mask ; xx = shift(xm) - xm ; returns xm + xx*x_? for ? in r,w,k,v,a,g  (6 tensors [B,T,D]).
+    stacked: the six coefficient vectors already stacked [6,D] (inference caches it; one launch less per call)."""
     D = x.shape[-1]
-    params = torch.cat([p.reshape(1, D) for p in (x_r, x_w, x_k, x_v, x_a, x_g)], 0).to(x.dtype)
+    params = stacked if stacked is not None else torch.cat([p.reshape(1, D) for p in (x_r, x_w, x_k, x_v, x_a, x_g)], 0).to(x.dtype)
     return _Mix.apply(x, x_prev, _mask_rows(mask, x), params)
 
 
@@ -336,6 +337,26 @@ class _LoRA(torch.autograd.Function):
 def lora_supported(x, rank):
     return (x.is_cuda and x.dtype == torch.bfloat16 and rank in (32, 64, 128) and x.shape[-1] % 64 == 0
             and x.numel() // x.shape[-1] >= LORA_MIN_ROWS)
+
+
+def lora_decode_supported(x, rank):
+    rows = x.numel() // x.shape[-1]
+    return (GEMV_MAX_ROWS and x.is_cuda and x.dtype == torch.bfloat16 and rows <= GEMV_MAX_ROWS and rank in (32, 64, 128)
+            and x.shape[-1] % 64 == 0 and not torch.is_grad_enabled())
+
+
+def lora_decode(x, w1, w2, bias, activation):
+    """act(x @ w1.T) @ w2.T + bias for at most 32 rows, one launch (rwkv7_lora32_bf16)."""
+    K, N, R = x.shape[-1], w2.shape[0], w1.shape[0]
+    rows = x.numel() // K
+    x2 = _c(x).view(rows, K)
+    b2 = None if bias is None else _c(bias)
+    y = torch.empty(rows, N, dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device_of(x):
+        rc = _lib.lib().rwkv7_lora32_bf16(rows, N, K, R, _ACT_ID[activation], _p(x2), _p(_c(w1)), _p(_c(w2)), _p(b2), _p(y),
+                                          _stream(x))
+    _lib.check(rc, "lora32")
+    return y.view(*x.shape[:-1], N)
 
 
 def lora(x, w1, w2, bias, activation):

@@ -313,3 +313,23 @@ def test_gemv32_decode_linear_vs_fp32_reference(M, K, N, with_bias):
     xg = x.to(DEV).requires_grad_(True)
     yg = fused.linear(xg, w.to(DEV), None if b is None else b.to(DEV))
     assert yg.requires_grad
+
+
+@pytest.mark.parametrize("M", [1, 32])
+@pytest.mark.parametrize("R,act,with_bias", [(32, None, True), (64, "tanh", True), (64, None, True), (128, "sigmoid", False)])
+def test_lora32_decode_pair_vs_reference(M, R, act, with_bias):
+    """rwkv7_lora32_bf16: act(x W1^T) W2^T + b for the decode batch in one launch; the intermediate is rounded to bf16 as
+    the tensor of the three-launch path would be."""
+    K, N = 1024, 1024
+    g = torch.Generator().manual_seed(M + R)
+    x = (torch.randn(M, K, generator=g)).bfloat16()
+    w1 = (torch.randn(R, K, generator=g) * K ** -0.5).bfloat16()
+    w2 = (torch.randn(N, R, generator=g) * R ** -0.5).bfloat16()
+    b = (torch.randn(N, generator=g) * 0.1).bfloat16() if with_bias else None
+    f = {None: lambda t: t, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
+    mid = f(x.float() @ w1.float().t()).bfloat16().float()
+    ref = mid @ w2.float().t() + (0 if b is None else b.float())
+    with torch.no_grad():
+        assert fused.lora_decode_supported(x.to(DEV), R)
+        y = fused.lora_decode(x.to(DEV), w1.to(DEV), w2.to(DEV), None if b is None else b.to(DEV), act)
+    _cmp_bf16(y, ref, "y", ulps=2.0)   # + a possible 1-ulp flip of the intermediate
