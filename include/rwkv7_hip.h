@@ -249,6 +249,12 @@ int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void 
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,
                                  const float *tinv, const float *e_kv, int ck_mode, void *dw, void *dq, void *dk, void *dv,
                                  void *da, void *db, rwkv7_stream_t stream);
+/* ---- optimizer step (train_spark_rwkv7speech.py:178-197; torch.optim.AdamW update rule, decoupled weight decay) on a
+ *      flat parameter buffer: fp32 master weights p32 and moments m, v updated in place from bf16 gradients g16; the
+ *      bf16 working copy p16 is rewritten in the same pass.  n % 4 == 0; step = 1 for the first update. ---- */
+int rwkv7_adamw_bf16(long n, float *p32, const void *g16, float *m, float *v, void *p16, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, rwkv7_stream_t stream);
+
 /* ---- decode-step linear layers: y[M,N] = x[M,K] @ w[N,K]^T (+ bias[N]), bf16, M <= 32 rows (one token per sequence and
  *      step), K % 64 == 0.  Replaces the nn.Linear calls of the per-token path (rwkv_s2s_single_ffn.py:482-506,545-549)
  *      for the decode batch; weight-streaming on MFMA, see csrc/gemv32.hip.  bias may be NULL. ---- */

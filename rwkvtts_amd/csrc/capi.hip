@@ -2,6 +2,7 @@
 // Argument checking mirrors the reference's asserts (wkv7_cuda.cu:136, rwkv7_state_fwd_fp16.cu:61,
 // rwkv_s2s_single_ffn.py:19-21) but reports through the return code instead of aborting the process.
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #include "../../include/rwkv7_hip.h"
 
@@ -32,6 +33,7 @@ int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int gemv32_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
+int adamw_step(long, float *, const void *, float *, float *, void *, float, float, float, float, float, float, float, hipStream_t);
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
@@ -336,6 +338,14 @@ int rwkv7_lora32_bf16(int M, int N, int K, int R, int act, const void *x, const 
     if (M <= 0 || M > 32 || N <= 0 || K <= 0 || K % 64 != 0 || (R != 32 && R != 64 && R != 128) || act < 0 || act > 2)
         return RWKV7_ESHAPE;
     return rwkv7::lora32_bf16(M, N, K, R, act, x, w1, w2, bias, y, (hipStream_t)stream);
+}
+int rwkv7_adamw_bf16(long n, float *p32, const void *g16, float *m, float *v, void *p16, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, rwkv7_stream_t stream) {
+    if (n <= 0 || step <= 0 || any_null({(const void *)p32, g16, (const void *)m, (const void *)v, p16})) return RWKV7_EINVAL;
+    if (n % 4 != 0) return RWKV7_ESHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    return rwkv7::adamw_step(n, p32, g16, m, v, p16, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+                             (float)(1.0 / sqrt(bc2)), (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {
     if (!in || !addr || !out) return RWKV7_EINVAL;

@@ -662,6 +662,45 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_bwd_kernel(long rows, in
     V8<float>::st(dpart + ((long)blockIdx.x * 2 + 1) * D + c, db);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// AdamW on fp32 master weights with bf16 gradients and a bf16 copy of the updated weights in one pass
+// (train_scripts/train_spark_rwkv7speech.py:178-197 builds torch.optim.AdamW / DeepSpeed FusedAdam; DeepSpeed's bf16
+// optimizer keeps fp32 masters the same way).  Update rule = torch.optim.AdamW (decoupled weight decay):
+//   p *= 1 - lr wd ;  m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2 ;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+// 4 floats per thread and iteration: 2 + 3*4 bytes read, 3*4 + 2 written per parameter (28 B) -- nothing else touches HBM.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(long n4, float *__restrict__ p32, const bf16_t *__restrict__ g16,
+                                                    float *__restrict__ m, float *__restrict__ v, bf16_t *__restrict__ p16,
+                                                    float lr, float beta1, float beta2, float eps, float wd, float inv_bc1,
+                                                    float inv_sqrt_bc2) {
+    const float decay = 1.f - lr * wd, step = lr * inv_bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 p = reinterpret_cast<float4 *>(p32)[i], mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        const float4 g = cvt4(ld4<bf16_t>(g16 + 4 * i, true));
+        auto upd = [&](float &pp, float &m1, float &v1, float gg) {
+            pp *= decay;
+            m1 = fmaf(beta1, m1, (1.f - beta1) * gg);
+            v1 = fmaf(beta2, v1, (1.f - beta2) * gg * gg);
+            pp -= step * m1 / (sqrtf(v1) * inv_sqrt_bc2 + eps);
+        };
+        upd(p.x, mm.x, vv.x, g.x); upd(p.y, mm.y, vv.y, g.y); upd(p.z, mm.z, vv.z, g.z); upd(p.w, mm.w, vv.w, g.w);
+        reinterpret_cast<float4 *>(p32)[i] = p;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+        st4(p16 + 4 * i, p);
+    }
+}
+
+int adamw_step(long n, float *p32, const void *g16, float *m, float *v, void *p16, float lr, float beta1, float beta2, float eps,
+               float wd, float inv_bc1, float inv_sqrt_bc2, hipStream_t st) {
+    (void)hipGetLastError();
+    const long n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, n4, p32, (const bf16_t *)g16, m, v, (bf16_t *)p16, lr, beta1,
+                       beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+    return (int)hipGetLastError();
+}
+
 static inline int finish() { return (int)hipGetLastError(); }
 
 template <typename T>

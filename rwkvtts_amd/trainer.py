@@ -146,11 +146,20 @@ class DataParallelTrainer:
         self.world = self.reducer.world
         self.master = self.flat.flat_param.float() if master_fp32 and self.flat.flat_param.dtype != torch.float32 \
             else self.flat.flat_param
-        self.master_grad = torch.zeros_like(self.master) if self.master is not self.flat.flat_param else None
-        self.master.grad = self.master_grad if self.master_grad is not None else self.flat.flat_grad
-        fused = self.master.is_cuda
-        self.opt = torch.optim.AdamW([self.master], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                                     fused=fused)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        # bf16 parameters on the HIP device: one kernel reads the bf16 gradients, updates the fp32 master weights and
+        # moments and rewrites the bf16 parameters (rwkv7_adamw_bf16) -- no fp32 gradient copy, no separate cast back
+        self.hip_adamw = (self.master is not self.flat.flat_param and self.master.is_cuda
+                          and self.flat.flat_param.dtype == torch.bfloat16 and self.flat.numel % 4 == 0)
+        if self.hip_adamw:
+            self.exp_avg = torch.zeros_like(self.master)
+            self.exp_avg_sq = torch.zeros_like(self.master)
+            self.master_grad, self.opt = None, None
+        else:
+            self.master_grad = torch.zeros_like(self.master) if self.master is not self.flat.flat_param else None
+            self.master.grad = self.master_grad if self.master_grad is not None else self.flat.flat_grad
+            self.opt = torch.optim.AdamW([self.master], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                         fused=self.master.is_cuda)
         self.lr, self.lr_final, self.warmup_steps, self.total_steps = lr, lr_final, warmup_steps, total_steps
         self.nan_guard = nan_guard
         self.step_idx = 0
@@ -174,12 +183,25 @@ class DataParallelTrainer:
             loss.backward()
             self.reducer.finish()
         lr = linear_warmup_decay(self.step_idx, self.total_steps, self.warmup_steps, self.lr, self.lr_final)
-        for g in self.opt.param_groups:
-            g["lr"] = lr
-        if self.master_grad is not None:
-            self.master_grad.copy_(self.flat.flat_grad)
-        self.opt.step()
-        if self.master is not self.flat.flat_param:
-            self.flat.flat_param.copy_(self.master)
+        if self.hip_adamw:
+            import ctypes
+            from . import _lib
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            f = ctypes.c_float
+            with torch.cuda.device_of(self.master):
+                rc = _lib.lib().rwkv7_adamw_bf16(ctypes.c_long(self.flat.numel), P(self.master), P(self.flat.flat_grad),
+                                                 P(self.exp_avg), P(self.exp_avg_sq), P(self.flat.flat_param), f(lr),
+                                                 f(self.betas[0]), f(self.betas[1]), f(self.eps), f(self.weight_decay),
+                                                 self.step_idx + 1,
+                                                 ctypes.c_void_p(torch.cuda.current_stream(self.master.device).cuda_stream))
+            _lib.check(rc, "adamw")
+        else:
+            for g in self.opt.param_groups:
+                g["lr"] = lr
+            if self.master_grad is not None:
+                self.master_grad.copy_(self.flat.flat_grad)
+            self.opt.step()
+            if self.master is not self.flat.flat_param:
+                self.flat.flat_param.copy_(self.master)
         self.step_idx += 1
         return loss.detach()

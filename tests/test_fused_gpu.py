@@ -333,3 +333,36 @@ def test_lora32_decode_pair_vs_reference(M, R, act, with_bias):
         assert fused.lora_decode_supported(x.to(DEV), R)
         y = fused.lora_decode(x.to(DEV), w1.to(DEV), w2.to(DEV), None if b is None else b.to(DEV), act)
     _cmp_bf16(y, ref, "y", ulps=2.0)   # + a possible 1-ulp flip of the intermediate
+
+
+def test_hip_adamw_matches_torch_adamw():
+    """rwkv7_adamw_bf16 (fp32 masters + moments from bf16 gradients, bf16 weights rewritten) against torch.optim.AdamW fed
+    the same gradients, over several steps with a changing learning rate."""
+    import ctypes
+    from rwkvtts_amd import _lib
+    n = 4 * 1000 + 8
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    grads = [(torch.randn(n, generator=g) * 0.1).bfloat16() for _ in range(5)]
+    lrs = [1e-3, 2e-3, 1.5e-3, 1e-3, 5e-4]
+    betas, eps, wd = (0.9, 0.95), 1e-8, 0.01
+    ref = p0.clone().to(DEV).requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=lrs[0], betas=betas, eps=eps, weight_decay=wd)
+    p32 = p0.clone().to(DEV)
+    m, v = torch.zeros_like(p32), torch.zeros_like(p32)
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    f = ctypes.c_float
+    for i, (gr, lr) in enumerate(zip(grads, lrs)):
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        ref.grad = gr.float().to(DEV)
+        opt.step()
+        rc = _lib.lib().rwkv7_adamw_bf16(ctypes.c_long(n), P(p32), P(gr.to(DEV)), P(m), P(v), P(p16), f(lr), f(betas[0]),
+                                         f(betas[1]), f(eps), f(wd), i + 1, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert (p32 - ref.detach()).abs().max().item() <= 2e-6 * max(1.0, ref.detach().abs().max().item()), i
+        assert torch.equal(p16, p32.bfloat16())
+    assert _lib.lib().rwkv7_adamw_bf16(ctypes.c_long(n + 1), P(p32), P(p16), P(m), P(v), P(p16), f(1e-3), f(0.9), f(0.95),
+                                       f(1e-8), f(0.0), 1, None) == -4
