@@ -249,6 +249,12 @@ int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void 
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,
                                  const float *tinv, const float *e_kv, int ck_mode, void *dw, void *dq, void *dk, void *dv,
                                  void *da, void *db, rwkv7_stream_t stream);
+/* ---- head loss: softmax cross-entropy of a chunk of bf16 logits [rows,V], forward and backward in one pass
+ *      (spark_llm.py:146-160, FusedLinearCrossEntropyLoss).  labels int64 [rows]; rows with label == ignore_index give 0.
+ *      loss_rows[rows] = logsumexp - logit[label]; logits are REPLACED by (softmax - onehot) * scale. ---- */
+int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
+                          rwkv7_stream_t stream);
+
 /* ---- optimizer step (train_spark_rwkv7speech.py:178-197; torch.optim.AdamW update rule, decoupled weight decay) on a
  *      flat parameter buffer: fp32 master weights p32 and moments m, v updated in place from bf16 gradients g16; the
  *      bf16 working copy p16 is rewritten in the same pass.  n % 4 == 0; step = 1 for the first update. ---- */

@@ -33,6 +33,7 @@ int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int gemv32_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
+int ce_fwd_bwd(long, int, void *, const long *, long, float, float *, hipStream_t);
 int adamw_step(long, float *, const void *, float *, float *, void *, float, float, float, float, float, float, float, hipStream_t);
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
@@ -346,6 +347,11 @@ int rwkv7_adamw_bf16(long n, float *p32, const void *g16, float *m, float *v, vo
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     return rwkv7::adamw_step(n, p32, g16, m, v, p16, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
                              (float)(1.0 / sqrt(bc2)), (hipStream_t)stream);
+}
+int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
+                          rwkv7_stream_t stream) {
+    if (rows <= 0 || V <= 0 || any_null({(const void *)logits, (const void *)labels, (const void *)loss_rows})) return RWKV7_EINVAL;
+    return rwkv7::ce_fwd_bwd(rows, V, logits, labels, ignore_index, scale, loss_rows, (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {
     if (!in || !addr || !out) return RWKV7_EINVAL;

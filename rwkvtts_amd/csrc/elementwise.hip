@@ -701,6 +701,51 @@ int adamw_step(long n, float *p32, const void *g16, float *m, float *v, void *p1
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// softmax cross-entropy of one chunk of head logits, forward and backward in one kernel
+// (model/llm/spark_llm.py:146-160 uses rwkvfla's FusedLinearCrossEntropyLoss; the chunking over tokens lives in
+// rwkvtts_amd/losses.py).  One wave per row: online max / sum-of-exp over the row (bf16 logits as the GEMM wrote them,
+// no fp32 copy), then the row is rewritten IN PLACE with d loss / d logits = (softmax - onehot(label)) * scale, or 0
+// for ignored rows; loss_rows[row] = (logsumexp - logit[label]) * valid.  Two reads (the second from L2) + one write.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_t *__restrict__ logits, const long *__restrict__ labels,
+                                                         long ignore_index, float scale, float *__restrict__ loss_rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    uint16_t *x = reinterpret_cast<uint16_t *>(logits) + row * V;
+    const long lab = labels[row];
+    const bool valid = lab != ignore_index;
+    float m = -INFINITY, ssum = 0.f;
+    for (int j = lane; j < V; j += 64) {
+        const float v = bf2f(x[j]);
+        const float mn = fmaxf(m, v);
+        ssum = ssum * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float mo = __shfl_xor(m, off), so = __shfl_xor(ssum, off);
+        const float mn = fmaxf(m, mo);
+        ssum = ssum * __expf(m - mn) + so * __expf(mo - mn);
+        m = mn;
+    }
+    const float lse = m + __logf(ssum);
+    if (lane == 0) loss_rows[row] = valid ? lse - bf2f(x[lab < 0 ? 0 : lab]) : 0.f;
+    const float sc = valid ? scale : 0.f;
+    for (int j = lane; j < V; j += 64) {
+        const float p = __expf(bf2f(x[j]) - lse) - (j == lab ? 1.f : 0.f);
+        x[j] = f2bf(p * sc);
+    }
+}
+
+int ce_fwd_bwd(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rows, V, (bf16_t *)logits, labels,
+                       ignore_index, scale, loss_rows);
+    return (int)hipGetLastError();
+}
+
 static inline int finish() { return (int)hipGetLastError(); }
 
 template <typename T>

@@ -23,9 +23,31 @@ class _FusedLinearCE(torch.autograd.Function):
         dh = torch.empty_like(hidden) if need[0] else None
         dw = torch.zeros_like(weight, dtype=torch.float32) if need[1] else None
         db = torch.zeros_like(bias, dtype=torch.float32) if (bias is not None and need[2]) else None
+        hip_ce = (hidden.is_cuda and hidden.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and bias is None
+                  and label_smoothing == 0 and labels.dtype == torch.int64)
         for s in range(0, N, chunk):
             h = hidden[s:s + chunk]
             lab = labels[s:s + chunk]
+            if hip_ce:
+                # bf16 logits straight from the GEMM; one kernel turns them into per-row losses and d loss / d logits
+                import ctypes
+                from . import _lib
+                pd = h @ weight.t()
+                rows = pd.shape[0]
+                loss_rows = torch.empty(rows, dtype=torch.float32, device=pd.device)
+                lab_c = lab.contiguous()
+                with torch.cuda.device_of(pd):
+                    rc = _lib.lib().rwkv7_ce_fwd_bwd_bf16(
+                        ctypes.c_long(rows), pd.shape[1], ctypes.c_void_p(pd.data_ptr()), ctypes.c_void_p(lab_c.data_ptr()),
+                        ctypes.c_long(ignore_index), ctypes.c_float(1.0), ctypes.c_void_p(loss_rows.data_ptr()),
+                        ctypes.c_void_p(torch.cuda.current_stream(pd.device).cuda_stream))
+                _lib.check(rc, "ce_fwd_bwd")
+                loss += loss_rows.sum()
+                if need[0]:
+                    dh[s:s + chunk] = pd @ weight
+                if need[1]:
+                    dw += (pd.t() @ h).float()
+                continue
             logits = (h @ weight.t()).float()
             if bias is not None:
                 logits = logits + bias.float()
@@ -55,13 +77,17 @@ class _FusedLinearCE(torch.autograd.Function):
                     dw += (pd.t() @ h).float()
                 if db is not None:
                     db += p.sum(0)
-        ctx.save_for_backward(dh, dw, db)
+        # the HIP path leaves dh / dw unscaled (scale = 1 in the kernel: 1/n_valid lives on the device); backward folds
+        # 1/n_valid into the incoming gradient
+        ctx.save_for_backward(dh, dw, db, inv if hip_ce else None)
         ctx.wdtype = weight.dtype
         return loss * inv
 
     @staticmethod
     def backward(ctx, g):
-        dh, dw, db = ctx.saved_tensors
+        dh, dw, db, post = ctx.saved_tensors
+        if post is not None:
+            g = g * post
         return (dh * g.to(dh.dtype) if dh is not None else None,
                 (dw * g).to(ctx.wdtype) if dw is not None else None,
                 (db * g).to(ctx.wdtype) if db is not None else None, None, None, None, None)

@@ -276,3 +276,25 @@ def test_cfg4_width_block_matches_oracle():
         h = model(inputs_embeds=x.to(DEV)).last_hidden_state.cpu()
         h_o, _ = R.backbone(p, rcfg, x, None)
     assert (h - h_o).abs().max().item() < 1e-3 * max(1.0, h_o.abs().max().item())
+
+
+def test_fused_linear_ce_hip_kernel_bf16():
+    """bf16 hidden/weight take rwkv7_ce_fwd_bwd_bf16 (loss + d logits in one pass over the bf16 logits): against fp32
+    cross_entropy on the same bf16-rounded logits.  V = 8193 (odd row length, as the Spark head)."""
+    g = torch.Generator().manual_seed(4)
+    N, D, V = 700, 128, 8193
+    h = (torch.randn(N, D, generator=g)).bfloat16().to(DEV).requires_grad_(True)
+    w = (torch.randn(V, D, generator=g) * 0.2).bfloat16().to(DEV).requires_grad_(True)
+    lab = torch.randint(0, V, (N,), generator=g).to(DEV)
+    lab[::5] = -100
+    l1 = fused_linear_cross_entropy(h, lab, w, None, -100, chunk=256)
+    l1.backward()
+    logits = (h.detach() @ w.detach().t()).float().requires_grad_(True)     # the bf16 logits the kernel sees
+    l2 = torch.nn.functional.cross_entropy(logits, lab, ignore_index=-100)
+    l2.backward()
+    assert abs(l1.item() - l2.item()) < 2e-4 * abs(l2.item())
+    dh_ref = logits.grad @ w.detach().float()
+    dw_ref = logits.grad.t() @ h.detach().float()
+    assert (h.grad.float() - dh_ref).abs().max().item() <= 2e-2 * dh_ref.abs().max().item()
+    assert (w.grad.float() - dw_ref).abs().max().item() <= 2e-2 * dw_ref.abs().max().item()
+    assert h.grad[::5].abs().max().item() == 0      # ignored rows contribute nothing
