@@ -123,7 +123,8 @@ __device__ __forceinline__ void put_tm(const float4 x, uint16_t *Th, uint16_t *T
     }
 }
 
-constexpr int kChunksPerWG = 4;  // the parallel kernels walk this many consecutive chunks, prefetching the next one's inputs
+constexpr int kChunksPerWG = 4;     // bwd_pre walks this many consecutive chunks per workgroup, prefetching the next one's inputs
+constexpr int kOutChunksPerWG = 8;  // bwd_out (measured: 4 -> 8 is +4 % for pre, -1 % for out)
 
 struct PreSmem {  // offsets in uint16 units
     // phase-1 inputs, contiguous: dead after phase 1 and overlaid by G1T and the M^T planes
@@ -500,13 +501,13 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         }
         return r;
     };
-    const int chunk0 = blockIdx.x * kChunksPerWG;
+    const int chunk0 = blockIdx.x * kOutChunksPerWG;
     In cur = load(chunk0, true);
-    for (int ci = 0; ci < kChunksPerWG; ci++) {
+    for (int ci = 0; ci < kOutChunksPerWG; ci++) {
     const int chunk = chunk0 + ci;
     if (chunk >= nchunks_total) break;
     In nxt = cur;
-    if (ci + 1 < kChunksPerWG && chunk + 1 < nchunks_total) {
+    if (ci + 1 < kOutChunksPerWG && chunk + 1 < nchunks_total) {
         nxt = load(chunk + 1, false);
         if ((chunk + 1) % nc != 0) {
 #pragma unroll
@@ -818,7 +819,7 @@ int chunk_bwd_out_bf16(int B, int T_, int H, int ck_mode, const void *w, const v
     }
     (void)hipGetLastError();
     const int total = B * H * (T_ / kC);
-    hipLaunchKernelGGL(wkv7c_bwd_out_kernel, dim3((total + kChunksPerWG - 1) / kChunksPerWG), dim3(256), OutSmem::bytes, st, T_, H,
+    hipLaunchKernelGGL(wkv7c_bwd_out_kernel, dim3((total + kOutChunksPerWG - 1) / kOutChunksPerWG), dim3(256), OutSmem::bytes, st, T_, H,
                        total, ck_mode, (const bf16_t *)w,
                        (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a, (const bf16_t *)b,
                        (const bf16_t *)dy, s, sa, tinv, e_kv, (bf16_t *)dw, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
