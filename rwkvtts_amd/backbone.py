@@ -199,9 +199,14 @@ class RWKV7Attention(nn.Module):
                 state_dict[prefix + f"x_{n}"] = x_x[i].reshape(1, 1, -1)
         super()._load_from_state_dict(state_dict, prefix, *args, **kw)
 
+    def train(self, mode: bool = True):
+        self._mix_key = None   # optimizers may rewrite parameter memory without touching the version counters
+        return super().train(mode)
+
     def _stacked_mix(self, dtype):
-        """[6,D] stack of x_r..x_g for inference (no autograd through it), rebuilt when a parameter changes."""
-        if torch.is_grad_enabled():
+        """[6,D] stack of x_r..x_g for inference (no autograd through it), rebuilt when a parameter changes or the module
+        switches between train() and eval()."""
+        if torch.is_grad_enabled() or self.training:
             return None
         ps = (self.x_r, self.x_w, self.x_k, self.x_v, self.x_a, self.x_g)
         key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (dtype,)
