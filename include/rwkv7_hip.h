@@ -266,6 +266,43 @@ int rwkv7_adamw_bf16(long n, float *p32, const void *g16, float *m, float *v, vo
  *      for the decode batch; weight-streaming on MFMA, see csrc/gemv32.hip.  bias may be NULL. ---- */
 int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const void *bias, void *y, rwkv7_stream_t stream);
 
+/* ---- one whole decode step (T = 1, B <= 32 sequences, bf16 weights) in ONE persistent kernel: replaces the per-token loop
+ *      body RWKV_x070.forward_one (model/llm/rwkv_s2s_single_ffn.py:417-445; TMix_one :482-506, CMix_one :545-549) /
+ *      forward_batch at T = 1 (model/llm/rwkv_asr_cuda_whisper.py:438-472) including the final norm and the head
+ *      projection.  See csrc/decode_step.hip.
+ *
+ *      layer_tbl: DEVICE array [L][RWKV7_DEC_COUNT] of device pointers in the order below (bf16 unless noted; entries a
+ *      layer does not have -- LN0 outside layer 0, the v branch in layer 0 -- may be NULL).  Weights are torch/rwkvfla
+ *      layouts: Linear [out,in], low-rank lora.0.weight [R,D] ("1"), lora.2.weight [D,R] ("2"), lora.2.bias [D] ("0").
+ *      State tensors are updated in place: att_x_prev/ffn_x_prev bf16 [B,D], att_kv fp32 [B,H,64,64] (row = value index).
+ *      x_in bf16 [B,D] = embeddings of the current tokens; logits fp32 [B,V] (head_b may be NULL).
+ *      workspace: rwkv7_decode_workspace_bytes() bytes, 256-byte aligned, owned by the caller, reused step after step;
+ *      its first 8 bytes are the barrier words {arrivals, timeout flag}: flag != 0 after a step means a grid barrier was not
+ *      met within ~0.1 s (the kernel then exits instead of hanging; the step's results are invalid).
+ *      persistent = 1: one launch, 7 L + 1 device-scope barriers; 0: the same phase bodies as 7 L + 2 ordinary launches.
+ *      Errors: RWKV7_ESHAPE unless B in [1,32], D = 64 H <= 4096, F % 64 == 0, every rank a multiple of 32, ranks sum <= 512. */
+enum {
+    RWKV7_DEC_LN0_W, RWKV7_DEC_LN0_B, RWKV7_DEC_LN1_W, RWKV7_DEC_LN1_B, RWKV7_DEC_LN2_W, RWKV7_DEC_LN2_B,
+    RWKV7_DEC_XR, RWKV7_DEC_XW, RWKV7_DEC_XK, RWKV7_DEC_XV, RWKV7_DEC_XA, RWKV7_DEC_XG,
+    RWKV7_DEC_WR, RWKV7_DEC_WK, RWKV7_DEC_WV, RWKV7_DEC_WO,
+    RWKV7_DEC_W1, RWKV7_DEC_W2, RWKV7_DEC_W0, RWKV7_DEC_A1, RWKV7_DEC_A2, RWKV7_DEC_A0,
+    RWKV7_DEC_V1, RWKV7_DEC_V2, RWKV7_DEC_V0, RWKV7_DEC_G1, RWKV7_DEC_G2,
+    RWKV7_DEC_KK, RWKV7_DEC_KA, RWKV7_DEC_RK, RWKV7_DEC_GNW, RWKV7_DEC_GNB,
+    RWKV7_DEC_FXK, RWKV7_DEC_WKEY, RWKV7_DEC_WVAL,
+    RWKV7_DEC_ATT_XPREV, RWKV7_DEC_ATT_KV /* fp32 */, RWKV7_DEC_FFN_XPREV,
+    RWKV7_DEC_COUNT
+};
+typedef struct rwkv7_decode_dims {
+    int B, D, H, L, F, V;      /* sequences, hidden, heads, layers, channel-mix width, head rows */
+    int Rw, Ra, Rv, Rg;        /* low-rank sizes of the decay / a / value-residual / gate branches */
+    float ln_eps, gn_eps;      /* LayerNorm eps; GroupNorm eps (64e-5, rwkv_s2s_single_ffn.py:504) */
+} rwkv7_decode_dims;
+int rwkv7_decode_layer_ptrs(void);   /* == RWKV7_DEC_COUNT of the library that was loaded */
+size_t rwkv7_decode_workspace_bytes(const rwkv7_decode_dims *dims);   /* 0: unsupported shape */
+int rwkv7_decode_step_bf16(const rwkv7_decode_dims *dims, const void *const *layer_tbl, const void *x_in, const void *norm_w,
+                           const void *norm_b, const void *head_w, const void *head_b, float *logits, void *workspace,
+                           int persistent, rwkv7_stream_t stream);
+
 /* the low-rank pair of the decode step in one launch: y[M,N] = act(x[M,K] @ w1[R,K]^T) @ w2[N,R]^T (+ bias); M <= 32,
  * K % 64 == 0, R in {32,64,128}, act 0 none / 1 tanh / 2 sigmoid (rwkv_s2s_single_ffn.py:497-500: w, a, v, g branches) */
 int rwkv7_lora32_bf16(int M, int N, int K, int R, int act, const void *x, const void *w1, const void *w2, const void *bias,

@@ -465,6 +465,14 @@ class RWKV7ForCausalLM(nn.Module):
     def get_input_embeddings(self):
         return self.model.embeddings
 
+    @property
+    def device(self):
+        return self.lm_head.weight.device
+
+    @property
+    def dtype(self):
+        return self.lm_head.weight.dtype
+
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, past_key_values=None, labels=None,
                 use_cache=None, **kwargs):
         out = self.model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,

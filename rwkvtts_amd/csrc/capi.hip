@@ -42,6 +42,10 @@ int chunk_state_bf16(int, int, const void *, const float *, float *, hipStream_t
 int chunk_bwd_out_bf16(int, int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                        const float *, const float *, const float *, const float *, void *, void *, void *, void *,
                        void *, void *, hipStream_t);
+int decode_layer_ptrs();
+size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
+int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *, const void *,
+                     const void *, const void *, const void *, float *, void *, int, hipStream_t);
 void fwd_force_shape(int);
 void bwd_force_shape(int);
 int lora_down_bf16(long, int, int, int, const void *, const void *, void *, hipStream_t);
@@ -352,6 +356,21 @@ int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, lo
                           rwkv7_stream_t stream) {
     if (rows <= 0 || V <= 0 || any_null({(const void *)logits, (const void *)labels, (const void *)loss_rows})) return RWKV7_EINVAL;
     return rwkv7::ce_fwd_bwd(rows, V, logits, labels, ignore_index, scale, loss_rows, (hipStream_t)stream);
+}
+int rwkv7_decode_layer_ptrs(void) { return rwkv7::decode_layer_ptrs(); }
+size_t rwkv7_decode_workspace_bytes(const rwkv7_decode_dims *dm) {
+    if (!dm) return 0;
+    return rwkv7::decode_workspace_bytes(dm->B, dm->D, dm->H, dm->F, dm->V, dm->Rw, dm->Ra, dm->Rv, dm->Rg);
+}
+int rwkv7_decode_step_bf16(const rwkv7_decode_dims *dm, const void *const *layer_tbl, const void *x_in, const void *norm_w,
+                           const void *norm_b, const void *head_w, const void *head_b, float *logits, void *workspace,
+                           int persistent, rwkv7_stream_t stream) {
+    if (!dm || any_null({(const void *)layer_tbl, x_in, norm_w, norm_b, head_w, (const void *)logits, (const void *)workspace}))
+        return RWKV7_EINVAL;
+    if (dm->H * RWKV7_HEAD_SIZE != dm->D) return RWKV7_EHEAD;
+    return rwkv7::decode_step_bf16(dm->B, dm->D, dm->H, dm->L, dm->F, dm->V, dm->Rw, dm->Ra, dm->Rv, dm->Rg, dm->ln_eps, dm->gn_eps,
+                                   layer_tbl, x_in, norm_w, norm_b, head_w, head_b, logits, workspace, persistent,
+                                   (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {
     if (!in || !addr || !out) return RWKV7_EINVAL;

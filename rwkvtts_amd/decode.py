@@ -1,31 +1,153 @@
-"""Persistent-state greedy decode with the per-token step captured in a hipGraph (BASELINE.json configs[4];
-reference loops: model/llm/rwkv_asr_cuda_whisper.py:694-717, rwkv_s2s_single_ffn.py:417-445, HF generate via
-inference/rwkv7speech_inference.py:99-107).
+"""Persistent-state greedy decode (BASELINE.json configs[4]; reference loops: model/llm/rwkv_asr_cuda_whisper.py:694-717,
+rwkv_s2s_single_ffn.py:417-445, HF generate via inference/rwkv7speech_inference.py:99-107).
 
-One decode step of the 0.4B model is ~25 small launches per layer; eagerly it is launch-bound (host ~3-4 us per
-launch).  The step -- embedding lookup of the previous ids, 24 layers on the in-place recurrent state
-(att_x_prev, att_kv, ffn_x_prev per layer), final norm, lm_head, suppress/argmax, bookkeeping -- is recorded once
-into a graph on static buffers and replayed per token; the ids never leave the device until the end.
+Two levels:
+  * DecodeStep -- the whole T = 1 step of the stack (all layers on the in-place recurrent state, final norm, head
+    projection) as ONE persistent HIP kernel, rwkv7_decode_step_bf16 (csrc/decode_step.hip): 7 grid-wide phases per layer
+    separated by device-scope barriers instead of ~18 launches per layer.
+  * GraphDecoder -- greedy loop around it: embedding lookup of the previous ids, the step, suppress/argmax and the
+    bookkeeping are recorded once into a hipGraph on static buffers and replayed per token; the ids never leave the device
+    until the end.  Models the step kernel does not cover (fp32 weights, B > 32, odd low-rank sizes) run the module-by-module
+    step inside the same graph.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Sequence
 
 import torch
+import torch.nn.functional as F
 
+from . import _lib
 from .backbone import Cache
+
+# order of include/rwkv7_hip.h: RWKV7_DEC_*
+_DEC_ORDER = ("ln0_w", "ln0_b", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g",
+              "wr", "wk", "wv", "wo", "w1", "w2", "w0", "a1", "a2", "a0", "v1", "v2", "v0", "g1", "g2",
+              "k_k", "k_a", "r_k", "gn_w", "gn_b", "fx_k", "wkey", "wval", "att_x_prev", "att_kv", "ffn_x_prev")
+
+
+class _Dims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "D", "H", "L", "F", "V", "Rw", "Ra", "Rv", "Rg")] + \
+               [("ln_eps", ctypes.c_float), ("gn_eps", ctypes.c_float)]
+
+
+class DecodeStep:
+    """logits[B,V] (fp32) = step(x_in[B,D] bf16) on the live `cache` of a bf16 RWKV7Model + head; the cache's state tensors
+    are updated in place.  Raises ValueError for shapes/dtypes the kernel does not cover (see `supported`)."""
+
+    def __init__(self, backbone, lm_head, cache: Cache, persistent: bool = True):
+        why = self.supported(backbone, lm_head, cache)
+        if why:
+            raise ValueError("rwkv7_decode_step_bf16: " + why)
+        cfg = backbone.config
+        lib = _lib.lib()
+        if lib.rwkv7_decode_layer_ptrs() != len(_DEC_ORDER):
+            raise _lib.Rwkv7HipError("librwkv7_hip.so and rwkvtts_amd/decode.py disagree on the layer pointer table")
+        self.B = cache[0].att_x_prev.shape[0]
+        a0 = backbone.layers[0].attn
+        self.dims = _Dims(self.B, cfg.hidden_size, cfg.num_heads, len(backbone.layers), backbone.layers[0].ffn.key.weight.shape[0],
+                          lm_head.weight.shape[0], a0.w_lora.rank, a0.a_lora.rank, backbone.layers[1].attn.v_lora.rank
+                          if len(backbone.layers) > 1 else 32, a0.g_lora.rank, cfg.norm_eps, a0.g_norm.eps)
+        lib.rwkv7_decode_workspace_bytes.restype = ctypes.c_size_t
+        nbytes = lib.rwkv7_decode_workspace_bytes(ctypes.byref(self.dims))
+        if nbytes == 0:
+            raise ValueError("rwkv7_decode_step_bf16: unsupported shape")
+        dev = lm_head.weight.device
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        rows = []
+        self._keep = []  # tensors whose addresses are in the table
+        for i, blk in enumerate(backbone.layers):
+            at, ff, st = blk.attn, blk.ffn, cache[i]
+            t = dict(ln0_w=blk.pre_norm.weight if i == 0 else None, ln0_b=blk.pre_norm.bias if i == 0 else None,
+                     ln1_w=blk.attn_norm.weight, ln1_b=blk.attn_norm.bias, ln2_w=blk.ffn_norm.weight, ln2_b=blk.ffn_norm.bias,
+                     x_r=at.x_r, x_w=at.x_w, x_k=at.x_k, x_v=at.x_v, x_a=at.x_a, x_g=at.x_g,
+                     wr=at.r_proj.weight, wk=at.k_proj.weight, wv=at.v_proj.weight, wo=at.o_proj.weight,
+                     w1=at.w_lora.lora[0].weight, w2=at.w_lora.lora[2].weight, w0=at.w_lora.lora[2].bias,
+                     a1=at.a_lora.lora[0].weight, a2=at.a_lora.lora[2].weight, a0=at.a_lora.lora[2].bias,
+                     v1=at.v_lora.lora[0].weight if i else None, v2=at.v_lora.lora[2].weight if i else None,
+                     v0=at.v_lora.lora[2].bias if i else None,
+                     g1=at.g_lora.lora[0].weight, g2=at.g_lora.lora[2].weight,
+                     k_k=at.k_k, k_a=at.k_a, r_k=at.r_k, gn_w=at.g_norm.weight, gn_b=at.g_norm.bias,
+                     fx_k=ff.x_k, wkey=ff.key.weight, wval=ff.value.weight,
+                     att_x_prev=st.att_x_prev, att_kv=st.att_kv, ffn_x_prev=st.ffn_x_prev)
+            row = []
+            for name in _DEC_ORDER:
+                ten = t[name]
+                if ten is not None:
+                    ten = ten.detach()
+                    self._keep.append(ten)
+                row.append(0 if ten is None else ten.data_ptr())
+            rows.append(row)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.norm, self.head = backbone.norm, lm_head
+        self.logits = torch.empty(self.B, self.dims.V, dtype=torch.float32, device=dev)
+        self.persistent = bool(persistent)
+
+    @staticmethod
+    def supported(backbone, lm_head, cache: Cache) -> Optional[str]:
+        """None if the step kernel covers this model/cache, else the reason."""
+        cfg = backbone.config
+        if cache is None or len(cache) != len(backbone.layers):
+            return "no per-layer cache"
+        B = cache[0].att_x_prev.shape[0]
+        if not 1 <= B <= 32:
+            return f"B = {B} (1..32)"
+        if cfg.hidden_size > 4096 or cfg.hidden_size % 64:
+            return "hidden size"
+        if not getattr(cfg, "norm_bias", True):
+            return "LayerNorm without bias"
+        tensors = [lm_head.weight] + [p for p in backbone.layers.parameters()] + list(backbone.norm.parameters())
+        if any(p.dtype != torch.bfloat16 or not p.is_cuda or not p.is_contiguous() for p in tensors):
+            return "parameters must be contiguous bf16 tensors on the HIP device"
+        a0 = backbone.layers[0].attn
+        ranks = [a0.w_lora.rank, a0.a_lora.rank, a0.g_lora.rank] + ([backbone.layers[1].attn.v_lora.rank] if len(backbone.layers) > 1 else [])
+        if any(r % 32 for r in ranks) or sum(ranks) > 512:
+            return f"low-rank sizes {ranks}"
+        if backbone.layers[0].ffn.key.weight.shape[0] % 64:
+            return "channel-mix width"
+        for st in cache.states:
+            if st.att_x_prev.dtype != torch.bfloat16 or st.att_kv.dtype != torch.float32 or st.ffn_x_prev.dtype != torch.bfloat16:
+                return "state dtypes"
+        return None
+
+    def __call__(self, x_in: torch.Tensor) -> torch.Tensor:
+        assert x_in.shape == (self.B, self.dims.D) and x_in.dtype == torch.bfloat16 and x_in.is_contiguous()
+        hb = self.head.bias
+        with torch.cuda.device_of(x_in):
+            rc = _lib.lib().rwkv7_decode_step_bf16(
+                ctypes.byref(self.dims), ctypes.c_void_p(self.table.data_ptr()), ctypes.c_void_p(x_in.data_ptr()),
+                ctypes.c_void_p(self.norm.weight.data_ptr()), ctypes.c_void_p(self.norm.bias.data_ptr()),
+                ctypes.c_void_p(self.head.weight.data_ptr()), ctypes.c_void_p(hb.data_ptr() if hb is not None else None),
+                ctypes.c_void_p(self.logits.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()), int(self.persistent),
+                ctypes.c_void_p(torch.cuda.current_stream(x_in.device).cuda_stream))
+        _lib.check(rc, "rwkv7_decode_step_bf16")
+        return self.logits
+
+    def barrier_timed_out(self) -> bool:
+        """True if a grid barrier of an earlier step was not met in time (the kernel bails out instead of hanging)."""
+        return bool(self.workspace[4:8].view(torch.int32).item())
 
 
 class GraphDecoder:
-    def __init__(self, model, batch_size: int):
+    def __init__(self, model, batch_size: int, step_kernel: Optional[bool] = None):
+        """step_kernel: True = require the persistent step kernel, False = module-by-module step, None = kernel when the
+        model is covered (DecodeStep.supported)."""
         self.model = model.eval()
         self.B = batch_size
         self.graph = None
+        self.step_kernel = step_kernel
+        self.step = None
 
     @torch.no_grad()
     def _step(self):
-        out = self.model(input_ids=self.ids.unsqueeze(1), past_key_values=self.cache, use_cache=True)
-        logits = out.logits[:, -1].float()
+        if self.step is not None:
+            x = F.embedding(self.ids, self.model.get_input_embeddings().weight)
+            logits = self.step(x).clone()
+            self.cache.seen_tokens += 1
+        else:
+            out = self.model(input_ids=self.ids.unsqueeze(1), past_key_values=self.cache, use_cache=True)
+            logits = out.logits[:, -1].float()
         if self.suppress is not None:
             logits.index_fill_(1, self.suppress, float("-inf"))
         nxt = torch.argmax(logits, dim=-1)
@@ -64,6 +186,13 @@ class GraphDecoder:
             self.unfinished &= first != self.eos
         if max_new_tokens <= 1:
             return self.out
+        self.step = None
+        if self.step_kernel is not False:
+            why = DecodeStep.supported(m.model, m.lm_head, self.cache)
+            if why is None:
+                self.step = DecodeStep(m.model, m.lm_head, self.cache)
+            elif self.step_kernel:
+                raise ValueError("persistent decode step unavailable: " + why)
         # capture one step on the live state tensors.  Warm-up (un-captured) steps would advance the state, so the
         # state/ids are snapshotted and restored around them.
         snap = [(s.att_x_prev.clone(), s.att_kv.clone(), s.ffn_x_prev.clone()) for s in self.cache.states]
@@ -94,4 +223,6 @@ class GraphDecoder:
         for _ in range(max_new_tokens - 1):
             self.graph.replay()
         self.cache.seen_tokens = seen0 + max_new_tokens - 1
+        if self.step is not None and self.step.barrier_timed_out():
+            raise _lib.Rwkv7HipError("rwkv7_decode_step_bf16: a grid barrier timed out; the generated ids are invalid")
         return self.out

@@ -1,0 +1,131 @@
+"""GPU (-m gpu): the one-kernel decode step (csrc/decode_step.hip, rwkv7_decode_step_bf16) against the module-by-module
+stateful path (reference forward_batch at T = 1, rwkv_asr_cuda_whisper.py:438-472) and against the same model run in fp32.
+
+The step kernel keeps fp32 between the projections where the module path rounds every tensor to bf16, so the yardstick is
+the fp32 twin of the model (same bf16-valued weights, fp32 arithmetic on the *_f32 kernels): the step kernel must be at least
+as close to it as the bf16 module path is, logits and recurrent state alike."""
+import copy
+
+import pytest
+import torch
+
+from rwkvtts_amd import backbone
+from rwkvtts_amd.backbone import Cache, RWKV7Config, RWKV7ForCausalLM
+from rwkvtts_amd.decode import DecodeStep, GraphDecoder
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(D, L, V, ranks, seed=0, head_bias=False):
+    cfg = RWKV7Config(hidden_size=D, num_hidden_layers=L, vocab_size=V, decay_low_rank_dim=ranks[0], a_low_rank_dim=ranks[1],
+                      v_low_rank_dim=ranks[2], gate_low_rank_dim=ranks[3])
+    torch.manual_seed(seed)
+    m = RWKV7ForCausalLM(cfg, head_bias=head_bias)
+    backbone.init_weights(m, cfg, seed=seed)
+    with torch.no_grad():
+        m.lm_head.weight.normal_(0, 0.05)
+        if head_bias:
+            m.lm_head.bias.normal_(0, 0.1)
+        for blk in m.model.layers:   # non-trivial norms and biases
+            for ln in (blk.attn_norm, blk.ffn_norm):
+                ln.weight.add_(torch.randn_like(ln.weight) * 0.1)
+                ln.bias.add_(torch.randn_like(ln.bias) * 0.1)
+    m16 = m.to(DEV).to(torch.bfloat16).eval()
+    m32 = copy.deepcopy(m16).float().eval()   # same (bf16-valued) weights, fp32 arithmetic
+    return cfg, m16, m32
+
+
+def _prefill(m, ids, B, dtype):
+    cache = Cache.zeros(m.config, B, DEV, dtype)
+    with torch.no_grad():
+        out = m(input_ids=ids, past_key_values=cache, use_cache=True)
+    return cache, out.logits[:, -1].float()
+
+
+def _clone_cache(c):
+    return Cache([backbone.LayerState(s.att_x_prev.clone(), s.att_kv.clone(), s.ffn_x_prev.clone()) for s in c.states], c.seen_tokens)
+
+
+@pytest.mark.parametrize("D,L,V,ranks,B,bias", [
+    (128, 3, 77, (32, 32, 32, 32), 5, True),        # odd batch, partial last head tile, head bias
+    (128, 2, 64, (64, 32, 32, 96), 32, False),
+    (1024, 2, 8193, (64, 64, 32, 128), 32, False),  # 0.4B widths (BASELINE configs[4]), two layers
+    (768, 2, 300, (64, 64, 32, 128), 7, False),     # 0.1B width: K splits that are not powers of two away from 1024
+    (2048, 2, 1025, (96, 96, 64, 256), 4, True),    # 1.5B widths
+])
+def test_step_kernel_vs_module_path_and_fp32(D, L, V, ranks, B, bias):
+    cfg, m16, m32 = _model(D, L, V, ranks, seed=D + B, head_bias=bias)
+    g = torch.Generator().manual_seed(B)
+    prompt = torch.randint(0, V, (B, 6), generator=g).to(DEV)
+    c16, lg = _prefill(m16, prompt, B, torch.bfloat16)
+    c32, lg32 = _prefill(m32, prompt, B, torch.float32)
+    ck = _clone_cache(c16)   # step kernel, persistent
+    cp = _clone_cache(c16)   # step kernel, one launch per phase
+    step_k = DecodeStep(m16.model, m16.lm_head, ck, persistent=True)
+    step_p = DecodeStep(m16.model, m16.lm_head, cp, persistent=False)
+    emb = m16.model.embeddings.weight
+    worst_mod = worst_ker = 0.0
+    for it in range(5):
+        ids = torch.argmax(lg32, -1)   # every path is fed the fp32 twin's greedy ids
+        with torch.no_grad():
+            lg32 = m32(input_ids=ids[:, None], past_key_values=c32, use_cache=True).logits[:, -1].float()
+            lmod = m16(input_ids=ids[:, None], past_key_values=c16, use_cache=True).logits[:, -1].float()
+            x = torch.nn.functional.embedding(ids, emb)
+            lk = step_k(x).clone()
+            lp = step_p(x).clone()
+        assert not step_k.barrier_timed_out()
+        assert torch.isfinite(lk).all()
+        # same arithmetic in both launch modes
+        assert torch.equal(lk, lp), (lk - lp).abs().max().item()
+        scale = lg32.abs().max().item()
+        worst_mod = max(worst_mod, (lmod - lg32).abs().max().item() / scale)
+        worst_ker = max(worst_ker, (lk - lg32).abs().max().item() / scale)
+    assert worst_ker < 3e-2, (worst_ker, worst_mod)
+    assert worst_ker < 1.5 * worst_mod + 2e-3, (worst_ker, worst_mod)
+    for sk, sp, s32 in zip(ck.states, cp.states, c32.states):
+        assert torch.equal(sk.att_kv, sp.att_kv) and torch.equal(sk.att_x_prev, sp.att_x_prev) and torch.equal(sk.ffn_x_prev, sp.ffn_x_prev)
+        ref = s32.att_kv
+        assert (sk.att_kv - ref).abs().max().item() < 3e-2 * ref.abs().max().item() + 1e-3
+        assert (sk.att_x_prev.float() - s32.att_x_prev).abs().max().item() < 5e-2 * s32.att_x_prev.abs().max().item() + 1e-2
+
+
+def test_graph_decoder_with_step_kernel_matches_fp32_greedy_ids():
+    """Greedy ids of the hipGraph loop around the step kernel == ids of the fp32 twin wherever the fp32 top-2 margin is
+    larger than the bf16 noise (north_star: bit-exact argmax ids; ties inside the rounding noise are not decidable)."""
+    D, L, V, B, P, NEW = 128, 3, 200, 6, 7, 24
+    cfg, m16, m32 = _model(D, L, V, (32, 32, 32, 64), seed=21)
+    prompt = torch.randint(0, V, (B, P), generator=torch.Generator().manual_seed(4)).to(DEV)
+    dec = GraphDecoder(m16, B, step_kernel=True)
+    got = dec.generate(input_ids=prompt, max_new_tokens=NEW)
+    assert dec.step is not None and not dec.step.barrier_timed_out()
+    # module-by-module loop inside the same graph machinery
+    want_mod = GraphDecoder(m16, B, step_kernel=False).generate(input_ids=prompt, max_new_tokens=NEW)
+    # fp32 twin, teacher-forced along `got`, with its top-2 margins
+    c32, lg = _prefill(m32, prompt, B, torch.float32)
+    alive = torch.ones(B, dtype=torch.bool, device=DEV)
+    checked = 0
+    for t in range(NEW):
+        top2 = torch.topk(lg, 2, -1)
+        margin = (top2.values[:, 0] - top2.values[:, 1]) / lg.abs().amax(-1)
+        sure = alive & (margin > 2e-2)
+        assert torch.equal(got[sure, t], top2.indices[sure, 0]), t
+        checked += int(sure.sum())
+        alive &= got[:, t] == top2.indices[:, 0]   # after a (tie-)divergence the histories differ
+        with torch.no_grad():
+            lg = m32(input_ids=got[:, t:t + 1], past_key_values=c32, use_cache=True).logits[:, -1].float()
+    assert checked > NEW * B // 2, checked
+    agree = (got == want_mod).float().mean().item()
+    assert agree > 0.8, agree
+
+
+def test_step_kernel_rejects_unsupported_models():
+    cfg, m16, m32 = _model(128, 2, 64, (32, 32, 16, 32))
+    cache = Cache.zeros(cfg, 4, DEV, torch.bfloat16)
+    assert DecodeStep.supported(m16.model, m16.lm_head, cache) is not None           # rank 16
+    with pytest.raises(ValueError):
+        DecodeStep(m16.model, m16.lm_head, cache)
+    cfg, m16, m32 = _model(128, 2, 64, (32, 32, 32, 32))
+    assert DecodeStep.supported(m32.model, m32.lm_head, Cache.zeros(cfg, 4, DEV, torch.float32)) is not None   # fp32 weights
+    assert DecodeStep.supported(m16.model, m16.lm_head, Cache.zeros(cfg, 33, DEV, torch.bfloat16)) is not None  # B > 32
+    assert DecodeStep.supported(m16.model, m16.lm_head, Cache.zeros(cfg, 32, DEV, torch.bfloat16)) is None
