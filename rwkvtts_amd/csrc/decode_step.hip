@@ -1,15 +1,13 @@
 // rwkvtts_amd/csrc/decode_step.hip -- one greedy-decode step (T = 1, B <= 32 sequences) of the whole RWKV-7 stack on gfx950
-// as ONE persistent kernel (BASELINE.json configs[4]: "persistent-state decode kernel").
+// (BASELINE.json configs[4]: "persistent-state decode kernel").
 //
 // Reference: the per-token path RWKV_x070.forward_one (model/llm/rwkv_s2s_single_ffn.py:417-445) with
 // RWKV_x070_TMix_one (:482-506) and RWKV_x070_CMix_one (:545-549); batched form forward_batch at T = 1
-// (model/llm/rwkv_asr_cuda_whisper.py:438-472).  There a step is ~25 launches per layer; even replayed from a hipGraph every
-// launch costs ~5 us of drain/fill, 430 of them make a 4 ms step whose HBM traffic (0.65 GB of weights + 0.4 GB of state)
-// would take 0.13 ms.
+// (model/llm/rwkv_asr_cuda_whisper.py:438-472).  Module by module a step is ~18 launches per layer; even replayed from a
+// hipGraph that is 430 launches and 4.0 ms for a step whose HBM traffic (0.65 GB of weights + 0.4 GB of state) would take
+// 0.13 ms.
 //
-// Here the step is 7 grid-wide phases per layer, executed by 256 resident workgroups (one per CU) that meet at a
-// device-scope barrier between phases (agent-scope release/acquire: L2 write-back + invalidate, the XCDs' L2s are not
-// coherent with each other):
+// Here the step is 7 grid-wide phases per layer:
 //   P0 row    x += previous channel-mix output (K-split partials); h = LayerNorm1(x); six token-shift lerps -> bf16 rows;
 //             att_x_prev <- h                                                      (rwkv_s2s_single_ffn.py:486-487)
 //   P1 gemv   r, k, v projections and the four low-rank down projections in one sweep: [32 x K] . W^T on MFMA, the batch
@@ -18,12 +16,22 @@
 //             normalisation, the 64x64 fp32 state update in place, y, GroupNorm, bonus, gate -> bf16 rows   (:493-505)
 //   P3 gemv   output projection -> partials                                                                  (:506)
 //   P4 row    x += attention output; h = LayerNorm2(x); channel-mix lerp; ffn_x_prev <- h                    (:546-547)
-//   P5 gemv   key projection -> partials                                                                     (:548)
-//   P6 gemv   value projection of relu(.)^2 (applied while the partials are summed on load) -> partials      (:548-549)
-// and a final row phase (last residual add + model norm) and the head projection -> fp32 logits.  Every GEMV phase writes
-// fp32 K-split partials [KS][32][N] that the consumer sums when it loads them, so no phase waits for a reduction.
-// The same phase bodies can be launched as 7 L + 2 separate kernels (persistent = 0): the safe mode, and the oracle for
-// the barrier path in tests/test_decode_step_gpu.py.
+//   P5 gemv   key projection, relu(.)^2 -> bf16 rows (no K split: the activation needs the whole sum)        (:548)
+//   P6 gemv   value projection -> partials                                                                   (:548-549)
+// and a final row phase (last residual add + model norm) and the head projection -> fp32 logits.  GEMV phases write fp32
+// K-split partials [KS][32][N] that the consumer sums when it loads them, so no phase waits for a reduction.  A phase is a
+// chain of load latencies, so every phase requests whatever does not depend on the previous phase (state rows, parameter
+// vectors, up-projection rows) before it reads the activations, and sums partials with all loads of a round in flight.
+//
+// Two ways to run the phases (same bodies, bit-identical results, tests/test_decode_step_gpu.py):
+//   persistent = 0  one launch per phase (7 L + 2), each sized to its item count.  Measured at configs[4] (0.4B, B = 32,
+//                   tools/decode_phase_profile.py): row phases 4.9 us, GEMV phases 5-8 us, head phase 13 us, 1.18 ms per
+//                   step in the replayed graph = 27 k tokens/s (module path: 4.0 ms, 8 k tokens/s).
+//   persistent = 1  ONE launch of 256 resident workgroups that meet at a device-scope barrier between phases.  Measured:
+//                   7.4 us per barrier -- 3.9 us for 256 arrivals + polling on one counter, 1.8 us for the agent-scope
+//                   release (L2 write-back) and 1.6 us for the acquire (invalidate); the XCDs' L2s are not coherent with
+//                   each other, so both are needed -- against ~1.5 us for a stream-ordered kernel boundary: 2.4 ms per step.
+//                   Kept as an option (and as a cross-check of the phase bodies); the Python host uses persistent = 0.
 #include "chunk_common.h"
 
 namespace rwkv7 {
@@ -43,15 +51,15 @@ enum DecPtr {
 struct DecodeDesc {
     int B, D, H, L, F, V;
     int Rw, Ra, Rv, Rg;
-    int ks_qkv, ks_o, ks_key, ks_val;
+    int ks_qkv, ks_o, ks_val;
     float ln_eps, gn_eps;
     const void *const *tbl;   // [L][DP_COUNT] device pointers
     const uint16_t *x_in;     // [B][D] bf16 embeddings of the current tokens
     const uint16_t *norm_w, *norm_b, *head_w, *head_b;
     float *logits;            // [B][V]
     // workspace
-    float *xa, *xb, *vfirst, *p_qkv, *p_att, *p_key, *p_val;
-    uint16_t *mixed, *yg, *kx, *hfin;
+    float *xa, *xb, *vfirst, *p_qkv, *p_att, *p_val;
+    uint16_t *mixed, *yg, *kx, *kact, *hfin;
     unsigned *bar;            // [0] arrival counter, [1] timeout flag
 };
 
@@ -97,95 +105,132 @@ __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x))
 __device__ __forceinline__ float tanh_(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
 __device__ __forceinline__ float softplus_d(float u) { return u > 20.f ? u : log1pf(__expf(u)); }
 
-__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned &target, unsigned nwg) {
+// One agent-scope release (L2 write-back) on arrival, a relaxed spin, one agent-scope acquire (cache invalidate) on exit: an
+// acquire inside the spin loop would invalidate this XCD's L2 under the workgroups that are still computing.
+// mode (debug): 1, 2 = full barrier; 3 = no fences; 4 = release only; 5 = acquire only
+__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned &target, unsigned nwg, int mode = 1) {
     __syncthreads();
     if (threadIdx.x == 0) {
         target += nwg;
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (mode <= 2 || mode == 4) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > kSpinLimit) {
-                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0u) {
+                if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (spins > kSpinLimit) {
+                    __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
         }
+        if (mode <= 2 || mode == 5) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// row phases: residual add, LayerNorm, token-shift lerps.  One workgroup per sequence.
-//   x_new = x_old + sum_s parts[s]      (layer 0: x_new = LayerNorm0(x_in))      -> x_out
-//   h = bf16(LayerNorm(x_new));   out_j = h + (x_prev - h) * mix_j ;   x_prev <- h        (NMIX = 0: h itself -> out)
-// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 bf4(uint2 r) {
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// Every thread owns float4 column groups g = tid + 256 i.  All loads of a group (residual, up to 8 partials at a time, norm
+// and lerp parameters, the shifted row) are issued before the first reduction: a phase is a chain of load latencies.
 template <int NMIX>
 __device__ __forceinline__ void row_phase(const DecodeDesc &d, int b, float *red, const float *x_old, const float *parts, int nparts,
-                          const uint16_t *x_in, const uint16_t *ln0w, const uint16_t *ln0b, float *x_out,
-                          const uint16_t *lnw, const uint16_t *lnb, uint16_t *x_prev, const uint16_t *const *mixp,
-                          uint16_t *out) {
-    const int D = d.D, tid = threadIdx.x;
+                                          const uint16_t *x_in, const uint16_t *ln0w, const uint16_t *ln0b, float *x_out,
+                                          const uint16_t *lnw, const uint16_t *lnb, uint16_t *x_prev, const uint16_t *const *mixp,
+                                          uint16_t *out) {
+    constexpr int NG = kMaxE / 4;
+    const int D = d.D, tid = threadIdx.x, D4 = D >> 2;
     const float invD = 1.f / (float)D;
-    float x[kMaxE];
+    const long rb = (long)b * D;
+    float4 x[NG];
+    uint2 wln[NG], bln[NG], xp[NG], mx[NMIX > 0 ? NMIX : 1][NG];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxE; i++) {
-        const int c = tid + kDecThreads * i;
-        x[i] = 0.f;
-        if (c < D) {
-            if (x_in) {
-                x[i] = bf2f(x_in[(long)b * D + c]);
-            } else {
-                float a = x_old[(long)b * D + c];
-                for (int p = 0; p < nparts; p++) a += parts[((long)p * kRows + b) * D + c];
-                x[i] = a;
+    for (int i = 0; i < NG; i++) {
+        const int g = tid + kDecThreads * i;
+        x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < D4) {
+            const int c = 4 * g;
+            wln[i] = *reinterpret_cast<const uint2 *>(lnw + c);
+            bln[i] = *reinterpret_cast<const uint2 *>(lnb + c);
+            if (NMIX > 0) {
+                xp[i] = *reinterpret_cast<const uint2 *>(x_prev + rb + c);
+#pragma unroll
+                for (int j = 0; j < NMIX; j++) mx[j][i] = *reinterpret_cast<const uint2 *>(mixp[j] + c);
             }
-            s += x[i];
+            if (x_in) {
+                x[i] = bf4(*reinterpret_cast<const uint2 *>(x_in + rb + c));
+            } else {
+                float4 acc = *reinterpret_cast<const float4 *>(x_old + rb + c);
+                for (int p0 = 0; p0 < nparts; p0 += 8) {
+                    float4 t[8];
+#pragma unroll
+                    for (int p = 0; p < 8; p++)
+                        t[p] = p0 + p < nparts ? *reinterpret_cast<const float4 *>(parts + ((long)(p0 + p) * kRows + b) * D + c)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int p = 0; p < 8; p++) acc = add4(acc, t[p]);
+                }
+                x[i] = acc;
+            }
+            s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
         }
     }
-    if (x_in) {  // pre_norm of the first block (rwkv_s2s_single_ffn.py:253-254)
-        const float mean = block_sum256(s, red) * invD;
+    auto sqdev = [&](float mean) {
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxE; i++) {
-            const int c = tid + kDecThreads * i;
-            if (c < D) q += (x[i] - mean) * (x[i] - mean);
+        for (int i = 0; i < NG; i++) {
+            if (tid + kDecThreads * i < D4) {
+                const float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, e = x[i].w - mean;
+                q += (a * a + bb * bb) + (c * c + e * e);
+            }
         }
-        const float rstd = rsqrtf(block_sum256(q, red) * invD + d.ln_eps);
+        return q;
+    };
+    if (x_in) {  // pre_norm of the first block (rwkv_s2s_single_ffn.py:253-254); its output is a bf16 tensor
+        const float mean = block_sum256(s, red) * invD;
+        const float rstd = rsqrtf(block_sum256(sqdev(mean), red) * invD + d.ln_eps);
         s = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxE; i++) {
-            const int c = tid + kDecThreads * i;
-            if (c < D) {
-                x[i] = bf2f(f2bf((x[i] - mean) * rstd * bf2f(ln0w[c]) + bf2f(ln0b[c])));
-                s += x[i];
+        for (int i = 0; i < NG; i++) {
+            const int g = tid + kDecThreads * i;
+            if (g < D4) {
+                const float4 w = bf4(*reinterpret_cast<const uint2 *>(ln0w + 4 * g)), bi = bf4(*reinterpret_cast<const uint2 *>(ln0b + 4 * g));
+                const uint32_t lo = cvt_pk((x[i].x - mean) * rstd * w.x + bi.x, (x[i].y - mean) * rstd * w.y + bi.y);
+                const uint32_t hi = cvt_pk((x[i].z - mean) * rstd * w.z + bi.z, (x[i].w - mean) * rstd * w.w + bi.w);
+                x[i] = bf4(make_uint2(lo, hi));
+                s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
             }
         }
     }
     const float mean = block_sum256(s, red) * invD;
-    float q = 0.f;
+    const float rstd = rsqrtf(block_sum256(sqdev(mean), red) * invD + d.ln_eps);
 #pragma unroll
-    for (int i = 0; i < kMaxE; i++) {
-        const int c = tid + kDecThreads * i;
-        if (c < D) q += (x[i] - mean) * (x[i] - mean);
-    }
-    const float rstd = rsqrtf(block_sum256(q, red) * invD + d.ln_eps);
-#pragma unroll
-    for (int i = 0; i < kMaxE; i++) {
-        const int c = tid + kDecThreads * i;
-        if (c < D) {
-            if (x_out) x_out[(long)b * D + c] = x[i];
-            const uint16_t hb = f2bf((x[i] - mean) * rstd * bf2f(lnw[c]) + bf2f(lnb[c]));
+    for (int i = 0; i < NG; i++) {
+        const int g = tid + kDecThreads * i;
+        if (g < D4) {
+            const int c = 4 * g;
+            if (x_out) *reinterpret_cast<float4 *>(x_out + rb + c) = x[i];
+            const float4 w = bf4(wln[i]), bi = bf4(bln[i]);
+            const uint2 hb = make_uint2(cvt_pk((x[i].x - mean) * rstd * w.x + bi.x, (x[i].y - mean) * rstd * w.y + bi.y),
+                                        cvt_pk((x[i].z - mean) * rstd * w.z + bi.z, (x[i].w - mean) * rstd * w.w + bi.w));
             if (NMIX == 0) {
-                out[(long)b * D + c] = hb;
+                *reinterpret_cast<uint2 *>(out + rb + c) = hb;
             } else {
-                const float h = bf2f(hb);
-                const float xx = bf2f(x_prev[(long)b * D + c]) - h;
+                const float4 h = bf4(hb), pv = bf4(xp[i]);
+                const float4 xx = make_float4(pv.x - h.x, pv.y - h.y, pv.z - h.z, pv.w - h.w);
 #pragma unroll
-                for (int j = 0; j < NMIX; j++)
-                    out[((long)j * kRows + b) * D + c] = f2bf(fmaf(xx, bf2f(mixp[j][c]), h));
-                x_prev[(long)b * D + c] = hb;
+                for (int j = 0; j < NMIX; j++) {
+                    const float4 m = bf4(mx[j][i]);
+                    *reinterpret_cast<uint2 *>(out + ((long)j * kRows + b) * D + c) =
+                        make_uint2(cvt_pk(fmaf(xx.x, m.x, h.x), fmaf(xx.y, m.y, h.y)), cvt_pk(fmaf(xx.z, m.z, h.z), fmaf(xx.w, m.w, h.w)));
+                }
+                *reinterpret_cast<uint2 *>(x_prev + rb + c) = hb;
             }
         }
     }
@@ -197,45 +242,27 @@ __device__ __forceinline__ void row_phase(const DecodeDesc &d, int b, float *red
 // ---------------------------------------------------------------------------------------------------------------------
 struct GemvSeg {
     const uint16_t *W;   // [ncols][K]
-    const uint16_t *X;   // bf16 [32][K] (XMODE 0)
+    const uint16_t *X;   // bf16 [32][K]
     int ntiles;          // 32-column tiles (the last one may be partial: ncols)
     int ncols;
 };
 
-template <int XMODE>  // 0: X is bf16; 1: X = relu(sum of nxp fp32 partials [nxp][32][K])^2
-__device__ __forceinline__ bf16x8 load_x(const uint16_t *xb, const float *xf, int nxp, long xpstride, long off) {
-    if constexpr (XMODE == 0) {
-        return *reinterpret_cast<const bf16x8 *>(xb + off);
-    } else {
-        float4 a = *reinterpret_cast<const float4 *>(xf + off), b = *reinterpret_cast<const float4 *>(xf + off + 4);
-        for (int p = 1; p < nxp; p++) {
-            const float4 a2 = *reinterpret_cast<const float4 *>(xf + p * xpstride + off);
-            const float4 b2 = *reinterpret_cast<const float4 *>(xf + p * xpstride + off + 4);
-            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
-            b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
-        }
-        auto rs = [](float v) { v = fmaxf(v, 0.f); return v * v; };
-        const uint4 o = make_uint4(cvt_pk(rs(a.x), rs(a.y)), cvt_pk(rs(a.z), rs(a.w)), cvt_pk(rs(b.x), rs(b.y)), cvt_pk(rs(b.z), rs(b.w)));
-        return __builtin_bit_cast(bf16x8, o);
-    }
-}
-
-template <int XMODE, int KSTEPS>
-__device__ __forceinline__ void gemv_steps(f32x16 &acc, const uint16_t *wp, const uint16_t *xb, const float *xf, int nxp,
-                                           long xpstride, long xoff) {
+template <int KSTEPS>
+__device__ __forceinline__ void gemv_steps(f32x16 &acc, const uint16_t *wp, const uint16_t *xp) {
     bf16x8 a[KSTEPS], b[KSTEPS];
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) {
         a[i] = *reinterpret_cast<const bf16x8 *>(wp + 16 * i);
-        b[i] = load_x<XMODE>(xb, xf, nxp, xpstride, xoff + 16 * i);
+        b[i] = *reinterpret_cast<const bf16x8 *>(xp + 16 * i);
     }
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
 }
 
-template <int XMODE, int NSEG>
-__device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, const GemvSeg (&segs)[NSEG], int K, int KS, const float *xf,
-                           int nxp, float *out, int ldo, const uint16_t *bias) {
+// OUTMODE 0: fp32 partials out[ks][n][col] (+ bias);  1: KS = 1 and out is bf16 [n][col] = relu(.)^2 (the channel-mix key)
+template <int OUTMODE, int NSEG>
+__device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, const GemvSeg (&segs)[NSEG], int K, int KS, void *out_,
+                                           int ldo, const uint16_t *bias) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int ntiles = 0;
 #pragma unroll
@@ -264,12 +291,12 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
         const int mrow = min(c0 + (lane & 31), sg.ncols - 1);
         const int kbeg = ks * (K / KS) + wave * kw + (lane >> 5) * 8;
         const uint16_t *wp = sg.W + (long)mrow * K + kbeg;
-        const long xoff = (long)nrow * K + kbeg;
+        const uint16_t *xp = sg.X + (long)nrow * K + kbeg;
         f32x16 acc = zero16();
         int k = 0;
-        for (; k + 128 <= kw; k += 128) gemv_steps<XMODE, 8>(acc, wp + k, sg.X, xf, nxp, (long)kRows * K, xoff + k);
-        for (; k + 32 <= kw; k += 32) gemv_steps<XMODE, 2>(acc, wp + k, sg.X, xf, nxp, (long)kRows * K, xoff + k);
-        for (; k + 16 <= kw; k += 16) gemv_steps<XMODE, 1>(acc, wp + k, sg.X, xf, nxp, (long)kRows * K, xoff + k);
+        for (; k + 128 <= kw; k += 128) gemv_steps<8>(acc, wp + k, xp + k);
+        for (; k + 32 <= kw; k += 32) gemv_steps<2>(acc, wp + k, xp + k);
+        for (; k + 16 <= kw; k += 16) gemv_steps<1>(acc, wp + k, xp + k);
         __syncthreads();  // part[] of the previous item has been consumed
         if (wave > 0) {
 #pragma unroll
@@ -278,7 +305,8 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
         __syncthreads();
         if (wave == 0) {
             const int n = lane & 31;
-            float *op = out + ((long)ks * kRows + n) * ldo + col_base + c0;
+            float *op = (float *)out_ + ((long)ks * kRows + n) * ldo + col_base + c0;
+            uint16_t *ob = (uint16_t *)out_ + (long)n * ldo + col_base + c0;
             const bool vec = (ldo & 3) == 0 && ((col_base + c0) & 3) == 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -289,7 +317,14 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
                     v[i] = acc[4 * j + i] + sm.part[0][lane][4 * j + i] + sm.part[1][lane][4 * j + i] + sm.part[2][lane][4 * j + i];
                     if (bias && c0 + c + i < sg.ncols) v[i] += bf2f(bias[col_base + c0 + c + i]);
                 }
-                if (n < d.B) {
+                if (OUTMODE == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        v[i] = fmaxf(v[i], 0.f);
+                        v[i] *= v[i];
+                    }
+                    if (n < d.B) *reinterpret_cast<uint2 *>(ob + c) = make_uint2(cvt_pk(v[0], v[1]), cvt_pk(v[2], v[3]));  // F % 64 == 0
+                } else if (n < d.B) {
                     if (vec && c0 + c + 3 < sg.ncols) {
                         *reinterpret_cast<float4 *>(op + c) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
@@ -304,9 +339,36 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// head phase: everything between the projections and the output projection, for one head and two sequences
+// head phase: everything between the projections and the output projection, for one head and two sequences.
+// What does not depend on this step's activations -- the state rows, the first 64 ranks of the up-projection rows, the
+// per-channel parameters -- is requested before the partial sums are read, so the phase pays two load latencies, not five.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ void head_phase(const DecodeDesc &d, DecSmem &smu, int l, const void *const *lp) {
+__device__ __forceinline__ float dot8(const uint4 w8, const float *hp, float acc) {
+    acc = fmaf(__uint_as_float(w8.x << 16), hp[0], acc);
+    acc = fmaf(__uint_as_float(w8.x & 0xffff0000u), hp[1], acc);
+    acc = fmaf(__uint_as_float(w8.y << 16), hp[2], acc);
+    acc = fmaf(__uint_as_float(w8.y & 0xffff0000u), hp[3], acc);
+    acc = fmaf(__uint_as_float(w8.z << 16), hp[4], acc);
+    acc = fmaf(__uint_as_float(w8.z & 0xffff0000u), hp[5], acc);
+    acc = fmaf(__uint_as_float(w8.w << 16), hp[6], acc);
+    acc = fmaf(__uint_as_float(w8.w & 0xffff0000u), hp[7], acc);
+    return acc;
+}
+// rest of an up-projection row beyond the prefetched ranks
+__device__ __forceinline__ float up_tail(const uint16_t *wr, int done, int R, const float *hid, float acc) {
+    for (int r0 = done; r0 < R; r0 += 64) {
+        uint4 w8[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) w8[j] = r0 + 8 * j < R ? *reinterpret_cast<const uint4 *>(wr + r0 + 8 * j) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (r0 + 8 * j < R) acc = dot8(w8[j], hid + r0 + 8 * j, acc);
+    }
+    return acc;
+}
+
+template <class LP>
+__device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, int l, const LP &lp) {
     HeadSm &sm = smu.h;
     const int tid = threadIdx.x, D = d.D, H = d.H;
     const int N2 = 3 * D + d.Rw + d.Ra + d.Rv + d.Rg;       // columns of the qkv/low-rank partials
@@ -321,59 +383,103 @@ __device__ void head_phase(const DecodeDesc &d, DecSmem &smu, int l, const void 
     const uint16_t *gnw = (const uint16_t *)lp[DP_GNW], *gnb = (const uint16_t *)lp[DP_GNB];
     float *kv_all = (float *)lp[DP_ATT_KV];
     const bool first = l == 0;
+    // thread roles: B (up projections): wave = (sequence, half), lane = channel; C/E: waves 0,1 = sequence, lane = channel;
+    // D (state): 128 threads per sequence, 16 lanes x float4 = one state row, 8 rows per pass
+    const int cB = tid & 63, bbB = (tid >> 6) & 1, half = tid >> 7;
+    const int bbD = tid >> 7, tt = tid & 127, k4 = (tt & 15) * 4, vr = tt >> 4;
+    const int total = 2 * Rtot + 3 * 2 * 64;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int h = item % H, bp = item / H;
         const int b0 = 2 * bp;
-        __syncthreads();  // LDS of the previous item is free
-        // A: low-rank hidden vectors (activation applied to the summed partials) and this head's r, k, v
-        for (int idx = tid; idx < 2 * Rtot; idx += kDecThreads) {
-            const int bb = idx / Rtot, r = idx - bb * Rtot;
-            const int b = min(b0 + bb, d.B - 1);
-            float s = 0.f;
-            for (int p = 0; p < d.ks_qkv; p++) s += d.p_qkv[((long)p * kRows + b) * N2 + 3 * D + r];
-            if (r < oA) s = tanh_(s);
-            else if (r >= oG) s = sigm(s);
-            sm.hid[bb][r] = s;
+        const int chB = h * 64 + cB;
+        // ---- requests that do not wait for this step's activations
+        const uint16_t *rowA = half == 0 ? w2 + (long)chB * d.Rw : v2w + (long)chB * d.Rv;
+        const uint16_t *rowB = half == 0 ? a2 + (long)chB * d.Ra : g2 + (long)chB * d.Rg;
+        const int RA = half == 0 ? d.Rw : (first ? 0 : d.Rv), RB = half == 0 ? d.Ra : d.Rg;
+        uint4 wa[8], wb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            wa[j] = 8 * j < RA ? *reinterpret_cast<const uint4 *>(rowA + 8 * j) : make_uint4(0, 0, 0, 0);
+            wb[j] = 8 * j < RB ? *reinterpret_cast<const uint4 *>(rowB + 8 * j) : make_uint4(0, 0, 0, 0);
         }
-        for (int idx = tid; idx < 3 * 2 * 64; idx += kDecThreads) {
-            const int which = idx / 128, bb = (idx >> 6) & 1, c = idx & 63;
-            const int b = min(b0 + bb, d.B - 1);
-            float s = 0.f;
-            for (int p = 0; p < d.ks_qkv; p++) s += d.p_qkv[((long)p * kRows + b) * N2 + which * D + h * 64 + c];
-            sm.rkv[which][bb][c] = s;
+        float biasA = 0.f, biasB = 0.f;
+        if (half == 0) {
+            biasA = bf2f(w0[chB]);
+            biasB = bf2f(a0[chB]);
+        } else if (!first) {
+            biasA = bf2f(v0[chB]);
         }
-        __syncthreads();
-        // B: up projections for the 64 channels of the head.  wave = (sequence, half): half 0 -> w and a, half 1 -> v and g
+        const bool liveD = b0 + bbD < d.B;
+        float *S = kv_all + ((long)min(b0 + bbD, d.B - 1) * H + h) * 64 * 64;
+        float4 st[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) st[i] = *reinterpret_cast<const float4 *>(S + (vr + 8 * i) * 64 + k4);
+        // per-channel parameters of steps C and E (waves 0,1)
+        const int chC = h * 64 + (tid & 63);
+        const float p_kk = bf2f(k_k[chC]), p_ka = bf2f(k_a[chC]), p_rk = bf2f(r_k[chC]), p_gw = bf2f(gnw[chC]), p_gb = bf2f(gnb[chC]);
+        const float p_vf = first ? 0.f : d.vfirst[(long)min(b0 + ((tid >> 6) & 1), d.B - 1) * D + chC];
+        // ---- A: low-rank hidden vectors (activation applied to the summed partials) and this head's r, k, v
         {
-            const int c = tid & 63, bb = (tid >> 6) & 1, half = tid >> 7;
-            const int ch = h * 64 + c;
-            auto up = [&](const uint16_t *W2, int R, int off) {
-                float acc = 0.f;
-                const uint16_t *wr = W2 + (long)ch * R;
-                for (int r = 0; r < R; r += 8) {
-                    const uint4 w8 = *reinterpret_cast<const uint4 *>(wr + r);
-                    const float *hp = &sm.hid[bb][off + r];
-                    acc = fmaf(__uint_as_float(w8.x << 16), hp[0], acc);
-                    acc = fmaf(__uint_as_float(w8.x & 0xffff0000u), hp[1], acc);
-                    acc = fmaf(__uint_as_float(w8.y << 16), hp[2], acc);
-                    acc = fmaf(__uint_as_float(w8.y & 0xffff0000u), hp[3], acc);
-                    acc = fmaf(__uint_as_float(w8.z << 16), hp[4], acc);
-                    acc = fmaf(__uint_as_float(w8.z & 0xffff0000u), hp[5], acc);
-                    acc = fmaf(__uint_as_float(w8.w << 16), hp[6], acc);
-                    acc = fmaf(__uint_as_float(w8.w & 0xffff0000u), hp[7], acc);
+            long addr[6];
+            float acc[6];
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int idx = tid + kDecThreads * it;
+                acc[it] = 0.f;
+                addr[it] = -1;
+                if (idx < 2 * Rtot) {
+                    const int bb = idx / Rtot, r = idx - bb * Rtot;
+                    addr[it] = (long)min(b0 + bb, d.B - 1) * N2 + 3 * D + r;
+                } else if (idx < total) {
+                    const int e = idx - 2 * Rtot, which = e >> 7, bb = (e >> 6) & 1, c = e & 63;
+                    addr[it] = (long)min(b0 + bb, d.B - 1) * N2 + which * D + h * 64 + c;
                 }
-                return acc;
-            };
-            if (half == 0) {
-                sm.up[0][bb][c] = up(w2, d.Rw, 0) + bf2f(w0[ch]);
-                sm.up[1][bb][c] = up(a2, d.Ra, oA) + bf2f(a0[ch]);
-            } else {
-                sm.up[2][bb][c] = first ? 0.f : up(v2w, d.Rv, oV) + bf2f(v0[ch]);
-                sm.up[3][bb][c] = up(g2, d.Rg, oG);
+            }
+            for (int p = 0; p < d.ks_qkv; p += 2) {   // two splits per round of loads
+                const float *pp = d.p_qkv + (long)p * kRows * N2;
+                const bool two = p + 1 < d.ks_qkv;
+                float t[6], u[6];
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    t[it] = addr[it] >= 0 ? pp[addr[it]] : 0.f;
+                    u[it] = addr[it] >= 0 && two ? pp[(long)kRows * N2 + addr[it]] : 0.f;
+                }
+#pragma unroll
+                for (int it = 0; it < 6; it++) acc[it] += t[it] + u[it];
+            }
+            __syncthreads();  // LDS of the previous item is free
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int idx = tid + kDecThreads * it;
+                if (idx < 2 * Rtot) {
+                    const int bb = idx / Rtot, r = idx - bb * Rtot;
+                    float v = acc[it];
+                    if (r < oA) v = tanh_(v);
+                    else if (r >= oG) v = sigm(v);
+                    sm.hid[bb][r] = v;
+                } else if (idx < total) {
+                    const int e = idx - 2 * Rtot;
+                    sm.rkv[e >> 7][(e >> 6) & 1][e & 63] = acc[it];
+                }
             }
         }
         __syncthreads();
-        // C: decay, gates, value residual, kk normalisation (rwkv_s2s_single_ffn.py:493-500); wave = sequence, lane = channel
+        // ---- B: up projections for the 64 channels of the head: half 0 -> w and a, half 1 -> v and g
+        {
+            const float *hA = &sm.hid[bbB][half == 0 ? 0 : oV], *hB = &sm.hid[bbB][half == 0 ? oA : oG];
+            float accA = biasA, accB = biasB;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (8 * j < RA) accA = dot8(wa[j], hA + 8 * j, accA);
+                if (8 * j < RB) accB = dot8(wb[j], hB + 8 * j, accB);
+            }
+            accA = up_tail(rowA, 64, RA, hA, accA);
+            accB = up_tail(rowB, 64, RB, hB, accB);
+            sm.up[half == 0 ? 0 : 2][bbB][cB] = accA;
+            sm.up[half == 0 ? 1 : 3][bbB][cB] = accB;
+        }
+        __syncthreads();
+        // ---- C: decay, gates, value residual, kk normalisation (rwkv_s2s_single_ffn.py:493-500)
         if (tid < 128) {
             const int c = tid & 63, bb = tid >> 6;
             const int b = min(b0 + bb, d.B - 1), ch = h * 64 + c;
@@ -384,13 +490,13 @@ __device__ void head_phase(const DecodeDesc &d, DecSmem &smu, int l, const void 
             if (first) {
                 if (b0 + bb < d.B) d.vfirst[(long)b * D + ch] = v;
             } else {
-                v = fmaf(d.vfirst[(long)b * D + ch] - v, sigm(sm.up[2][bb][c]), v);
+                v = fmaf(p_vf - v, sigm(sm.up[2][bb][c]), v);
             }
-            const float kkr = k * bf2f(k_k[ch]);
+            const float kkr = k * p_kk;
             const float ss = wave_sum(kkr * kkr);
             const float kk = kkr / fmaxf(sqrtf(ss), 1e-12f);
-            const float k2 = k * fmaf(a - 1.f, bf2f(k_a[ch]), 1.f);
-            const float dot = wave_sum(r * k2 * bf2f(r_k[ch]));
+            const float k2 = k * fmaf(a - 1.f, p_ka, 1.f);
+            const float dot = wave_sum(r * k2 * p_rk);
             sm.vec[0][bb][c] = r;
             sm.vec[1][bb][c] = __expf(-__expf(w));
             sm.vec[2][bb][c] = k2;
@@ -400,36 +506,28 @@ __device__ void head_phase(const DecodeDesc &d, DecSmem &smu, int l, const void 
             if (c == 0) sm.dot[bb] = dot;
         }
         __syncthreads();
-        // D: state update in place.  128 threads per sequence; 16 lanes x float4 = one state row (value index), 8 rows per pass
+        // ---- D: state update in place
         {
-            const int bb = tid >> 7, tt = tid & 127;
-            const int k4 = (tt & 15) * 4, vr = tt >> 4;
-            if (b0 + bb < d.B) {
-                float *S = kv_all + ((long)(b0 + bb) * H + h) * 64 * 64;
-                float4 st[8];
+            const float4 rr = *reinterpret_cast<const float4 *>(&sm.vec[0][bbD][k4]);
+            const float4 dc = *reinterpret_cast<const float4 *>(&sm.vec[1][bbD][k4]);
+            const float4 kk = *reinterpret_cast<const float4 *>(&sm.vec[2][bbD][k4]);
+            const float4 aa = *reinterpret_cast<const float4 *>(&sm.vec[4][bbD][k4]);
+            const float4 bv = *reinterpret_cast<const float4 *>(&sm.vec[5][bbD][k4]);
 #pragma unroll
-                for (int i = 0; i < 8; i++) st[i] = *reinterpret_cast<const float4 *>(S + (vr + 8 * i) * 64 + k4);
-                const float4 rr = *reinterpret_cast<const float4 *>(&sm.vec[0][bb][k4]);
-                const float4 dc = *reinterpret_cast<const float4 *>(&sm.vec[1][bb][k4]);
-                const float4 kk = *reinterpret_cast<const float4 *>(&sm.vec[2][bb][k4]);
-                const float4 aa = *reinterpret_cast<const float4 *>(&sm.vec[4][bb][k4]);
-                const float4 bv = *reinterpret_cast<const float4 *>(&sm.vec[5][bb][k4]);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float vv = sm.vec[3][bb][vr + 8 * i];
-                    const float sa = sum16(st[i].x * aa.x + st[i].y * aa.y + st[i].z * aa.z + st[i].w * aa.w);
-                    st[i].x = fmaf(st[i].x, dc.x, fmaf(sa, bv.x, vv * kk.x));
-                    st[i].y = fmaf(st[i].y, dc.y, fmaf(sa, bv.y, vv * kk.y));
-                    st[i].z = fmaf(st[i].z, dc.z, fmaf(sa, bv.z, vv * kk.z));
-                    st[i].w = fmaf(st[i].w, dc.w, fmaf(sa, bv.w, vv * kk.w));
-                    *reinterpret_cast<float4 *>(S + (vr + 8 * i) * 64 + k4) = st[i];
-                    const float y = sum16(st[i].x * rr.x + st[i].y * rr.y + st[i].z * rr.z + st[i].w * rr.w);
-                    if ((tt & 15) == 0) sm.y[bb][vr + 8 * i] = y;
-                }
+            for (int i = 0; i < 8; i++) {
+                const float vv = sm.vec[3][bbD][vr + 8 * i];
+                const float sa = sum16(st[i].x * aa.x + st[i].y * aa.y + st[i].z * aa.z + st[i].w * aa.w);
+                st[i].x = fmaf(st[i].x, dc.x, fmaf(sa, bv.x, vv * kk.x));
+                st[i].y = fmaf(st[i].y, dc.y, fmaf(sa, bv.y, vv * kk.y));
+                st[i].z = fmaf(st[i].z, dc.z, fmaf(sa, bv.z, vv * kk.z));
+                st[i].w = fmaf(st[i].w, dc.w, fmaf(sa, bv.w, vv * kk.w));
+                if (liveD) *reinterpret_cast<float4 *>(S + (vr + 8 * i) * 64 + k4) = st[i];
+                const float y = sum16(st[i].x * rr.x + st[i].y * rr.y + st[i].z * rr.z + st[i].w * rr.w);
+                if ((tt & 15) == 0) sm.y[bbD][vr + 8 * i] = y;
             }
         }
         __syncthreads();
-        // E: GroupNorm over the head, bonus, gate (rwkv_s2s_single_ffn.py:504-505)
+        // ---- E: GroupNorm over the head, bonus, gate (rwkv_s2s_single_ffn.py:504-505)
         if (tid < 128) {
             const int c = tid & 63, bb = tid >> 6;
             const int ch = h * 64 + c;
@@ -437,14 +535,21 @@ __device__ void head_phase(const DecodeDesc &d, DecSmem &smu, int l, const void 
             const float mean = wave_sum(y) * (1.f / 64.f);
             const float dv = y - mean;
             const float rstd = rsqrtf(wave_sum(dv * dv) * (1.f / 64.f) + d.gn_eps);
-            const float o = (fmaf(dv * rstd, bf2f(gnw[ch]), bf2f(gnb[ch])) + sm.dot[bb] * sm.vec[3][bb][c]) * sm.up[3][bb][c];
+            const float o = (fmaf(dv * rstd, p_gw, p_gb) + sm.dot[bb] * sm.vec[3][bb][c]) * sm.up[3][bb][c];
             if (b0 + bb < d.B) d.yg[(long)(b0 + bb) * D + ch] = f2bf(o);
         }
     }
 }
 
-__device__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, int ph) {
-    const void *const *lp = d.tbl + (long)(l < d.L ? l : 0) * DP_COUNT;
+// the layer's pointers: a row of the device table.  (Passing the 38 pointers as kernel arguments instead -- no dependent
+// table load at the head of a phase -- measured SLOWER: 0.5-1.5 us per phase for the 300 bytes of extra kernarg.)
+struct TblRow {
+    const void *const *base;
+    __device__ __forceinline__ const void *operator[](int i) const { return base[i]; }
+};
+
+template <class LP>
+__device__ __forceinline__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, int ph, const LP &lp) {
     const int D = d.D;
     if (l == d.L) {  // tail: last residual add + model norm, then the head
         if (ph == 0) {
@@ -453,7 +558,7 @@ __device__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, int ph) {
                              nullptr, d.hfin);
         } else {
             const GemvSeg seg[1] = {{d.head_w, d.hfin, (d.V + 31) / 32, d.V}};
-            gemv_phase<0, 1>(d, sm, seg, D, 1, nullptr, 0, d.logits, d.V, d.head_b);
+            gemv_phase<0, 1>(d, sm, seg, D, 1, d.logits, d.V, d.head_b);
         }
         return;
     }
@@ -477,7 +582,7 @@ __device__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, int ph) {
                                  {(const uint16_t *)lp[DP_A1], d.mixed + 4 * RS, d.Ra / 32, d.Ra},
                                  {(const uint16_t *)(l == 0 ? lp[DP_A1] : lp[DP_V1]), d.mixed + 3 * RS, l == 0 ? 0 : d.Rv / 32, d.Rv},
                                  {(const uint16_t *)lp[DP_G1], d.mixed + 5 * RS, d.Rg / 32, d.Rg}};
-        gemv_phase<0, 7>(d, sm, segs, D, d.ks_qkv, nullptr, 0, d.p_qkv, 3 * D + d.Rw + d.Ra + d.Rv + d.Rg, nullptr);
+        gemv_phase<0, 7>(d, sm, segs, D, d.ks_qkv, d.p_qkv, 3 * D + d.Rw + d.Ra + d.Rv + d.Rg, nullptr);
         break;
     }
     case 2:
@@ -485,7 +590,7 @@ __device__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, int ph) {
         break;
     case 3: {
         const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WO], d.yg, D / 32, D}};
-        gemv_phase<0, 1>(d, sm, seg, D, d.ks_o, nullptr, 0, d.p_att, D, nullptr);
+        gemv_phase<0, 1>(d, sm, seg, D, d.ks_o, d.p_att, D, nullptr);
         break;
     }
     case 4: {
@@ -497,66 +602,67 @@ __device__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, int ph) {
     }
     case 5: {
         const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WKEY], d.kx, d.F / 32, d.F}};
-        gemv_phase<0, 1>(d, sm, seg, D, d.ks_key, nullptr, 0, d.p_key, d.F, nullptr);
+        gemv_phase<1, 1>(d, sm, seg, D, 1, d.kact, d.F, nullptr);
         break;
     }
     default: {
-        const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WVAL], nullptr, D / 32, D}};
-        gemv_phase<1, 1>(d, sm, seg, d.F, d.ks_val, d.p_key, d.ks_key, d.p_val, D, nullptr);
+        const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WVAL], d.kact, D / 32, D}};
+        gemv_phase<0, 1>(d, sm, seg, d.F, d.ks_val, d.p_val, D, nullptr);
         break;
     }
     }
 }
 
-__global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDesc d) {
+// mode 1: the step; mode 2 (debug): the barriers alone
+__global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDesc d, int mode) {
     __shared__ DecSmem sm;
     unsigned target = 0;
-    for (int l = 0; l < d.L; l++) {
-        for (int ph = 0; ph < 7; ph++) {
-            run_phase(d, sm, l, ph);
-            grid_barrier(d.bar, target, gridDim.x);
-        }
+    const int nphase = 7 * d.L + 2;
+    for (int idx = 0; idx < nphase; idx++) {   // one call site: the phase bodies are inlined once
+        const int l = idx / 7, ph = idx - 7 * l;
+        if (mode == 1) run_phase(d, sm, l, ph, TblRow{d.tbl + (long)(l < d.L ? l : 0) * DP_COUNT});
+        if (idx + 1 < nphase) grid_barrier(d.bar, target, gridDim.x, mode);
     }
-    run_phase(d, sm, d.L, 0);
-    grid_barrier(d.bar, target, gridDim.x);
-    run_phase(d, sm, d.L, 1);
 }
 
+// (Reading the descriptor from device memory through a 16-byte kernel argument instead was measured 3 % slower in the
+// replayed graph: one more dependent load at the head of every phase.)
 __global__ __launch_bounds__(kDecThreads) void decode_phase_kernel(DecodeDesc d, int l, int ph) {
     __shared__ DecSmem sm;
-    run_phase(d, sm, l, ph);
+    run_phase(d, sm, l, ph, TblRow{d.tbl + (long)(l < d.L ? l : 0) * DP_COUNT});
 }
 
-// largest per-workgroup K work is minimised; ties go to the smaller split (fewer partials to sum)
+// K split of a GEMV phase: minimise the work of the busiest workgroup, where an item costs its K range plus a fixed
+// latency worth ~256 k (measured: a 16-way split of the r/k/v sweep -- 7 short items per workgroup -- took 13 us, the 2-way
+// split 5 us); ties go to the smaller split (fewer partials to sum)
 int pick_ks(int ntiles, int K, int grid) {
-    int best = 1;
+    int best = 0;
     long best_cost = -1;
     for (int ks = 1; ks <= 16; ks *= 2) {
         if (K % (ks * 4 * 16) != 0) continue;
-        const long cost = (long)((ntiles * ks + grid - 1) / grid) * (K / ks);
+        const long cost = (long)((ntiles * ks + grid - 1) / grid) * (K / ks + 256);
         if (best_cost < 0 || cost < best_cost) {
             best = ks;
             best_cost = cost;
         }
     }
-    return best_cost < 0 ? 0 : best;
+    return best;
 }
 
 constexpr int kGrid = 256;
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t xa, xb, vfirst, p_qkv, p_att, p_key, p_val, mixed, yg, kx, hfin, bar, total;
-    int ks_qkv, ks_o, ks_key, ks_val;
+    size_t xa, xb, vfirst, p_qkv, p_att, kact, p_val, mixed, yg, kx, hfin, bar, total;
+    int ks_qkv, ks_o, ks_val;
 };
 
 bool ws_layout(int D, int F, int Rw, int Ra, int Rv, int Rg, WsLayout &w) {
     const int N2 = 3 * D + Rw + Ra + Rv + Rg;
     w.ks_qkv = pick_ks(N2 / 32, D, kGrid);
     w.ks_o = pick_ks(D / 32, D, kGrid);
-    w.ks_key = pick_ks(F / 32, D, kGrid);
     w.ks_val = pick_ks(D / 32, F, kGrid);
-    if (!w.ks_qkv || !w.ks_o || !w.ks_key || !w.ks_val) return false;
+    if (!w.ks_qkv || !w.ks_o || !w.ks_val || D % 64 != 0) return false;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
     w.bar = take(256);   // first: [0] arrival counter, [1] timeout flag (the host reads byte offset 4)
@@ -565,7 +671,7 @@ bool ws_layout(int D, int F, int Rw, int Ra, int Rv, int Rg, WsLayout &w) {
     w.vfirst = take((size_t)kRows * D * 4);
     w.p_qkv = take((size_t)w.ks_qkv * kRows * N2 * 4);
     w.p_att = take((size_t)w.ks_o * kRows * D * 4);
-    w.p_key = take((size_t)w.ks_key * kRows * F * 4);
+    w.kact = take((size_t)kRows * F * 2);
     w.p_val = take((size_t)w.ks_val * kRows * D * 4);
     w.mixed = take((size_t)6 * kRows * D * 2);
     w.yg = take((size_t)kRows * D * 2);
@@ -600,7 +706,7 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
     DecodeDesc d;
     d.B = B; d.D = D; d.H = H; d.L = L; d.F = F; d.V = V;
     d.Rw = Rw; d.Ra = Ra; d.Rv = Rv; d.Rg = Rg;
-    d.ks_qkv = w.ks_qkv; d.ks_o = w.ks_o; d.ks_key = w.ks_key; d.ks_val = w.ks_val;
+    d.ks_qkv = w.ks_qkv; d.ks_o = w.ks_o; d.ks_val = w.ks_val;
     d.ln_eps = ln_eps; d.gn_eps = gn_eps;
     d.tbl = layer_tbl;
     d.x_in = (const uint16_t *)x_in;
@@ -608,7 +714,7 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
     d.head_w = (const uint16_t *)head_w; d.head_b = (const uint16_t *)head_b;
     d.logits = logits;
     d.xa = (float *)(ws + w.xa); d.xb = (float *)(ws + w.xb); d.vfirst = (float *)(ws + w.vfirst);
-    d.p_qkv = (float *)(ws + w.p_qkv); d.p_att = (float *)(ws + w.p_att); d.p_key = (float *)(ws + w.p_key);
+    d.p_qkv = (float *)(ws + w.p_qkv); d.p_att = (float *)(ws + w.p_att); d.kact = (uint16_t *)(ws + w.kact);
     d.p_val = (float *)(ws + w.p_val);
     d.mixed = (uint16_t *)(ws + w.mixed); d.yg = (uint16_t *)(ws + w.yg); d.kx = (uint16_t *)(ws + w.kx);
     d.hfin = (uint16_t *)(ws + w.hfin);
@@ -623,11 +729,18 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
         const int grid = cus < kGrid ? cus : kGrid;
         e = hipMemsetAsync(d.bar, 0, 8, st);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(decode_persistent_kernel, dim3(grid), dim3(kDecThreads), 0, st, d);
+        hipLaunchKernelGGL(decode_persistent_kernel, dim3(grid), dim3(kDecThreads), 0, st, d, persistent);
     } else {
-        for (int l = 0; l <= L; l++)
-            for (int ph = 0; ph < (l == L ? 2 : 7); ph++)
-                hipLaunchKernelGGL(decode_phase_kernel, dim3(kGrid), dim3(kDecThreads), 0, st, d, l, ph);
+        // one launch per phase, each sized to its own item count
+        const int N2 = 3 * D + Rw + Ra + Rv + Rg;
+        const int g_phase[7] = {B, (N2 / 32) * w.ks_qkv, H * ((B + 1) / 2), (D / 32) * w.ks_o, B, F / 32, (D / 32) * w.ks_val};
+        for (int l = 0; l < L; l++)
+            for (int ph = 0; ph < 7; ph++) {
+                const int items = l == 0 && ph == 1 ? g_phase[1] - (Rv / 32) * w.ks_qkv : g_phase[ph];
+                hipLaunchKernelGGL(decode_phase_kernel, dim3(items), dim3(kDecThreads), 0, st, d, l, ph);
+            }
+        hipLaunchKernelGGL(decode_phase_kernel, dim3(B), dim3(kDecThreads), 0, st, d, L, 0);
+        hipLaunchKernelGGL(decode_phase_kernel, dim3((V + 31) / 32), dim3(kDecThreads), 0, st, d, L, 1);
     }
     return (int)hipGetLastError();
 }

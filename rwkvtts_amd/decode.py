@@ -3,8 +3,9 @@ rwkv_s2s_single_ffn.py:417-445, HF generate via inference/rwkv7speech_inference.
 
 Two levels:
   * DecodeStep -- the whole T = 1 step of the stack (all layers on the in-place recurrent state, final norm, head
-    projection) as ONE persistent HIP kernel, rwkv7_decode_step_bf16 (csrc/decode_step.hip): 7 grid-wide phases per layer
-    separated by device-scope barriers instead of ~18 launches per layer.
+    projection) through rwkv7_decode_step_bf16 (csrc/decode_step.hip): 7 grid-wide phases per layer instead of ~18
+    module-level launches, either as one launch per phase (default) or as ONE persistent kernel with device-scope barriers
+    between the phases (persistent=1; slower on MI355X, the barrier costs 7.4 us against ~1.5 us for a kernel boundary).
   * GraphDecoder -- greedy loop around it: embedding lookup of the previous ids, the step, suppress/argmax and the
     bookkeeping are recorded once into a hipGraph on static buffers and replayed per token; the ids never leave the device
     until the end.  Models the step kernel does not cover (fp32 weights, B > 32, odd low-rank sizes) run the module-by-module
@@ -36,7 +37,7 @@ class DecodeStep:
     """logits[B,V] (fp32) = step(x_in[B,D] bf16) on the live `cache` of a bf16 RWKV7Model + head; the cache's state tensors
     are updated in place.  Raises ValueError for shapes/dtypes the kernel does not cover (see `supported`)."""
 
-    def __init__(self, backbone, lm_head, cache: Cache, persistent: bool = True):
+    def __init__(self, backbone, lm_head, cache: Cache, persistent: int = 0):
         why = self.supported(backbone, lm_head, cache)
         if why:
             raise ValueError("rwkv7_decode_step_bf16: " + why)
@@ -82,7 +83,7 @@ class DecodeStep:
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.norm, self.head = backbone.norm, lm_head
         self.logits = torch.empty(self.B, self.dims.V, dtype=torch.float32, device=dev)
-        self.persistent = bool(persistent)
+        self.persistent = int(persistent)   # 2 (debug): the barriers of the persistent kernel without the phases
 
     @staticmethod
     def supported(backbone, lm_head, cache: Cache) -> Optional[str]:

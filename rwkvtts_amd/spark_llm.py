@@ -135,6 +135,9 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
         out = self(input_ids=input_ids if inputs_embeds is None else None, inputs_embeds=inputs_embeds,
                    attention_mask=attention_mask, past_key_values=cache, use_cache=True, logits_to_keep=1)
         logits = out.logits[:, -1].float()
+        # per-token steps: the whole stack through rwkv7_decode_step_bf16 when the model is covered (bf16, B <= 32)
+        from .decode import DecodeStep
+        step_kernel = DecodeStep(self.model, self.lm_head, cache) if DecodeStep.supported(self.model, self.lm_head, cache) is None else None
         unfinished = torch.ones(B, dtype=torch.bool, device=dev)
         new_tokens = []
         for step in range(max_new_tokens):
@@ -149,8 +152,12 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
                 unfinished &= nxt != e
             if eos and not bool(unfinished.any()):
                 break
-            out = self(input_ids=nxt.unsqueeze(1), past_key_values=cache, use_cache=True)
-            logits = out.logits[:, -1].float()
+            if step_kernel is not None:
+                logits = step_kernel(F.embedding(nxt, self.model.embeddings.weight)).clone()
+                cache.seen_tokens += 1
+            else:
+                out = self(input_ids=nxt.unsqueeze(1), past_key_values=cache, use_cache=True)
+                logits = out.logits[:, -1].float()
         seq = torch.stack(new_tokens, 1) if new_tokens else torch.empty(B, 0, dtype=torch.long, device=dev)
         if input_ids is not None and inputs_embeds is None:
             seq = torch.cat([input_ids, seq], 1)
