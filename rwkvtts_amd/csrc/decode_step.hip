@@ -63,6 +63,21 @@ struct DecodeDesc {
     unsigned *bar;            // [0] arrival counter, [1] timeout flag
 };
 
+#ifdef WKV7C_TIMING
+// profiling build only (python -m rwkvtts_amd.build --timing): cycle totals of the head phase's steps, workgroup 0,
+// accumulated in the workspace's barrier block at byte offset 64 (tools/decode_phase_profile.py stamps)
+#define DSTAMP(i)                                                                                   \
+    do {                                                                                            \
+        const long long now_ = __builtin_readcyclecounter();                                        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)(d.bar + 16) + (i), (unsigned long long)(now_ - tprev_)); \
+        tprev_ = now_;                                                                              \
+    } while (0)
+#define DSTAMP_INIT long long tprev_ = __builtin_readcyclecounter()
+#else
+#define DSTAMP(i) do { } while (0)
+#define DSTAMP_INIT do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kDecThreads = 256;
@@ -71,8 +86,10 @@ constexpr int kMaxE = 16;                  // D <= 4096: elements per thread in 
 constexpr int kMaxR = 512;                 // Rw + Ra + Rv + Rg
 constexpr unsigned kSpinLimit = 1u << 21;  // ~0.1 s: a barrier that is not met by then raises the flag instead of hanging the GPU
 
+constexpr int kHidLD = kMaxR + 8;          // bf16 hidden rows, padded
+constexpr int kUpFrags = 24;               // 16-wide k-steps of the two up-projection jobs of a wave: (Rw + Rv) / 16, (Ra + Rg) / 16
 struct HeadSm {
-    float hid[2][kMaxR];
+    __attribute__((aligned(16))) uint16_t hid[2][kHidLD];   // activated low-rank hidden vectors, bf16 like the reference's tensors
     float rkv[3][2][64];
     float up[4][2][64];
     float vec[6][2][64];   // r, decay, k2, v2, a_in, b_in
@@ -340,33 +357,9 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
 
 // ---------------------------------------------------------------------------------------------------------------------
 // head phase: everything between the projections and the output projection, for one head and two sequences.
-// What does not depend on this step's activations -- the state rows, the first 64 ranks of the up-projection rows, the
+// What does not depend on this step's activations -- the state rows, the up-projection rows (as MFMA fragments), the
 // per-channel parameters -- is requested before the partial sums are read, so the phase pays two load latencies, not five.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dot8(const uint4 w8, const float *hp, float acc) {
-    acc = fmaf(__uint_as_float(w8.x << 16), hp[0], acc);
-    acc = fmaf(__uint_as_float(w8.x & 0xffff0000u), hp[1], acc);
-    acc = fmaf(__uint_as_float(w8.y << 16), hp[2], acc);
-    acc = fmaf(__uint_as_float(w8.y & 0xffff0000u), hp[3], acc);
-    acc = fmaf(__uint_as_float(w8.z << 16), hp[4], acc);
-    acc = fmaf(__uint_as_float(w8.z & 0xffff0000u), hp[5], acc);
-    acc = fmaf(__uint_as_float(w8.w << 16), hp[6], acc);
-    acc = fmaf(__uint_as_float(w8.w & 0xffff0000u), hp[7], acc);
-    return acc;
-}
-// rest of an up-projection row beyond the prefetched ranks
-__device__ __forceinline__ float up_tail(const uint16_t *wr, int done, int R, const float *hid, float acc) {
-    for (int r0 = done; r0 < R; r0 += 64) {
-        uint4 w8[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) w8[j] = r0 + 8 * j < R ? *reinterpret_cast<const uint4 *>(wr + r0 + 8 * j) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (r0 + 8 * j < R) acc = dot8(w8[j], hid + r0 + 8 * j, acc);
-    }
-    return acc;
-}
-
 template <class LP>
 __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, int l, const LP &lp) {
     HeadSm &sm = smu.h;
@@ -383,31 +376,32 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
     const uint16_t *gnw = (const uint16_t *)lp[DP_GNW], *gnb = (const uint16_t *)lp[DP_GNB];
     float *kv_all = (float *)lp[DP_ATT_KV];
     const bool first = l == 0;
-    // thread roles: B (up projections): wave = (sequence, half), lane = channel; C/E: waves 0,1 = sequence, lane = channel;
-    // D (state): 128 threads per sequence, 16 lanes x float4 = one state row, 8 rows per pass
-    const int cB = tid & 63, bbB = (tid >> 6) & 1, half = tid >> 7;
+    // thread roles: B (up projections on MFMA): wave 0/1 = 32-channel tile 0/1 of the w and v branches, wave 2/3 = tile 0/1 of
+    // the a and g branches; C/E: waves 0,1 = sequence, lane = channel; D (state): 128 threads per sequence, 16 lanes x float4
+    // = one state row, 8 rows per pass
+    const int wave = tid >> 6, lane = tid & 63;
     const int bbD = tid >> 7, tt = tid & 127, k4 = (tt & 15) * 4, vr = tt >> 4;
     const int total = 2 * Rtot + 3 * 2 * 64;
+    const int tileB = wave & 1;
+    const int R1 = wave < 2 ? d.Rw : d.Ra, R2 = wave < 2 ? (first ? 0 : d.Rv) : d.Rg;     // the wave's two jobs
+    const int off1 = wave < 2 ? 0 : oA, off2 = wave < 2 ? oV : oG;
+    const int n1 = R1 >> 4, n2 = R2 >> 4;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int h = item % H, bp = item / H;
         const int b0 = 2 * bp;
-        const int chB = h * 64 + cB;
+        DSTAMP_INIT;
         // ---- requests that do not wait for this step's activations
-        const uint16_t *rowA = half == 0 ? w2 + (long)chB * d.Rw : v2w + (long)chB * d.Rv;
-        const uint16_t *rowB = half == 0 ? a2 + (long)chB * d.Ra : g2 + (long)chB * d.Rg;
-        const int RA = half == 0 ? d.Rw : (first ? 0 : d.Rv), RB = half == 0 ? d.Ra : d.Rg;
-        uint4 wa[8], wb[8];
+        // up-projection rows as MFMA A fragments: lane = channel 32 tile + (lane & 31), k = 16 i + 8 (lane >> 5)
+        bf16x8 wf[kUpFrags];
+        {
+            const int chB = h * 64 + tileB * 32 + (lane & 31);
+            const uint16_t *row1 = (wave < 2 ? w2 : a2) + (long)chB * R1 + (lane >> 5) * 8;
+            const uint16_t *row2 = (wave < 2 ? v2w : g2) + (long)chB * (wave < 2 ? d.Rv : d.Rg) + (lane >> 5) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            wa[j] = 8 * j < RA ? *reinterpret_cast<const uint4 *>(rowA + 8 * j) : make_uint4(0, 0, 0, 0);
-            wb[j] = 8 * j < RB ? *reinterpret_cast<const uint4 *>(rowB + 8 * j) : make_uint4(0, 0, 0, 0);
-        }
-        float biasA = 0.f, biasB = 0.f;
-        if (half == 0) {
-            biasA = bf2f(w0[chB]);
-            biasB = bf2f(a0[chB]);
-        } else if (!first) {
-            biasA = bf2f(v0[chB]);
+            for (int i = 0; i < kUpFrags; i++) {
+                if (i < n1) wf[i] = *reinterpret_cast<const bf16x8 *>(row1 + 16 * i);
+                else if (i < n1 + n2) wf[i] = *reinterpret_cast<const bf16x8 *>(row2 + 16 * (i - n1));
+            }
         }
         const bool liveD = b0 + bbD < d.B;
         float *S = kv_all + ((long)min(b0 + bbD, d.B - 1) * H + h) * 64 * 64;
@@ -418,6 +412,7 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
         const int chC = h * 64 + (tid & 63);
         const float p_kk = bf2f(k_k[chC]), p_ka = bf2f(k_a[chC]), p_rk = bf2f(r_k[chC]), p_gw = bf2f(gnw[chC]), p_gb = bf2f(gnb[chC]);
         const float p_vf = first ? 0.f : d.vfirst[(long)min(b0 + ((tid >> 6) & 1), d.B - 1) * D + chC];
+        const float p_w0 = bf2f(w0[chC]), p_a0 = bf2f(a0[chC]), p_v0 = first ? 0.f : bf2f(v0[chC]);
         // ---- A: low-rank hidden vectors (activation applied to the summed partials) and this head's r, k, v
         {
             long addr[6];
@@ -448,6 +443,7 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
                 for (int it = 0; it < 6; it++) acc[it] += t[it] + u[it];
             }
             __syncthreads();  // LDS of the previous item is free
+            DSTAMP(0);
 #pragma unroll
             for (int it = 0; it < 6; it++) {
                 const int idx = tid + kDecThreads * it;
@@ -456,7 +452,7 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
                     float v = acc[it];
                     if (r < oA) v = tanh_(v);
                     else if (r >= oG) v = sigm(v);
-                    sm.hid[bb][r] = v;
+                    sm.hid[bb][r] = f2bf(v);
                 } else if (idx < total) {
                     const int e = idx - 2 * Rtot;
                     sm.rkv[e >> 7][(e >> 6) & 1][e & 63] = acc[it];
@@ -464,33 +460,43 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
             }
         }
         __syncthreads();
-        // ---- B: up projections for the 64 channels of the head: half 0 -> w and a, half 1 -> v and g
+        DSTAMP(1);
+        // ---- B: up projections on MFMA: D[m = channel][n = sequence], only n = 0, 1 are real (the B operand repeats them)
         {
-            const float *hA = &sm.hid[bbB][half == 0 ? 0 : oV], *hB = &sm.hid[bbB][half == 0 ? oA : oG];
-            float accA = biasA, accB = biasB;
+            const uint16_t *hp = &sm.hid[lane & 1][(lane >> 5) * 8];
+            f32x16 acc1 = zero16(), acc2 = zero16();
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (8 * j < RA) accA = dot8(wa[j], hA + 8 * j, accA);
-                if (8 * j < RB) accB = dot8(wb[j], hB + 8 * j, accB);
+            for (int i = 0; i < kUpFrags; i++) {
+                if (i < n1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], *reinterpret_cast<const bf16x8 *>(hp + off1 + 16 * i), acc1, 0, 0, 0);
+                } else if (i < n1 + n2) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], *reinterpret_cast<const bf16x8 *>(hp + off2 + 16 * (i - n1)), acc2, 0, 0, 0);
+                }
             }
-            accA = up_tail(rowA, 64, RA, hA, accA);
-            accB = up_tail(rowB, 64, RB, hB, accB);
-            sm.up[half == 0 ? 0 : 2][bbB][cB] = accA;
-            sm.up[half == 0 ? 1 : 3][bbB][cB] = accB;
+            if ((lane & 31) < 2) {
+                const int n = lane & 31;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = tileB * 32 + d_row(r, lane);
+                    sm.up[wave < 2 ? 0 : 1][n][m] = acc1[r];
+                    sm.up[wave < 2 ? 2 : 3][n][m] = acc2[r];
+                }
+            }
         }
         __syncthreads();
+        DSTAMP(2);
         // ---- C: decay, gates, value residual, kk normalisation (rwkv_s2s_single_ffn.py:493-500)
         if (tid < 128) {
             const int c = tid & 63, bb = tid >> 6;
             const int b = min(b0 + bb, d.B - 1), ch = h * 64 + c;
             const float r = sm.rkv[0][bb][c], k = sm.rkv[1][bb][c];
             float v = sm.rkv[2][bb][c];
-            const float w = -softplus_d(-sm.up[0][bb][c]) - 0.5f;
-            const float a = sigm(sm.up[1][bb][c]);
+            const float w = -softplus_d(-(sm.up[0][bb][c] + p_w0)) - 0.5f;
+            const float a = sigm(sm.up[1][bb][c] + p_a0);
             if (first) {
                 if (b0 + bb < d.B) d.vfirst[(long)b * D + ch] = v;
             } else {
-                v = fmaf(p_vf - v, sigm(sm.up[2][bb][c]), v);
+                v = fmaf(p_vf - v, sigm(sm.up[2][bb][c] + p_v0), v);
             }
             const float kkr = k * p_kk;
             const float ss = wave_sum(kkr * kkr);
@@ -506,6 +512,7 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
             if (c == 0) sm.dot[bb] = dot;
         }
         __syncthreads();
+        DSTAMP(3);
         // ---- D: state update in place
         {
             const float4 rr = *reinterpret_cast<const float4 *>(&sm.vec[0][bbD][k4]);
@@ -527,6 +534,7 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
             }
         }
         __syncthreads();
+        DSTAMP(4);
         // ---- E: GroupNorm over the head, bonus, gate (rwkv_s2s_single_ffn.py:504-505)
         if (tid < 128) {
             const int c = tid & 63, bb = tid >> 6;
@@ -538,6 +546,7 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
             const float o = (fmaf(dv * rstd, p_gw, p_gb) + sm.dot[bb] * sm.vec[3][bb][c]) * sm.up[3][bb][c];
             if (b0 + bb < d.B) d.yg[(long)(b0 + bb) * D + ch] = f2bf(o);
         }
+        DSTAMP(5);
     }
 }
 
@@ -684,7 +693,7 @@ bool ws_layout(int D, int F, int Rw, int Ra, int Rv, int Rg, WsLayout &w) {
 bool shape_ok(int B, int D, int H, int F, int V, int Rw, int Ra, int Rv, int Rg) {
     auto r_ok = [](int r) { return r >= 32 && r % 32 == 0; };
     return B >= 1 && B <= kRows && D == H * 64 && D % 64 == 0 && D <= kDecThreads * kMaxE && F % 64 == 0 && V >= 1 && r_ok(Rw) &&
-           r_ok(Ra) && r_ok(Rv) && r_ok(Rg) && Rw + Ra + Rv + Rg <= kMaxR;
+           r_ok(Ra) && r_ok(Rv) && r_ok(Rg) && Rw + Ra + Rv + Rg <= kMaxR && (Rw + Rv) / 16 <= kUpFrags && (Ra + Rg) / 16 <= kUpFrags;
 }
 
 }  // namespace
