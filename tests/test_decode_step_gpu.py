@@ -129,3 +129,53 @@ def test_step_kernel_rejects_unsupported_models():
     assert DecodeStep.supported(m32.model, m32.lm_head, Cache.zeros(cfg, 4, DEV, torch.float32)) is not None   # fp32 weights
     assert DecodeStep.supported(m16.model, m16.lm_head, Cache.zeros(cfg, 33, DEV, torch.bfloat16)) is not None  # B > 32
     assert DecodeStep.supported(m16.model, m16.lm_head, Cache.zeros(cfg, 32, DEV, torch.bfloat16)) is None
+
+
+def test_step_kernel_against_cpu_oracle():
+    """The step kernel on a bf16 Spark model against oracle/rwkv7_ref.py (the reference's PyTorch-CPU path, fp32, stateful:
+    forward_batch semantics of rwkv_asr_cuda_whisper.py:438-472) holding the same bf16-valued weights: prefill on both sides,
+    then T = 1 steps.  Tolerance: bf16 activations at the MFMA inputs -> 2e-2 of the logit range; argmax ids equal wherever the
+    oracle's top-2 margin exceeds that."""
+    from oracle import rwkv7_ref as R
+    from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
+    dims = dict(hidden_size=128, num_hidden_layers=3, decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=32, gate_low_rank_dim=64)
+    V, B, P, STEPS = 257, 6, 9, 8
+    cfg = RWKV7SpeechConfig(vocab_size=V, text_vocab_size=300, audio_global_vocab_size=64, **dims)
+    rcfg = R.RefConfig(vocab_size=V, **dims)
+    p = R.init_params(rcfg, seed=11)
+    p["lm_head.weight"] = torch.randn(V, 128, generator=torch.Generator().manual_seed(5)) * 0.05
+    p = {k: v.to(torch.bfloat16).float() for k, v in p.items()}   # bf16-valued weights on both sides
+    model = RWKV7ForSpeech(cfg)
+    sd = dict(p)
+    for n in ("text_embedder", "global_embedder", "tts_tag_embedder"):
+        sd[n + ".weight"] = getattr(model, n).weight.detach().clone()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(B, P, 128, generator=g) * 0.5).to(torch.bfloat16)
+    with torch.no_grad():
+        _, lo, st = R.spark_forward(p, rcfg, x.float(), None, None, states=R.zero_states(rcfg, B))
+    cache = Cache.zeros(cfg, B, DEV, torch.bfloat16)
+    with torch.no_grad():
+        model(inputs_embeds=x.to(DEV), past_key_values=cache, use_cache=True)
+    step = DecodeStep(model.model, model.lm_head, cache)
+    emb = p["model.embeddings.weight"]
+    lo = lo[:, -1]
+    checked = 0
+    for t in range(STEPS):
+        ids = lo.argmax(-1)
+        xe = emb[ids]
+        with torch.no_grad():
+            _, lo, st = R.spark_forward(p, rcfg, xe[:, None], None, None, states=st)
+        lo = lo[:, -1]
+        lk = step(xe.to(DEV).to(torch.bfloat16)).float().cpu()
+        scale = lo.abs().max().item()
+        assert (lk - lo).abs().max().item() < 2e-2 * scale, (t, (lk - lo).abs().max().item(), scale)
+        top2 = torch.topk(lo, 2, -1)
+        sure = (top2.values[:, 0] - top2.values[:, 1]) > 2e-2 * scale
+        assert torch.equal(lk.argmax(-1)[sure], top2.indices[sure, 0])
+        checked += int(sure.sum())
+    assert checked > 0
+    for i, s in enumerate(cache.states):
+        ref = st[3 * i + 1]
+        assert (s.att_kv.cpu() - ref).abs().max().item() < 3e-2 * ref.abs().max().item() + 1e-3
