@@ -261,6 +261,11 @@ int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, lo
 int rwkv7_adamw_bf16(long n, float *p32, const void *g16, float *m, float *v, void *p16, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, rwkv7_stream_t stream);
 
+/* ---- last step of a split weight gradient (the dW of nn.Linear under autograd, e.g. rwkv_s2s_single_ffn.py:171-174,195,
+ *      228-229, reduced over B*T in S row slabs with fp32 partials): out[n] (bf16) = (accumulate ? out[n] : 0) +
+ *      sum_s parts[s][n].  out may be the parameter's slice of the flat gradient buffer.  n % 4 == 0. ---- */
+int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, rwkv7_stream_t stream);
+
 /* ---- decode-step linear layers: y[M,N] = x[M,K] @ w[N,K]^T (+ bias[N]), bf16, M <= 32 rows (one token per sequence and
  *      step), K % 64 == 0.  Replaces the nn.Linear calls of the per-token path (rwkv_s2s_single_ffn.py:482-506,545-549)
  *      for the decode batch; weight-streaming on MFMA, see csrc/gemv32.hip.  bias may be NULL. ---- */

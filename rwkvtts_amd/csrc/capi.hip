@@ -42,6 +42,7 @@ int chunk_state_bf16(int, int, const void *, const float *, float *, hipStream_t
 int chunk_bwd_out_bf16(int, int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                        const float *, const float *, const float *, const float *, void *, void *, void *, void *,
                        void *, void *, hipStream_t);
+int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int decode_layer_ptrs();
 size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
 int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *, const void *,
@@ -356,6 +357,11 @@ int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, lo
                           rwkv7_stream_t stream) {
     if (rows <= 0 || V <= 0 || any_null({(const void *)logits, (const void *)labels, (const void *)loss_rows})) return RWKV7_EINVAL;
     return rwkv7::ce_fwd_bwd(rows, V, logits, labels, ignore_index, scale, loss_rows, (hipStream_t)stream);
+}
+int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, rwkv7_stream_t stream) {
+    if (n <= 0 || S <= 0 || any_null({(const void *)parts, (const void *)out})) return RWKV7_EINVAL;
+    if (n % 4 != 0) return RWKV7_ESHAPE;
+    return rwkv7::sum_slabs_bf16(n, S, parts, out, accumulate, (hipStream_t)stream);
 }
 int rwkv7_decode_layer_ptrs(void) { return rwkv7::decode_layer_ptrs(); }
 size_t rwkv7_decode_workspace_bytes(const rwkv7_decode_dims *dm) {

@@ -746,6 +746,37 @@ int ce_fwd_bwd(long rows, int V, void *logits, const long *labels, long ignore_i
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// out[n] (bf16) = (accumulate ? out[n] : 0) + sum_s parts[s][n] (fp32): the last step of the split weight gradient
+// (fused.wgrad_splitk) written straight into the gradient buffer -- replaces reduce + cast + accumulate launches
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_slabs_kernel(long n4, int S, const float *__restrict__ parts, bf16_t *__restrict__ out,
+                                                        int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (accumulate) a = cvt4(ld4<bf16_t>(out + i * 4, true));
+        for (int s0 = 0; s0 < S; s0 += 4) {
+            float4 t[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+                t[s] = s0 + s < S ? *reinterpret_cast<const float4 *>(parts + ((long)(s0 + s) * n4 + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                a.x += t[s].x; a.y += t[s].y; a.z += t[s].z; a.w += t[s].w;
+            }
+        }
+        st4(out + i * 4, a);
+    }
+}
+
+int sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, hipStream_t st) {
+    (void)hipGetLastError();
+    const long n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid), dim3(256), 0, st, n4, S, parts, (bf16_t *)out, accumulate);
+    return (int)hipGetLastError();
+}
+
 static inline int finish() { return (int)hipGetLastError(); }
 
 template <typename T>

@@ -370,18 +370,45 @@ def lora(x, w1, w2, bias, activation):
 WGRAD_MIN_ROWS = 4096
 
 
-def wgrad_splitk(dy2, x2):
+def wgrad_splitk(dy2, x2, out=None):
     """dy2[M,N]^T @ x2[M,K] -> [N,K].  The reduction runs over M = B*T rows (32768 at BASELINE configs[1]) while the
     result is at most a few 256x256 tiles, so one BLAS call leaves most CUs idle (measured on MI355X, tools/
     bench_wgrad_splitk.py: 1024x1024 209 us, 64x1024 115 us).  Batched over S slabs of rows with fp32 partials,
-    then one reduction: 82 us and 31 us."""
+    then one reduction (rwkv7_sum_slabs_bf16): 82 us and 31 us.  `out`: a contiguous bf16 [N,K] tensor to write into
+    (the parameter's slice of the trainer's flat gradient buffer), else a new tensor."""
     M, N = dy2.shape
     K = x2.shape[1]
     S = 8 if N * K <= 1024 * 1024 else 4
     if M < WGRAD_MIN_ROWS or M % (S * 8) != 0:
-        return torch.mm(dy2.t(), x2)
+        res = torch.mm(dy2.t(), x2)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
     part = torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K), out_dtype=torch.float32)
-    return part.sum(0).to(dy2.dtype)
+    if dy2.dtype != torch.bfloat16 or (N * K) % 4 != 0:
+        res = part.sum(0).to(dy2.dtype)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.bfloat16, device=dy2.device)
+    with torch.cuda.device_of(part):
+        rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(N * K), S, _p(part), _p(out), 0, _stream(part))
+    _lib.check(rc, "sum_slabs")
+    return out
+
+
+def _grad_slot(param):
+    """The trainer's slice of the flat gradient buffer for `param`, if this backward pass may write the gradient there
+    directly (trainer.FlatBuffers hands the slices out; first writer per backward pass only -- a second use of the same
+    parameter goes through a fresh tensor and autograd's own accumulation)."""
+    slot = getattr(param, "_grad_slot", None)
+    if slot is None or getattr(param, "_grad_slot_used", True) or param.grad is not None:
+        return None
+    param._grad_slot_used = True
+    return slot
 
 
 class _Linear(torch.autograd.Function):
@@ -389,6 +416,7 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.wparam = weight
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -398,7 +426,12 @@ class _Linear(torch.autograd.Function):
         dy2 = _c(dy).view(-1, dy.shape[-1])
         x2 = _c(x).view(-1, K)
         dx = torch.mm(dy2, weight).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = wgrad_splitk(dy2, x2) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            slot = _grad_slot(ctx.wparam)
+            dw = wgrad_splitk(dy2, x2, out=slot)
+            if slot is not None:
+                dw = slot.view_as(weight)   # a fresh view object: autograd adopts it as .grad without a copy
         db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 

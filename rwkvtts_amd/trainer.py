@@ -44,7 +44,13 @@ def init_distributed(backend: Optional[str] = None):
 
 
 class FlatBuffers:
-    """Re-homes every parameter (and its .grad) of `model` into two contiguous buffers."""
+    """Re-homes every parameter (and its .grad) of `model` into two contiguous buffers.
+
+    Gradients reach the flat buffer without an accumulate pass: before backward every .grad is None, so autograd ADOPTS the
+    tensor a backward node returns instead of adding it to a zeroed buffer; a post-accumulate hook then copies it into the
+    parameter's slice -- unless the node already wrote there (`param._grad_slot`, used by fused._Linear's split weight
+    gradient: 14 matrices per layer arrive with no extra launch at all) -- and re-attaches the slice as .grad.  Slices of
+    parameters that received no gradient in a pass are zeroed by `finish_backward()`."""
 
     def __init__(self, model: torch.nn.Module):
         params = [p for p in model.parameters() if p.requires_grad]
@@ -59,16 +65,56 @@ class FlatBuffers:
         self.numel = n
         self.flat_param = torch.zeros(n, dtype=dt, device=dev)
         self.flat_grad = torch.zeros(n, dtype=dt, device=dev)
-        for p, o in zip(params, self.offsets):
+        self.views = []
+        self.fired = [False] * len(params)
+        self.on_ready = None   # callable(i): parameter i's slice is final (BucketedAllReduce)
+        for i, (p, o) in enumerate(zip(params, self.offsets)):
             self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_param[o:o + p.numel()].view_as(p)
-            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+            v = self.flat_grad[o:o + p.numel()].view_as(p)
+            self.views.append(v)
+            p.grad = v
+            p._grad_slot = v
+            p._grad_slot_used = True   # armed by zero_grad()
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            v = self.views[i]
+            g = param.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+            param.grad = v
+            self.fired[i] = True
+            if self.on_ready is not None:
+                self.on_ready(i)
+        return hook
 
     def zero_grad(self):
+        """Plain mode: zero the buffer and attach the slices as .grad; backward then accumulates into them."""
         self.flat_grad.zero_()
-        for p, o in zip(self.params, self.offsets):  # autograd may have replaced .grad; re-attach the views
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
-                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        for i, p in enumerate(self.params):
+            p.grad = self.views[i]
+            p._grad_slot_used = True
+            self.fired[i] = False
+
+    def arm(self):
+        """Fast mode (DataParallelTrainer.step): nothing is zeroed, the next backward pass overwrites the slices;
+        finish_backward() must follow it."""
+        for i, p in enumerate(self.params):
+            p.grad = None
+            p._grad_slot_used = False
+            self.fired[i] = False
+
+    def finish_backward(self, ran_backward: bool = True):
+        """After backward (or instead of it): zero the slices that received nothing, re-attach every .grad."""
+        if not ran_backward:
+            self.flat_grad.zero_()
+        for i, p in enumerate(self.params):
+            if ran_backward and not self.fired[i]:
+                self.views[i].zero_()
+            p.grad = self.views[i]
+            p._grad_slot_used = True
 
 
 class BucketedAllReduce:
@@ -94,16 +140,13 @@ class BucketedAllReduce:
         self.works = []
         self.enabled = self.world > 1
         if self.enabled:
-            for i, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+            flat.on_ready = self._ready
 
-    def _make_hook(self, i):
-        def hook(param):
-            b = self.param_bucket[i]
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                self._launch(b)
-        return hook
+    def _ready(self, i):
+        b = self.param_bucket[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
@@ -115,8 +158,9 @@ class BucketedAllReduce:
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
             view.copy_((tmp / self.world).to(view.dtype))
 
-    def finish(self):
+    def finish(self, ran_backward: bool = True):
         """Wait for every bucket (also launches buckets whose hooks never fired, e.g. unused params)."""
+        self.flat.finish_backward(ran_backward)
         if not self.enabled:
             return
         for b, left in enumerate(self.pending):
@@ -166,7 +210,7 @@ class DataParallelTrainer:
 
     def step(self, **batch):
         """One optimisation step on this rank's shard of the batch.  Returns the (detached) loss tensor."""
-        self.flat.zero_grad()
+        self.flat.arm()
         out = self.model(**batch)
         loss = out.loss
         skip = False
@@ -178,7 +222,7 @@ class DataParallelTrainer:
         if skip:
             # the reference backpropagates loss*0 on every rank (:676-687); the update it then applies has zero
             # gradient.  Same effect, without propagating NaN*0: no backward, zero gradient, optimizer step.
-            self.reducer.finish()
+            self.reducer.finish(ran_backward=False)
         else:
             loss.backward()
             self.reducer.finish()

@@ -298,3 +298,35 @@ def test_fused_linear_ce_hip_kernel_bf16():
     assert (h.grad.float() - dh_ref).abs().max().item() <= 2e-2 * dh_ref.abs().max().item()
     assert (w.grad.float() - dw_ref).abs().max().item() <= 2e-2 * dw_ref.abs().max().item()
     assert h.grad[::5].abs().max().item() == 0      # ignored rows contribute nothing
+
+
+def test_trainer_fast_gradient_path_equals_accumulate_path():
+    """DataParallelTrainer.step arms the flat gradient buffer (no zero fill, .grad = None, the split weight gradients are
+    written into their slices by rwkv7_sum_slabs_bf16, everything else is adopted and copied by the hook); the result must be
+    the buffer that plain zero-then-accumulate autograd produces, bit for bit, also for parameters that get no gradient."""
+    from rwkvtts_amd import backbone, trainer
+    cfg = RWKV7SpeechConfig(vocab_size=257, text_vocab_size=64, audio_global_vocab_size=64, hidden_size=128, num_hidden_layers=2,
+                            decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=32, gate_low_rank_dim=32)
+    model = RWKV7ForSpeech(cfg).init_weights(3).to(DEV).to(torch.bfloat16).train()
+    fb = trainer.FlatBuffers(model)
+    B, T = 2, 2048   # 4096 rows: the weight gradients take the split path
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(B, T, 128, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    labels = torch.randint(0, 256, (B, T), generator=g).to(DEV)
+    model.dropout.p = 0.0
+
+    fb.zero_grad()
+    model(inputs_embeds=x, labels=labels).loss.backward()
+    want = fb.flat_grad.clone()
+    assert want.abs().sum() > 0
+
+    fb.flat_grad.fill_(7.0)   # stale garbage: the fast path must overwrite or zero every slice
+    fb.arm()
+    model(inputs_embeds=x, labels=labels).loss.backward()
+    fb.finish_backward()
+    assert torch.equal(fb.flat_grad, want), (fb.flat_grad.float() - want.float()).abs().max().item()
+    direct = sum(1 for p, v in zip(fb.params, fb.views) if p.grad.data_ptr() == v.data_ptr())
+    assert direct == len(fb.params)
+    # the embedders are not used with inputs_embeds: their slices were zeroed, not left at 7
+    o = fb.offsets[[i for i, p in enumerate(fb.params) if p is model.text_embedder.weight][0]]
+    assert fb.flat_grad[o:o + 8].abs().sum() == 0
