@@ -67,6 +67,7 @@ class FlatBuffers:
         self.flat_grad = torch.zeros(n, dtype=dt, device=dev)
         self.views = []
         self.fired = [False] * len(params)
+        self.to_copy = []
         self.on_ready = None   # callable(i): parameter i's slice is final (BucketedAllReduce)
         for i, (p, o) in enumerate(zip(params, self.offsets)):
             self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
@@ -80,15 +81,27 @@ class FlatBuffers:
 
     def _make_hook(self, i):
         def hook(param):
-            v = self.views[i]
             g = param.grad
-            if g is not None and g.data_ptr() != v.data_ptr():
-                v.copy_(g)
-            param.grad = v
+            if g is not None and g.data_ptr() != self.views[i].data_ptr():
+                self.to_copy.append(i)   # moved into its slice by flush(): one multi-tensor copy for many parameters
             self.fired[i] = True
             if self.on_ready is not None:
                 self.on_ready(i)
         return hook
+
+    def flush(self):
+        """Copy the adopted gradients collected so far into their slices (one multi-tensor launch) and attach the slices."""
+        if self.to_copy:
+            src = [self.params[i].grad for i in self.to_copy]
+            dst = [self.views[i] for i in self.to_copy]
+            if src[0].is_cuda and all(s.dtype == d.dtype for s, d in zip(src, dst)):
+                torch._foreach_copy_(dst, src)
+            else:
+                for d, s_ in zip(dst, src):
+                    d.copy_(s_)
+            for i in self.to_copy:
+                self.params[i].grad = self.views[i]
+            self.to_copy = []
 
     def zero_grad(self):
         """Plain mode: zero the buffer and attach the slices as .grad; backward then accumulates into them."""
@@ -108,6 +121,7 @@ class FlatBuffers:
 
     def finish_backward(self, ran_backward: bool = True):
         """After backward (or instead of it): zero the slices that received nothing, re-attach every .grad."""
+        self.flush()
         if not ran_backward:
             self.flat_grad.zero_()
         for i, p in enumerate(self.params):
@@ -149,6 +163,7 @@ class BucketedAllReduce:
             self._launch(b)
 
     def _launch(self, b):
+        self.flat.flush()   # the bucket's slices must hold the final gradients
         s, e, _ = self.buckets[b]
         view = self.flat.flat_grad[s:e]
         if self.backend == "nccl":
