@@ -16,6 +16,8 @@ Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json, plus
                  from the committed PMC pass (profiles/pmc_wkv7.json: 2*FETCH_SIZE + WRITE_SIZE, KiB), else null.
   cpu_baseline : the oracle's eager-PyTorch fp32 CPU restatement of the same training step (oracle/rwkv7_ref.py,
                  the reference's PyTorch-CPU path) timed on this box's host cores on a bounded sample.
+  decode       : (N = 1 only, after the timed region, not part of `value`) greedy decode of the same model at
+                 BASELINE.json configs[4] -- B=32, prompt 128 -- tokens/s and ms per step (decode.GraphDecoder).
 """
 import argparse
 import json
@@ -63,6 +65,37 @@ def cpu_baseline(seconds_budget=25.0):
                       f"B={B} T={T}, {n} steps in {dt:.1f}s"}
 
 
+def decode_rate(model, dev, B=32, P=128, n1=64, n2=448):
+    """BASELINE.json configs[4] on the model that was just trained: greedy decode, B = 32, prompt 128, through
+    decode.GraphDecoder (rwkv7_decode_step_bf16 phases replayed from a hipGraph).  Two generate() calls of different length
+    separate the per-step time from prefill + capture.  Outside the timed region; rank 0, one GPU only."""
+    from rwkvtts_amd.decode import GraphDecoder
+    was_training = model.training
+    model.eval()
+    g = torch.Generator().manual_seed(1234)
+    emb = (torch.randn(B, P, model.config.hidden_size, generator=g) * 0.5).to(dev, torch.bfloat16)
+    mask = torch.ones(B, P, dtype=torch.long, device=dev)
+    eos = model.config.vocab_size - 1   # suppressed, as in the synthetic workload (SURVEY 8d)
+
+    def run(n):
+        dec = GraphDecoder(model, B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=n, suppress_tokens=[eos])
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, dec.step is not None
+
+    run(8)
+    t1, _ = run(n1)
+    t2, kernel = run(n2)
+    step = (t2 - t1) / (n2 - n1)
+    if was_training:
+        model.train()
+    return {"metric": "greedy decode tokens/s, RWKV7-0.4B B=32 prompt=128 (BASELINE.json configs[4])", "value": round(B / step, 1),
+            "unit": "tokens/s", "ms_per_step": round(step * 1e3, 4), "batch": B, "prompt": P, "new_tokens": n2,
+            "path": "rwkv7_decode_step_bf16, one launch per phase, hipGraph replay" if kernel else "module by module, hipGraph replay"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +106,7 @@ def main():
     ap.add_argument("--model", default="0.4b", choices=["0.1b", "0.4b", "1.5b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-checkpoint", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement (BASELINE configs[4]) after the timed region")
     ap.add_argument("--scalar-wkv-fwd", action="store_true", help="A/B: scalar WKV7 forward instead of the chunked MFMA one")
     ap.add_argument("--scalar-wkv-bwd", action="store_true", help="A/B: row-split scalar WKV7 backward instead of the chunked MFMA one")
     a = ap.parse_args()
@@ -189,6 +223,11 @@ def main():
                                  "achieved": round(th * WKV_FWD_BYTES_PER_TOKEN_HEAD / (fwd_ms * 1e-3) / 1e9, 1)}
                          if fwd_ms else None},
         }
+        if world == 1 and not a.no_decode:
+            try:
+                out["decode"] = decode_rate(model, dev)
+            except Exception as e:  # the headline number must not depend on the secondary measurement
+                out["decode"] = {"error": repr(e)}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
