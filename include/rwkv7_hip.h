@@ -232,6 +232,18 @@ int rwkv7_wkv_chunk_fwd_bf16(int B, int T, int H, const void *w, const void *q, 
 int rwkv7_wkv_chunk_fwd_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                             const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
                             rwkv7_stream_t stream);
+/* Packed variable-length rows (fla chunk_rwkv7's `cu_seqlens`; the reference passes it for its packed Spark batches,
+ * train_spark_rwkv7speech.py:238-239, data/utils/spark_dataset.py:111-162): the caller lays the sequences out 32-aligned
+ * and passes seq_chunk_off, int32 [nseq + 1] on the device: sequence s owns the 32-step chunks seq_chunk_off[s] ..
+ * seq_chunk_off[s+1] - 1, counted over the whole [B][T/32] chunk space (a sequence does not span rows).  Every sequence
+ * starts from the zero state and gets its own workgroups, so the sequences of a row run in parallel; chunks that belong to
+ * no sequence are left untouched.  seq_chunk_off == NULL: the plain ops above (one sequence per row). */
+int rwkv7_wkv_chunk_fwd_seq_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                                 const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                                 const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_fwd_seq_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                                const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                                const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
 /* ---- chunked backward, bf16 (csrc/wkv7_chunk_bwd.hip).  With H = S^T and the chunk quantities above, the adjoint state
  *      obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
  *   bwd_pre : parallel over chunks.  mt  = M_c^T as bf16 hi/lo planes, uint16 [B*H*T/32][2][64][64];
@@ -241,6 +253,8 @@ int rwkv7_wkv_chunk_fwd_f32(int B, int T, int H, const void *w, const void *q, c
 int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
                                  const void *dy, const float *tinv, void *mt, float *np, rwkv7_stream_t stream);
 int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_kv, rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const float *np, float *e_kv, const int *seq_chunk_off,
+                                   int nseq, rwkv7_stream_t stream);   /* packed rows: see rwkv7_wkv_chunk_fwd_seq_bf16 */
 /*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from the forward's saved
  *             tensors, tinv and the adjoint states of `state`.  ck_mode 0: s, sa as saved by rwkv7_wkv_fwd_bf16 (fp32
  *             checkpoints every 16 steps); ck_mode 1: s = hs of rwkv7_wkv_chunk_fwd_bf16 (state at the start of every

@@ -165,6 +165,8 @@ class Cache:
 # Training runs prepare -> scan -> post as one autograd node (fused._TmixCore: row-split scan backward, gradient sums
 # folded into the prepare backward).  False selects the three separate nodes (same forward kernels).
 FUSED_TMIX_CORE = True
+# cu_seqlens batches run on the chunked kernels' sequence flags (bf16); False: always unpack into a padded masked batch
+PACKED_NATIVE = True
 
 
 class RWKV7Attention(nn.Module):
@@ -215,9 +217,10 @@ class RWKV7Attention(nn.Module):
             self._mix_key = key
         return self._mix_cache
 
-    def forward(self, x, mask, v_first, state: Optional[LayerState] = None):
+    def forward(self, x, mask, v_first, state: Optional[LayerState] = None, seq_start=None):
         """x [B,T,D] (LayerNorm'ed), mask [B,T,1] or None.  Returns (out, v_first).
-        With `state`, token shift and the WKV state are carried (and updated in place)."""
+        With `state`, token shift and the WKV state are carried (and updated in place).
+        seq_start (int32 [nseq+1] chunk offsets): packed rows, see RWKV7Model._forward_packed."""
         B, T, D = x.shape
         H, N = self.num_heads, self.head_dim
         x_prev = None if state is None else state.att_x_prev
@@ -236,9 +239,10 @@ class RWKV7Attention(nn.Module):
             v_first = v
         if mask is not None:
             r = r * mask
-        if state is None and torch.is_grad_enabled() and (r.requires_grad or w_pre.requires_grad) and FUSED_TMIX_CORE:
+        if seq_start is not None or (state is None and torch.is_grad_enabled() and (r.requires_grad or w_pre.requires_grad)
+                                     and FUSED_TMIX_CORE):
             y = fused.tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, self.k_k, self.k_a, self.g_norm.weight,
-                                self.g_norm.bias, self.r_k, mask, H, self.g_norm.eps, self.layer_idx == 0)
+                                self.g_norm.bias, self.r_k, mask, H, self.g_norm.eps, self.layer_idx == 0, seq_start)
             return self.o_proj(y), v_first
         w, k2, v2, a_in, b_in = fused.tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, self.k_k, self.k_a, mask,
                                                    H, self.layer_idx == 0)
@@ -286,7 +290,7 @@ class RWKV7Block(nn.Module):
         self.ffn_norm = nn.LayerNorm(D, eps=cfg.norm_eps, bias=cfg.norm_bias)
         self.ffn = RWKV7FeedForward(cfg, layer_idx)
 
-    def forward(self, x, delta, mask, v_first, state: Optional[LayerState] = None):
+    def forward(self, x, delta, mask, v_first, state: Optional[LayerState] = None, seq_start=None):
         """The block input is x + delta (delta = the previous block's channel-mix output, None for the first
         block): every residual add is fused with the LayerNorm that follows it (fused.add_layer_norm), so this
         block's own last add is left to the next block / the model's final norm.  Returns (x, delta, v_first)."""
@@ -299,7 +303,7 @@ class RWKV7Block(nn.Module):
             h = fused.layer_norm(x, self.attn_norm)
         else:
             x, h = fused.add_layer_norm(x, delta, self.attn_norm)
-        att, v_first = self.attn(h, mask, v_first, state)
+        att, v_first = self.attn(h, mask, v_first, state, seq_start)
         x, h = fused.add_layer_norm(x, att, self.ffn_norm)
         return x, self.ffn(h, mask, state), v_first
 
@@ -357,15 +361,7 @@ class RWKV7Model(nn.Module):
             x = torch.cat([x.new_zeros(B, pad, D), x], 1)
             m = torch.ones(B, T, 1, dtype=x.dtype, device=x.device) if mask is None else mask
             mask = torch.cat([m.new_zeros(B, pad, 1), m], 1)
-        v_first = delta = None
-        for i, layer in enumerate(self.layers):
-            st = past_key_values[i] if stateful else None
-            if self.gradient_checkpointing and self.training and not stateful:
-                x, delta, v_first = torch.utils.checkpoint.checkpoint(layer, x, delta, mask, v_first, None,
-                                                                      use_reentrant=False)
-            else:
-                x, delta, v_first = layer(x, delta, mask, v_first, st)
-        x = fused.add_layer_norm(x, delta, self.norm)[1] if delta is not None else fused.layer_norm(x, self.norm)
+        x = self._run_layers(x, mask, past_key_values if stateful else None)
         if pad:
             x = x[:, pad:]
         if stateful:
@@ -373,15 +369,52 @@ class RWKV7Model(nn.Module):
         return ModelOutput(last_hidden_state=x, past_key_values=past_key_values if stateful else None)
 
 
+    def _run_layers(self, x, mask, cache: Optional[Cache], seq_start=None):
+        v_first = delta = None
+        for i, layer in enumerate(self.layers):
+            st = cache[i] if cache is not None else None
+            if self.gradient_checkpointing and self.training and cache is None:
+                x, delta, v_first = torch.utils.checkpoint.checkpoint(layer, x, delta, mask, v_first, None, seq_start,
+                                                                      use_reentrant=False)
+            else:
+                x, delta, v_first = layer(x, delta, mask, v_first, st, seq_start)
+        return fused.add_layer_norm(x, delta, self.norm)[1] if delta is not None else fused.layer_norm(x, self.norm)
+
     def _forward_packed(self, x, cu_seqlens):
         """Packed variable-length batch (data/utils/spark_dataset.py:111-162,
-        train_spark_rwkv7speech.py:238-239): x is ONE row [1, sum T, D], sequence i occupies
-        [cu_seqlens[i], cu_seqlens[i+1]); WKV state and token shift restart at every boundary.  Sequences never
-        interact, so the row is unpacked into a right-padded masked batch, run, and packed again; positions past
-        cu_seqlens[-1] (the reference's builder may append one overflowing sample) come back as zeros."""
+        train_spark_rwkv7speech.py:238-239; fla's `cu_seqlens`): x is ONE row [1, sum T, D], sequence i occupies
+        [cu_seqlens[i], cu_seqlens[i+1]); WKV state and token shift restart at every boundary.  Positions past
+        cu_seqlens[-1] (the reference's builder may append one overflowing sample) come back as zeros.
+
+        bf16 on the chunked kernels: the row is re-laid out with every sequence starting on a 32-step chunk boundary and
+        followed by at least one masked position (<= 32 wasted positions per sequence instead of padding every sequence to
+        the longest).  The masked position makes the token shift of the next sequence start from zero with the ordinary
+        mask handling; the chunked WKV7 kernels take the sequences' chunk ranges and give every (sequence, head) its own
+        workgroups, each starting from the zero state -- forward and adjoint recurrences of different sequences run in
+        parallel.  Everything else is position-wise.  Other dtypes: unpack into a right-padded masked
+        batch, run, pack again."""
         assert x.shape[0] == 1, "cu_seqlens expects a packed [1, total, D] row"
         cu = cu_seqlens.tolist()
         lens = [b - a for a, b in zip(cu[:-1], cu[1:])]
+        if (PACKED_NATIVE and x.is_cuda and x.dtype == torch.bfloat16 and fused.CHUNKED_WKV_FWD and fused.CHUNKED_WKV_BWD
+                and sum(lens) > 0):
+            C = ops.CHUNK_T
+            D = x.shape[-1]
+            starts, t_al = [], 0
+            for n in lens:
+                starts.append(t_al)
+                if n > 0:
+                    t_al += (n // C + 1) * C      # >= n + 1, multiple of 32
+            dest = torch.cat([torch.arange(s_, s_ + n) for s_, n in zip(starts, lens) if n > 0]).to(x.device)
+            seq_off = torch.tensor([s_ // C for s_, n in zip(starts, lens) if n > 0] + [t_al // C], dtype=torch.int32)
+            src = x[0, cu[0]:cu[-1]]
+            x_al = x.new_zeros(t_al, D).index_copy(0, dest, src)
+            mask = x.new_zeros(t_al, 1).index_fill_(0, dest, 1.0)
+            out = self._run_layers(x_al.unsqueeze(0), mask.unsqueeze(0), None, seq_off.to(x.device))
+            packed = out[0].index_select(0, dest)
+            if cu[0] > 0 or packed.shape[0] < x.shape[1]:
+                packed = torch.cat([packed.new_zeros(cu[0], D), packed, packed.new_zeros(x.shape[1] - cu[-1], D)], 0)
+            return ModelOutput(last_hidden_state=packed.unsqueeze(0), past_key_values=None)
         seqs = list(x[0, :cu[-1]].split(lens))
         xb = torch.nn.utils.rnn.pad_sequence(seqs, batch_first=True)
         mask = torch.zeros(len(lens), xb.shape[1], dtype=torch.long, device=x.device)

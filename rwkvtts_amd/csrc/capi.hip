@@ -27,9 +27,9 @@ int wkv_bwd_split_f32(int, int, int, const void *, const void *, const void *, c
 int chunk_prep_bf16(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_prep_f32(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
-                   const float *, void *, float *, float *, hipStream_t);
+                   const float *, void *, float *, float *, const int *, int, hipStream_t);
 int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
-                  const float *, void *, float *, float *, hipStream_t);
+                  const float *, void *, float *, float *, const int *, int, hipStream_t);
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int gemv32_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
@@ -38,7 +38,7 @@ int adamw_step(long, float *, const void *, float *, float *, void *, float, flo
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
-int chunk_state_bf16(int, int, const void *, const float *, float *, hipStream_t);
+int chunk_state_bf16(int, int, int, const void *, const float *, float *, const int *, int, hipStream_t);
 int chunk_bwd_out_bf16(int, int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                        const float *, const float *, const float *, const float *, void *, void *, void *, void *,
                        void *, void *, hipStream_t);
@@ -305,7 +305,15 @@ EW_DEFINE(f32, float)
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
         if ((sa == nullptr) != (hs == nullptr)) return RWKV7_EINVAL;                                                \
         if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;                                                            \
-        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, (hipStream_t)stream);             \
+        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, nullptr, 0, (hipStream_t)stream); \
+    }                                                                                                               \
+    int rwkv7_wkv_chunk_fwd_seq_##SFX(int B, int T, int H, const void *w, const void *q, const void *k, const void *v, \
+                                      const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs, \
+                                      const int *seq_chunk_off, int nseq, rwkv7_stream_t stream) {                  \
+        if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
+        if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;    \
+        if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;                                                            \
+        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, (hipStream_t)stream); \
     }
 CHUNK_DEFINE(bf16)
 CHUNK_DEFINE(f32)
@@ -319,7 +327,13 @@ int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void 
 }
 int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_kv, rwkv7_stream_t stream) {
     if (BH <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_kv})) return RWKV7_EINVAL;
-    return rwkv7::chunk_state_bf16(BH, nchunks, mt, np, e_kv, (hipStream_t)stream);
+    return rwkv7::chunk_state_bf16(BH, nchunks, 1, mt, np, e_kv, nullptr, 0, (hipStream_t)stream);
+}
+int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const float *np, float *e_kv, const int *seq_chunk_off,
+                                   int nseq, rwkv7_stream_t stream) {
+    if (B <= 0 || H <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_kv})) return RWKV7_EINVAL;
+    if (seq_chunk_off != nullptr && nseq <= 0) return RWKV7_EINVAL;
+    return rwkv7::chunk_state_bf16(B * H, nchunks, H, mt, np, e_kv, seq_chunk_off, nseq, (hipStream_t)stream);
 }
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                  const void *a, const void *b, const void *dy, const float *s, const float *sa,

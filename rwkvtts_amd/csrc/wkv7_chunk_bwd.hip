@@ -293,8 +293,8 @@ struct StateSmem {  // E planes of one half of the value columns, [32 v][64 k], 
 };
 }  // namespace
 
-__global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t *__restrict__ mt_, const float *__restrict__ np_,
-                                                          float *__restrict__ e_kv) {
+__global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const uint16_t *__restrict__ mt_, const float *__restrict__ np_,
+                                                          float *__restrict__ e_kv, const int *__restrict__ seq_off_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = StateSmem;
     // the value columns of E never mix (E_c = M^T E + N' acts on columns): one workgroup per (head, half of the value
@@ -312,6 +312,17 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int mt = wave;
+    // packed rows: one workgroup pair per (sequence, head) walks only that sequence's chunks (see wkv7c_fwd_kernel)
+    int c0 = 0, c1 = nc;
+    if (seq_off_) {
+        const int sq = bh / H, hh = bh - sq * H;
+        const int g0 = seq_off_[sq], g1 = seq_off_[sq + 1];
+        const int bb = g0 / nc;
+        c0 = g0 - bb * nc;
+        c1 = c0 + (g1 - g0);
+        bh = bb * H + hh;
+        if (c1 <= c0) return;
+    }
 
     struct In {
         bf16x8 mh[4], ml[4];
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t
     };
     auto load = [&](int c) {
         In r;
-        if (c >= 0) {
+        if (c >= c0) {
             const uint16_t *mp = mt_ + (((long)bh * nc + c) * 4 + mt * 2) * 4 * 512 + lane * 8;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -366,16 +377,16 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, const uint16_t
         lds_barrier();
         cur ^= 1;
     };
-    In r0 = load(nc - 1), r1 = load(nc - 2), r2 = load(nc - 3);
+    In r0 = load(c1 - 1), r1 = load(c1 - 2), r2 = load(c1 - 3);
     lds_barrier();
-    for (int c = nc - 1; c >= 0; c -= 3) {
+    for (int c = c1 - 1; c >= c0; c -= 3) {
         step(c, r0);
         r0 = load(c - 3);
-        if (c - 1 >= 0) {
+        if (c - 1 >= c0) {
             step(c - 1, r1);
             r1 = load(c - 4);
         }
-        if (c - 2 >= 0) {
+        if (c - 2 >= c0) {
             step(c - 2, r2);
             r2 = load(c - 5);
         }
@@ -795,7 +806,8 @@ int chunk_bwd_pre_bf16(int B, int T_, int H, const void *w, const void *q, const
     return (int)hipGetLastError();
 }
 
-int chunk_state_bf16(int BH, int nc, const void *mt, const float *np, float *e_kv, hipStream_t st) {
+int chunk_state_bf16(int BH, int nc, int H, const void *mt, const float *np, float *e_kv, const int *seq_off, int nseq,
+                     hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_state_kernel),
@@ -804,7 +816,8 @@ int chunk_state_bf16(int BH, int nc, const void *mt, const float *np, float *e_k
         attr = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(wkv7c_state_kernel, dim3(BH * 2), dim3(128), StateSmem::bytes, st, nc, (const uint16_t *)mt, np, e_kv);
+    hipLaunchKernelGGL(wkv7c_state_kernel, dim3((seq_off ? nseq * H : BH) * 2), dim3(128), StateSmem::bytes, st, nc, H, (const uint16_t *)mt,
+                       np, e_kv, seq_off);
     return (int)hipGetLastError();
 }
 

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
                                                         const T *__restrict__ k_, const T *__restrict__ v_,
                                                         const T *__restrict__ a_, const T *__restrict__ b_,
                                                         const float *__restrict__ tinv_, T *__restrict__ y_,
-                                                        float *__restrict__ sa_, float *__restrict__ hs_) {
+                                                        float *__restrict__ sa_, float *__restrict__ hs_,
+                                                        const int *__restrict__ seq_off_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     float *fm = reinterpret_cast<float *>(sm + FwdSmem::end16);
     constexpr int kStageLD = 36;  // fp32 staging tiles [32][36]: conflict-free float4 reads with the step index across lanes
@@ -164,9 +165,25 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         vh = blockIdx.x & 1;
         bh = blockIdx.x >> 1;
     }
-    const int bb = bh / H, hh = bh - bb * H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nc = T_ / kC;
+    // Packed rows (fla chunk_rwkv7's cu_seqlens): seq_off_[s] .. seq_off_[s+1] is the range of 32-step chunks (counted over the
+    // whole [B][T/32] chunk space) of sequence s; the grid then has one workgroup pair per (sequence, head), each starting
+    // from the zero state -- sequences of one row run in parallel instead of one after the other.
+    int bb, hh, c0 = 0, c1 = nc;
+    if (seq_off_) {
+        const int sq = bh / H;
+        hh = bh - sq * H;
+        const int g0 = seq_off_[sq], g1 = seq_off_[sq + 1];
+        bb = g0 / nc;
+        c0 = g0 - bb * nc;
+        c1 = c0 + (g1 - g0);
+        bh = bb * H + hh;
+        if (c1 <= c0) return;
+    } else {
+        bb = bh / H;
+        hh = bh - bb * H;
+    }
     const long tstride = (long)H * kN;
     const long head_base = ((long)bb * T_ * H + hh) * kN;
 
@@ -224,16 +241,16 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
         }
         rv.r = *reinterpret_cast<const RawVec *>(raw + 5 * kC * RS + pt * RSV + pv);
     };
-    issue(0);
+    issue(c0);
     lds_barrier();
 
 #ifdef WKV7C_TIMING
     long long tprev_ = __builtin_readcyclecounter();
 #endif
-    for (int c = 0; c < nc; c++) {
+    for (int c = c0; c < c1; c++) {
         TSTAMP(0);
         restage();
-        if (c + 1 < nc) issue(c + 1);  // next chunk's raw inputs fly during the whole chunk
+        if (c + 1 < c1) issue(c + 1);  // next chunk's raw inputs fly during the whole chunk
         // ---- phase 1: log-decay and its cumulative sum over the chunk ---------------------------------------
         float lw[8], qv[8], kv[8], av[8], bv[8], vv[4];
         {
@@ -462,7 +479,8 @@ static int launch_prep(int B, int T_, int H, const void *w, const void *a, const
 
 template <typename T, bool SAVE>
 static int launch_fwd_t(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                        const void *b, const float *tinv, void *y, float *sa, float *hs, hipStream_t st) {
+                        const void *b, const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq,
+                        hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_fwd_kernel<T, SAVE>),
@@ -471,8 +489,8 @@ static int launch_fwd_t(int B, int T_, int H, const void *w, const void *q, cons
         attr = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((wkv7c_fwd_kernel<T, SAVE>), dim3(B * H * 2), dim3(256), FwdSmem::total<T>(), st, T_, H, (const T *)w,
-                       (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, tinv, (T *)y, sa, hs);
+    hipLaunchKernelGGL((wkv7c_fwd_kernel<T, SAVE>), dim3((seq_off ? nseq : B) * H * 2), dim3(256), FwdSmem::total<T>(), st, T_, H,
+                       (const T *)w, (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, tinv, (T *)y, sa, hs, seq_off);
     return (int)hipGetLastError();
 }
 
@@ -483,14 +501,14 @@ int chunk_prep_f32(int B, int T_, int H, const void *w, const void *a, const voi
     return launch_prep<float>(B, T_, H, w, a, b, tinv, st);
 }
 int chunk_fwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                   const void *b, const float *tinv, void *y, float *sa, float *hs, hipStream_t st) {
-    return (sa && hs) ? launch_fwd_t<bf16_t, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, st)
-                      : launch_fwd_t<bf16_t, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, st);
+                   const void *b, const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq, hipStream_t st) {
+    return (sa && hs) ? launch_fwd_t<bf16_t, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st)
+                      : launch_fwd_t<bf16_t, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, seq_off, nseq, st);
 }
 int chunk_fwd_f32(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                  const void *b, const float *tinv, void *y, float *sa, float *hs, hipStream_t st) {
-    return (sa && hs) ? launch_fwd_t<float, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, st)
-                      : launch_fwd_t<float, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, st);
+                  const void *b, const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq, hipStream_t st) {
+    return (sa && hs) ? launch_fwd_t<float, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st)
+                      : launch_fwd_t<float, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, seq_off, nseq, st);
 }
 #ifdef WKV7C_TIMING
 extern "C" int rwkv7_debug_chunk_timing(long long *out, int reset) {

@@ -205,7 +205,7 @@ class _TmixCore(torch.autograd.Function):
     two partial sets are added in fp32 inside rwkv7_tmix_prepare_bwd_sum instead of by autograd's bf16 add kernels."""
 
     @staticmethod
-    def forward(ctx, r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask, H, eps):
+    def forward(ctx, r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask, H, eps, seq_start=None):
         from . import ops
         B, T, D = k.shape
         if T % ops.CHUNK_LEN != 0:
@@ -221,9 +221,11 @@ class _TmixCore(torch.autograd.Function):
               _p(mask), _p(k_k), _p(k_a), _p(w), _p(k2), _p(v2), _p(a_in), _p(b_in), min(rows, _FWD_BLOCKS))
         v4 = lambda t: t.view(B, T, H, 64)
         chunked = CHUNKED_WKV_FWD and CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0
+        if seq_start is not None and not chunked:
+            raise ValueError("packed rows (seq_start) need the chunked WKV7 kernels: bf16 tensors, T % 32 == 0")
         if chunked:
             # all-MFMA pair: saves T^-1, sa and the state at the start of every 32-step chunk (half the checkpoint bytes)
-            y4, tinv, sa, s = ops.wkv7_chunk_forward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in))
+            y4, tinv, sa, s = ops.wkv7_chunk_forward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), seq_off=seq_start)
             y = y4.view(B, T, D)
         else:
             tinv = None
@@ -236,7 +238,7 @@ class _TmixCore(torch.autograd.Function):
               ctypes.c_float(eps), _p(out), min(rows, _FWD_BLOCKS))
         ctx.save_for_backward(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
                               w, k2, v2, a_in, b_in, y, s, sa, tinv)
-        ctx.H, ctx.eps, ctx.chunked_fwd = H, eps, chunked
+        ctx.H, ctx.eps, ctx.chunked_fwd, ctx.seq_start = H, eps, chunked, seq_start
         return out
 
     @staticmethod
@@ -259,7 +261,7 @@ class _TmixCore(torch.autograd.Function):
         v4 = lambda t: t.view(B, T, H, 64)
         if ctx.chunked_fwd or (CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0):
             dw, dq, dk, dv, da, db = ops.wkv7_chunk_backward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(d_y), s, sa,
-                                                             tinv=tinv, ck_mode=1 if ctx.chunked_fwd else 0)
+                                                             tinv=tinv, ck_mode=1 if ctx.chunked_fwd else 0, seq_off=ctx.seq_start)
             dw2, dq2, dk2, da2, db2 = [(g, None) for g in (dw, dq, dk, da, db)]
         else:
             dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in),
@@ -278,17 +280,18 @@ class _TmixCore(torch.autograd.Function):
         dp = part.sum(0).to(k.dtype)
         dpp = part_post.sum(0).to(k.dtype)
         return (d_r, d_wpre, d_k, d_v, d_apre, d_g, d_vpre, d_vf, dp[0], dp[1], dpp[0], dpp[1], dpp[2], None, None,
-                None)
+                None, None)
 
 
-def tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_bias, r_k, mask, H, eps, is_layer0):
+def tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_bias, r_k, mask, H, eps, is_layer0,
+              seq_start=None):
     """Training-time time-mix core: tmix_post(RUN_CUDA_RWKV7g(r, *tmix_prepare(...)), ...) as one autograd node.
-    r must already be masked (r * mask) when a mask is used."""
+    r must already be masked (r * mask) when a mask is used.  seq_start: ops.wkv7_chunk_forward's seq_off (packed rows)."""
     assert k.shape[-1] == H * 64
     if is_layer0:
         v_pre = v_first = None
     return _TmixCore.apply(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_bias, r_k.reshape(-1),
-                           _mask_rows(mask, k), H, eps)
+                           _mask_rows(mask, k), H, eps, seq_start)
 
 
 _ACT_ID = {None: 0, "tanh": 1, "sigmoid": 2}

@@ -49,7 +49,7 @@ class _timed:
 
 
 def _p(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
 def _stream(t):
@@ -245,8 +245,10 @@ def wkv7_chunk_prep(w, a, b):
     return tinv
 
 
-def wkv7_chunk_forward(w, q, k, v, a, b, save=True):
-    """Chunked forward.  Returns y, and (tinv, sa, hs) when save (what the chunked backward consumes)."""
+def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None):
+    """Chunked forward.  Returns y, and (tinv, sa, hs) when save (what the chunked backward consumes).
+    seq_off: packed rows -- int32 [nseq + 1] device tensor of cumulative 32-step chunk counts over the [B][T/32] chunk
+    space; sequence s owns chunks seq_off[s] .. seq_off[s+1] - 1 and starts from the zero state."""
     B, T, H, C = w.shape
     sfx = _sfx([w, q, k, v, a, b], "wkv7_chunk_forward")
     if T % CHUNK_T != 0:
@@ -256,14 +258,22 @@ def wkv7_chunk_forward(w, q, k, v, a, b, save=True):
     sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device) if save else None
     hs = torch.empty(B, H, T // CHUNK_T, C, C, dtype=torch.float32, device=w.device) if save else None
     with torch.cuda.device_of(w), _timed("wkv7c_fwd", w):
-        rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_" + sfx)(
+        rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_seq_" + sfx)(
             B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(tinv), _p(y),
-            None if sa is None else _p(sa), None if hs is None else _p(hs), _stream(w))
+            None if sa is None else _p(sa), None if hs is None else _p(hs), *_seq_args(seq_off), _stream(w))
     _lib.check(rc, "wkv7_chunk_forward")
     return (y, tinv, sa, hs) if save else y
 
 
-def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv):
+def _seq_args(seq_off):
+    if seq_off is None:
+        return None, 0
+    if seq_off.dtype != torch.int32 or seq_off.dim() != 1 or seq_off.numel() < 2 or not seq_off.is_contiguous() or not seq_off.is_cuda:
+        raise TypeError("seq_off must be a contiguous int32 [nseq + 1] device tensor")
+    return _p(seq_off), seq_off.numel() - 1
+
+
+def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off=None):
     """First two stages of the chunked backward (bf16): per-chunk M^T / N' (parallel) and the adjoint-state recurrence
     E_c = M_c^T E_{c+1} + N'_c (sequential over chunks).  Returns (mt, np, e_kv): e_kv[b,h,c][k][v] = E_{c+1}."""
     B, T, H, C = w.shape
@@ -282,19 +292,19 @@ def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv):
                                                          _stream(w))
         _lib.check(rc, "wkv7_chunk_bwd_pre")
         with _timed("wkv7c_state", w):
-            rc = _lib.lib().rwkv7_wkv_chunk_state_bf16(B * H, nc, _p(mt), _p(np_), _p(e_kv), _stream(w))
+            rc = _lib.lib().rwkv7_wkv_chunk_state_seq_bf16(B, H, nc, _p(mt), _p(np_), _p(e_kv), *_seq_args(seq_off), _stream(w))
         _lib.check(rc, "wkv7_chunk_state")
     return mt, np_, e_kv
 
 
-def wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa, tinv=None, ck_mode=0):
+def wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa, tinv=None, ck_mode=0, seq_off=None):
     """Chunked (MFMA) WKV7 backward, bf16: same inputs and outputs as torch.ops.wind_backstepping.backward, T % 32 == 0.
     ck_mode 0: s, sa = what wind_backstepping.forward saved; ck_mode 1: s = hs, sa, tinv = what wkv7_chunk_forward saved.
     Launches: (T inverse,) M^T/N', adjoint-state recurrence, per-chunk gradients.  Returns (dw, dq, dk, dv, da, db)."""
     B, T, H, C = w.shape
     if tinv is None:
         tinv = wkv7_chunk_prep(w, a, b)
-    mt, np_, e_kv = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv)
+    mt, np_, e_kv = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off)
     del mt, np_
     grads = [torch.empty_like(w) for _ in range(6)]
     with torch.cuda.device_of(w), _timed("wkv7c_bwd_out", w):

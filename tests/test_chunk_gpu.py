@@ -183,3 +183,30 @@ def test_full_size_config2_chunked_pair_vs_oracle_slices(c_oracle):
         tol = 2.0 ** -6 * torch.clamp(mag, min=mag.mean().item())
         frac = (err > tol).float().mean().item()
         assert frac < 1e-3, f"{n}: {frac:.2e} of the elements break linearity in dy"
+
+
+def test_packed_sequences_equal_separate_sequences_vs_oracle(c_oracle):
+    """Packed rows (rwkv7_wkv_chunk_fwd_seq_bf16 / rwkv7_wkv_chunk_state_seq_bf16, fla chunk_rwkv7's cu_seqlens): rows whose
+    chunks 0, 2, 3 (row 0) and 0, 1 (row 1) start new sequences must give, segment by segment, exactly what the C oracle gives
+    for each segment run on its own from the zero state -- outputs and all six gradients, same bars as the plain tests."""
+    B, T, H, seed = 2, 160, 3, 7
+    nc = T // 32
+    ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).bfloat16()
+    starts = [[0, 2, 3], [0, 1]]   # chunk indices (32 steps each), 5 chunks per row
+    off = sorted(b * nc + c for b, st in enumerate(starts) for c in st) + [B * nc]
+    seq_off = torch.tensor(off, dtype=torch.int32, device=DEV)
+    d = [t.to(DEV) for t in ins]
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d, seq_off=seq_off)
+    grads = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv=tinv, ck_mode=1, seq_off=seq_off)
+    torch.cuda.synchronize()
+    for b, st in enumerate(starts):
+        bounds = [32 * c for c in st] + [T]
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            seg = [t[b:b + 1, lo:hi].contiguous() for t in ins]
+            dseg = dy[b:b + 1, lo:hi].contiguous()
+            y_o, s_o, sa_o = c_oracle.wkv7_fwd(*seg)
+            g_o = c_oracle.wkv7_bwd(*seg, dseg, s_o, sa_o)
+            _assert_bf16_close(y[b:b + 1, lo:hi], y_o, f"y[{b},{lo}:{hi}]")
+            for n, g, go in zip(NAMES, grads, g_o):
+                _assert_bf16_close(g[b:b + 1, lo:hi], go, f"{n}[{b},{lo}:{hi}]", ulps=2.0)

@@ -330,3 +330,52 @@ def test_trainer_fast_gradient_path_equals_accumulate_path():
     # the embedders are not used with inputs_embeds: their slices were zeroed, not left at 7
     o = fb.offsets[[i for i, p in enumerate(fb.params) if p is model.text_embedder.weight][0]]
     assert fb.flat_grad[o:o + 8].abs().sum() == 0
+
+
+@pytest.mark.parametrize("lens", [[70, 33, 128, 5], [32, 64], [1, 1, 200]])
+def test_packed_rows_native_sequence_ranges(lens):
+    """cu_seqlens batches in bf16 run on the chunked WKV7 kernels' per-sequence chunk ranges (32-aligned re-layout; forward
+    recurrence in rwkv7_wkv_chunk_fwd_seq_bf16 and adjoint recurrence in rwkv7_wkv_chunk_state_seq_bf16 per sequence) instead
+    of being unpacked into a padded batch.  Both ways must agree -- hidden states, loss, every parameter gradient, the input gradient -- and each
+    sequence must come out as if it had been run alone (state and token shift restart at the boundaries, including lengths
+    that are exact multiples of 32 and lengths of 1)."""
+    from rwkvtts_amd import backbone
+    cfg = RWKV7Config(hidden_size=128, num_hidden_layers=3, vocab_size=64, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=32, gate_low_rank_dim=32)
+    torch.manual_seed(1)
+    model = RWKV7Model(cfg)
+    backbone.init_weights(model, cfg, seed=9)
+    model = model.to(DEV).to(torch.bfloat16).train()
+    total = sum(lens)
+    g = torch.Generator().manual_seed(total)
+    x0 = (torch.randn(1, total + 3, 128, generator=g) * 0.5).to(DEV).to(torch.bfloat16)   # 3 overflow positions
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    wgt = torch.randn(1, total + 3, 128, generator=g).to(DEV)
+
+    def run(native):
+        backbone.PACKED_NATIVE = native
+        try:
+            model.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            h = model(inputs_embeds=x, cu_seqlens=cu).last_hidden_state
+            (h.float() * wgt).sum().backward()
+            return h.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            backbone.PACKED_NATIVE = True
+
+    h1, dx1, g1 = run(True)
+    h0, dx0, g0 = run(False)
+    assert h1.shape == h0.shape and torch.isfinite(h1).all()
+    assert (h1[0, total:] == 0).all() and (dx1[0, total:] == 0).all()
+    assert (h1 - h0).abs().max().item() < 3e-2 * h0.abs().max().item()
+    assert (dx1 - dx0).abs().max().item() < 4e-2 * dx0.abs().max().item()
+    assert g1.keys() == g0.keys()
+    for n in g0:
+        assert (g1[n] - g0[n]).abs().max().item() < 4e-2 * g0[n].abs().max().item() + 1e-3, n
+    # each sequence alone
+    with torch.no_grad():
+        o = 0
+        for n in lens:
+            alone = model(inputs_embeds=x0[:, o:o + n]).last_hidden_state.float()
+            assert (h1[:, o:o + n] - alone).abs().max().item() < 3e-2 * alone.abs().max().item(), (o, n)
+            o += n
