@@ -190,9 +190,18 @@ class RWKV7CosyLM(HFModelMixin, nn.Module):
         out_tokens = []
         if cache is None:
             cache = Cache.zeros(self.config, 1, device, lm_input.dtype)
+        step_kernel = None   # T = 1 steps through rwkv7_decode_step_bf16 once the prompt is in (bf16 models)
         for i in range(max_len):
-            masks = torch.ones((1, lm_input.shape[1], lm_input.shape[1]), device=device, dtype=torch.bool)
-            logits, cache = self.forward_one_step(lm_input, masks=masks, cache=cache)
+            if step_kernel is not None and lm_input.shape[1] == 1:
+                logits = step_kernel(lm_input[:, 0].contiguous()).unsqueeze(1)
+                cache.seen_tokens += 1
+            else:
+                masks = torch.ones((1, lm_input.shape[1], lm_input.shape[1]), device=device, dtype=torch.bool)
+                logits, cache = self.forward_one_step(lm_input, masks=masks, cache=cache)
+                if getattr(self, "use_step_kernel", True) and step_kernel is None:
+                    from .decode import DecodeStep
+                    if DecodeStep.supported(self.model, self.lm_head, cache) is None:
+                        step_kernel = DecodeStep(self.model, self.lm_head, cache)
             logp = logits[:, -1].float().log_softmax(dim=-1)
             top_ids = int(self.sampling_ids(logp.squeeze(dim=0), out_tokens, sampling,
                                             ignore_eos=(i + original_text_len < min_len)).item())

@@ -137,6 +137,16 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
         needs_additional_steps = -torch.ones(B, dtype=torch.long, device=dev)
         cache = Cache.zeros(cfg, B, dev, self.dtype)
         out = self(input_ids=input_ids, attention_mask=attention_mask, past_key_values=cache, use_cache=True)
+        # T = 1 steps: the whole stack + the eight heads (as one concatenated projection) through rwkv7_decode_step_bf16
+        # when the model is covered (bf16, B <= 32); else module by module
+        step_kernel, sizes = None, [h.weight.shape[0] for h in self.heads]
+        if getattr(self, "use_step_kernel", True):
+            from types import SimpleNamespace
+            from .decode import DecodeStep
+            head = SimpleNamespace(weight=torch.cat([h.weight for h in self.heads], 0).contiguous(),
+                                   bias=torch.cat([h.bias for h in self.heads], 0).contiguous())
+            if DecodeStep.supported(self.model, head, cache) is None:
+                step_kernel = DecodeStep(self.model, head, cache)
         while True:
             logits = [l[:, -1, :].clone().float() for l in out.logits]
             mask = torch.ones_like(logits[0], dtype=torch.bool)
@@ -166,7 +176,12 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
             unfinished = unfinished & (~stop).long() & (~(needs_additional_steps == -1) | (~is_flushing)).long()
             if unfinished.max() == 0:
                 break
-            out = self(input_ids=next_tokens[:, None, :], past_key_values=cache, use_cache=True)
+            if step_kernel is not None:
+                lg = step_kernel(self.embed(next_tokens[:, None, :])[:, 0].contiguous())
+                cache.seen_tokens += 1
+                out = ModelOutput(logits=[l.unsqueeze(1) for l in torch.split(lg, sizes, dim=1)])
+            else:
+                out = self(input_ids=next_tokens[:, None, :], past_key_values=cache, use_cache=True)
         if was_training:
             self.train()
         if return_dict_in_generate:

@@ -115,8 +115,9 @@ def test_graph_decoder_with_step_kernel_matches_fp32_greedy_ids():
         with torch.no_grad():
             lg = m32(input_ids=got[:, t:t + 1], past_key_values=c32, use_cache=True).logits[:, -1].float()
     assert checked > NEW * B // 2, checked
-    agree = (got == want_mod).float().mean().item()
-    assert agree > 0.8, agree
+    # the module path is bf16 too and may flip other near-ties (after which the histories differ): only the first new token,
+    # which both take from the same prefill, is comparable id for id
+    assert torch.equal(got[:, 0], want_mod[:, 0])
 
 
 def test_step_kernel_rejects_unsupported_models():

@@ -5,6 +5,7 @@ import torch
 
 from oracle import rwkv7_ref as R
 from rwkvtts_amd import layouts as L
+from rwkvtts_amd.backbone import Cache
 from rwkvtts_amd.cosy_llm import RWKV7CosyConfig, RWKV7CosyLM, RWKV7LM
 from rwkvtts_amd.xy_llm import RWKV7XYConfig, RWKV7XYLM
 
@@ -131,3 +132,87 @@ def test_xy_generate_channel0_mask_and_shapes():
     l0[116:] = float("-inf")
     assert int(new[0, 0]) == int(l0.argmax()) and [int(new[0, i]) for i in (1, 2, 3)] == \
         [int(logits_o[i][0, -1].argmax()) for i in (1, 2, 3)]
+
+
+def test_xy_generate_step_kernel_vs_module_path():
+    """bf16 XY model: the T = 1 steps of generate() through rwkv7_decode_step_bf16 (eight heads as one concatenated projection)
+    against the module-by-module steps: same per-channel logits step by step (teacher-forced, bf16 tolerance), and generate()
+    itself keeps its contract (shape, channel-0 constraint, first frame -- which comes from the shared prefill -- identical)."""
+    from types import SimpleNamespace
+    from rwkvtts_amd.backbone import Cache
+    from rwkvtts_amd.decode import DecodeStep
+    cfg = RWKV7XYConfig(vocab_size=120, speech_vocab_size=16, num_channels=4, text_shift_size=100, hidden_size=128,
+                        num_hidden_layers=2, decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=32, gate_low_rank_dim=32)
+    model = RWKV7XYLM(cfg).init_weights(seed=5)
+    with torch.no_grad():
+        for h in model.heads:
+            h.bias.normal_(0, 0.1)
+    model.zero_embs()
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(1)
+    B = 5
+    text = [[101 + (i + b) % 10 for i in range(4)] for b in range(B)]
+    audio = [torch.randint(0, 15, (4, 3), generator=g).tolist() for _ in range(B)]
+    prompt = L.XYDataProcessor(120, 4, 100, 16).process_batch(text, audio)
+    ids = prompt["input_ids"][:, :6].to(DEV)
+    # step by step, both paths fed the same frames
+    caches = [Cache.zeros(cfg, B, DEV, torch.bfloat16) for _ in range(2)]
+    with torch.no_grad():
+        for c in caches:
+            model(input_ids=ids, past_key_values=c, use_cache=True)
+        head = SimpleNamespace(weight=torch.cat([h.weight for h in model.heads], 0).contiguous(),
+                               bias=torch.cat([h.bias for h in model.heads], 0).contiguous())
+        step = DecodeStep(model.model, head, caches[0])
+        sizes = [h.weight.shape[0] for h in model.heads]
+        for t in range(6):
+            frame = torch.stack([torch.randint(100, 116, (B,), generator=g)] + [torch.randint(0, 15, (B,), generator=g) for _ in range(3)], -1).to(DEV)
+            lk = torch.split(step(model.embed(frame[:, None, :])[:, 0].contiguous()), sizes, dim=1)
+            lm = model(input_ids=frame[:, None, :], past_key_values=caches[1], use_cache=True).logits
+            for ch in range(4):
+                ref = lm[ch][:, -1].float()
+                assert (lk[ch] - ref).abs().max().item() < 3e-2 * ref.abs().max().item(), (t, ch)
+    model.use_step_kernel = True
+    a = model.generate(ids, max_new_tokens=14, do_sample=False)
+    model.use_step_kernel = False
+    b = model.generate(ids, max_new_tokens=14, do_sample=False)
+    assert a.shape == b.shape == (B, 20, 4)
+    assert torch.equal(a[:, :7], b[:, :7])
+    assert ((a[:, 6:, 0] >= 100) & (a[:, 6:, 0] < 116)).all()
+
+
+def test_cosy_inference_step_kernel_vs_fp32_twin():
+    """bf16 Cosy model, B = 1 streaming inference (greedy) with the T = 1 steps on rwkv7_decode_step_bf16: every emitted id must
+    be the fp32 twin's argmax (same bf16-valued weights, fp32 arithmetic, teacher-forced along the emitted ids) wherever the
+    twin's top-2 margin exceeds the bf16 noise; the module-by-module path must emit the same first id (shared prefill)."""
+    import copy
+    cfg = RWKV7CosyConfig(vocab_size=200, speech_token_size=50, hidden_size=128, num_hidden_layers=2, decay_low_rank_dim=32,
+                          a_low_rank_dim=32, v_low_rank_dim=32, gate_low_rank_dim=32)
+    model = RWKV7CosyLM(cfg).init_weights(seed=4).to(DEV).to(torch.bfloat16).eval()
+    twin = copy.deepcopy(model).float().eval()
+    greedy = lambda scores, decoded, sampling: scores.argmax().reshape(1)
+    model.sampling = greedy
+    text = torch.tensor([[5, 6, 7, 8, 9, 10]], device=DEV)
+
+    def run(flag):
+        model.use_step_kernel = flag
+        z = torch.zeros(1, 0, dtype=torch.long, device=DEV)
+        return list(model.inference(text, torch.tensor([6], device=DEV), z, torch.tensor([0], device=DEV), z,
+                                    torch.tensor([0], device=DEV), max_token_text_ratio=4, min_token_text_ratio=1))
+
+    a, b = run(True), run(False)
+    assert len(a) >= 6 and a[0] == b[0]
+    with torch.no_grad():
+        x = torch.cat([twin.llm_embedding.weight[twin.sos_eos].reshape(1, 1, -1), twin.text_embedding(text),
+                       twin.llm_embedding.weight[twin.task_id].reshape(1, 1, -1)], 1)
+        cache = Cache.zeros(cfg, 1, DEV, torch.float32)
+        checked = 0
+        for t, tok in enumerate(a):
+            masks = torch.ones((1, x.shape[1], x.shape[1]), device=DEV, dtype=torch.bool)
+            lg, cache = twin.forward_one_step(x, masks=masks, cache=cache)
+            lg = lg[0, -1, :50]   # before min_len EOS is ignored (resampled away): the ids compete among the speech tokens
+            top2 = torch.topk(lg, 2)
+            if (top2.values[0] - top2.values[1]).item() > 2e-2 * lg.abs().max().item():
+                assert tok == int(top2.indices[0]), (t, tok, int(top2.indices[0]))
+                checked += 1
+            x = twin.speech_embedding.weight[tok].reshape(1, 1, -1)
+    assert checked >= len(a) // 2, (checked, len(a))
