@@ -121,7 +121,8 @@ int rwkv7_mix_bwd_f32(int B, int T, int D, int nmix, const void *const *grad_out
  *   w = (-softplus(-w_pre) - 0.5)*mask ; k,v *= mask ; v += (v_first - v)*sigmoid(v_pre) (v_pre != NULL)
  *   a = sigmoid(a_pre) ; kk = l2norm_head(k*k_k)*mask ; k2 = k*(1 + (a-1)*k_a) ; v2 = v*mask
  * outputs w, k2, v2, ain = -kk, bin = kk*a (the scan's w,k,v,a,b).  v_pre/v_first NULL for layer 0.
- * backward partials: P = 2 (dk_k, dk_a). */
+ * backward partials: P = 5 (dk_k, dk_a, and the column sums of d_wpre, d_apre, d_vpre -- the bias gradients of the
+ * low-rank branches that produced w_pre, a_pre, v_pre; the last is zero when v_pre is NULL). */
 int rwkv7_tmix_prepare_fwd_bf16(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
                                 const void *v_pre, const void *v_first, const void *mask, const void *k_k,
                                 const void *k_a, void *w, void *k2, void *v2, void *ain, void *bin, int nblocks,

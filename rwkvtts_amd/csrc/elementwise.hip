@@ -267,14 +267,14 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
                                         const T *__restrict__ d_ain, const T *__restrict__ d_bin,
                                         T *__restrict__ d_wpre, T *__restrict__ d_k, T *__restrict__ d_v,
                                         T *__restrict__ d_apre, T *__restrict__ d_vpre, T *__restrict__ d_vfirst,
-                                        float *__restrict__ dpart /* [nblk][2][D]: dk_k, dk_a */,
+                                        float *__restrict__ dpart /* [nblk][5][D]: dk_k, dk_a, column sums of d_wpre, d_apre, d_vpre */,
                                         PrepBwdExtra<T> ex) {
     const int c = threadIdx.x * 8;
-    float kk_p[8], ka_p[8], dkk_acc[8], dka_acc[8];
+    float kk_p[8], ka_p[8], dkk_acc[8], dka_acc[8], sw_acc[8], sa_acc[8], sv_acc[8];
     V8<T>::ld(k_k + c, kk_p);
     V8<T>::ld(k_a + c, ka_p);
 #pragma unroll
-    for (int j = 0; j < 8; j++) dkk_acc[j] = dka_acc[j] = 0.f;
+    for (int j = 0; j < 8; j++) dkk_acc[j] = dka_acc[j] = sw_acc[j] = sa_acc[j] = sv_acc[j] = 0.f;
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
         const long o = row * D + c;
         const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
@@ -332,7 +332,10 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
         dot = sum8(dot);
         // d_wpre
 #pragma unroll
-        for (int j = 0; j < 8; j++) o1[j] = gw[j] * m * sigmoidf_(-z[j]);
+        for (int j = 0; j < 8; j++) {
+            o1[j] = gw[j] * m * sigmoidf_(-z[j]);
+            sw_acc[j] += o1[j];   // the low-rank branches' bias gradients are these column sums
+        }
         V8<T>::st(d_wpre + o, o1);
         // d_k, d_apre, parameter partials
 #pragma unroll
@@ -345,6 +348,7 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
             dka_acc[j] = fmaf(gk2[j] * kx[j], a[j] - 1.f, dka_acc[j]);
             o1[j] = dkx * m;
             o2[j] = da * a[j] * (1.f - a[j]);
+            sa_acc[j] += o2[j];
         }
         V8<T>::st(d_k + o, o1);
         V8<T>::st(d_apre + o, o2);
@@ -360,6 +364,7 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
                 o1[j] = g2 * (1.f - s) * m;              // d_v
                 o2[j] = g2 * (vf[j] - vx[j]) * s * (1.f - s);  // d_vpre
                 o3[j] = g2 * s;                          // d_vfirst
+                sv_acc[j] += o2[j];
             }
             V8<T>::st(d_v + o, o1);
             V8<T>::st(d_vpre + o, o2);
@@ -370,8 +375,11 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
             V8<T>::st(d_v + o, o1);
         }
     }
-    V8<float>::st(dpart + ((long)blockIdx.x * 2 + 0) * D + c, dkk_acc);
-    V8<float>::st(dpart + ((long)blockIdx.x * 2 + 1) * D + c, dka_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 0) * D + c, dkk_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 1) * D + c, dka_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 2) * D + c, sw_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 3) * D + c, sa_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 4) * D + c, sv_acc);
 }
 
 // ------------------------------------------------------------------------------------------------------

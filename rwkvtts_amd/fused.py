@@ -142,11 +142,12 @@ class _TmixPrepare(torch.autograd.Function):
         d_wpre, d_k, d_v, d_apre = [torch.empty_like(k) for _ in range(4)]
         d_vpre = torch.empty_like(k) if v_pre is not None else None
         d_vf = torch.empty_like(k) if v_pre is not None else None
-        part = torch.empty(nb, 2, D, dtype=torch.float32, device=k.device)
+        part = torch.empty(nb, 5, D, dtype=torch.float32, device=k.device)
         _call("tmix_prepare_bwd", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first), _p(mask),
               _p(k_k), _p(k_a), *[_p(g) for g in gs], _p(d_wpre), _p(d_k), _p(d_v), _p(d_apre), _p(d_vpre), _p(d_vf),
               _p(part), nb)
         dp = part.sum(0).to(k.dtype)
+        _attach_colsums(dp, d_wpre, d_apre, d_vpre)
         return d_wpre, d_k, d_v, d_apre, d_vpre, d_vf, dp[0], dp[1], None
 
 
@@ -270,7 +271,7 @@ class _TmixCore(torch.autograd.Function):
         d_wpre, d_k, d_v, d_apre, d_r = [torch.empty_like(k) for _ in range(5)]
         d_vpre = torch.empty_like(k) if v_pre is not None else None
         d_vf = torch.empty_like(k) if v_pre is not None else None
-        part = torch.empty(nb, 2, D, dtype=torch.float32, device=k.device)
+        part = torch.empty(nb, 5, D, dtype=torch.float32, device=k.device)
         gsum = [dw2[0], dw2[1], dk2[0], dk2[1], d_k2_post, dv, d_v2_post, da2[0], da2[1], db2[0], db2[1],
                 dq2[0], dq2[1], d_r_post]
         ptrs = (ctypes.c_void_p * 14)(*[None if t is None else t.data_ptr() for t in gsum])
@@ -279,6 +280,7 @@ class _TmixCore(torch.autograd.Function):
               _p(d_r), _p(part), nb)
         dp = part.sum(0).to(k.dtype)
         dpp = part_post.sum(0).to(k.dtype)
+        _attach_colsums(dp, d_wpre, d_apre, d_vpre)
         return (d_r, d_wpre, d_k, d_v, d_apre, d_g, d_vpre, d_vf, dp[0], dp[1], dpp[0], dpp[1], dpp[2], None, None,
                 None, None)
 
@@ -414,6 +416,21 @@ def _grad_slot(param):
     return slot
 
 
+def _attach_colsums(dp, d_wpre, d_apre, d_vpre):
+    """The prepare backward already walks every row of d_wpre / d_apre / d_vpre; it leaves their column sums in rows 2..4
+    of its partials.  They are the bias gradients of the low-rank branches whose Linear produced w_pre / a_pre / v_pre, so
+    they ride along on the gradient tensors (`_colsum`) and _Linear.backward takes them instead of launching a reduction
+    over B*T rows.  If autograd hands _Linear a different tensor object (the gradient was accumulated with another one,
+    hooks, ...), the attribute is simply absent and the reduction runs."""
+    d_wpre._colsum = dp[2]
+    d_apre._colsum = dp[3]
+    if d_vpre is not None:
+        d_vpre._colsum = dp[4]
+
+
+COLSUM_HITS = [0]   # how often _Linear.backward found a ready column sum (tests)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -435,7 +452,13 @@ class _Linear(torch.autograd.Function):
             dw = wgrad_splitk(dy2, x2, out=slot)
             if slot is not None:
                 dw = slot.view_as(weight)   # a fresh view object: autograd adopts it as .grad without a copy
-        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = getattr(dy, "_colsum", None)
+            if db is not None and db.shape[0] == dy2.shape[1] and db.dtype == dy2.dtype:
+                COLSUM_HITS[0] += 1
+            else:
+                db = dy2.sum(0)
         return dx, dw, db
 
 

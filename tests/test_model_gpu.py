@@ -379,3 +379,37 @@ def test_packed_rows_native_sequence_ranges(lens):
             alone = model(inputs_embeds=x0[:, o:o + n]).last_hidden_state.float()
             assert (h1[:, o:o + n] - alone).abs().max().item() < 3e-2 * alone.abs().max().item(), (o, n)
             o += n
+
+
+def test_lora_bias_gradients_come_from_the_prepare_backward():
+    """The bias gradients of the w / a / v low-rank branches are the column sums the prepare backward leaves in its partials
+    (no reduction over B*T rows per bias): the hand-over must actually happen (COLSUM_HITS) and give the gradients that the
+    plain reduction gives."""
+    from rwkvtts_amd import backbone, fused
+    cfg = RWKV7Config(hidden_size=128, num_hidden_layers=2, vocab_size=64, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=32, gate_low_rank_dim=32)
+    torch.manual_seed(2)
+    model = RWKV7Model(cfg)
+    backbone.init_weights(model, cfg, seed=2)
+    model = model.to(DEV).to(torch.bfloat16).train()
+    x = (torch.randn(2, 2048, 128, generator=torch.Generator().manual_seed(3)) * 0.5).to(DEV).to(torch.bfloat16)
+    wgt = torch.randn(2, 2048, 128, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def grads(use):
+        orig = fused._attach_colsums
+        if not use:
+            fused._attach_colsums = lambda *a: None
+        try:
+            model.zero_grad(set_to_none=True)
+            fused.COLSUM_HITS[0] = 0
+            (model(inputs_embeds=x).last_hidden_state.float() * wgt).sum().backward()
+            return fused.COLSUM_HITS[0], {n: p.grad.float().clone() for n, p in model.named_parameters() if "lora.2.bias" in n}
+        finally:
+            fused._attach_colsums = orig
+
+    hits, g1 = grads(True)
+    none, g0 = grads(False)
+    assert hits == 5 and none == 0, (hits, none)    # layer 0: w, a; layer 1: w, a, v
+    assert g1.keys() == g0.keys() and len(g1) == 5
+    for n in g0:
+        assert (g1[n] - g0[n]).abs().max().item() < 2e-2 * g0[n].abs().max().item() + 1e-3, n
