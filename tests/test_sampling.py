@@ -30,3 +30,30 @@ def test_repetition_branch_fires_on_a_repeated_history():
     nucleus_ids = {int(C.nucleus_sampling(scores, 0.8, 25, torch.Generator().manual_seed(s))) for s in range(50)}
     ras_ids = {int(C.ras_sampling(scores, hist, 25, generator=torch.Generator().manual_seed(s))) for s in range(200)}
     assert not ras_ids <= nucleus_ids
+
+
+def test_spark_sampling_filter_matches_hf_warpers():
+    """inference/rwkv7speech_inference.py:99-107 samples through HF generate (transformers pinned in the reference's
+    requirements.txt:245): temperature -> top-k -> top-p warpers, then one multinomial draw.  sample_next must keep exactly
+    the candidates the HF warpers keep and, under the same seed, draw the same ids."""
+    import pytest
+    tf = pytest.importorskip("transformers")
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from rwkvtts_amd.spark_llm import sample_next
+    g = torch.Generator().manual_seed(5)
+    for V, temp, k, p in [(8193, 1.0, 50, 0.95), (8193, 0.8, 0, 0.9), (300, 1.3, 20, 1.0), (64, 0.7, 5, 0.5)]:
+        logits = torch.randn(4, V, generator=g) * 3
+        ids = torch.zeros(4, 1, dtype=torch.long)
+        x = logits.clone()
+        if temp != 1.0:
+            x = TemperatureLogitsWarper(temp)(ids, x)
+        if k:
+            x = TopKLogitsWarper(k)(ids, x)
+        if p < 1.0:
+            x = TopPLogitsWarper(p)(ids, x)
+        torch.manual_seed(11)
+        want = torch.multinomial(torch.softmax(x, -1), 1).squeeze(1)
+        torch.manual_seed(11)
+        got = sample_next(logits.clone(), True, k, p, temp)
+        assert torch.equal(got, want), (V, temp, k, p)
+    assert torch.equal(sample_next(torch.tensor([[1.0, 3.0, 3.0, 2.0]])), torch.tensor([1]))   # greedy: first max
