@@ -152,6 +152,7 @@ class BucketedAllReduce:
                 cur_end, cnt = cur_start, 0
         self.pending = [b[2] for b in self.buckets]
         self.works = []
+        self.use_avg, self.summed = True, []
         self.enabled = self.world > 1
         if self.enabled:
             flat.on_ready = self._ready
@@ -167,7 +168,14 @@ class BucketedAllReduce:
         s, e, _ = self.buckets[b]
         view = self.flat.flat_grad[s:e]
         if self.backend == "nccl":
-            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+            if self.use_avg:
+                try:
+                    self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                    return
+                except RuntimeError:   # a collective library without AVG for this dtype: SUM now, one scale in finish()
+                    self.use_avg = False
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.summed.append((s, e))
         else:  # gloo (CPU tests): no AVG, and bf16 support varies -> reduce in fp32
             tmp = view.float()
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
@@ -184,6 +192,9 @@ class BucketedAllReduce:
         for w in self.works:
             w.wait()
         self.works = []
+        for s, e in self.summed:
+            self.flat.flat_grad[s:e].mul_(1.0 / self.world)
+        self.summed = []
         self.pending = [b[2] for b in self.buckets]
 
 
