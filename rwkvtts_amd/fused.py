@@ -12,7 +12,9 @@ import torch
 
 from . import _lib
 
-_FWD_BLOCKS = 4096   # workgroups walking the rows (D/8 threads each)
+_FWD_BLOCKS = 32768  # workgroups walking the rows (D/8 threads each): one row per workgroup at B*T = 32768 beats a row loop
+                     # (tools/bench_fwd_blocks.py: prepare 178 -> 165 us, post 80 -> 71, add+LayerNorm 48 -> 44.5)
+_MIX_FWD_BLOCKS = 2048   # the token-shift kernel re-reads the previous row at the start of a run: fewer, longer runs (106 -> 103 us)
 _BWD_BLOCKS = 2048   # also the number of parameter-gradient partials (1024: same step time, 512: +4 %)
 _MIX_BWD_ROWS = 4     # rows per run in mix_bwd (neighbours carried in registers inside a run)
 _MIX_BWD_BLOCKS = 1024
@@ -64,7 +66,7 @@ class _Mix(torch.autograd.Function):
         nmix = params.shape[0]
         out = torch.empty(nmix, B, T, D, dtype=x.dtype, device=x.device)
         xp = None if x_prev is None else _c(x_prev.to(x.dtype))
-        _call("mix_fwd", x, B, T, D, nmix, _p(x), _p(xp), _p(mask), _p(params), _p(out), min(B * T, _FWD_BLOCKS))
+        _call("mix_fwd", x, B, T, D, nmix, _p(x), _p(xp), _p(mask), _p(params), _p(out), min(B * T, _MIX_FWD_BLOCKS))
         ctx.save_for_backward(x, xp, mask, params)
         return tuple(out[i] for i in range(nmix))
 
