@@ -478,18 +478,21 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     const long tstride = (long)H * kN;
     const long nck = T_ / kChunk;  // scalar-forward checkpoints (every 16 steps), s[b,h,n][k][v]
 
-    // everything a chunk reads from global memory, held in registers one chunk ahead
-    struct In {
+    // Everything a chunk reads from global memory is requested one chunk ahead: the raw rows at the start of the previous
+    // chunk, the three 64x64 fp32 matrices (48 registers) only after its phase D -- held any longer they push the phase A-D
+    // working set into AGPR spills (30 % of the kernel's VALU instructions were v_accvgpr moves).
+    struct Rows {
         Raw8 w, q, k, a, b, v, dy;
         float4 u0, u1, tm;
-        float4 ekv[4], h0[4], hc[4];  // 64x64 fp32: piece p = tid + 256 i = row p >> 4, columns 4 (p & 15) .. +4
         long off;
     };
-    // first: load H0 as well; otherwise H0 of this chunk is H_C of the previous one (same head), already in registers
-    auto load = [&](int chunk, bool first) {
+    struct Mats {
+        float4 ekv[4], h0[4], hc[4];  // 64x64 fp32: piece p = tid + 256 i = row p >> 4, columns 4 (p & 15) .. +4
+    };
+    auto load_rows = [&](int chunk) {
         const int bh = chunk / nc, c = chunk - bh * nc;
         const int bb = bh / H, hh = bh - bb * H;
-        In r;
+        Rows r;
         // row-contiguous mapping for global memory (8 lanes = the 64 channels of one step); the compute mapping (step index
         // across lanes) is reached through the LDS restaging below, and left the same way for the six outputs
         r.off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + lt) * tstride + lk;
@@ -498,33 +501,44 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         r.u0 = *reinterpret_cast<const float4 *>(sa_ + r.off);
         r.u1 = *reinterpret_cast<const float4 *>(sa_ + r.off + 4);
         r.tm = *reinterpret_cast<const float4 *>(tinv_ + (long)chunk * kC * kC + tid * 4);
+        return r;
+    };
+    const long n_ck = ck_mode ? nc : nck;
+    // H at the start of a chunk (ck_mode 0: checkpoint 2c-1; 1: hs entry c)
+    auto load_h0 = [&](int chunk, float4 (&h0)[4]) {
+        const int bh = chunk / nc, c = chunk - bh * nc;
+        const int i0 = ck_mode ? c : 2 * c - 1;
+        const bool has0 = ck_mode ? true : c > 0;
+        const float *h0p = s_ + ((long)bh * n_ck + i0) * kN * kN;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            h0[i] = has0 ? *reinterpret_cast<const float4 *>(h0p + (tid + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // first: load H0 as well; otherwise H0 of this chunk is H_C of the previous one (same head), already in registers
+    auto load_mats = [&](int chunk, bool first, Mats &r) {
+        const int bh = chunk / nc, c = chunk - bh * nc;
         const float *ekv = e_kv + (long)chunk * kN * kN;
-        const long n_ck = ck_mode ? nc : nck;
-        const int i0 = ck_mode ? c : 2 * c - 1, iC = ck_mode ? c + 1 : 2 * c + 1;
-        const bool has0 = ck_mode ? true : c > 0, hasC = ck_mode ? c + 1 < nc : true;  // E = 0 after the last chunk: H_C unused
-        const float *h0p = s_ + ((long)bh * n_ck + i0) * kN * kN, *hcp = s_ + ((long)bh * n_ck + iC) * kN * kN;
+        const int iC = ck_mode ? c + 1 : 2 * c + 1;
+        const bool hasC = ck_mode ? c + 1 < nc : true;  // E = 0 after the last chunk: H_C unused
+        const float *hcp = s_ + ((long)bh * n_ck + iC) * kN * kN;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i;
             r.ekv[i] = *reinterpret_cast<const float4 *>(ekv + p * 4);
-            if (first || c == 0) r.h0[i] = has0 ? *reinterpret_cast<const float4 *>(h0p + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             r.hc[i] = hasC ? *reinterpret_cast<const float4 *>(hcp + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        return r;
+        if (first || c == 0) load_h0(chunk, r.h0);
     };
     const int chunk0 = blockIdx.x * kOutChunksPerWG;
-    In cur = load(chunk0, true);
+    Rows cur = load_rows(chunk0);
+    Mats curm;
+    load_mats(chunk0, true, curm);
     for (int ci = 0; ci < kOutChunksPerWG; ci++) {
     const int chunk = chunk0 + ci;
     if (chunk >= nchunks_total) break;
-    In nxt = cur;
-    if (ci + 1 < kOutChunksPerWG && chunk + 1 < nchunks_total) {
-        nxt = load(chunk + 1, false);
-        if ((chunk + 1) % nc != 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) nxt.h0[i] = cur.hc[i];
-        }
-    }
+    const bool more = ci + 1 < kOutChunksPerWG && chunk + 1 < nchunks_total;
+    Rows nxt = cur;
+    if (more) nxt = load_rows(chunk + 1);
     BSTAMP_INIT;
     const long off = cur.off;
     Raw8 rw, rq, rk, ra, rb, rv, rdy;
@@ -554,13 +568,12 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         ru0 = *reinterpret_cast<const float4 *>(rsu + pt * L::kStLD + pk);
         ru1 = *reinterpret_cast<const float4 *>(rsu + pt * L::kStLD + pk + 4);
     }
-    float4 rekv[4], rh0[4];
+    float4 rekv[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        rekv[i] = cur.ekv[i];
-        rh0[i] = cur.h0[i];
+        rekv[i] = curm.ekv[i];
         // rowsum(E * H_C): the 16 lanes tid & 15 share a row
-        const float part = rekv[i].x * cur.hc[i].x + rekv[i].y * cur.hc[i].y + rekv[i].z * cur.hc[i].z + rekv[i].w * cur.hc[i].w;
+        const float part = rekv[i].x * curm.hc[i].x + rekv[i].y * curm.hc[i].y + rekv[i].z * curm.hc[i].z + rekv[i].w * curm.hc[i].w;
         const float t = sum16(part);
         if ((tid & 15) == 0) sh_dterm[(tid + 256 * i) >> 4] = t;
     }
@@ -686,6 +699,15 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     }
     lds_barrier();
     BSTAMP(6);
+    // the next chunk's matrices are requested here (see Mats); H0 of THIS chunk, needed again in phase E2, stays in curm.h0
+    Mats nxtm = curm;
+    if (more) {
+        load_mats(chunk + 1, false, nxtm);
+        if ((chunk + 1) % nc != 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) nxtm.h0[i] = curm.hc[i];
+        }
+    }
     BSTAMP(7);
     // ---- phase F1: dV out; dK (waves 0,1) and dB (waves 2,3), unscaled, to staging -------------------------------------------------
     float dVv[8];  // written out with the other gradients in the epilogue
@@ -717,7 +739,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
-            put4(sm + L::XTh, sm + L::XTl, row, c4, rh0[i], 1.f, 1.f, 1.f, 1.f);
+            put4(sm + L::XTh, sm + L::XTl, row, c4, curm.h0[i], 1.f, 1.f, 1.f, 1.f);
         }
         if (wave <= 1) mask_lower_T<false>(acc, lane);
         else mask_lower_T<true>(acc, lane);
@@ -783,6 +805,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     BSTAMP(11);
     lds_barrier();  // the next chunk's prologue overwrites what the epilogue reads
     cur = nxt;
+    curm = nxtm;
     }  // chunk loop
 }
 
