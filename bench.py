@@ -228,7 +228,7 @@ def main():
                 out["decode"] = decode_rate(model, dev)
             except Exception as e:  # the headline number must not depend on the secondary measurement
                 out["decode"] = {"error": repr(e)}
-        if not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
