@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "librwkv7_hip.so")
+SO_PATH = os.environ.get("RWKV7_HIP_SO") or os.path.join(_HERE, "lib", "librwkv7_hip.so")   # override: A/B builds
 
 _ERR = {-1: "RWKV7_EINVAL: null pointer or non-positive size",
         -2: "RWKV7_ECHUNK: T must be a multiple of 16 (reference assert, wkv7_cuda.cu:136)",

@@ -25,6 +25,13 @@ using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
 
 constexpr int kC = 32;        // chunk length
 constexpr int kPad = 8;       // plane row padding (elements)
+// Number of independent accumulator chains inside one tile product.  A lone wave per SIMD cannot hide the latency of
+// back-to-back dependent MFMAs; two chains (even / odd MFMAs, summed at the end) do, at the price of 16 more registers.
+// Per translation unit (define WKV7C_MMA_CHAINS before including) or per call (last template argument).
+#ifndef WKV7C_MMA_CHAINS
+#define WKV7C_MMA_CHAINS 1
+#endif
+constexpr int kMmaChains = WKV7C_MMA_CHAINS;
 
 typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
@@ -46,7 +53,7 @@ __device__ __forceinline__ void split2(float x, uint16_t &hi, uint16_t &lo) {
 }
 
 // acc += X[m0 + (0..31)][0..K) . Y[n0 + (0..31)][0..K)^T     (single planes)
-template <int K>
+template <int K, int CH = kMmaChains>
 __device__ __forceinline__ void mma_tile(f32x16 &acc, const uint16_t *X, int ldx, const uint16_t *Y, int ldy, int lane) {
     const uint16_t *xp = X + (lane & 31) * ldx + (lane >> 5) * 8;
     const uint16_t *yp = Y + (lane & 31) * ldy + (lane >> 5) * 8;
@@ -60,7 +67,7 @@ __device__ __forceinline__ void mma_tile(f32x16 &acc, const uint16_t *X, int ldx
 // both operands split: Xh Yh + Xh Yl + Xl Yh.  All fragments are fetched first, then the MFMAs issue back to back
 // (hipcc otherwise interleaves each ds_read pair with its dependent MFMA and the lone wave eats the LDS latency
 // K/16 * 3 times per product).
-template <int K>
+template <int K, int CH = kMmaChains>
 __device__ __forceinline__ void mma_tile3(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx,
                                           const uint16_t *Yh, const uint16_t *Yl, int ldy, int lane) {
     constexpr int NK = K / 16;
@@ -73,15 +80,17 @@ __device__ __forceinline__ void mma_tile3(f32x16 &acc, const uint16_t *Xh, const
         xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
         yl[i] = *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
     }
+    f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 1) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0);
     }
+    if (CH == 2) acc += acc_b;
 }
 // Y exact in bf16 (raw v / dy): Xh Y + Xl Y
-template <int K>
+template <int K, int CH = kMmaChains>
 __device__ __forceinline__ void mma_tile2x(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx,
                                            const uint16_t *Y, int ldy, int lane) {
     constexpr int NK = K / 16;
@@ -93,14 +102,16 @@ __device__ __forceinline__ void mma_tile2x(f32x16 &acc, const uint16_t *Xh, cons
         y[i] = *reinterpret_cast<const bf16x8 *>(Y + yo + 16 * i);
         xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
     }
+    f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 1) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc, 0, 0, 0);
     }
+    if (CH == 2) acc += acc_b;
 }
 // X exact in bf16: X Yh + X Yl
-template <int K>
+template <int K, int CH = kMmaChains>
 __device__ __forceinline__ void mma_tile2y(f32x16 &acc, const uint16_t *X, int ldx, const uint16_t *Yh,
                                            const uint16_t *Yl, int ldy, int lane) {
     constexpr int NK = K / 16;
@@ -112,11 +123,13 @@ __device__ __forceinline__ void mma_tile2y(f32x16 &acc, const uint16_t *X, int l
         yh[i] = *reinterpret_cast<const bf16x8 *>(Yh + yo + 16 * i);
         yl[i] = *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
     }
+    f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], yh[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], yl[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], yh[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], yh[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 1) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], yl[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], yl[i], acc, 0, 0, 0);
     }
+    if (CH == 2) acc += acc_b;
 }
 
 // ---- operands whose contraction index is the ROW index of the stored plane (k-major, P[k][n]) ---------------------------
@@ -136,7 +149,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t *P, int ld, int k0, int
     return __builtin_bit_cast(bf16x8, v);
 }
 // acc += X[m][0..K) . Y where Y is k-major: Y[k][n_base + n];  X split, Y split
-template <int K>
+template <int K, int CH = kMmaChains>
 __device__ __forceinline__ void mma_tile3_yK(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx, const uint16_t *Yh,
                                              const uint16_t *Yl, int ldy, int n_base, int lane) {
     constexpr int NK = K / 16;
@@ -149,15 +162,17 @@ __device__ __forceinline__ void mma_tile3_yK(f32x16 &acc, const uint16_t *Xh, co
         yh[i] = frag_tr(Yh, ldy, 16 * i, n_base, lane);
         yl[i] = frag_tr(Yl, ldy, 16 * i, n_base, lane);
     }
+    f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 1) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0);
     }
+    if (CH == 2) acc += acc_b;
 }
 // X split, Y exact (single plane), k-major
-template <int K>
+template <int K, int CH = kMmaChains>
 __device__ __forceinline__ void mma_xs_yeK(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx, const uint16_t *Y,
                                            int ldy, int n_base, int lane) {
     constexpr int NK = K / 16;
@@ -169,17 +184,19 @@ __device__ __forceinline__ void mma_xs_yeK(f32x16 &acc, const uint16_t *Xh, cons
         xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
         y[i] = frag_tr(Y, ldy, 16 * i, n_base, lane);
     }
+    f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 1) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc, 0, 0, 0);
     }
+    if (CH == 2) acc += acc_b;
 }
 
 // General tile product: acc[m][n] += sum_k X[m][k] Y[n][k] over K, where each operand is either row-major (free index = row,
 // k contiguous; `base` = first row) or k-major (k = row, free index contiguous; `base` = first column; fetched with
 // frag_tr), and either exact bf16 (one plane) or split hi/lo.  Terms: Xh Yh (+ Xl Yh) (+ Xh Yl).
-template <int K, bool XKM, bool XSPLIT, bool YKM, bool YSPLIT>
+template <int K, bool XKM, bool XSPLIT, bool YKM, bool YSPLIT, int CH = kMmaChains>
 __device__ __forceinline__ void mma_gen(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx, int xbase,
                                         const uint16_t *Yh, const uint16_t *Yl, int ldy, int ybase, int lane) {
     constexpr int NK = K / 16;
@@ -192,12 +209,14 @@ __device__ __forceinline__ void mma_gen(f32x16 &acc, const uint16_t *Xh, const u
         if (XSPLIT) xl[i] = XKM ? frag_tr(Xl, ldx, 16 * i, xbase, lane) : *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
         if (YSPLIT) yl[i] = YKM ? frag_tr(Yl, ldy, 16 * i, ybase, lane) : *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
     }
+    f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
-        if (YSPLIT) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0);
-        if (XSPLIT) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[i], acc, 0, 0, 0);
+        if (YSPLIT) { if (CH == 2 && ((i + 1) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[i], acc, 0, 0, 0); }
+        if (XSPLIT) { if (CH == 2 && ((i + 0) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc_b, 0, 0, 0); else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[i], acc, 0, 0, 0); }
     }
+    if (CH == 2) acc += acc_b;
 }
 
 // row index of accumulator register r for this lane

@@ -47,7 +47,7 @@ __device__ __forceinline__ void mask_upper_T(f32x16 &acc, int lane) {
 }
 
 // X split, Y exact (single plane)
-template <int K>
+template <int K, int CH = kMmaChains>
 __device__ __forceinline__ void mma_xs_ye(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int ldx, const uint16_t *Y,
                                           int ldy, int lane) {
     constexpr int NK = K / 16;
@@ -59,11 +59,15 @@ __device__ __forceinline__ void mma_xs_ye(f32x16 &acc, const uint16_t *Xh, const
         y[i] = *reinterpret_cast<const bf16x8 *>(Y + yo + 16 * i);
         xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
     }
+    f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NK; i++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc, 0, 0, 0);
+        if (CH == 2 && (i & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc_b, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], y[i], acc, 0, 0, 0);
+        if (CH == 2 && ((i + 1) & 1)) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc_b, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], y[i], acc, 0, 0, 0);
     }
+    if (CH == 2) acc += acc_b;
 }
 
 struct Raw8 {
@@ -223,13 +227,13 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
         // ---- phase 1: A_qb^T (wave 0), W = T A~ (waves 1, 2) -----------------------------------------------------------
         if (wave == 0) {
             f32x16 acc = zero16();  // D[m = t][n = s] = q~_t . b^_s, kept for t >= s; stored as QBT[s][t]
-            mma_tile3<kN>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::BHh, sm + L::BHl, LDK, lane);
+            mma_tile3<kN, 2>(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::BHh, sm + L::BHl, LDK, lane);
             mask_upper_T<false>(acc, lane);
             store_T_split(acc, sm + L::QBTh, sm + L::QBTl, LDC, lane);
         } else if (wave <= 2) {
             const int kt = wave - 1;
             f32x16 acc = zero16();  // D[m = t][n = k] = sum_s T[t][s] a~[s][k]; stored as WT[k][t]
-            mma_tile3<kC>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::ATTh + kt * 32 * LDC, sm + L::ATTl + kt * 32 * LDC, LDC, lane);
+            mma_tile3<kC, 2>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::ATTh + kt * 32 * LDC, sm + L::ATTl + kt * 32 * LDC, LDC, lane);
             store_T_split(acc, sm + L::WTh + kt * 32 * LDC, sm + L::WTl + kt * 32 * LDC, LDC, lane);
         }
         lds_barrier();
@@ -237,14 +241,14 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
         if (wave <= 1) {
             const int vt = wave;
             f32x16 acc = zero16();  // D[m = s][n = v] = sum_t QBT[s][t] dY[t][v]; stored as G1T[v][s]
-            mma_xs_ye<kC>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
+            mma_xs_ye<kC, 2>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
             store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
         } else {
             const int mt = wave - 2;  // rows k' of the product below
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
                 f32x16 acc = zero16();  // D[m = k'][n = k] = sum_t (b^ g_C)[t][k'] W[t][k]; stored as M^T[k][k']
-                mma_tile3<kC>(acc, sm + L::BCTh + mt * 32 * LDC, sm + L::BCTl + mt * 32 * LDC, LDC, sm + L::WTh + nt * 32 * LDC,
+                mma_tile3<kC, 2>(acc, sm + L::BCTh + mt * 32 * LDC, sm + L::BCTl + mt * 32 * LDC, LDC, sm + L::WTh + nt * 32 * LDC,
                               sm + L::WTl + nt * 32 * LDC, LDC, lane);
                 if (mt == nt) {
                     const int n = lane & 31;
@@ -260,8 +264,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
         {
             const int mt = wave >> 1, nt = wave & 1;
             f32x16 acc = zero16();  // D[m = k][n = v]
-            mma_xs_ye<kC>(acc, sm + L::QTTh + mt * 32 * LDC, sm + L::QTTl + mt * 32 * LDC, LDC, sm + L::DYT + nt * 32 * LDC, LDC, lane);
-            mma_tile3<kC>(acc, sm + L::WTh + mt * 32 * LDC, sm + L::WTl + mt * 32 * LDC, LDC, sm + L::G1Th + nt * 32 * LDC,
+            mma_xs_ye<kC, 2>(acc, sm + L::QTTh + mt * 32 * LDC, sm + L::QTTl + mt * 32 * LDC, LDC, sm + L::DYT + nt * 32 * LDC, LDC, lane);
+            mma_tile3<kC, 2>(acc, sm + L::WTh + mt * 32 * LDC, sm + L::WTl + mt * 32 * LDC, LDC, sm + L::G1Th + nt * 32 * LDC,
                           sm + L::G1Tl + nt * 32 * LDC, LDC, lane);
             float *o = np_ + (((long)chunk * 4 + wave) * 64 + lane) * 16;
 #pragma unroll

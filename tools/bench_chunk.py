@@ -1,4 +1,4 @@
-"""Per-kernel HIP-event timing of the chunked WKV7 backward (prep, pre, state, out) at B=8, T=4096, H=16 bf16."""
+"""Per-kernel HIP-event timing of the chunked WKV7 kernels (prep, fwd, pre, state, out) at B=8, T=4096, H=16 bf16."""
 import os
 import sys
 
@@ -17,10 +17,12 @@ s = torch.empty(B, H, T // 16, 64, 64, device=dev)
 sa = torch.empty(B, T, H, 64, device=dev)
 torch.ops.wind_backstepping.forward(w, q, k, v, a, b, y, s, sa)
 for _ in range(3):
+    ops.wkv7_chunk_forward(w, q, k, v, a, b)
     ops.wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa)
 torch.cuda.synchronize()
 ops.KERNEL_TIMERS = {}
 for _ in range(10):
+    ops.wkv7_chunk_forward(w, q, k, v, a, b)
     ops.wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa)
 torch.cuda.synchronize()
 tot = 0.0
