@@ -369,13 +369,16 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
             eh[i] = *reinterpret_cast<const bf16x8 *>(Eh + 16 * i);
             el[i] = *reinterpret_cast<const bf16x8 *>(El + 16 * i);
         }
+        // three independent accumulator chains (one per hi/lo term): this loop is the sequential critical path, and
+        // back-to-back dependent MFMAs of a lone wave expose their latency (one chain 171 us, two or three 163 us)
+        f32x16 acc_b = zero16(), acc_c = zero16();
 #pragma unroll
         for (int i = 0; i < 4; i++) {  // D[m = k][n = v] += sum_k' M^T[k][k'] E[k'][v]
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.mh[i], eh[i], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.mh[i], el[i], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.ml[i], eh[i], acc, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.mh[i], el[i], acc_b, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.ml[i], eh[i], acc_c, 0, 0, 0);
         }
-        E = acc;
+        E = acc + (acc_b + acc_c);
         uint16_t *Oh = sm + (cur ? L::E0h : L::E1h), *Ol = Oh + kC * LDK;
         store_T_split(E, Oh + mt * 32, Ol + mt * 32, LDK, lane);  // planes [v (this half)][k]
         lds_barrier();
