@@ -470,7 +470,7 @@ __device__ __forceinline__ void put4(uint16_t *Ph, uint16_t *Pl, int row, int c4
 
 // ck_mode 0: s_ = checkpoints of wkv7_fwd.hip (every 16 steps: H at the start of chunk c is entry 2c-1, at its end 2c+1);
 // ck_mode 1: s_ = hs of wkv7_chunk_fwd.hip (state at the START of every 32-step chunk: entries c and c+1).  [k][v] both.
-__global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wkv7c_bwd_out_kernel(
     int T_, int H, int nchunks_total, int ck_mode, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
     const bf16_t *__restrict__ v_, const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_, const bf16_t *__restrict__ dy_,
     const float *__restrict__ s_, const float *__restrict__ sa_, const float *__restrict__ tinv_, const float *__restrict__ e_kv, bf16_t *__restrict__ dw_, bf16_t *__restrict__ dq_, bf16_t *__restrict__ dk_,
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         long off;
     };
     struct Mats {
-        float4 ekv[4], h0[4], hc[4];  // 64x64 fp32: piece p = tid + 256 i = row p >> 4, columns 4 (p & 15) .. +4
+        float4 ekv[4], hc[4];  // 64x64 fp32: piece p = tid + 256 i = row p >> 4, columns 4 (p & 15) .. +4
     };
     auto load_rows = [&](int chunk) {
         const int bh = chunk / nc, c = chunk - bh * nc;
@@ -521,8 +521,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
         for (int i = 0; i < 4; i++)
             h0[i] = has0 ? *reinterpret_cast<const float4 *>(h0p + (tid + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    // first: load H0 as well; otherwise H0 of this chunk is H_C of the previous one (same head), already in registers
-    auto load_mats = [&](int chunk, bool first, Mats &r) {
+    auto load_mats = [&](int chunk, Mats &r) {
         const int bh = chunk / nc, c = chunk - bh * nc;
         const float *ekv = e_kv + (long)chunk * kN * kN;
         const int iC = ck_mode ? c + 1 : 2 * c + 1;
@@ -534,18 +533,15 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
             r.ekv[i] = *reinterpret_cast<const float4 *>(ekv + p * 4);
             r.hc[i] = hasC ? *reinterpret_cast<const float4 *>(hcp + p * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (first || c == 0) load_h0(chunk, r.h0);
     };
     const int chunk0 = blockIdx.x * kOutChunksPerWG;
     Rows cur = load_rows(chunk0);
     Mats curm;
-    load_mats(chunk0, true, curm);
+    load_mats(chunk0, curm);
     for (int ci = 0; ci < kOutChunksPerWG; ci++) {
     const int chunk = chunk0 + ci;
     if (chunk >= nchunks_total) break;
     const bool more = ci + 1 < kOutChunksPerWG && chunk + 1 < nchunks_total;
-    Rows nxt = cur;
-    if (more) nxt = load_rows(chunk + 1);
     BSTAMP_INIT;
     const long off = cur.off;
     Raw8 rw, rq, rk, ra, rb, rv, rdy;
@@ -706,15 +702,11 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     }
     lds_barrier();
     BSTAMP(6);
-    // the next chunk's matrices are requested here (see Mats); H0 of THIS chunk, needed again in phase E2, stays in curm.h0
-    Mats nxtm = curm;
-    if (more) {
-        load_mats(chunk + 1, false, nxtm);
-        if ((chunk + 1) % nc != 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) nxtm.h0[i] = curm.hc[i];
-        }
-    }
+    // H0 of this chunk for phase E2 (an L2 hit: the previous chunk read it as its H_C); nothing else is held across the
+    // product phases -- every register carried through them is one the compiler cannot use to keep a product's fragment
+    // loads in flight (with 40 + 48 prefetch registers live it issued them four at a time between dependent MFMAs)
+    float4 h0e[4];
+    load_h0(chunk, h0e);
     BSTAMP(7);
     // ---- phase F1: dV out; dK (waves 0,1) and dB (waves 2,3), unscaled, to staging -------------------------------------------------
     float dVv[8];  // written out with the other gradients in the epilogue
@@ -746,7 +738,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + 256 * i, row = p >> 4, c4 = (p & 15) * 4;
-            put4(sm + L::XTh, sm + L::XTl, row, c4, curm.h0[i], 1.f, 1.f, 1.f, 1.f);
+            put4(sm + L::XTh, sm + L::XTl, row, c4, h0e[i], 1.f, 1.f, 1.f, 1.f);
         }
         if (wave <= 1) mask_lower_T<false>(acc, lane);
         else mask_lower_T<true>(acc, lane);
@@ -754,6 +746,9 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     }
     lds_barrier();
     BSTAMP(9);
+    // the next chunk's raw rows: requested two phases (~4k cycles) ahead of their use
+    Rows nxt = cur;
+    if (more) nxt = load_rows(chunk + 1);
     // ---- phase F2: dQ (waves 0,1) and dA (waves 2,3), unscaled, to staging ---------------------------------------------------------
     {
         const int kt = wave & 1;
@@ -772,6 +767,9 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_out_kernel(
     }
     lds_barrier();
     BSTAMP(10);
+    // the next chunk's E and H_C (needed ~1k cycles into its prologue)
+    Mats nxtm = curm;
+    if (more) load_mats(chunk + 1, nxtm);
     // ---- epilogue: decay scaling, decay gradient, stores ----------------------------------------------------------------------------
     float dQ[8], dK[8], dB[8], dA[8], e[8];
     ld_stage8(reinterpret_cast<const float *>(sm + L::sQ), pt, pk, dQ);
