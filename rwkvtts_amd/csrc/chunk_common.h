@@ -80,6 +80,7 @@ __device__ __forceinline__ void mma_tile3(f32x16 &acc, const uint16_t *Xh, const
         xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
         yl[i] = *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
     }
+    __builtin_amdgcn_sched_barrier(0);  // fragment loads stay above, MFMAs below
     f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
@@ -102,6 +103,7 @@ __device__ __forceinline__ void mma_tile2x(f32x16 &acc, const uint16_t *Xh, cons
         y[i] = *reinterpret_cast<const bf16x8 *>(Y + yo + 16 * i);
         xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
     }
+    __builtin_amdgcn_sched_barrier(0);  // fragment loads stay above, MFMAs below
     f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
@@ -123,6 +125,7 @@ __device__ __forceinline__ void mma_tile2y(f32x16 &acc, const uint16_t *X, int l
         yh[i] = *reinterpret_cast<const bf16x8 *>(Yh + yo + 16 * i);
         yl[i] = *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
     }
+    __builtin_amdgcn_sched_barrier(0);  // fragment loads stay above, MFMAs below
     f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
@@ -162,6 +165,7 @@ __device__ __forceinline__ void mma_tile3_yK(f32x16 &acc, const uint16_t *Xh, co
         yh[i] = frag_tr(Yh, ldy, 16 * i, n_base, lane);
         yl[i] = frag_tr(Yl, ldy, 16 * i, n_base, lane);
     }
+    __builtin_amdgcn_sched_barrier(0);  // fragment loads stay above, MFMAs below
     f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
@@ -184,6 +188,7 @@ __device__ __forceinline__ void mma_xs_yeK(f32x16 &acc, const uint16_t *Xh, cons
         xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
         y[i] = frag_tr(Y, ldy, 16 * i, n_base, lane);
     }
+    __builtin_amdgcn_sched_barrier(0);  // fragment loads stay above, MFMAs below
     f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {
@@ -209,6 +214,7 @@ __device__ __forceinline__ void mma_gen(f32x16 &acc, const uint16_t *Xh, const u
         if (XSPLIT) xl[i] = XKM ? frag_tr(Xl, ldx, 16 * i, xbase, lane) : *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
         if (YSPLIT) yl[i] = YKM ? frag_tr(Yl, ldy, 16 * i, ybase, lane) : *reinterpret_cast<const bf16x8 *>(Yl + yo + 16 * i);
     }
+    __builtin_amdgcn_sched_barrier(0);  // fragment loads stay above, MFMAs below
     f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // CH == 2: second, independent MFMA chain
 #pragma unroll
     for (int i = 0; i < NK; i++) {

@@ -59,6 +59,7 @@ __device__ __forceinline__ void mma_xs_ye(f32x16 &acc, const uint16_t *Xh, const
         y[i] = *reinterpret_cast<const bf16x8 *>(Y + yo + 16 * i);
         xl[i] = *reinterpret_cast<const bf16x8 *>(Xl + xo + 16 * i);
     }
+    __builtin_amdgcn_sched_barrier(0);  // fragment loads stay above, MFMAs below
     f32x16 acc_b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NK; i++) {
