@@ -48,6 +48,7 @@ size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
 int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *, const void *,
                      const void *, const void *, const void *, float *, void *, int, hipStream_t);
 void fwd_force_shape(int);
+void chunk_fwd_force_waves(int);
 void bwd_force_shape(int);
 int lora_down_bf16(long, int, int, int, const void *, const void *, void *, hipStream_t);
 int lora_dgrad_up_bf16(long, int, int, int, const void *, const void *, const void *, void *, hipStream_t);
@@ -154,6 +155,7 @@ int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_b
     return 0;
 }
 void rwkv7_debug_set_fwd_shape(int cols_per_lane) { rwkv7::fwd_force_shape(cols_per_lane); }
+void rwkv7_debug_set_chunk_fwd_waves(int waves) { rwkv7::chunk_fwd_force_waves(waves); }
 void rwkv7_debug_set_bwd_shape(int wide) { rwkv7::bwd_force_shape(wide); }
 
 #define STATE_BODY(IMPL)                                                                              \

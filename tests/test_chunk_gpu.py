@@ -210,3 +210,25 @@ def test_packed_sequences_equal_separate_sequences_vs_oracle(c_oracle):
             _assert_bf16_close(y[b:b + 1, lo:hi], y_o, f"y[{b},{lo}:{hi}]")
             for n, g, go in zip(NAMES, grads, g_o):
                 _assert_bf16_close(g[b:b + 1, lo:hi], go, f"{n}[{b},{lo}:{hi}]", ulps=2.0)
+
+
+def test_eight_wave_forward_kernel_equals_four_wave_kernel():
+    """wkv7_chunk_fwd8.hip (producer / consumer, experimental, selected with rwkv7_debug_set_chunk_fwd_waves) does the same
+    arithmetic in the same order as the 4-wave kernel: y, sa and the chunk states must be bit-identical, also on packed rows."""
+    from rwkvtts_amd import _lib
+    lib = _lib.lib()
+    B, T, H = 2, 256, 3
+    ins = [t.to(DEV) for t in make_wkv_inputs(B, T, H, 5, torch.bfloat16)]
+    nc = T // 32
+    seq_off = torch.tensor([0, 3, nc, nc + 1, 2 * nc], dtype=torch.int32, device=DEV)
+    try:
+        outs = {}
+        for waves in (4, 8):
+            lib.rwkv7_debug_set_chunk_fwd_waves(waves)
+            outs[waves] = (ops.wkv7_chunk_forward(*ins), ops.wkv7_chunk_forward(*ins, seq_off=seq_off))
+            torch.cuda.synchronize()
+    finally:
+        lib.rwkv7_debug_set_chunk_fwd_waves(4)
+    for a, b in zip(outs[4], outs[8]):
+        for x, y_ in zip(a, b):
+            assert torch.equal(x, y_)
