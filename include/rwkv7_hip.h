@@ -66,7 +66,7 @@ int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_b
 
 /* measurement aid: force the forward kernel's shape (4 or 8 state columns per lane; 0 = automatic by B*H) */
 void rwkv7_debug_set_fwd_shape(int cols_per_lane);
-/* chunked bf16 forward: 4 = the 4-wave kernel (default), 8 = the experimental producer/consumer kernel (A/B, cross-check) */
+/* chunked bf16 forward: 8 = the producer/consumer kernel (default), 4 = the 4-wave kernel (A/B, cross-check) */
 void rwkv7_debug_set_chunk_fwd_waves(int waves);
 /* row-split backward: 0 = 256 threads, 2 state rows per lane tile (default); 1 = 512 threads, 1 row per lane tile */
 void rwkv7_debug_set_bwd_shape(int wide);

@@ -500,12 +500,12 @@ int chunk_prep_bf16(int B, int T_, int H, const void *w, const void *a, const vo
 int chunk_prep_f32(int B, int T_, int H, const void *w, const void *a, const void *b, float *tinv, hipStream_t st) {
     return launch_prep<float>(B, T_, H, w, a, b, tinv, st);
 }
-// bf16: rwkv7_debug_set_chunk_fwd_waves(8) selects the experimental 8-wave producer / consumer kernel (wkv7_chunk_fwd8.hip:
-// same results, measured 570 us against 500 us for this 4-wave kernel at B=8, T=4096, H=16 -- see its header)
+// bf16 tensors run the 8-wave producer / consumer kernel (wkv7_chunk_fwd8.hip: 400 us against 495 us for this 4-wave kernel at
+// B=8, T=4096, H=16); rwkv7_debug_set_chunk_fwd_waves(4) selects this one (A/B, cross-check).  fp32 tensors always run here.
 int chunk_fwd8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const float *,
                     void *, float *, float *, const int *, int, hipStream_t);
-static int g_chunk_fwd_waves = 4;
-void chunk_fwd_force_waves(int n) { g_chunk_fwd_waves = n == 8 ? 8 : 4; }
+static int g_chunk_fwd_waves = 8;
+void chunk_fwd_force_waves(int n) { g_chunk_fwd_waves = n == 4 ? 4 : 8; }
 
 int chunk_fwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                    const void *b, const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq, hipStream_t st) {

@@ -5,17 +5,18 @@
 // prologue: restaging the raw rows, exp / decay prefix sums, scaling, hi/lo splitting and writing the eight operand planes.
 // Here four extra waves (the producer, waves 4-7) do that for chunk c + 1 into a second set of planes while waves 0-3 (the
 // consumer) run the matrix phases of chunk c:
-//     interval 1   consumer: A_ak, A_qb, A_qk, T planes            producer: prefetched raw rows -> LDS staging
-//     interval 2   consumer: R = A~ H0 + A_ak V ; Q~ H0 + A_qk V    producer: rows in compute mapping, next prefetch, exp, prefix sums
-//     interval 3   consumer: U = T R                                producer: scaled hi/lo planes of chunk c + 1, V plane, g_C
-//     interval 4   consumer: Y += A_qb U ; state update             producer: --
+//     interval 1   consumer: A_ak, A_qb, A_qk, T planes            producer: staged rows in compute mapping, next prefetch, exp
+//     interval 2   consumer: R = A~ H0 + A_ak V ; Q~ H0 + A_qk V    producer: decay prefix sums (DPP)
+//     interval 3   consumer: U = T R                                producer: scaling, hi/lo splits (kept in registers)
+//     interval 4   consumer: Y += A_qb U ; state update             producer: plane stores, V, g_C; next rows -> LDS staging
 // The workgroup barrier is the only hardware barrier, so both groups pass the same four barriers per chunk; an interval
 // lasts as long as its longer half.
-// STATUS: correct (tests/test_chunk_gpu.py passes with it selected) but NOT the default: 570 us against 500 us for the
-// 4-wave kernel at B=8, T=4096, H=16.  The producer's intervals 2 and 3 (prefix sums; plane stores) are each longer than the
-// consumer phase they run beside, so the lock-step costs what the overlap saves, and at 512 threads the register file
-// leaves 256 registers per thread without AGPR spill space (30 registers go to scratch).  To pay off, the producer work
-// has to be cut into four pieces no longer than the consumer phases.
+// Measured (tools/bench_chunk_fwd_waves.py, B=8, T=4096, H=16): 400 us against 495 us for the 4-wave kernel.  Two things
+// made the difference between a loss (570 us in the first cut) and this: (1) the producer's work is cut into four pieces
+// that each fit beside a consumer phase -- read/convert/exp, prefix sums, scale/split (results held in registers), plane
+// stores -- and the LDS staging of the NEXT chunk's rows moved to the end of interval 4; (2) the two roles are separate code
+// paths (if / else around two loops with the same barrier count), so their loop-carried registers are allocated separately:
+// one interleaved loop needed 256 registers plus 109 spilled to scratch, the split one 186 and none.
 // LDS: 2 x 38.5 KB of operand planes + 39 KB of matrices + 9.5 KB fp32 + 25 KB staging = 151 KB, one workgroup (two
 // value-column halves of a head -> two workgroups, as before) per CU.
 #include "chunk_common.h"
@@ -114,181 +115,218 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
         }
         gv = ld4<bf16_t>(v_ + off + vh * VH + lv, true);
     };
-    if (role == 1) issue(c0);
-    float lw[8], Gc[8], qv[8], kv[8], av[8], bv[8], vv[4];  // producer values between intervals 2 and 3
+    using RawVec = decltype(Raw4<bf16_t>::r);
+    auto stage_raw = [&]() {  // prefetched rows -> LDS staging (read back in the compute mapping one barrier later)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            *reinterpret_cast<RawVec *>(raw + (0 * kC + lt) * RS + lk + 4 * i) = gw[i].r;
+            *reinterpret_cast<RawVec *>(raw + (1 * kC + lt) * RS + lk + 4 * i) = gq[i].r;
+            *reinterpret_cast<RawVec *>(raw + (2 * kC + lt) * RS + lk + 4 * i) = gk[i].r;
+            *reinterpret_cast<RawVec *>(raw + (3 * kC + lt) * RS + lk + 4 * i) = ga[i].r;
+            *reinterpret_cast<RawVec *>(raw + (4 * kC + lt) * RS + lk + 4 * i) = gb[i].r;
+        }
+        *reinterpret_cast<RawVec *>(raw + 5 * kC * RS + lt * RSV + lv) = gv.r;
+    };
+    if (role == 1) {
+        issue(c0);
+        stage_raw();
+    }
+    // producer values carried between intervals
+    float lw[8], Gc[8], qv[8], kv[8], av[8], bv[8], vv[4], gamL[8];
+    uint4 pq[2], pa[2], pkk[2], pb[2];
     lds_barrier();
 
+    // The two roles run disjoint code (separate register allocation) with the same barrier sequence: four per iteration.
+    if (role == 0) {
     for (int it = c0 - 1; it < c1; it++) {
-        const int cc = it, pc = it + 1;
-        const bool cons = role == 0 && cc >= c0, prod = role == 1 && pc < c1;
-        uint16_t *bufc = sm + (cc & 1) * L::BUF, *bufp = sm + (pc & 1) * L::BUF;
-        const float *gCc = sh_gC2 + (cc & 1) * kN;
-        float *gCp = sh_gC2 + (pc & 1) * kN;
-        // =============================================================== interval 1
-        if (cons) {
-            if (wave == 0) {
-                f32x16 acc = zero16();  // D[m = s][n = t] = k^_s . a~_t = A_ak[t][s]
-                mma_tile3<kN>(acc, bufc + L::KHh, bufc + L::KHl, LDK, bufc + L::ATh, bufc + L::ATl, LDK, lane);
-                mask_lower_T<true>(acc, lane);
-                store_T_split(acc, sm + L::AKh, sm + L::AKl, LDC, lane);
-            } else if (wave == 1) {
-                f32x16 acc = zero16();  // b^_s . q~_t = A_qb[t][s]
-                mma_tile3<kN>(acc, bufc + L::BHh, bufc + L::BHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
-                mask_lower_T<false>(acc, lane);
-                store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
-            } else if (wave == 2) {
-                f32x16 acc = zero16();  // k^_s . q~_t = A_qk[t][s]
-                mma_tile3<kN>(acc, bufc + L::KHh, bufc + L::KHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
-                mask_lower_T<false>(acc, lane);
-                store_T_split(acc, sm + L::QKh, sm + L::QKl, LDC, lane);
-            } else {
-                // T = (I - A_ab)^-1 of this chunk (wkv7c_prep_kernel), fp32 [32][32] -> planes Tm[t][r]
-                const float *tp = tinv_ + ((long)bh * nc + cc) * kC * kC;
-                const int tr = lane >> 1, tc = (lane & 1) * 16;
-                uint32_t hi[8], lo[8];
-#pragma unroll
+            const int cc = it, pc = it + 1;
+            uint16_t *bufc = sm + (cc & 1) * L::BUF, *bufp = sm + (pc & 1) * L::BUF;
+            const float *gCc = sh_gC2 + (cc & 1) * kN;
+            float *gCp = sh_gC2 + (pc & 1) * kN;
+            // =============================================================== interval 1
+            if (cc >= c0) {
+                if (wave == 0) {
+                    f32x16 acc = zero16();  // D[m = s][n = t] = k^_s . a~_t = A_ak[t][s]
+                    mma_tile3<kN>(acc, bufc + L::KHh, bufc + L::KHl, LDK, bufc + L::ATh, bufc + L::ATl, LDK, lane);
+                    mask_lower_T<true>(acc, lane);
+                    store_T_split(acc, sm + L::AKh, sm + L::AKl, LDC, lane);
+                } else if (wave == 1) {
+                    f32x16 acc = zero16();  // b^_s . q~_t = A_qb[t][s]
+                    mma_tile3<kN>(acc, bufc + L::BHh, bufc + L::BHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
+                    mask_lower_T<false>(acc, lane);
+                    store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
+                } else if (wave == 2) {
+                    f32x16 acc = zero16();  // k^_s . q~_t = A_qk[t][s]
+                    mma_tile3<kN>(acc, bufc + L::KHh, bufc + L::KHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
+                    mask_lower_T<false>(acc, lane);
+                    store_T_split(acc, sm + L::QKh, sm + L::QKl, LDC, lane);
+                } else {
+                    // T = (I - A_ab)^-1 of this chunk (wkv7c_prep_kernel), fp32 [32][32] -> planes Tm[t][r]
+                    const float *tp = tinv_ + ((long)bh * nc + cc) * kC * kC;
+                    const int tr = lane >> 1, tc = (lane & 1) * 16;
+                    uint32_t hi[8], lo[8];
+    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float4 x = *reinterpret_cast<const float4 *>(tp + tr * kC + tc + 4 * j);
+                        split_pk(x.x, x.y, hi[2 * j], lo[2 * j]);
+                        split_pk(x.z, x.w, hi[2 * j + 1], lo[2 * j + 1]);
+                    }
+    #pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int o = tr * LDC + tc + 8 * j;
+                        *reinterpret_cast<uint4 *>(&sm[L::TMh + o]) = make_uint4(hi[4 * j], hi[4 * j + 1], hi[4 * j + 2], hi[4 * j + 3]);
+                        *reinterpret_cast<uint4 *>(&sm[L::TMl + o]) = make_uint4(lo[4 * j], lo[4 * j + 1], lo[4 * j + 2], lo[4 * j + 3]);
+                    }
+                }
+            }
+            lds_barrier();
+            // =============================================================== interval 2
+            f32x16 accY = zero16();  // consumer wave 3: the part of Y that does not need U, finished in interval 4
+            if (cc >= c0) {
+                // R = A~ H0 + A_ak V   (D[t][v]) ; wave 3: Q~ H0 + A_qk V
+                if (wave == 0) {
+                    f32x16 acc = zero16();
+                    mma_tile3<kN>(acc, bufc + L::ATh, bufc + L::ATl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
+                    mma_gen<kC, false, true, true, false>(acc, sm + L::AKh, sm + L::AKl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
+                    store_T_split(acc, sm + L::Rh, sm + L::Rl, LDC, lane);
+                } else if (wave == 3) {
+                    mma_tile3<kN>(accY, bufc + L::QTh, bufc + L::QTl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
+                    mma_gen<kC, false, true, true, false>(accY, sm + L::QKh, sm + L::QKl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
+                }
+            }
+            lds_barrier();
+            // =============================================================== interval 3
+            if (cc >= c0) {
+                if (wave == 0) {  // U = T R
+                    f32x16 acc = zero16();
+                    mma_tile3<kC>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::Rh, sm + L::Rl, LDC, lane);
+                    store_T_split(acc, sm + L::Uh, sm + L::Ul, LDC, lane);
+                    if (SAVE) {
+    #pragma unroll
+                        for (int r = 0; r < 16; r++) sh_U[d_row(r, lane) * kStageLD + (lane & 31)] = acc[r];
+                    }
+                }
+            }
+            lds_barrier();
+            // =============================================================== interval 4
+            if (cc >= c0) {
+                if (wave == 3) {
+                    mma_tile3<kC>(accY, sm + L::QBh, sm + L::QBl, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
+    #pragma unroll
+                    for (int r = 0; r < 16; r++) sh_Y[d_row(r, lane) * kStageLD + (lane & 31)] = accY[r];
+                } else if (wave == 1 || wave == 2) {
+                    const int kt = wave - 1;  // rows (key channels) [32 kt, 32 kt + 32)
+                    if (SAVE) {
+                        // state at the START of chunk cc, hs[b,h,c][k][v]
+                        float *hp = hs_ + ((long)bh * nc + cc) * kN * kN + vh * VH + (lane & 31);
+    #pragma unroll
+                        for (int r = 0; r < 16; r++) hp[(long)(kt * 32 + d_row(r, lane)) * kN] = Smaster[r];
+                    }
+                    f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
+                    mma_gen<kC, true, true, false, true>(acc, bufc + L::BHh, bufc + L::BHl, LDK, kt * 32, sm + L::Uh, sm + L::Ul, LDC, 0, lane);
+                    mma_gen<kC, true, true, true, false>(acc, bufc + L::KHh, bufc + L::KHl, LDK, kt * 32, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
+    #pragma unroll
+                    for (int r = 0; r < 16; r++) Smaster[r] = gCc[kt * 32 + d_row(r, lane)] * (Smaster[r] + acc[r]);
+                }
+            }
+            lds_barrier();
+            if (cc >= c0) {
+                // y (and sa) of this chunk: thread (pt, pv) owns 4 value columns of one step
+                const long o = head_base + (long)(cc * kC + pt) * tstride + vh * VH + pv;
+                const float4 yv = *reinterpret_cast<const float4 *>(&sh_Y[pt * kStageLD + pv]);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(y_) + o) = make_uint2(cvt_pk(yv.x, yv.y), cvt_pk(yv.z, yv.w));
+                if (SAVE) *reinterpret_cast<float4 *>(sa_ + o) = *reinterpret_cast<const float4 *>(&sh_U[pt * kStageLD + pv]);
+                // publish the new state planes S[v][k] (read again in interval 2 of the next iteration, two barriers away)
+                if (wave == 1 || wave == 2) store_T_split(Smaster, sm + L::Sh + (wave - 1) * 32, sm + L::Sl + (wave - 1) * 32, LDK, lane);
+            }
+        }
+    } else {
+    for (int it = c0 - 1; it < c1; it++) {
+            const int cc = it, pc = it + 1;
+            uint16_t *bufc = sm + (cc & 1) * L::BUF, *bufp = sm + (pc & 1) * L::BUF;
+            const float *gCc = sh_gC2 + (cc & 1) * kN;
+            float *gCp = sh_gC2 + (pc & 1) * kN;
+            // =============================================================== interval 1
+            if (pc < c1) {
+                // rows of chunk pc in the compute mapping (staged one interval ago), the chunk after it requested from HBM
+                Raw4<bf16_t> rw[2], rq[2], rk[2], ra[2], rb[2], rv;
+    #pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    rw[i].r = *reinterpret_cast<const RawVec *>(raw + (0 * kC + pt) * RS + pk + 4 * i);
+                    rq[i].r = *reinterpret_cast<const RawVec *>(raw + (1 * kC + pt) * RS + pk + 4 * i);
+                    rk[i].r = *reinterpret_cast<const RawVec *>(raw + (2 * kC + pt) * RS + pk + 4 * i);
+                    ra[i].r = *reinterpret_cast<const RawVec *>(raw + (3 * kC + pt) * RS + pk + 4 * i);
+                    rb[i].r = *reinterpret_cast<const RawVec *>(raw + (4 * kC + pt) * RS + pk + 4 * i);
+                }
+                rv.r = *reinterpret_cast<const RawVec *>(raw + 5 * kC * RS + pt * RSV + pv);
+                if (pc + 1 < c1) issue(pc + 1);
+                const float4 w0 = cvt4(rw[0]), w1 = cvt4(rw[1]);
+                const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    #pragma unroll
+                for (int j = 0; j < 8; j++) lw[j] = -fast_exp(wr[j]);
+                const float4 q0 = cvt4(rq[0]), q1 = cvt4(rq[1]), k0 = cvt4(rk[0]), k1 = cvt4(rk[1]);
+                const float4 a0 = cvt4(ra[0]), a1 = cvt4(ra[1]), b0 = cvt4(rb[0]), b1 = cvt4(rb[1]), v0 = cvt4(rv);
+                qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+                kv[0] = k0.x; kv[1] = k0.y; kv[2] = k0.z; kv[3] = k0.w; kv[4] = k1.x; kv[5] = k1.y; kv[6] = k1.z; kv[7] = k1.w;
+                av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+                bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+                vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w;
+            }
+            lds_barrier();
+            // =============================================================== interval 2
+            if (pc < c1) {
+                // inclusive cumulative log-decay over the chunk: DPP prefix sum across the 32 lanes that hold the 32 steps
+    #pragma unroll
+                for (int j = 0; j < 8; j++) Gc[j] = scan32(lw[j]);
+            }
+            lds_barrier();
+            // =============================================================== interval 3
+            if (pc < c1) {
+                // scaled operands of chunk pc, split into bf16 hi/lo pairs (stored in interval 4)
+                float qs[8], as_[8], ks[8], bs[8];
+    #pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float gam = fast_exp(Gc[j]), gprev = fast_exp(Gc[j] - lw[j]), ig = fast_exp(-Gc[j]);
+                    qs[j] = qv[j] * gam;
+                    as_[j] = av[j] * gprev;
+                    ks[j] = kv[j] * ig;
+                    bs[j] = bv[j] * ig;
+                    gamL[j] = gam;
+                }
+                uint32_t qh[4], ql[4], ah[4], al[4], kh[4], kl[4], bhh[4], bl[4];
+    #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float4 x = *reinterpret_cast<const float4 *>(tp + tr * kC + tc + 4 * j);
-                    split_pk(x.x, x.y, hi[2 * j], lo[2 * j]);
-                    split_pk(x.z, x.w, hi[2 * j + 1], lo[2 * j + 1]);
+                    split_pk(qs[2 * j], qs[2 * j + 1], qh[j], ql[j]);
+                    split_pk(as_[2 * j], as_[2 * j + 1], ah[j], al[j]);
+                    split_pk(ks[2 * j], ks[2 * j + 1], kh[j], kl[j]);
+                    split_pk(bs[2 * j], bs[2 * j + 1], bhh[j], bl[j]);
                 }
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int o = tr * LDC + tc + 8 * j;
-                    *reinterpret_cast<uint4 *>(&sm[L::TMh + o]) = make_uint4(hi[4 * j], hi[4 * j + 1], hi[4 * j + 2], hi[4 * j + 3]);
-                    *reinterpret_cast<uint4 *>(&sm[L::TMl + o]) = make_uint4(lo[4 * j], lo[4 * j + 1], lo[4 * j + 2], lo[4 * j + 3]);
+                auto pack = [](const uint32_t (&x)[4]) { return make_uint4(x[0], x[1], x[2], x[3]); };
+                pq[0] = pack(qh); pq[1] = pack(ql); pa[0] = pack(ah); pa[1] = pack(al);
+                pkk[0] = pack(kh); pkk[1] = pack(kl); pb[0] = pack(bhh); pb[1] = pack(bl);
+            }
+            lds_barrier();
+            // =============================================================== interval 4
+            if (pc < c1) {
+                // planes of chunk pc into its buffer (the consumer reads the other one); then the next chunk's raw rows -> staging
+                const int o = pt * LDK + pk;
+                *reinterpret_cast<uint4 *>(&bufp[L::QTh + o]) = pq[0];
+                *reinterpret_cast<uint4 *>(&bufp[L::QTl + o]) = pq[1];
+                *reinterpret_cast<uint4 *>(&bufp[L::ATh + o]) = pa[0];
+                *reinterpret_cast<uint4 *>(&bufp[L::ATl + o]) = pa[1];
+                *reinterpret_cast<uint4 *>(&bufp[L::KHh + o]) = pkk[0];
+                *reinterpret_cast<uint4 *>(&bufp[L::KHl + o]) = pkk[1];
+                *reinterpret_cast<uint4 *>(&bufp[L::BHh + o]) = pb[0];
+                *reinterpret_cast<uint4 *>(&bufp[L::BHl + o]) = pb[1];
+                *reinterpret_cast<uint2 *>(&bufp[L::Vt + pt * LDC + pv]) = make_uint2(cvt_pk(vv[0], vv[1]), cvt_pk(vv[2], vv[3]));  // bf16 v: exact
+                if (pt == kC - 1) {
+    #pragma unroll
+                    for (int j = 0; j < 8; j++) gCp[pk + j] = gamL[j];
                 }
+                if (pc + 1 < c1) stage_raw();
             }
-        } else if (prod) {
-            // prefetched rows -> LDS staging (read back in the compute mapping after the barrier)
-            using RawVec = decltype(Raw4<bf16_t>::r);
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                *reinterpret_cast<RawVec *>(raw + (0 * kC + lt) * RS + lk + 4 * i) = gw[i].r;
-                *reinterpret_cast<RawVec *>(raw + (1 * kC + lt) * RS + lk + 4 * i) = gq[i].r;
-                *reinterpret_cast<RawVec *>(raw + (2 * kC + lt) * RS + lk + 4 * i) = gk[i].r;
-                *reinterpret_cast<RawVec *>(raw + (3 * kC + lt) * RS + lk + 4 * i) = ga[i].r;
-                *reinterpret_cast<RawVec *>(raw + (4 * kC + lt) * RS + lk + 4 * i) = gb[i].r;
-            }
-            *reinterpret_cast<RawVec *>(raw + 5 * kC * RS + lt * RSV + lv) = gv.r;
-        }
-        lds_barrier();
-        // =============================================================== interval 2
-        f32x16 accY = zero16();  // consumer wave 3: the part of Y that does not need U, finished in interval 4
-        if (cons) {
-            // R = A~ H0 + A_ak V   (D[t][v]) ; wave 3: Q~ H0 + A_qk V
-            if (wave == 0) {
-                f32x16 acc = zero16();
-                mma_tile3<kN>(acc, bufc + L::ATh, bufc + L::ATl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
-                mma_gen<kC, false, true, true, false>(acc, sm + L::AKh, sm + L::AKl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
-                store_T_split(acc, sm + L::Rh, sm + L::Rl, LDC, lane);
-            } else if (wave == 3) {
-                mma_tile3<kN>(accY, bufc + L::QTh, bufc + L::QTl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
-                mma_gen<kC, false, true, true, false>(accY, sm + L::QKh, sm + L::QKl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
-            }
-        } else if (prod) {
-            using RawVec = decltype(Raw4<bf16_t>::r);
-            Raw4<bf16_t> rw[2], rq[2], rk[2], ra[2], rb[2], rv;
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                rw[i].r = *reinterpret_cast<const RawVec *>(raw + (0 * kC + pt) * RS + pk + 4 * i);
-                rq[i].r = *reinterpret_cast<const RawVec *>(raw + (1 * kC + pt) * RS + pk + 4 * i);
-                rk[i].r = *reinterpret_cast<const RawVec *>(raw + (2 * kC + pt) * RS + pk + 4 * i);
-                ra[i].r = *reinterpret_cast<const RawVec *>(raw + (3 * kC + pt) * RS + pk + 4 * i);
-                rb[i].r = *reinterpret_cast<const RawVec *>(raw + (4 * kC + pt) * RS + pk + 4 * i);
-            }
-            rv.r = *reinterpret_cast<const RawVec *>(raw + 5 * kC * RS + pt * RSV + pv);
-            if (pc + 1 < c1) issue(pc + 1);  // the chunk after: in flight for a whole iteration
-            const float4 w0 = cvt4(rw[0]), w1 = cvt4(rw[1]);
-            const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int j = 0; j < 8; j++) lw[j] = -fast_exp(wr[j]);
-            const float4 q0 = cvt4(rq[0]), q1 = cvt4(rq[1]), k0 = cvt4(rk[0]), k1 = cvt4(rk[1]);
-            const float4 a0 = cvt4(ra[0]), a1 = cvt4(ra[1]), b0 = cvt4(rb[0]), b1 = cvt4(rb[1]), v0 = cvt4(rv);
-            qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
-            kv[0] = k0.x; kv[1] = k0.y; kv[2] = k0.z; kv[3] = k0.w; kv[4] = k1.x; kv[5] = k1.y; kv[6] = k1.z; kv[7] = k1.w;
-            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
-            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-            vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w;
-            // inclusive cumulative log-decay over the chunk: DPP prefix sum across the 32 lanes that hold the 32 steps
-#pragma unroll
-            for (int j = 0; j < 8; j++) Gc[j] = scan32(lw[j]);
-        }
-        lds_barrier();
-        // =============================================================== interval 3
-        if (cons) {
-            if (wave == 0) {  // U = T R
-                f32x16 acc = zero16();
-                mma_tile3<kC>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::Rh, sm + L::Rl, LDC, lane);
-                store_T_split(acc, sm + L::Uh, sm + L::Ul, LDC, lane);
-                if (SAVE) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) sh_U[d_row(r, lane) * kStageLD + (lane & 31)] = acc[r];
-                }
-            }
-        } else if (prod) {
-            // scaled operands of chunk pc into the hi/lo planes of its buffer
-            float qs[8], as_[8], ks[8], bs[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float gam = fast_exp(Gc[j]), gprev = fast_exp(Gc[j] - lw[j]), ig = fast_exp(-Gc[j]);
-                qs[j] = qv[j] * gam;
-                as_[j] = av[j] * gprev;
-                ks[j] = kv[j] * ig;
-                bs[j] = bv[j] * ig;
-                if (pt == kC - 1) gCp[pk + j] = gam;
-            }
-            uint32_t qh[4], ql[4], ah[4], al[4], kh[4], kl[4], bhh[4], bl[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                split_pk(qs[2 * j], qs[2 * j + 1], qh[j], ql[j]);
-                split_pk(as_[2 * j], as_[2 * j + 1], ah[j], al[j]);
-                split_pk(ks[2 * j], ks[2 * j + 1], kh[j], kl[j]);
-                split_pk(bs[2 * j], bs[2 * j + 1], bhh[j], bl[j]);
-            }
-            auto pack = [](const uint32_t (&x)[4]) { return make_uint4(x[0], x[1], x[2], x[3]); };
-            const int o = pt * LDK + pk;
-            *reinterpret_cast<uint4 *>(&bufp[L::QTh + o]) = pack(qh);
-            *reinterpret_cast<uint4 *>(&bufp[L::QTl + o]) = pack(ql);
-            *reinterpret_cast<uint4 *>(&bufp[L::ATh + o]) = pack(ah);
-            *reinterpret_cast<uint4 *>(&bufp[L::ATl + o]) = pack(al);
-            *reinterpret_cast<uint4 *>(&bufp[L::KHh + o]) = pack(kh);
-            *reinterpret_cast<uint4 *>(&bufp[L::KHl + o]) = pack(kl);
-            *reinterpret_cast<uint4 *>(&bufp[L::BHh + o]) = pack(bhh);
-            *reinterpret_cast<uint4 *>(&bufp[L::BHl + o]) = pack(bl);
-            *reinterpret_cast<uint2 *>(&bufp[L::Vt + pt * LDC + pv]) = make_uint2(cvt_pk(vv[0], vv[1]), cvt_pk(vv[2], vv[3]));  // bf16 v: exact
-        }
-        lds_barrier();
-        // =============================================================== interval 4
-        if (cons) {
-            if (wave == 3) {
-                mma_tile3<kC>(accY, sm + L::QBh, sm + L::QBl, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
-#pragma unroll
-                for (int r = 0; r < 16; r++) sh_Y[d_row(r, lane) * kStageLD + (lane & 31)] = accY[r];
-            } else if (wave == 1 || wave == 2) {
-                const int kt = wave - 1;  // rows (key channels) [32 kt, 32 kt + 32)
-                if (SAVE) {
-                    // state at the START of chunk cc, hs[b,h,c][k][v]
-                    float *hp = hs_ + ((long)bh * nc + cc) * kN * kN + vh * VH + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) hp[(long)(kt * 32 + d_row(r, lane)) * kN] = Smaster[r];
-                }
-                f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
-                mma_gen<kC, true, true, false, true>(acc, bufc + L::BHh, bufc + L::BHl, LDK, kt * 32, sm + L::Uh, sm + L::Ul, LDC, 0, lane);
-                mma_gen<kC, true, true, true, false>(acc, bufc + L::KHh, bufc + L::KHl, LDK, kt * 32, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
-#pragma unroll
-                for (int r = 0; r < 16; r++) Smaster[r] = gCc[kt * 32 + d_row(r, lane)] * (Smaster[r] + acc[r]);
-            }
-        }
-        lds_barrier();
-        if (cons) {
-            // y (and sa) of this chunk: thread (pt, pv) owns 4 value columns of one step
-            const long o = head_base + (long)(cc * kC + pt) * tstride + vh * VH + pv;
-            const float4 yv = *reinterpret_cast<const float4 *>(&sh_Y[pt * kStageLD + pv]);
-            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(y_) + o) = make_uint2(cvt_pk(yv.x, yv.y), cvt_pk(yv.z, yv.w));
-            if (SAVE) *reinterpret_cast<float4 *>(sa_ + o) = *reinterpret_cast<const float4 *>(&sh_U[pt * kStageLD + pv]);
-            // publish the new state planes S[v][k] (read again in interval 2 of the next iteration, two barriers away)
-            if (wave == 1 || wave == 2) store_T_split(Smaster, sm + L::Sh + (wave - 1) * 32, sm + L::Sl + (wave - 1) * 32, LDK, lane);
+            lds_barrier();
+            
         }
     }
 }
