@@ -36,12 +36,20 @@ def _stale():
 
 
 def build(force: bool = False, verbose: bool = False, extra=()) -> str:
+    # objects compiled with other flags (e.g. a --timing build that was interrupted) must not be linked into a normal build
+    stamp, flags = os.path.join(LIBDIR, ".flags"), " ".join(FLAGS + list(extra))
+    if os.path.exists(stamp) and open(stamp).read() != flags:
+        force = True
+    elif not os.path.exists(stamp) and extra:
+        force = True
     if not force and not _stale():
         return SO
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: librwkv7_hip.so cannot be built (and there is no fallback)")
     os.makedirs(LIBDIR, exist_ok=True)
+    with open(stamp, "w") as f:
+        f.write("INCOMPLETE")   # replaced by the flags after a complete build: an interrupted build forces the next one
     objs = []
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src).replace(".hip", ".o"))
@@ -56,6 +64,8 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(flags)
     return SO
 
 

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
     // producer values carried between intervals
     float lw[8], Gc[8], qv[8], kv[8], av[8], bv[8], vv[4], gamL[8];
     uint4 pq[2], pa[2], pkk[2], pb[2];
+    float ksL[8], bsL[8];
+    float4 tmreg = make_float4(0.f, 0.f, 0.f, 0.f);
     lds_barrier();
 
     // The two roles run disjoint code (separate register allocation) with the same barrier sequence: four per iteration.
@@ -160,24 +162,7 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                     mma_tile3<kN>(acc, bufc + L::KHh, bufc + L::KHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
                     mask_lower_T<false>(acc, lane);
                     store_T_split(acc, sm + L::QKh, sm + L::QKl, LDC, lane);
-                } else {
-                    // T = (I - A_ab)^-1 of this chunk (wkv7c_prep_kernel), fp32 [32][32] -> planes Tm[t][r]
-                    const float *tp = tinv_ + ((long)bh * nc + cc) * kC * kC;
-                    const int tr = lane >> 1, tc = (lane & 1) * 16;
-                    uint32_t hi[8], lo[8];
-    #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float4 x = *reinterpret_cast<const float4 *>(tp + tr * kC + tc + 4 * j);
-                        split_pk(x.x, x.y, hi[2 * j], lo[2 * j]);
-                        split_pk(x.z, x.w, hi[2 * j + 1], lo[2 * j + 1]);
-                    }
-    #pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const int o = tr * LDC + tc + 8 * j;
-                        *reinterpret_cast<uint4 *>(&sm[L::TMh + o]) = make_uint4(hi[4 * j], hi[4 * j + 1], hi[4 * j + 2], hi[4 * j + 3]);
-                        *reinterpret_cast<uint4 *>(&sm[L::TMl + o]) = make_uint4(lo[4 * j], lo[4 * j + 1], lo[4 * j + 2], lo[4 * j + 3]);
-                    }
-                }
+                }   // wave 3: idle here (the T planes come from the producer)
             }
             lds_barrier();
             // =============================================================== interval 2
@@ -260,6 +245,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                 }
                 rv.r = *reinterpret_cast<const RawVec *>(raw + 5 * kC * RS + pt * RSV + pv);
                 if (pc + 1 < c1) issue(pc + 1);
+                // T = (I - A_ab)^-1 of chunk pc (wkv7c_prep_kernel): requested here, written as planes in interval 4 -- after the
+                // consumer's phase-5 read of the previous chunk's T and a whole iteration before it reads this one
+                tmreg = *reinterpret_cast<const float4 *>(tinv_ + ((long)bh * nc + pc) * kC * kC + ltid * 4);
                 const float4 w0 = cvt4(rw[0]), w1 = cvt4(rw[1]);
                 const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
     #pragma unroll
@@ -293,22 +281,34 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                     bs[j] = bv[j] * ig;
                     gamL[j] = gam;
                 }
-                uint32_t qh[4], ql[4], ah[4], al[4], kh[4], kl[4], bhh[4], bl[4];
+                uint32_t qh[4], ql[4], ah[4], al[4];
     #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     split_pk(qs[2 * j], qs[2 * j + 1], qh[j], ql[j]);
                     split_pk(as_[2 * j], as_[2 * j + 1], ah[j], al[j]);
-                    split_pk(ks[2 * j], ks[2 * j + 1], kh[j], kl[j]);
-                    split_pk(bs[2 * j], bs[2 * j + 1], bhh[j], bl[j]);
                 }
                 auto pack = [](const uint32_t (&x)[4]) { return make_uint4(x[0], x[1], x[2], x[3]); };
                 pq[0] = pack(qh); pq[1] = pack(ql); pa[0] = pack(ah); pa[1] = pack(al);
-                pkk[0] = pack(kh); pkk[1] = pack(kl); pb[0] = pack(bhh); pb[1] = pack(bl);
+    #pragma unroll
+                for (int j = 0; j < 8; j++) {   // k^, b^ are split in interval 4: this interval is the producer's longest
+                    ksL[j] = ks[j];
+                    bsL[j] = bs[j];
+                }
             }
             lds_barrier();
             // =============================================================== interval 4
             if (pc < c1) {
                 // planes of chunk pc into its buffer (the consumer reads the other one); then the next chunk's raw rows -> staging
+                {
+                    uint32_t kh[4], kl[4], bhh[4], bl[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        split_pk(ksL[2 * j], ksL[2 * j + 1], kh[j], kl[j]);
+                        split_pk(bsL[2 * j], bsL[2 * j + 1], bhh[j], bl[j]);
+                    }
+                    pkk[0] = make_uint4(kh[0], kh[1], kh[2], kh[3]); pkk[1] = make_uint4(kl[0], kl[1], kl[2], kl[3]);
+                    pb[0] = make_uint4(bhh[0], bhh[1], bhh[2], bhh[3]); pb[1] = make_uint4(bl[0], bl[1], bl[2], bl[3]);
+                }
                 const int o = pt * LDK + pk;
                 *reinterpret_cast<uint4 *>(&bufp[L::QTh + o]) = pq[0];
                 *reinterpret_cast<uint4 *>(&bufp[L::QTl + o]) = pq[1];
@@ -322,6 +322,14 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                 if (pt == kC - 1) {
     #pragma unroll
                     for (int j = 0; j < 8; j++) gCp[pk + j] = gamL[j];
+                }
+                {   // T planes Tm[t][r] of chunk pc: thread = row ltid >> 3, columns 4 (ltid & 7) .. +4
+                    uint32_t h0, l0, h1, l1;
+                    split_pk(tmreg.x, tmreg.y, h0, l0);
+                    split_pk(tmreg.z, tmreg.w, h1, l1);
+                    const int ot = (ltid >> 3) * LDC + (ltid & 7) * 4;
+                    *reinterpret_cast<uint2 *>(&sm[L::TMh + ot]) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(&sm[L::TMl + ot]) = make_uint2(l0, l1);
                 }
                 if (pc + 1 < c1) stage_raw();
             }
