@@ -500,7 +500,7 @@ int chunk_prep_bf16(int B, int T_, int H, const void *w, const void *a, const vo
 int chunk_prep_f32(int B, int T_, int H, const void *w, const void *a, const void *b, float *tinv, hipStream_t st) {
     return launch_prep<float>(B, T_, H, w, a, b, tinv, st);
 }
-// bf16 tensors run the 8-wave producer / consumer kernel (wkv7_chunk_fwd8.hip: 400 us against 495 us for this 4-wave kernel at
+// bf16 tensors run the 8-wave producer / consumer kernel (wkv7_chunk_fwd8.hip: 335 us against 495 us for this 4-wave kernel at
 // B=8, T=4096, H=16); rwkv7_debug_set_chunk_fwd_waves(4) selects this one (A/B, cross-check).  fp32 tensors always run here.
 int chunk_fwd8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const float *,
                     void *, float *, float *, const int *, int, hipStream_t);

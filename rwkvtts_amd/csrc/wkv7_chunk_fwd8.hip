@@ -5,13 +5,13 @@
 // prologue: restaging the raw rows, exp / decay prefix sums, scaling, hi/lo splitting and writing the eight operand planes.
 // Here four extra waves (the producer, waves 4-7) do that for chunk c + 1 into a second set of planes while waves 0-3 (the
 // consumer) run the matrix phases of chunk c:
-//     interval 1   consumer: A_ak, A_qb, A_qk, T planes            producer: staged rows in compute mapping, next prefetch, exp
+//     interval 1   consumer: A_ak, A_qb, A_qk                        producer: staged rows in compute mapping, next prefetch, T^-1 request, exp
 //     interval 2   consumer: R = A~ H0 + A_ak V ; Q~ H0 + A_qk V    producer: decay prefix sums (DPP)
-//     interval 3   consumer: U = T R                                producer: scaling, hi/lo splits (kept in registers)
-//     interval 4   consumer: Y += A_qb U ; state update             producer: plane stores, V, g_C; next rows -> LDS staging
+//     interval 3   consumer: U = T R                                producer: scaling, hi/lo splits of q~, a~ (kept in registers)
+//     interval 4   consumer: Y += A_qb U ; state update             producer: splits of k^, b^; plane stores, V, g_C, T planes; next rows -> LDS staging
 // The workgroup barrier is the only hardware barrier, so both groups pass the same four barriers per chunk; an interval
 // lasts as long as its longer half.
-// Measured (tools/bench_chunk_fwd_waves.py, B=8, T=4096, H=16): 400 us against 495 us for the 4-wave kernel.  Two things
+// Measured (tools/bench_chunk_fwd_waves.py, B=8, T=4096, H=16): 335 us against 495 us for the 4-wave kernel.  Two things
 // made the difference between a loss (570 us in the first cut) and this: (1) the producer's work is cut into four pieces
 // that each fit beside a consumer phase -- read/convert/exp, prefix sums, scale/split (results held in registers), plane
 // stores -- and the LDS staging of the NEXT chunk's rows moved to the end of interval 4; (2) the two roles are separate code
