@@ -52,14 +52,23 @@ __global__ __launch_bounds__(64) void wkv7c_prep_kernel(int T_, int H, const T *
     const int lane = threadIdx.x;
     const long base = (((long)bb * T_ + (long)c * kC) * H + hh) * kN + lane;
     const long tstride = (long)H * kN;
-    float G = 0.f;
-#pragma unroll 4
+    // all 96 loads of the chunk are requested before the first use: issued four steps at a time (as this loop once was) the
+    // kernel spent most of its 31k cycles waiting for eight rounds of HBM latency
+    float wv[kC], av_[kC], bv_[kC];
+#pragma unroll
     for (int t = 0; t < kC; t++) {
         const long idx = base + t * tstride;
-        const float lw = -fast_exp(ld_scalar<T>(w_ + idx));
-        const float at = ld_scalar<T>(a_ + idx) * fast_exp(G);  // a * gamma_{t-1}
+        wv[t] = ld_scalar<T>(w_ + idx);
+        av_[t] = ld_scalar<T>(a_ + idx);
+        bv_[t] = ld_scalar<T>(b_ + idx);
+    }
+    float G = 0.f;
+#pragma unroll
+    for (int t = 0; t < kC; t++) {
+        const float lw = -fast_exp(wv[t]);
+        const float at = av_[t] * fast_exp(G);  // a * gamma_{t-1}
         G += lw;
-        const float bh_ = ld_scalar<T>(b_ + idx) * fast_exp(-G);  // b / gamma_t
+        const float bh_ = bv_[t] * fast_exp(-G);  // b / gamma_t
         split2(at, ATh[t * LD + lane], ATl[t * LD + lane]);
         split2(bh_, BHh[t * LD + lane], BHl[t * LD + lane]);
     }
