@@ -2,30 +2,40 @@
 """bench.py -- the headline metric of BASELINE.json on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+With N > 1 and no WORLD_SIZE in the environment the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`
+(one rank per GPU over RCCL); launched under torchrun by somebody else it just joins the group it is given.
 
 A "step" is one full training step of the hot path over one synthetic batch: RWKV7-0.4B, Spark layout,
 B=8 sequences of L=4096 text+speech-token positions per GPU (BASELINE.json configs[1]; configs[2] for N>1):
-embedding lookups -> 24 RWKV-7 layers (HIP WKV7 fwd/bwd + fused stages, library GEMMs) -> fused linear+CE ->
-backward -> bucketed RCCL gradient all-reduce (N>1) -> AdamW on fp32 master weights.  Nothing is skipped.
+embedding lookups (with their backward) -> 24 RWKV-7 layers (HIP WKV7 fwd/bwd + fused stages, library GEMMs) ->
+fused linear+CE -> backward -> bucketed RCCL gradient all-reduce (N>1) -> AdamW on fp32 master weights.
+Nothing is skipped and nothing in the step waits for the device (the NaN flag stays on the device, trainer.py).
 
 Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json, plus
-  roofline     : the dominant kernel (WKV7 backward): algorithmic bytes per launch (13*64*2 B per token-head,
+  roofline     : the dominant kernel group (WKV7 backward): algorithmic bytes per launch (13*64*2 B per token-head,
                  SURVEY.md section 8d) / its average launch duration measured live with HIP events on the launch
-                 stream, against the 8 TB/s HBM peak (MI355X_MICROARCH.md).  `traffic` = HBM bytes per launch
-                 from the committed PMC pass (profiles/pmc_wkv7.json: 2*FETCH_SIZE + WRITE_SIZE, KiB), else null.
-  cpu_baseline : the oracle's eager-PyTorch fp32 CPU restatement of the same training step (oracle/rwkv7_ref.py,
-                 the reference's PyTorch-CPU path) timed on this box's host cores on a bounded sample.
+                 stream, against the 8 TB/s HBM peak (MI355X_MICROARCH.md).  `traffic` = HBM bytes per launch,
+                 `mfma_util` / `valu_frac` = MFMA-busy and VALU-issue fractions of the SIMD time, all from the
+                 committed PMC pass (profiles/pmc_wkv7.json, tools/pmc_wkv.sh), null when it does not cover
+                 this shape.  `fwd` = the forward pair, `fwd_bwd` = forward + backward together (the unit the
+                 north-star target of 0.40 is stated on).
+  cpu_baseline : the oracle's eager-PyTorch fp32 CPU restatement of the reference's training step on
+                 BASELINE.json configs[0] -- RWKV7-0.1B, Cosy layout, B=2, L=512, fwd+bwd, per-token torch scan,
+                 all host cores -- plus the WKV scan alone at (B,T,H,N) = (2,512,12,64) through the C oracle
+                 (SURVEY.md section 8d); bounded to ~25 s.
   decode       : (N = 1 only, after the timed region, not part of `value`) greedy decode of the same model at
-                 BASELINE.json configs[4] -- B=32, prompt 128 -- tokens/s and ms per step (decode.GraphDecoder).
+                 BASELINE.json configs[4] -- B=32, prompt 128, 2048 new tokens -- tokens/s, ms per step and the
+                 fraction of the weight+state streaming bound (decode.GraphDecoder).
+  comm         : (N > 1) bytes all-reduced per step, bucket count, exposed (non-overlapped) wait per step.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,40 +45,82 @@ WKV_BWD_BYTES_PER_TOKEN_HEAD = 13 * 64 * 2  # read w,q,k,v,a,b,dy ; write 6 grad
 WKV_FWD_BYTES_PER_TOKEN_HEAD = 7 * 64 * 2
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` (the form the driver uses) -> N ranks under torch.distributed.run on this node."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
+
+
 def cpu_baseline(seconds_budget=25.0):
-    """Reference PyTorch-CPU path (the oracle's restatement), bounded sample of the same workload:
-    0.4B Spark model, fp32, fwd+bwd on B=1 sequences of T=128."""
+    """BASELINE.json configs[0] on the host cores: the reference's PyTorch-CPU training step (oracle/rwkv7_ref.py: fp32
+    eager, per-token torch scan) on the 0.1B Cosy model, B=2, L=512, and the WKV scan alone at (2,512,12,64) through
+    the C oracle.  Whole steps are repeated until ~60 % of the budget is used (at least one: a step is 20-60 s of CPU work)."""
+    import torch
+    from oracle import c_oracle
     from oracle import rwkv7_ref as R
-    torch.manual_seed(0)
-    # the per-token scan is thousands of tiny ops: beyond ~16 threads the fork/join cost of each op dominates
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    cfg = R.RefConfig(hidden_size=1024, num_hidden_layers=24, vocab_size=8193)
+    from rwkvtts_amd.layouts import synthetic_cosy_batch
+    from rwkvtts_amd.synthetic import make_wkv_inputs
+    cores = R.pick_threads()   # fastest thread count for the per-token scan on this host (more is not faster), of os.cpu_count()
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    D, L, V = 768, 12, 6562
+    cfg = R.RefConfig(hidden_size=D, num_hidden_layers=L, vocab_size=0)
     p = R.init_params(cfg, seed=0)
-    p["lm_head.weight"] = torch.randn(8193, 1024) * 0.02
+    g = torch.Generator().manual_seed(0)
+    p.update({"llm_embedding.weight": torch.randn(2, D, generator=g) * 0.02,
+              "text_embedding.weight": torch.randn(65548, D, generator=g) * 0.02,
+              "speech_embedding.weight": torch.randn(V, D, generator=g) * 0.02,
+              "lm_head.weight": torch.randn(V, D, generator=g) * 0.02, "lm_head.bias": torch.zeros(V)})
     for v in p.values():
         v.requires_grad_(True)
-    B, T = 1, 32
-    x = torch.randn(B, T, 1024) * 0.5
-    labels = torch.randint(0, 8192, (B, T))
+    batch = synthetic_cosy_batch(2, seed=1234)
+    B, T = 2, 512
     t0 = time.time()
     n = 0
     while True:
-        loss, _, _ = R.spark_forward(p, cfg, x, None, labels)
+        loss, _, _ = R.cosy_forward(p, cfg, batch, V - 1, 0.0, True)
         loss.backward()
         n += 1
         if time.time() - t0 > seconds_budget * 0.6:
             break
     dt = time.time() - t0
-    return {"value": round(n * B * T / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"RWKV7-0.4B Spark fwd+bwd, fp32 eager PyTorch on CPU (oracle/rwkv7_ref.py, per-token torch scan), "
-                      f"B={B} T={T}, {n} steps in {dt:.1f}s"}
+    # the scan alone (C oracle = scalar restatement of wkv7_cuda.cu, one core)
+    ins = make_wkv_inputs(2, 512, 12, 1234, torch.float32)
+    c_oracle.wkv7_fwd(*ins)
+    t1 = time.time()
+    reps = 3
+    for _ in range(reps):
+        c_oracle.wkv7_fwd(*ins)
+    scan_ms = (time.time() - t1) / reps * 1e3
+    return {"value": round(n * B * T / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port", "cpu": cpu_model,
+            "sample": f"BASELINE configs[0]: RWKV7-0.1B Cosy layout train step fwd+bwd (LabelSmoothing KL), fp32 eager PyTorch "
+                      f"(oracle/rwkv7_ref.py, per-token torch scan), B={B} L={T}, {n} step(s) in {dt:.1f} s on {cores} threads (fastest of 4/8/16/32 on this host, {os.cpu_count()} cores present)",
+            "wkv_scan_fwd_ms": round(scan_ms, 2),
+            "wkv_scan_sample": "C oracle (oracle/wkv7_oracle.c, 1 thread) forward scan at (B,T,H,N)=(2,512,12,64) fp32"}
 
 
-def decode_rate(model, dev, B=32, P=128, n1=64, n2=448):
-    """BASELINE.json configs[4] on the model that was just trained: greedy decode, B = 32, prompt 128, through
+def decode_rate(model, dev, B=32, P=128, n1=256, n2=2048):
+    """BASELINE.json configs[4] on the model that was just trained: greedy decode, B = 32, prompt 128, 2048 new tokens through
     decode.GraphDecoder (rwkv7_decode_step_bf16 phases replayed from a hipGraph).  Two generate() calls of different length
     separate the per-step time from prefill + capture.  Outside the timed region; rank 0, one GPU only."""
+    import torch
     from rwkvtts_amd.decode import GraphDecoder
     was_training = model.training
     model.eval()
@@ -91,8 +143,15 @@ def decode_rate(model, dev, B=32, P=128, n1=64, n2=448):
     step = (t2 - t1) / (n2 - n1)
     if was_training:
         model.train()
-    return {"metric": "greedy decode tokens/s, RWKV7-0.4B B=32 prompt=128 (BASELINE.json configs[4])", "value": round(B / step, 1),
-            "unit": "tokens/s", "ms_per_step": round(step * 1e3, 4), "batch": B, "prompt": P, "new_tokens": n2,
+    # streaming bound of one step: every bf16 weight of the stack + head once, the fp32 state read and written
+    cfg = model.config
+    wbytes = 2 * (sum(p.numel() for p in model.model.layers.parameters()) + model.lm_head.weight.numel())
+    sbytes = 2 * B * cfg.num_heads * 64 * 64 * 4 * cfg.num_hidden_layers
+    floor = (wbytes + sbytes) / HBM_PEAK
+    return {"metric": "greedy decode tokens/s, RWKV7-0.4B B=32 prompt=128 gen=2048 (BASELINE.json configs[4])",
+            "value": round(B / step, 1), "unit": "tokens/s", "ms_per_step": round(step * 1e3, 4), "batch": B, "prompt": P,
+            "new_tokens": n2, "total_s_incl_prefill_capture": round(t2, 3),
+            "bytes_per_step": wbytes + sbytes, "hbm_floor_ms": round(floor * 1e3, 4), "frac_of_hbm_bound": round(floor / step, 4),
             "path": "rwkv7_decode_step_bf16, one launch per phase, hipGraph replay" if kernel else "module by module, hipGraph replay"}
 
 
@@ -101,51 +160,78 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
-    ap.add_argument("--seq-len", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (default 8; 4 for --layout xy)")
+    ap.add_argument("--seq-len", type=int, default=None, help="positions per sequence (default 4096; 8192 for --layout xy)")
     ap.add_argument("--model", default="0.4b", choices=["0.1b", "0.4b", "1.5b"])
+    ap.add_argument("--layout", default="spark", choices=["spark", "xy"],
+                    help="xy: BASELINE.json configs[3] (8 channels, V0 = 66661, 8 fused linear+CE heads; use with --model 1.5b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-checkpoint", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement (BASELINE configs[4]) after the timed region")
-    ap.add_argument("--scalar-wkv-fwd", action="store_true", help="A/B: scalar WKV7 forward instead of the chunked MFMA one")
-    ap.add_argument("--scalar-wkv-bwd", action="store_true", help="A/B: row-split scalar WKV7 backward instead of the chunked MFMA one")
+    ap.add_argument("--scalar-wkv", action="store_true", help="A/B: scalar WKV7 kernels (reference schema fwd, row-split bwd) instead of the chunked MFMA pair")
     a = ap.parse_args()
-    if a.scalar_wkv_bwd:
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)   # does not return
+
+    import torch
+    if a.scalar_wkv:
         from rwkvtts_amd import fused as _fused
         _fused.CHUNKED_WKV_BWD = False
-    if a.scalar_wkv_fwd:
-        from rwkvtts_amd import fused as _fused
         _fused.CHUNKED_WKV_FWD = False
 
     from rwkvtts_amd import build
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         build.build()  # no-op when the prebuilt .so is current; one rank per node, the others wait at the barrier below
     from rwkvtts_amd import backbone, ops, trainer
-    from rwkvtts_amd.layouts import synthetic_spark_batch
-    from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
+    from rwkvtts_amd.layouts import synthetic_spark_batch, synthetic_xy_batch
 
     rank, local_rank, world = trainer.init_distributed()
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or let bench.py launch itself)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         torch.distributed.barrier()
 
     base = {"0.1b": backbone.config_0p1b, "0.4b": backbone.config_0p4b, "1.5b": backbone.config_1p5b}[a.model]()
-    cfg = RWKV7SpeechConfig(**{k: v for k, v in base.to_dict().items() if k in backbone.RWKV7Config.__dataclass_fields__
-                               and k != "extra"})
-    model = RWKV7ForSpeech(cfg).init_weights(seed=0).to(device=dev, dtype=torch.bfloat16).train()
+    base_kw = {k: v for k, v in base.to_dict().items() if k in backbone.RWKV7Config.__dataclass_fields__ and k != "extra"}
+    if a.layout == "spark":
+        from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
+        B, T = a.batch or 8, a.seq_len or 4096
+        model = RWKV7ForSpeech(RWKV7SpeechConfig(**base_kw)).init_weights(seed=0)
+    else:
+        from rwkvtts_amd.xy_llm import RWKV7XYConfig, RWKV7XYLM
+        B, T = a.batch or 4, a.seq_len or 8192
+        base_kw["vocab_size"] = 66661
+        model = RWKV7XYLM(RWKV7XYConfig(speech_vocab_size=1025, num_channels=8, text_shift_size=65536, **base_kw)).init_weights(seed=0)
+        model.zero_embs()
+    cfg = model.config
+    model = model.to(device=dev, dtype=torch.bfloat16).train()
     if a.grad_checkpoint:
         model.gradient_checkpointing_enable()
     tr = trainer.DataParallelTrainer(model, lr=1e-4, warmup_steps=10, total_steps=1000)
-    B, T = a.batch, a.seq_len
     H = cfg.num_heads
 
+    if a.layout == "spark":
+        def make_batch(i):
+            # built inside the step WITH autograd, as data/utils/spark_dataset.py:163-239 does under the reference's training
+            # loop (train_spark_rwkv7speech.py:630-634): the four embedding tables get gradients, their backward is timed
+            return synthetic_spark_batch(model, B, T, seed=1234 + rank + 1000 * i)
+    else:
+        xy_cache = {}
+
+        def make_batch(i):
+            # ids are built on the host once per distinct seed (the reference's collator does it in the DataLoader workers)
+            k = i % 4
+            if k not in xy_cache:
+                b = synthetic_xy_batch(B, T1=128, T2=T - 128 - 7, seed=1234 + rank + 1000 * k)
+                b = {n: v.to(dev) for n, v in b.items()}
+                backbone.mark_all_ones(b["attention_mask"], True)
+                xy_cache[k] = b
+            return dict(xy_cache[k], use_cache=False)
+
     def one_step(i):
-        with torch.no_grad():
-            batch = synthetic_spark_batch(model, B, T, seed=1234 + rank + 1000 * i)
-        batch["inputs_embeds"] = batch["inputs_embeds"].detach()
-        return tr.step(**batch)
+        return tr.step(**make_batch(i))
 
     def sync():
         if world > 1:
@@ -156,13 +242,14 @@ def main():
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params, B={B} T={T}")
+    log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params, layout {a.layout}, B={B} T={T}, world {world}")
     for i in range(a.warmup):
         loss = one_step(i)
         torch.cuda.synchronize()
         log(f"warmup step {i} done, loss {float(loss):.4f}, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     ops.KERNEL_TIMERS = {}
+    tr.reducer.measure, tr.reducer.wait_events = world > 1, []
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = one_step(a.warmup + i)
@@ -180,50 +267,72 @@ def main():
         value = world * B * T * a.steps / dt
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items() if v}
         th = B * T * H
-        bwd_ms = kern.get("wkv7_bwd")
-        bwd_name = "wkv7_bwd_kernel<bf16,2,4> (row-split scalar WKV7 backward, 24 launches/step)"
-        pmc_key = "wkv7_bwd"
-        chunk_parts = ["wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bwd_out"]
-        fwd_ms, fwd_name = kern.get("wkv7_fwd"), "wkv7_fwd_kernel (scalar)"
-        if "wkv7c_fwd" in kern:   # chunked forward: T^-1 (wkv7c_prep, reused by the backward) + the chunk kernel
-            fwd_ms, fwd_name = kern["wkv7c_fwd"] + kern.get("wkv7c_prep", 0.0), "wkv7c_prep + wkv7c_fwd (chunked MFMA)"
-        if bwd_ms is None and all(k in kern for k in chunk_parts):
-            # chunked MFMA backward: three launches per layer (four when the forward was scalar and T^-1 is computed here)
-            bwd_ms = sum(kern[k] for k in chunk_parts) + (0.0 if "wkv7c_fwd" in kern else kern.get("wkv7c_prep", 0.0))
-            bwd_name = "WKV7 backward, chunked MFMA (wkv7c_bwd_pre + wkv7c_state + wkv7c_bwd_out, 24x per step)"
-            pmc_key = "wkv7c_bwd"
-        achieved = th * WKV_BWD_BYTES_PER_TOKEN_HEAD / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_wkv7.json")
-        if os.path.exists(pmc):
-            try:
-                d = json.load(open(pmc))[pmc_key]
-                if d.get("B") == B and d.get("T") == T and d.get("H") == H:
-                    traffic = int((2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024)
-            except Exception:
-                traffic = None
+        chunk_parts = [k for k in ("wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bwd_out") if k in kern]
+        if "wkv7c_bwd_out" in kern:
+            bwd_ms = sum(kern[k] for k in chunk_parts)
+            bwd_name = "WKV7 backward, chunked MFMA (" + " + ".join(chunk_parts) + f", {cfg.num_hidden_layers}x per step)"
+            fwd_ms = kern["wkv7c_fwd"] + kern.get("wkv7c_prep", 0.0)
+            fwd_name = "wkv7c_prep + wkv7c_fwd (chunked MFMA)"
+            pmc_bwd, pmc_fwd = "wkv7c_bwd", "wkv7c_fwd"
+        else:
+            bwd_ms, bwd_name = kern.get("wkv7_bwd"), "wkv7_bwd_kernel<bf16,2,4> (row-split scalar WKV7 backward)"
+            fwd_ms, fwd_name = kern.get("wkv7_fwd"), "wkv7_fwd_kernel (scalar)"
+            pmc_bwd, pmc_fwd = "wkv7_bwd", "wkv7_fwd"
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_wkv7.json")))
+        except Exception:
+            pass
+
+        def pmc_of(key):
+            d = pmc.get(key) or {}
+            if d.get("B") == B and d.get("T") == T and d.get("H") == H:
+                return d
+            return {}
+
+        def traffic(d):
+            return int((2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in d else None
+
+        gbs = lambda nbytes, t_ms: nbytes / (t_ms * 1e-3) / 1e9 if t_ms else None
+        b_bytes, f_bytes = th * WKV_BWD_BYTES_PER_TOKEN_HEAD, th * WKV_FWD_BYTES_PER_TOKEN_HEAD
+        ach = gbs(b_bytes, bwd_ms)
+        pb, pf = pmc_of(pmc_bwd), pmc_of(pmc_fwd)
+        roof = {"kernel": bwd_name, "bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(ach * 1e9 / HBM_PEAK, 4) if ach else None, "traffic": traffic(pb),
+                "mfma_util": pb.get("mfma_util"), "valu_frac": pb.get("valu_frac"), "pmc_source": pb.get("source"),
+                "algorithmic_bytes_per_launch": b_bytes, "launch_ms": round(bwd_ms, 4) if bwd_ms else None}
+        if fwd_ms:
+            roof["fwd"] = {"kernel": fwd_name, "launch_ms": round(fwd_ms, 4), "achieved": round(gbs(f_bytes, fwd_ms), 1),
+                           "frac": round(gbs(f_bytes, fwd_ms) * 1e9 / HBM_PEAK, 4), "traffic": traffic(pf),
+                           "mfma_util": pf.get("mfma_util"), "valu_frac": pf.get("valu_frac"), "algorithmic_bytes_per_launch": f_bytes}
+        if fwd_ms and bwd_ms:
+            both = gbs(f_bytes + b_bytes, fwd_ms + bwd_ms)
+            roof["fwd_bwd"] = {"launch_ms": round(fwd_ms + bwd_ms, 4), "achieved": round(both, 1), "frac": round(both * 1e9 / HBM_PEAK, 4),
+                               "target_frac": 0.40}
+        which = {("spark", 1): 1, ("spark", 0): 2, ("xy", 1): 3, ("xy", 0): 3}[(a.layout, 1 if world == 1 else 0)]
         out = {
             "metric": "audio-tokens/sec/GPU (train fwd+bwd) RWKV7-0.4B L=4096; 1->8 GPU scaling",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "per_gpu": round(value / world, 1),
-            "config": {"workload": f"RWKV7-{a.model.upper()} Spark layout train step (fwd+bwd+AdamW), B={B}/GPU L={T}, "
-                                   f"synthetic text+speech tokens, random init (BASELINE.json configs[{1 if world == 1 else 2}])",
+            "config": {"workload": f"RWKV7-{a.model.upper()} {'Spark' if a.layout == 'spark' else 'XY_LM (8 channels)'} layout train step "
+                                   f"(fwd+bwd+AdamW), B={B}/GPU L={T}, synthetic text+speech tokens, random init "
+                                   f"(BASELINE.json configs[{which}])",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
                        "grad_allreduce": "bucketed RCCL AVG, bf16, overlapped with backward" if world > 1 else "none"},
             "loss": round(loss_val, 4),
+            "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
-            "roofline": {"kernel": bwd_name, "bound": "hbm",
-                         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved * 1e9 / HBM_PEAK, 4) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": th * WKV_BWD_BYTES_PER_TOKEN_HEAD,
-                         "launch_ms": round(bwd_ms, 4) if bwd_ms else None,
-                         "fwd": {"kernel": fwd_name, "launch_ms": round(fwd_ms, 4),
-                                 "achieved": round(th * WKV_FWD_BYTES_PER_TOKEN_HEAD / (fwd_ms * 1e-3) / 1e9, 1)}
-                         if fwd_ms else None},
+            "roofline": roof,
         }
-        if world == 1 and not a.no_decode:
+        if world > 1:
+            r = tr.reducer
+            out["comm"] = {"rccl_ranks": world, "backend": r.backend, "bytes_allreduced_per_step": tr.flat.numel * tr.flat.flat_grad.element_size(),
+                           "buckets": len(r.buckets), "bucket_mib": [round((e - s) * tr.flat.flat_grad.element_size() / 2**20, 1) for s, e, _ in r.buckets],
+                           "exposed_wait_ms_per_step": round(sum(s_.elapsed_time(e_) for s_, e_ in r.wait_events) / a.steps, 3),
+                           "note": "exposed = time the compute stream stalls on the buckets' wait() after backward has been enqueued (HIP events, rank 0)"}
+        if world == 1 and not a.no_decode and a.layout == "spark":
             try:
                 out["decode"] = decode_rate(model, dev)
             except Exception as e:  # the headline number must not depend on the secondary measurement

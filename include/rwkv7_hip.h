@@ -277,6 +277,15 @@ int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, lo
  *      bf16 working copy p16 is rewritten in the same pass.  n % 4 == 0; step = 1 for the first update. ---- */
 int rwkv7_adamw_bf16(long n, float *p32, const void *g16, float *m, float *v, void *p16, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, rwkv7_stream_t stream);
+/*      Parameter groups (train_scripts/train_cosy_rwkv7speech_multiple_dataset.py:162-202: `lr_2x` for
+ *      'attn.w_lora.lora.2.bias', a weight-decay group for >= 2-D non-LoRA `.weight`, `my_lr_scale`): slab_group[n / 128]
+ *      (uint8, one entry per 128 consecutive elements -- the host aligns every parameter to 128 elements) indexes
+ *      group_tab[ngroups][2] = {lr scale, weight decay}, both in device memory; both NULL = one group {1, 0}.
+ *      skip_flag: device float or NULL; != 0 makes the step run on a zero gradient (the reference's NaN-loss step,
+ *      train_spark_rwkv7speech.py:664-687) without the host ever reading the flag.  n % 128 == 0 with groups. ---- */
+int rwkv7_adamw_groups_bf16(long n, float *p32, const void *g16, float *m, float *v, void *p16, const unsigned char *slab_group,
+                            const float *group_tab, int ngroups, const float *skip_flag, float lr, float beta1, float beta2,
+                            float eps, int step, rwkv7_stream_t stream);
 
 /* ---- last step of a split weight gradient (the dW of nn.Linear under autograd, e.g. rwkv_s2s_single_ffn.py:171-174,195,
  *      228-229, reduced over B*T in S row slabs with fp32 partials): out[n] (bf16) = (accumulate ? out[n] : 0) +

@@ -315,3 +315,28 @@ def xy_forward(p, cfg: RefConfig, input_ids, attention_mask, labels, num_channel
         loss = sum(F.cross_entropy(l.reshape(-1, l.shape[-1]), labels[:, :, i].reshape(-1), label_smoothing=lsm_weight)
                    for i, l in enumerate(logits))
     return loss, logits
+
+
+def pick_threads(candidates=(4, 8, 16, 32)):
+    """The per-token scan is thousands of tiny ops ([B,H,64,64] elementwise + small matmuls): beyond a handful of threads
+    the fork/join cost of each op dominates and more cores make the step SLOWER (measured: 8 threads 57 s, 4 threads 24 s per
+    configs[0] step in the authoring container).  Times a 48-step scan at each candidate and keeps the fastest; the caller
+    reports the number it used."""
+    import os
+    import time
+    g = torch.Generator().manual_seed(0)
+    mk = lambda s=0.1: torch.randn(2, 48, 12, 64, generator=g) * s
+    r, k, v, a, b = mk(), mk(), mk(), mk(), mk()
+    w = -F.softplus(-mk(1.0)) - 0.5
+    best, best_t = None, None
+    ncpu = os.cpu_count() or 1
+    for n in sorted({min(c, ncpu) for c in candidates}):
+        torch.set_num_threads(n)
+        wkv7_scan(r, w, k, v, a, b)
+        t0 = time.perf_counter()
+        wkv7_scan(r, w, k, v, a, b)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best, best_t = n, dt
+    torch.set_num_threads(best)
+    return best

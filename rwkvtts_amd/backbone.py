@@ -162,6 +162,14 @@ class Cache:
                     for _ in range(cfg.num_hidden_layers)])
 
 
+def mark_all_ones(attention_mask: torch.Tensor, all_ones: bool):
+    """Host-side knowledge about a mask (True: no padding anywhere; False: padded): RWKV7Model.forward then decides
+    whether to apply it without reading it back from the device -- `bool(mask.all())` is a host synchronisation in the
+    middle of the training step, which delays the first gradient bucket of the previous step's overlap window."""
+    attention_mask._rwkv7_all_ones = bool(all_ones)
+    return attention_mask
+
+
 # Training runs prepare -> scan -> post as one autograd node (fused._TmixCore: row-split scan backward, gradient sums
 # folded into the prepare backward).  False selects the three separate nodes (same forward kernels).
 FUSED_TMIX_CORE = True
@@ -347,10 +355,13 @@ class RWKV7Model(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("RWKV7Model runs on the HIP device only (no CPU path); move the model and inputs to cuda")
         mask = None
-        if attention_mask is not None and not bool(attention_mask[:, -T:].all()):
-            # an all-ones mask (unpadded batches, the common training case) is dropped: multiplying by it is
-            # the identity and only costs HBM traffic
-            mask = attention_mask[:, -T:].to(x.dtype).unsqueeze(-1)
+        if attention_mask is not None:
+            # an all-ones mask (unpadded batches, the common training case) is dropped: multiplying by it is the
+            # identity and only costs HBM traffic.  Batch builders that know the answer on the host say so
+            # (mark_all_ones); only an unmarked mask costs a device round trip here.
+            known = getattr(attention_mask, "_rwkv7_all_ones", None)
+            if not (known if known is not None else bool(attention_mask[:, -T:].all())):
+                mask = attention_mask[:, -T:].to(x.dtype).unsqueeze(-1)
         if use_cache and past_key_values is None:
             past_key_values = Cache.zeros(self.config, B, x.device, x.dtype)
         stateful = past_key_values is not None and len(past_key_values) > 0

@@ -34,7 +34,8 @@ int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t)
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int gemv32_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 int ce_fwd_bwd(long, int, void *, const long *, long, float, float *, hipStream_t);
-int adamw_step(long, float *, const void *, float *, float *, void *, float, float, float, float, float, float, float, hipStream_t);
+int adamw_step(long, float *, const void *, float *, float *, void *, const uint8_t *, const float *, const float *, float, float, float, float,
+               float, float, float, hipStream_t);
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
@@ -361,13 +362,23 @@ int rwkv7_lora32_bf16(int M, int N, int K, int R, int act, const void *x, const 
         return RWKV7_ESHAPE;
     return rwkv7::lora32_bf16(M, N, K, R, act, x, w1, w2, bias, y, (hipStream_t)stream);
 }
+int rwkv7_adamw_groups_bf16(long n, float *p32, const void *g16, float *m, float *v, void *p16, const unsigned char *slab_group,
+                            const float *group_tab, int ngroups, const float *skip_flag, float lr, float beta1, float beta2, float eps,
+                            int step, rwkv7_stream_t stream) {
+    if (n <= 0 || step <= 0 || any_null({(const void *)p32, g16, (const void *)m, (const void *)v, p16})) return RWKV7_EINVAL;
+    if ((slab_group == nullptr) != (group_tab == nullptr) || (slab_group && (ngroups <= 0 || ngroups > 256))) return RWKV7_EINVAL;
+    if (n % 4 != 0 || (slab_group && n % 128 != 0)) return RWKV7_ESHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    return rwkv7::adamw_step(n, p32, g16, m, v, p16, slab_group, group_tab, skip_flag, lr, beta1, beta2, eps, 0.f, (float)(1.0 / bc1),
+                             (float)(1.0 / sqrt(bc2)), (hipStream_t)stream);
+}
 int rwkv7_adamw_bf16(long n, float *p32, const void *g16, float *m, float *v, void *p16, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, rwkv7_stream_t stream) {
     if (n <= 0 || step <= 0 || any_null({(const void *)p32, g16, (const void *)m, (const void *)v, p16})) return RWKV7_EINVAL;
     if (n % 4 != 0) return RWKV7_ESHAPE;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    return rwkv7::adamw_step(n, p32, g16, m, v, p16, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-                             (float)(1.0 / sqrt(bc2)), (hipStream_t)stream);
+    return rwkv7::adamw_step(n, p32, g16, m, v, p16, nullptr, nullptr, nullptr, lr, beta1, beta2, eps, weight_decay,
+                             (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), (hipStream_t)stream);
 }
 int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
                           rwkv7_stream_t stream) {

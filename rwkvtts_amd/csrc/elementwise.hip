@@ -677,14 +677,28 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_bwd_kernel(long rows, in
 //   p *= 1 - lr wd ;  m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2 ;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
 // 4 floats per thread and iteration: 2 + 3*4 bytes read, 3*4 + 2 written per parameter (28 B) -- nothing else touches HBM.
 // ------------------------------------------------------------------------------------------------------
+// GROUPS: per-slab parameter groups (train_cosy_rwkv7speech_multiple_dataset.py:162-202): slab_group[e / 128] indexes
+// group_tab[g] = {lr scale, weight decay}; the trainer's flat buffer aligns every parameter to 128 elements, so a float4 never
+// straddles two parameters.  skip_flag (device, may be NULL): != 0 -> the step runs on a ZERO gradient (the reference's
+// NaN-loss step, train_spark_rwkv7speech.py:664-687), decided on the device so that the host never waits for the flag.
+template <bool GROUPS>
 __global__ __launch_bounds__(256) void adamw_kernel(long n4, float *__restrict__ p32, const bf16_t *__restrict__ g16,
                                                     float *__restrict__ m, float *__restrict__ v, bf16_t *__restrict__ p16,
-                                                    float lr, float beta1, float beta2, float eps, float wd, float inv_bc1,
-                                                    float inv_sqrt_bc2) {
-    const float decay = 1.f - lr * wd, step = lr * inv_bc1;
+                                                    const uint8_t *__restrict__ slab_group, const float2 *__restrict__ group_tab,
+                                                    const float *__restrict__ skip_flag, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
+    const bool skip = skip_flag != nullptr && *skip_flag != 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float lr_i = lr, wd_i = wd;
+        if (GROUPS) {
+            const float2 g = group_tab[slab_group[i >> 5]];
+            lr_i = lr * g.x;
+            wd_i = g.y;
+        }
+        const float decay = 1.f - lr_i * wd_i, step = lr_i * inv_bc1;
         float4 p = reinterpret_cast<float4 *>(p32)[i], mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
-        const float4 g = cvt4(ld4<bf16_t>(g16 + 4 * i, true));
+        float4 g = cvt4(ld4<bf16_t>(g16 + 4 * i, true));
+        if (skip) g = make_float4(0.f, 0.f, 0.f, 0.f);
         auto upd = [&](float &pp, float &m1, float &v1, float gg) {
             pp *= decay;
             m1 = fmaf(beta1, m1, (1.f - beta1) * gg);
@@ -699,13 +713,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(long n4, float *__restrict__
     }
 }
 
-int adamw_step(long n, float *p32, const void *g16, float *m, float *v, void *p16, float lr, float beta1, float beta2, float eps,
-               float wd, float inv_bc1, float inv_sqrt_bc2, hipStream_t st) {
+int adamw_step(long n, float *p32, const void *g16, float *m, float *v, void *p16, const uint8_t *slab_group, const float *group_tab,
+               const float *skip_flag, float lr, float beta1, float beta2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2,
+               hipStream_t st) {
     (void)hipGetLastError();
     const long n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, n4, p32, (const bf16_t *)g16, m, v, (bf16_t *)p16, lr, beta1,
-                       beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+    if (slab_group)
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, st, n4, p32, (const bf16_t *)g16, m, v, (bf16_t *)p16,
+                           slab_group, reinterpret_cast<const float2 *>(group_tab), skip_flag, lr, beta1, beta2, eps, wd, inv_bc1,
+                           inv_sqrt_bc2);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid), dim3(256), 0, st, n4, p32, (const bf16_t *)g16, m, v, (bf16_t *)p16,
+                           slab_group, reinterpret_cast<const float2 *>(group_tab), skip_flag, lr, beta1, beta2, eps, wd, inv_bc1,
+                           inv_sqrt_bc2);
     return (int)hipGetLastError();
 }
 

@@ -171,7 +171,8 @@ class GraphDecoder:
         self.eos = None if eos_token_id is None else torch.tensor(eos_token_id, device=dev)
         self.pad_t = torch.tensor(pad_token_id if pad_token_id is not None else (eos_token_id or 0), device=dev)
         self.unfinished = torch.ones(B, dtype=torch.bool, device=dev)
-        self.out = torch.zeros(B, max_new_tokens, dtype=torch.long, device=dev)
+        # >= 3 columns: the two un-captured warm-up steps below scatter into columns 1 and 2 before the state is restored
+        self.out = torch.zeros(B, max(max_new_tokens, 3), dtype=torch.long, device=dev)
         self.pos = torch.zeros(1, 1, dtype=torch.long, device=dev)
         # prefill (eager, state-carrying kernel over the whole prompt) + first token
         o = m(input_ids=input_ids if inputs_embeds is None else None, inputs_embeds=inputs_embeds,
@@ -186,7 +187,7 @@ class GraphDecoder:
         if self.eos is not None:
             self.unfinished &= first != self.eos
         if max_new_tokens <= 1:
-            return self.out
+            return self.out[:, :max_new_tokens]
         self.step = None
         if self.step_kernel is not False:
             why = DecodeStep.supported(m.model, m.lm_head, self.cache)
@@ -226,4 +227,4 @@ class GraphDecoder:
         self.cache.seen_tokens = seen0 + max_new_tokens - 1
         if self.step is not None and self.step.barrier_timed_out():
             raise _lib.Rwkv7HipError("rwkv7_decode_step_bf16: a grid barrier timed out; the generated ids are invalid")
-        return self.out
+        return self.out[:, :max_new_tokens]

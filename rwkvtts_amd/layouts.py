@@ -12,6 +12,8 @@ from typing import List, Sequence
 
 import torch
 
+from .backbone import mark_all_ones
+
 
 def spark_embed_sample(llm, text_ids: Sequence[int], global_ids: Sequence[int], semantic_ids: Sequence[int]):
     """[1, 3 + len(text) + len(global) + len(semantic), D] embedding sequence of one sample."""
@@ -55,7 +57,7 @@ def synthetic_spark_batch(llm, B: int, T: int = 4096, seed: int = 1234, n_text: 
                       llm.model.embeddings(sem)], dim=1)
     labels = torch.full((B, T), -100, dtype=torch.long, device=dev)
     labels[:, T - n_sem:] = sem
-    mask = torch.ones(B, T, dtype=torch.long, device=dev)
+    mask = mark_all_ones(torch.ones(B, T, dtype=torch.long, device=dev), True)
     return dict(inputs_embeds=embs, attention_mask=mask, labels=labels)
 
 
@@ -93,6 +95,7 @@ def process_single_batch(batch, rwkv7speech_model, eos_token_id=8192):
         n = sems[i].numel()
         labels[i, -n - 1:-1] = sems[i].to(device)
         labels[i, -1] = eos_token_id
+    mark_all_ones(attention_mask, all(e.shape[1] == L for e in embs))   # known on the host: no read-back in the model
     return {"input_embs": torch.cat(out, dim=0), "attention_mask": attention_mask, "labels": labels}
 
 
@@ -138,6 +141,7 @@ def create_inputs_and_labels(text_ids: List[Sequence[int]], global_tokens: List[
     mask = torch.zeros(len(embs), max(lengths), dtype=torch.long, device=dev)
     for i, n in enumerate(lengths):
         mask[i, :n] = 1
+    mark_all_ones(mask, min(lengths) == max(lengths))
     return {"input_embs": torch.nn.utils.rnn.pad_sequence(embs, batch_first=True, padding_value=0.0),
             "labels": torch.nn.utils.rnn.pad_sequence(labs, batch_first=True, padding_value=-100),
             "attention_mask": mask}

@@ -88,7 +88,9 @@ class _FusedLinearCE(torch.autograd.Function):
         dh, dw, db, post = ctx.saved_tensors
         if post is not None:
             g = g * post
-        return (dh * g.to(dh.dtype) if dh is not None else None,
+        # scale in fp32 and round once: rounding the scalar to bf16 first would put a systematic error of up to 2^-9 on
+        # every hidden-state gradient relative to the (fp32-scaled) head-weight gradient
+        return ((dh.float() * g).to(dh.dtype) if dh is not None else None,
                 (dw * g).to(ctx.wdtype) if dw is not None else None,
                 (db * g).to(ctx.wdtype) if db is not None else None, None, None, None, None)
 

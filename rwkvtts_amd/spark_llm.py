@@ -83,6 +83,14 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
             ignore_index = getattr(self.criterion, "ignore_index", -100)
             labels = labels.to(hidden_states.device)
             labels = torch.cat((labels[..., 1:], torch.full_like(labels[:, :1], ignore_index)), 1)
+            cu = kwargs.get("cu_seqlens")
+            if cu is not None:
+                # packed rows: the reference's builder appends the sample that overflows max_cu_seqlens WITHOUT a cu_seqlens
+                # entry (data/utils/spark_dataset.py:150-158, reproduced bit for bit in layouts.process_single_batch_culens);
+                # the backbone returns zeros there, so those labels would add log(V)-sized terms with no useful gradient
+                # and inflate the valid-token count that scales the whole step -- they are ignored instead
+                pos = torch.arange(labels.shape[1], device=labels.device)
+                labels = torch.where(pos.unsqueeze(0) >= cu[-1].to(labels.device), torch.full_like(labels, ignore_index), labels)
             if fuse:
                 loss = fused_linear_cross_entropy(hidden_states, labels, self.lm_head.weight, self.lm_head.bias,
                                                   ignore_index)

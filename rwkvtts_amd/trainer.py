@@ -134,7 +134,9 @@ class FlatBuffers:
 class BucketedAllReduce:
     """Gradient all-reduce in buckets, launched from backward hooks as soon as a bucket is complete."""
 
-    def __init__(self, flat: FlatBuffers, bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, flat: FlatBuffers, bucket_bytes: int = 32 << 20, group=None, force: bool = False):
+        """force: run the collectives even in a group of one rank (tests: the whole hook -> flush -> RCCL -> wait path on a
+        single GPU, where the exchange is the identity)."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
@@ -153,7 +155,8 @@ class BucketedAllReduce:
         self.pending = [b[2] for b in self.buckets]
         self.works = []
         self.use_avg, self.summed = True, []
-        self.enabled = self.world > 1
+        self.measure, self.wait_events = False, []
+        self.enabled = self.world > 1 or (force and dist.is_initialized())
         if self.enabled:
             flat.on_ready = self._ready
 
@@ -189,8 +192,16 @@ class BucketedAllReduce:
         for b, left in enumerate(self.pending):
             if left > 0:
                 self._launch(b)
+        # wait() makes the compute stream wait for RCCL's stream; what the compute stream then stalls is the exposed
+        # (non-overlapped) part of the exchange -- bracketed by two events when `measure` is on (bench.py)
+        if self.measure and self.works:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self.works:
             w.wait()
+        if self.measure and self.works:
+            e1.record()
+            self.wait_events.append((e0, e1))
         self.works = []
         for s, e in self.summed:
             self.flat.flat_grad[s:e].mul_(1.0 / self.world)
@@ -206,72 +217,167 @@ def linear_warmup_decay(step, total_steps, warmup_steps, lr, lr_final):
     return lr * max(lr_final / lr, 1.0 - progress * (1.0 - lr_final / lr))
 
 
+def cosine_warmup_decay(step, total_steps, warmup_steps, lr, lr_final):
+    """train_cosy_rwkv7speech_multiple_dataset.py:224-234: warmup from 1 % of lr, then half a cosine down to lr_final."""
+    if step < warmup_steps:
+        return lr * (0.01 + 0.99 * step / warmup_steps)
+    progress = float(step - warmup_steps) / float(max(1, total_steps - warmup_steps))
+    progress = max(0.0, min(1.0, progress))
+    f = lr_final / lr
+    return lr * ((0.5 + f / 2) + (0.5 - f / 2) * math.cos(math.pi * progress))
+
+
+SCHEDULES = {"linear": linear_warmup_decay, "cosine": cosine_warmup_decay}
+
+
+def reference_param_groups(model: torch.nn.Module, weight_decay: float):
+    """The parameter groups of configure_optimizer (train_cosy_rwkv7speech_multiple_dataset.py:162-190), one entry per
+    trainable parameter in model.parameters() order: (group name, lr scale, weight decay).
+      lr_2x    : names containing 'attn.w_lora.lora.2.bias' (the decay bias w0)            -> lr x 2, no decay
+      lr_decay : >= 2-D (after squeeze) '.weight' tensors outside the LoRAs, if weight_decay > 0 -> lr x 1, decay
+      lr_1x    : everything else                                                            -> lr x 1, no decay"""
+    out = []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if "attn.w_lora.lora.2.bias" in n:
+            out.append(("lr_2x", 2.0, 0.0))
+        elif len(p.squeeze().shape) >= 2 and weight_decay > 0 and ".weight" in n and "lora" not in n:
+            out.append(("lr_decay", 1.0, float(weight_decay)))
+        else:
+            out.append(("lr_1x", 1.0, 0.0))
+    return out
+
+
 class DataParallelTrainer:
+    """param_groups: None = one group (train_spark_rwkv7speech.py:178-197: every parameter lr x 1, `weight_decay` on all);
+    "reference" = reference_param_groups(model, weight_decay) (the Cosy trainer's lr_2x / lr_decay split); or a list of
+    (name, lr scale, weight decay), one per trainable parameter.  schedule: "linear" (Spark trainer) or "cosine" (Cosy)."""
+
     def __init__(self, model: torch.nn.Module, lr=1e-4, lr_final=1e-5, warmup_steps=100, total_steps=100000,
                  weight_decay=0.0, betas=(0.9, 0.95), eps=1e-18, bucket_bytes=32 << 20, nan_guard=True,
-                 master_fp32=True):
+                 master_fp32=True, param_groups=None, schedule="linear", force_allreduce=False):
         self.model = model
         self.flat = FlatBuffers(model)
-        self.reducer = BucketedAllReduce(self.flat, bucket_bytes)
+        self.reducer = BucketedAllReduce(self.flat, bucket_bytes, force=force_allreduce)
         self.world = self.reducer.world
         self.master = self.flat.flat_param.float() if master_fp32 and self.flat.flat_param.dtype != torch.float32 \
             else self.flat.flat_param
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        if param_groups == "reference":
+            param_groups = reference_param_groups(model, weight_decay)
+        if param_groups is None:
+            param_groups = [("all", 1.0, float(weight_decay))] * len(self.flat.params)
+        assert len(param_groups) == len(self.flat.params), "one (name, lr scale, weight decay) per trainable parameter"
+        self.group_defs = []          # distinct (name, lr scale, weight decay)
+        self.param_group_idx = []
+        for g in param_groups:
+            g = (g[0], float(g[1]), float(g[2]))
+            if g not in self.group_defs:
+                self.group_defs.append(g)
+            self.param_group_idx.append(self.group_defs.index(g))
+        assert len(self.group_defs) <= 256
+        dev = self.master.device
+        self.schedule = SCHEDULES[schedule] if isinstance(schedule, str) else schedule
         # bf16 parameters on the HIP device: one kernel reads the bf16 gradients, updates the fp32 master weights and
-        # moments and rewrites the bf16 parameters (rwkv7_adamw_bf16) -- no fp32 gradient copy, no separate cast back
+        # moments and rewrites the bf16 parameters (rwkv7_adamw_groups_bf16) -- no fp32 gradient copy, no separate cast
+        # back; the group of every 128-element slab of the flat buffer comes from a uint8 table (FlatBuffers aligns the
+        # parameters to 128 elements), the NaN flag stays on the device
         self.hip_adamw = (self.master is not self.flat.flat_param and self.master.is_cuda
-                          and self.flat.flat_param.dtype == torch.bfloat16 and self.flat.numel % 4 == 0)
+                          and self.flat.flat_param.dtype == torch.bfloat16 and self.flat.numel % 128 == 0)
+        self.exp_avg = torch.zeros_like(self.master)
+        self.exp_avg_sq = torch.zeros_like(self.master)
         if self.hip_adamw:
-            self.exp_avg = torch.zeros_like(self.master)
-            self.exp_avg_sq = torch.zeros_like(self.master)
-            self.master_grad, self.opt = None, None
+            slab = torch.zeros(self.flat.numel // 128, dtype=torch.uint8)
+            ends = self.flat.offsets[1:] + [self.flat.numel]
+            for o, e, gi in zip(self.flat.offsets, ends, self.param_group_idx):
+                slab[o // 128:e // 128] = gi
+            self.slab_group = slab.to(dev)
+            self.group_tab = torch.tensor([[g[1], g[2]] for g in self.group_defs], dtype=torch.float32).to(dev)
         else:
+            # CPU (gloo tests) / fp32 models: the same update rule in torch, group by group on runs of the flat buffers
             self.master_grad = torch.zeros_like(self.master) if self.master is not self.flat.flat_param else None
-            self.master.grad = self.master_grad if self.master_grad is not None else self.flat.flat_grad
-            self.opt = torch.optim.AdamW([self.master], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                                         fused=self.master.is_cuda)
+            self.runs = []   # (start, end, group index): consecutive parameters of one group merged
+            ends = self.flat.offsets[1:] + [self.flat.numel]
+            for o, e, gi in zip(self.flat.offsets, ends, self.param_group_idx):
+                if self.runs and self.runs[-1][2] == gi and self.runs[-1][1] == o:
+                    self.runs[-1] = (self.runs[-1][0], e, gi)
+                else:
+                    self.runs.append((o, e, gi))
         self.lr, self.lr_final, self.warmup_steps, self.total_steps = lr, lr_final, warmup_steps, total_steps
         self.nan_guard = nan_guard
+        self.nan_flag = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_idx = 0
+        self.last_lr = None
+        # modules that cache tensors derived from parameters (RWKV7Attention._stacked_mix): the optimizer kernel rewrites
+        # parameter memory through raw pointers without touching autograd's version counters, so they are told explicitly
+        self._param_caches = [m for m in model.modules() if hasattr(m, "_mix_key") or hasattr(m, "_stacked_mix")]
+
+    def current_lr(self):
+        return self.schedule(self.step_idx, self.total_steps, self.warmup_steps, self.lr, self.lr_final)
+
+    def group_lrs(self):
+        """{group name: lr of the next step} -- what update_learning_rate writes into optimizer.param_groups (:236-241)."""
+        base = self.current_lr()
+        return {g[0]: base * g[1] for g in self.group_defs}
+
+    def _torch_adamw(self, lr, skip):
+        g_all = self.flat.flat_grad
+        b1, b2 = self.betas
+        t = self.step_idx + 1
+        bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+        for s, e, gi in self.runs:
+            _, scale, wd = self.group_defs[gi]
+            p, m, v = self.master[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e]
+            g = g_all[s:e].to(p.dtype)
+            g = torch.where(skip.to(torch.bool), torch.zeros_like(g), g)
+            lr_g = lr * scale
+            p.mul_(1.0 - lr_g * wd)
+            m.mul_(b1).add_(g, alpha=1.0 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+            p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(self.eps), value=-lr_g / bc1)
+        if self.master is not self.flat.flat_param:
+            self.flat.flat_param.copy_(self.master)
 
     def step(self, **batch):
-        """One optimisation step on this rank's shard of the batch.  Returns the (detached) loss tensor."""
+        """One optimisation step on this rank's shard of the batch.  Returns the (detached) loss tensor.
+
+        No host synchronisation anywhere in the step: the reference's NaN guard (forward -> 1-element all_reduce(MAX) of
+        `isnan(loss)` -> every rank backpropagates loss * 0 and steps on a zero gradient, train_spark_rwkv7speech.py:
+        664-687) keeps its flag on the device -- the all-reduce is enqueued before backward, backward runs regardless,
+        and the optimizer kernel reads the flag and substitutes a zero gradient.  Nothing waits for `flag.item()`, so
+        the gradient buckets start as soon as backward reaches them."""
         self.flat.arm()
         out = self.model(**batch)
         loss = out.loss
-        skip = False
+        flag_work = None
         if self.nan_guard:
-            flag = (~torch.isfinite(loss.detach())).float().reshape(1)
+            self.nan_flag.copy_((~torch.isfinite(loss.detach())).reshape(1))
             if self.world > 1:
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # 1-element NaN flag, :664-670
-            skip = bool(flag.item())
-        if skip:
-            # the reference backpropagates loss*0 on every rank (:676-687); the update it then applies has zero
-            # gradient.  Same effect, without propagating NaN*0: no backward, zero gradient, optimizer step.
-            self.reducer.finish(ran_backward=False)
+                flag_work = dist.all_reduce(self.nan_flag, op=dist.ReduceOp.MAX, async_op=True)  # :664-670
         else:
-            loss.backward()
-            self.reducer.finish()
-        lr = linear_warmup_decay(self.step_idx, self.total_steps, self.warmup_steps, self.lr, self.lr_final)
+            self.nan_flag.zero_()
+        loss.backward()
+        self.reducer.finish()
+        if flag_work is not None:
+            flag_work.wait()
+        lr = self.current_lr()
+        self.last_lr = lr
         if self.hip_adamw:
             import ctypes
             from . import _lib
             P = lambda t: ctypes.c_void_p(t.data_ptr())
             f = ctypes.c_float
             with torch.cuda.device_of(self.master):
-                rc = _lib.lib().rwkv7_adamw_bf16(ctypes.c_long(self.flat.numel), P(self.master), P(self.flat.flat_grad),
-                                                 P(self.exp_avg), P(self.exp_avg_sq), P(self.flat.flat_param), f(lr),
-                                                 f(self.betas[0]), f(self.betas[1]), f(self.eps), f(self.weight_decay),
-                                                 self.step_idx + 1,
-                                                 ctypes.c_void_p(torch.cuda.current_stream(self.master.device).cuda_stream))
+                rc = _lib.lib().rwkv7_adamw_groups_bf16(
+                    ctypes.c_long(self.flat.numel), P(self.master), P(self.flat.flat_grad), P(self.exp_avg), P(self.exp_avg_sq),
+                    P(self.flat.flat_param), P(self.slab_group), P(self.group_tab), len(self.group_defs), P(self.nan_flag),
+                    f(lr), f(self.betas[0]), f(self.betas[1]), f(self.eps), self.step_idx + 1,
+                    ctypes.c_void_p(torch.cuda.current_stream(self.master.device).cuda_stream))
             _lib.check(rc, "adamw")
         else:
-            for g in self.opt.param_groups:
-                g["lr"] = lr
-            if self.master_grad is not None:
-                self.master_grad.copy_(self.flat.flat_grad)
-            self.opt.step()
-            if self.master is not self.flat.flat_param:
-                self.flat.flat_param.copy_(self.master)
+            self._torch_adamw(lr, self.nan_flag)
+        for m in self._param_caches:
+            m._mix_key = None
         self.step_idx += 1
         return loss.detach()

@@ -366,3 +366,65 @@ def test_hip_adamw_matches_torch_adamw():
         assert torch.equal(p16, p32.bfloat16())
     assert _lib.lib().rwkv7_adamw_bf16(ctypes.c_long(n + 1), P(p32), P(p16), P(m), P(v), P(p16), f(1e-3), f(0.9), f(0.95),
                                        f(1e-8), f(0.0), 1, None) == -4
+
+
+def test_hip_adamw_groups_and_device_skip_flag_match_torch_adamw():
+    """rwkv7_adamw_groups_bf16: per-slab parameter groups {lr scale, weight decay} (the lr_1x / lr_2x / lr_decay split of
+    train_cosy_rwkv7speech_multiple_dataset.py:162-202) against torch.optim.AdamW with the same three groups; then one step
+    with the device-side skip flag set and NaN gradients: moments and weights move as for a zero gradient, nothing becomes NaN."""
+    import ctypes
+    from rwkvtts_amd import _lib
+    sizes = [128 * 3, 128 * 1, 128 * 5, 128 * 2]          # four "parameters", slab aligned
+    gid = [0, 1, 2, 0]                                    # lr_1x, lr_2x, lr_decay, lr_1x
+    tab = [[1.0, 0.0], [2.0, 0.0], [1.0, 0.1]]
+    n = sum(sizes)
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(n, generator=g)
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    refs = [p0[o:o + s].clone().to(DEV).requires_grad_(True) for o, s in zip(offs, sizes)]
+    opt = torch.optim.AdamW([{"params": [r for r, gi in zip(refs, gid) if gi == k], "weight_decay": tab[k][1], "scale": tab[k][0]}
+                             for k in range(3)], lr=1e-3, betas=(0.9, 0.95), eps=1e-18)
+    p32 = p0.clone().to(DEV)
+    m, v = torch.zeros_like(p32), torch.zeros_like(p32)
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    slab = torch.cat([torch.full((s // 128,), k, dtype=torch.uint8) for s, k in zip(sizes, gid)]).to(DEV)
+    gtab = torch.tensor(tab, dtype=torch.float32, device=DEV)
+    flag = torch.zeros(1, device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    f = ctypes.c_float
+    lib = _lib.lib()
+
+    def hip_step(gr, lr, i):
+        rc = lib.rwkv7_adamw_groups_bf16(ctypes.c_long(n), P(p32), P(gr), P(m), P(v), P(p16), P(slab), P(gtab), 3, P(flag), f(lr),
+                                         f(0.9), f(0.95), f(1e-18), i + 1, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+
+    lrs = [1e-3, 2e-3, 5e-4]
+    for i, lr in enumerate(lrs):
+        gr = (torch.randn(n, generator=g) * 0.1).bfloat16().to(DEV)
+        for grp in opt.param_groups:
+            grp["lr"] = lr * grp["scale"]
+        for r, o, s in zip(refs, offs, sizes):
+            r.grad = gr[o:o + s].float()
+        opt.step()
+        hip_step(gr, lr, i)
+        want = torch.cat([r.detach() for r in refs])
+        assert (p32 - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()), i
+        assert torch.equal(p16, p32.bfloat16())
+    # NaN step: flag set on the device, gradient full of NaN -> the update of a ZERO gradient
+    flag.fill_(1.0)
+    for grp in opt.param_groups:
+        grp["lr"] = 1e-3 * grp["scale"]
+    for r in refs:
+        r.grad = torch.zeros_like(r)
+    opt.step()
+    hip_step(torch.full((n,), float("nan"), dtype=torch.bfloat16, device=DEV), 1e-3, 3)
+    want = torch.cat([r.detach() for r in refs])
+    assert torch.isfinite(p32).all() and torch.isfinite(m).all() and torch.isfinite(v).all()
+    assert (p32 - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+    # argument checks
+    assert lib.rwkv7_adamw_groups_bf16(ctypes.c_long(n), P(p32), P(p16), P(m), P(v), P(p16), P(slab), None, 3, None, f(1e-3), f(0.9),
+                                       f(0.95), f(1e-8), 1, None) == -1      # table without groups
+    assert lib.rwkv7_adamw_groups_bf16(ctypes.c_long(n + 4), P(p32), P(p16), P(m), P(v), P(p16), P(slab), P(gtab), 3, None, f(1e-3),
+                                       f(0.9), f(0.95), f(1e-8), 1, None) == -4  # n % 128 != 0 with groups

@@ -20,9 +20,15 @@ class Toy(torch.nn.Module):
         self.b = torch.nn.Linear(64, 64)
         self.c = torch.nn.Linear(64, 4)
         self.unused = torch.nn.Parameter(torch.zeros(7))  # never touched by forward: its bucket must still reduce
+        # a parameter with the NAME the reference's optimizer groups key on ('attn.w_lora.lora.2.bias' -> lr x 2,
+        # train_cosy_rwkv7speech_multiple_dataset.py:169) and LoRA weights (never weight-decayed, :171)
+        self.attn = torch.nn.Module()
+        self.attn.w_lora = torch.nn.Module()
+        self.attn.w_lora.lora = torch.nn.Sequential(torch.nn.Linear(64, 8, bias=False), torch.nn.Tanh(), torch.nn.Linear(8, 64))
 
     def forward(self, x, y, poison=False):
-        h = torch.tanh(self.b(torch.tanh(self.a(x))))
+        h = torch.tanh(self.a(x))
+        h = torch.tanh(self.b(h) + self.attn.w_lora.lora(h))
         loss = torch.nn.functional.mse_loss(self.c(h), y)
         if poison:
             loss = loss * float("nan")
@@ -76,19 +82,68 @@ def test_two_rank_gloo_matches_single_process_average():
         assert p.exitcode == 0
     (_, p0, b0, _), (_, p1, b1, _) = [(r, torch.from_numpy(a), torch.from_numpy(b), l) for r, a, b, l in res]
     assert torch.equal(p0, p1) and torch.equal(b0, b1), "replicas diverged"
-    # single-process reference: average of the two ranks' gradients == gradient of the mean of the two losses
+    # single-process reference: torch.optim.AdamW on an untouched copy of the model, fed the gradient of the mean of the two
+    # ranks' losses (= the average of the two ranks' gradients)
     model = Toy()
-    tr = trainer.DataParallelTrainer(model, lr=1e-2, warmup_steps=0, total_steps=100)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-18, weight_decay=0.0)
     for step in range(3):
-        tr.flat.zero_grad()
+        opt.zero_grad()
         loss = sum(model(*_data(r, step)).loss for r in range(2)) / 2
         loss.backward()
-        for g_ in tr.opt.param_groups:
-            g_["lr"] = trainer.linear_warmup_decay(tr.step_idx, 100, 0, 1e-2, 1e-5)
-        tr.opt.step()
-        tr.step_idx += 1
-    assert torch.allclose(tr.flat.flat_param, b0, atol=1e-6), (tr.flat.flat_param - b0).abs().max()
+        model.unused.grad = torch.zeros_like(model.unused)
+        for g_ in opt.param_groups:
+            g_["lr"] = trainer.linear_warmup_decay(step, 100, 0, 1e-2, 1e-5)
+        opt.step()
+    ref = torch.cat([torch.nn.functional.pad(p.detach().reshape(-1), (0, (-p.numel()) % 128)) for p in model.parameters()])
+    assert torch.allclose(ref, b0, atol=1e-6), (ref - b0).abs().max()
     assert torch.isfinite(p0).all()  # the poisoned step did not write NaNs into the weights
+
+
+def test_reference_param_groups_and_cosine_schedule_match_torch_adamw():
+    """Grouped optimizer + cosine schedule of the Cosy trainer (train_cosy_rwkv7speech_multiple_dataset.py:162-202,224-244):
+    lr_2x for 'attn.w_lora.lora.2.bias', weight decay on >= 2-D non-LoRA '.weight', everything else plain -- our flat-buffer
+    update against torch.optim.AdamW built with the same three groups, five steps, lr driven by the cosine schedule."""
+    wd = 0.1
+    m1, m2 = Toy(), Toy()
+    tr = trainer.DataParallelTrainer(m1, lr=1e-2, lr_final=1e-3, warmup_steps=2, total_steps=5, weight_decay=wd,
+                                     param_groups="reference", schedule="cosine", nan_guard=True)
+    names = [n for n, _ in m2.named_parameters()]
+    groups = dict(zip(names, trainer.reference_param_groups(m2, wd)))
+    assert groups["attn.w_lora.lora.2.bias"] == ("lr_2x", 2.0, 0.0)
+    assert groups["a.weight"] == ("lr_decay", 1.0, wd) and groups["a.bias"] == ("lr_1x", 1.0, 0.0)
+    assert groups["attn.w_lora.lora.0.weight"] == ("lr_1x", 1.0, 0.0) and groups["attn.w_lora.lora.2.weight"][0] == "lr_1x"
+    assert groups["unused"][0] == "lr_1x"
+    by = {}
+    for n, p in m2.named_parameters():
+        by.setdefault(groups[n], []).append(p)
+    opt = torch.optim.AdamW([{"params": ps, "weight_decay": g[2], "my_lr_scale": g[1]} for g, ps in by.items()],
+                            lr=1e-2, betas=(0.9, 0.95), eps=1e-18)
+    for step in range(5):
+        x, y = _data(0, step)
+        base = trainer.cosine_warmup_decay(step, 5, 2, 1e-2, 1e-3)
+        assert tr.group_lrs() == {"lr_1x": base, "lr_2x": 2 * base, "lr_decay": base}
+        tr.step(x=x, y=y)
+        opt.zero_grad()
+        m2(x, y).loss.backward()
+        m2.unused.grad = torch.zeros_like(m2.unused)
+        for g_ in opt.param_groups:
+            g_["lr"] = base * g_["my_lr_scale"]
+        opt.step()
+    for (n, a), b in zip(m1.named_parameters(), m2.parameters()):
+        assert torch.allclose(a, b, atol=2e-6, rtol=1e-5), (n, (a - b).abs().max())
+
+
+def test_cosine_schedule_matches_reference_function_values():
+    """Golden values: tests/golden/lr_schedule.npz holds what the reference's own update_learning_rate
+    (train_cosy_rwkv7speech_multiple_dataset.py:224-244, executed by oracle/pin_optimizer.py) wrote into the three param groups."""
+    from conftest import load_golden
+    g = load_golden("lr_schedule.npz")
+    total, warm, lr, lr_final = int(g["total_steps"]), int(g["warmup_steps"]), float(g["lr"]), float(g["lr_final"])
+    for i, step in enumerate(g["steps"].tolist()):
+        base = trainer.cosine_warmup_decay(step, total, warm, lr, lr_final)
+        assert abs(base - float(g["lr_1x"][i])) <= 1e-12 * max(1.0, abs(base))
+        assert abs(2 * base - float(g["lr_2x"][i])) <= 1e-12
+        assert abs(base - float(g["lr_decay"][i])) <= 1e-12
 
 
 def test_flat_buffers_alias_parameters_and_grads():
@@ -111,3 +166,23 @@ def test_lr_schedule_matches_reference_lambda():
     assert trainer.linear_warmup_decay(5, 100, 10, 1.0, 0.1) == 0.5
     assert abs(trainer.linear_warmup_decay(55, 100, 10, 1.0, 0.1) - (1 - 0.5 * 0.9)) < 1e-12
     assert trainer.linear_warmup_decay(1000, 100, 10, 1.0, 0.1) == 0.1
+
+
+def test_param_groups_match_reference_configure_optimizer_golden():
+    """tests/golden/optimizer_groups.npz: the groups the reference's own configure_optimizer assigned to every parameter of a
+    small RWKV7CosyLM (names are rwkvfla's, matched by substring as the reference does), for weight_decay 0 and 0.1."""
+    import numpy as np
+    import os
+    from conftest import GOLDEN
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "oracle"))
+    from oracle.pin_optimizer import small_cosy_model
+    z = np.load(os.path.join(GOLDEN, "optimizer_groups.npz"))
+    model = small_cosy_model()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    for tag, wd in (("wd0", 0.0), ("wd", 0.1)):
+        assert names == z[f"names_{tag}"].tolist()
+        ours = trainer.reference_param_groups(model, wd)
+        assert [g[0] for g in ours] == z[f"group_{tag}"].tolist()
+        assert [g[1] for g in ours] == z[f"scale_{tag}"].tolist() and [g[2] for g in ours] == z[f"decay_{tag}"].tolist()
+    assert "lr_2x" in z["group_wd0"].tolist() and "lr_decay" in z["group_wd"].tolist()
