@@ -64,12 +64,26 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
  * them in Python, rwkv_s2s_single_ffn.py:22-24): s = fp32 [B,H,T/16,64,64] state checkpoints, sa = fp32 [B,T,H,64]. */
 int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_bytes);
 
-/* measurement aid: force the forward kernel's shape (4 or 8 state columns per lane; 0 = automatic by B*H) */
-void rwkv7_debug_set_fwd_shape(int cols_per_lane);
-/* chunked bf16 forward: 8 = the producer/consumer kernel (default), 4 = the 4-wave kernel (A/B, cross-check) */
-void rwkv7_debug_set_chunk_fwd_waves(int waves);
-/* row-split backward: 0 = 256 threads, 2 state rows per lane tile (default); 1 = 512 threads, 1 row per lane tile */
-void rwkv7_debug_set_bwd_shape(int wide);
+/* Measurement / cross-check variants.  The library keeps NO process-global state: every entry point is re-entrant and safe
+ * from several host threads on different streams (threading row); which kernel shape runs is an explicit
+ * argument of these `_variant` twins, never a hidden switch that changes what the plain entry points above launch.
+ *   cols_per_lane : state columns per lane of the scalar forward kernel -- 0 automatic by B*H (what the plain entry does), 4, 8
+ *   wide          : row-split backward -- 0 = 256 threads, 2 state rows per lane tile (plain entry); 1 = 512 threads, 1 row
+ *   waves         : chunked bf16 forward -- 8 = producer/consumer kernel (plain entry), 4 = the 4-wave kernel */
+int rwkv7_wkv_fwd_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                               const void *a, const void *b, void *y, float *s, float *sa, int cols_per_lane, rwkv7_stream_t stream);
+int rwkv7_wkv_fwd_variant_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                              const void *a, const void *b, void *y, float *s, float *sa, int cols_per_lane, rwkv7_stream_t stream);
+int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, const void *r, const void *w,
+                                     const void *k, const void *v, const void *a, const void *b, void *y, int cols_per_lane,
+                                     rwkv7_stream_t stream);
+int rwkv7_wkv_bwd_split_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                                     const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                                     void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
+                                     void *const *db, int wide, rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                                         const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                                         const int *seq_chunk_off, int nseq, int waves, rwkv7_stream_t stream);
 
 /* ---- same backward with each head split over two workgroups (32 state rows each) so that 256 CUs are busy at
  *      B*H = 128.  dv is complete; dw,dq,dk,da,db are HOST arrays of 2 device pointers receiving the two partial

@@ -68,6 +68,12 @@ class RWKV7Config:
         cfg.extra = {k: v for k, v in d.items() if k not in names}
         return cfg
 
+    @property
+    def auto_map(self):
+        """config.json's `auto_map` (model/test/audio_rwkv.config:9-13): transformers' Auto* loaders read it from the config
+        object to find the remote-code classes."""
+        return self.extra.get("auto_map") or {}
+
     def to_dict(self):
         d = asdict(self)
         extra = d.pop("extra")
@@ -75,9 +81,18 @@ class RWKV7Config:
         return d
 
     @classmethod
-    def from_pretrained(cls, path):
+    def from_pretrained(cls, path, return_unused_kwargs=False, **kwargs):
+        """config.json of a checkpoint directory.  Signature as transformers' AutoConfig calls it for `auto_map` classes."""
         with open(os.path.join(path, "config.json")) as f:
-            return cls.from_dict(json.load(f))
+            cfg = cls.from_dict(json.load(f))
+        drop = {"trust_remote_code", "code_revision", "cache_dir", "force_download", "local_files_only", "token", "revision",
+                "proxies", "subfolder", "name_or_path", "_from_auto", "_commit_hash"}
+        rest = {k: v for k, v in kwargs.items() if k not in drop}
+        return (cfg, rest) if return_unused_kwargs else cfg
+
+    @classmethod
+    def register_for_auto_class(cls, auto_class="AutoConfig"):
+        """called by transformers' AutoConfig on `auto_map` classes; nothing to record"""
 
 
 # canonical sizes (SURVEY.md section 8 table; read config.json for real checkpoints)

@@ -8,9 +8,9 @@
 
 namespace rwkv7 {
 int wkv_fwd_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
-                 void *, float *, float *, float *, hipStream_t);
+                 void *, float *, float *, float *, int, hipStream_t);
 int wkv_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
-                void *, float *, float *, float *, hipStream_t);
+                void *, float *, float *, float *, int, hipStream_t);
 int wkv_bwd_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                  const void *, const float *, const float *, void *, void *, void *, void *, void *, void *,
                  hipStream_t);
@@ -20,14 +20,14 @@ int wkv_bwd_f32(int, int, int, const void *, const void *, const void *, const v
 
 int wkv_bwd_split_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                        const void *, const float *, const float *, void *const *, void *const *, void *const *, void *,
-                       void *const *, void *const *, hipStream_t);
+                       void *const *, void *const *, int, hipStream_t);
 int wkv_bwd_split_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                       const void *, const float *, const float *, void *const *, void *const *, void *const *, void *,
-                      void *const *, void *const *, hipStream_t);
+                      void *const *, void *const *, int, hipStream_t);
 int chunk_prep_bf16(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_prep_f32(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
-                   const float *, void *, float *, float *, const int *, int, hipStream_t);
+                   const float *, void *, float *, float *, const int *, int, int, hipStream_t);
 int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                   const float *, void *, float *, float *, const int *, int, hipStream_t);
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
@@ -48,9 +48,6 @@ int decode_layer_ptrs();
 size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
 int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *, const void *,
                      const void *, const void *, const void *, float *, void *, int, hipStream_t);
-void fwd_force_shape(int);
-void chunk_fwd_force_waves(int);
-void bwd_force_shape(int);
 int lora_down_bf16(long, int, int, int, const void *, const void *, void *, hipStream_t);
 int lora_dgrad_up_bf16(long, int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 struct bf16_t;
@@ -79,19 +76,28 @@ extern "C" {
 
 const char *rwkv7_version(void) { return "rwkv7_hip 0.1.0 gfx950"; }
 
-#define FWD_BODY(IMPL)                                                                       \
+#define FWD_BODY(IMPL, CW)                                                                   \
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, y})) return RWKV7_EINVAL; \
     if ((s == nullptr) != (sa == nullptr)) return RWKV7_EINVAL;                              \
     if (T % RWKV7_CHUNK_LEN != 0) return RWKV7_ECHUNK;                                       \
-    return rwkv7::IMPL(B, T, H, w, q, k, v, a, b, y, s, sa, nullptr, (hipStream_t)stream);
+    if ((CW) != 0 && (CW) != 4 && (CW) != 8) return RWKV7_ESHAPE;                            \
+    return rwkv7::IMPL(B, T, H, w, q, k, v, a, b, y, s, sa, nullptr, CW, (hipStream_t)stream);
 
 int rwkv7_wkv_fwd_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                        const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream) {
-    FWD_BODY(wkv_fwd_bf16)
+    FWD_BODY(wkv_fwd_bf16, 0)
 }
 int rwkv7_wkv_fwd_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                       const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream) {
-    FWD_BODY(wkv_fwd_f32)
+    FWD_BODY(wkv_fwd_f32, 0)
+}
+int rwkv7_wkv_fwd_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                               const void *a, const void *b, void *y, float *s, float *sa, int cols_per_lane, rwkv7_stream_t stream) {
+    FWD_BODY(wkv_fwd_bf16, cols_per_lane)
+}
+int rwkv7_wkv_fwd_variant_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                              const void *a, const void *b, void *y, float *s, float *sa, int cols_per_lane, rwkv7_stream_t stream) {
+    FWD_BODY(wkv_fwd_f32, cols_per_lane)
 }
 
 #define BWD_BODY(IMPL)                                                                                          \
@@ -111,25 +117,31 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
     BWD_BODY(wkv_bwd_f32)
 }
 
-#define BWD2_BODY(IMPL)                                                                                   \
+#define BWD2_BODY(IMPL, WIDE)                                                                                 \
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db}))   \
         return RWKV7_EINVAL;                                                                               \
     for (int i = 0; i < 2; i++)                                                                            \
         if (!dw[i] || !dq[i] || !dk[i] || !da[i] || !db[i]) return RWKV7_EINVAL;                           \
     if (T % RWKV7_CHUNK_LEN != 0) return RWKV7_ECHUNK;                                                     \
-    return rwkv7::IMPL(B, T, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, (hipStream_t)stream);
+    return rwkv7::IMPL(B, T, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, (WIDE) ? 1 : 0, (hipStream_t)stream);
 
 int rwkv7_wkv_bwd_split_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                              const void *a, const void *b, const void *dy, const float *s, const float *sa,
                              void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
                              void *const *db, rwkv7_stream_t stream) {
-    BWD2_BODY(wkv_bwd_split_bf16)
+    BWD2_BODY(wkv_bwd_split_bf16, 0)
 }
 int rwkv7_wkv_bwd_split_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                             const void *a, const void *b, const void *dy, const float *s, const float *sa,
                             void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
                             void *const *db, rwkv7_stream_t stream) {
-    BWD2_BODY(wkv_bwd_split_f32)
+    BWD2_BODY(wkv_bwd_split_f32, 0)
+}
+int rwkv7_wkv_bwd_split_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                                     const void *a, const void *b, const void *dy, const float *s, const float *sa,
+                                     void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
+                                     void *const *db, int wide, rwkv7_stream_t stream) {
+    BWD2_BODY(wkv_bwd_split_bf16, wide)
 }
 
 static bool lora_shape_ok(long M, int K, int R, int act) {
@@ -155,24 +167,27 @@ int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_b
     *sa_bytes = (size_t)B * T * H * RWKV7_HEAD_SIZE * sizeof(float);
     return 0;
 }
-void rwkv7_debug_set_fwd_shape(int cols_per_lane) { rwkv7::fwd_force_shape(cols_per_lane); }
-void rwkv7_debug_set_chunk_fwd_waves(int waves) { rwkv7::chunk_fwd_force_waves(waves); }
-void rwkv7_debug_set_bwd_shape(int wide) { rwkv7::bwd_force_shape(wide); }
 
-#define STATE_BODY(IMPL)                                                                              \
+#define STATE_BODY(IMPL, CW)                                                                          \
     if (B <= 0 || T <= 0 || H <= 0 || any_null({state, r, w, k, v, a, b, y})) return RWKV7_EINVAL;   \
     if (H * RWKV7_HEAD_SIZE != C) return RWKV7_EHEAD;                                                 \
-    return rwkv7::IMPL(B, T, H, w, r, k, v, a, b, y, nullptr, nullptr, state, (hipStream_t)stream);
+    if ((CW) != 0 && (CW) != 4 && (CW) != 8) return RWKV7_ESHAPE;                                     \
+    return rwkv7::IMPL(B, T, H, w, r, k, v, a, b, y, nullptr, nullptr, state, CW, (hipStream_t)stream);
 
 int rwkv7_wkv_state_fwd_bf16(int B, int T, int C, int H, float *state, const void *r, const void *w,
                              const void *k, const void *v, const void *a, const void *b, void *y,
                              rwkv7_stream_t stream) {
-    STATE_BODY(wkv_fwd_bf16)
+    STATE_BODY(wkv_fwd_bf16, 0)
 }
 int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void *r, const void *w,
                             const void *k, const void *v, const void *a, const void *b, void *y,
                             rwkv7_stream_t stream) {
-    STATE_BODY(wkv_fwd_f32)
+    STATE_BODY(wkv_fwd_f32, 0)
+}
+int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, const void *r, const void *w,
+                                     const void *k, const void *v, const void *a, const void *b, void *y, int cols_per_lane,
+                                     rwkv7_stream_t stream) {
+    STATE_BODY(wkv_fwd_bf16, cols_per_lane)
 }
 
 
@@ -295,7 +310,7 @@ EW_DEFINE(f32, float)
 
 
 // ---- chunked (MFMA) WKV7 -----------------------------------------------------------------------------------------
-#define CHUNK_DEFINE(SFX)                                                                                          \
+#define CHUNK_DEFINE(SFX, WAVES_ARG)                                                                                          \
     int rwkv7_wkv_chunk_prep_##SFX(int B, int T, int H, const void *w, const void *a, const void *b, float *tinv,   \
                                    rwkv7_stream_t stream) {                                                         \
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, a, b, tinv})) return RWKV7_EINVAL;                           \
@@ -308,7 +323,7 @@ EW_DEFINE(f32, float)
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
         if ((sa == nullptr) != (hs == nullptr)) return RWKV7_EINVAL;                                                \
         if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;                                                            \
-        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, nullptr, 0, (hipStream_t)stream); \
+        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, nullptr, 0, WAVES_ARG (hipStream_t)stream); \
     }                                                                                                               \
     int rwkv7_wkv_chunk_fwd_seq_##SFX(int B, int T, int H, const void *w, const void *q, const void *k, const void *v, \
                                       const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs, \
@@ -316,10 +331,21 @@ EW_DEFINE(f32, float)
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
         if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;    \
         if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;                                                            \
-        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, (hipStream_t)stream); \
+        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, WAVES_ARG (hipStream_t)stream); \
     }
-CHUNK_DEFINE(bf16)
-CHUNK_DEFINE(f32)
+#define RWKV7_COMMA ,
+CHUNK_DEFINE(bf16, 8 RWKV7_COMMA)
+CHUNK_DEFINE(f32, )
+// A/B and cross-check: the 4-wave kernel (waves = 4) or the 8-wave producer/consumer kernel (8, what the plain entry launches)
+int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                                         const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                                         const int *seq_chunk_off, int nseq, int waves, rwkv7_stream_t stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;
+    if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;
+    if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;
+    if (waves != 4 && waves != 8) return RWKV7_ESHAPE;
+    return rwkv7::chunk_fwd_bf16(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, waves, (hipStream_t)stream);
+}
 
 // chunked backward (bf16): see csrc/wkv7_chunk_bwd.hip
 int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,

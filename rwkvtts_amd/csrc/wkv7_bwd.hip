@@ -328,11 +328,9 @@ static int launch_bwd(int B, int T_, int H, const void *w, const void *q, const 
     return (int)hipGetLastError();
 }
 
-// 0: <2,4> (256 threads, default), 1: <1,8> (512 threads); rwkv7_debug_set_bwd_shape.  Measured at B=8,T=4096,H=16:
+// wide 0: <2,4> (256 threads, default), 1: <1,8> (512 threads; rwkv7_wkv_bwd_split_variant_*).  Measured at B=8,T=4096,H=16:
 // <2,4> 2.11 ms, <1,8> 2.56 ms -- with 8 waves the 9 ds_read_b128 per wave and step saturate the LDS return path
 // (8 x ~60 cycles per step per CU), so the second wave per SIMD buys nothing.
-static int g_bwd_split_wide = 0;
-void bwd_force_shape(int wide) { g_bwd_split_wide = wide ? 1 : 0; }
 
 template <typename T>
 static int bwd_full(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
@@ -346,13 +344,13 @@ static int bwd_full(int B, int T_, int H, const void *w, const void *q, const vo
 template <typename T>
 static int bwd_split(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                      const void *b, const void *dy, const float *s, const float *sa, void *const *dw, void *const *dq,
-                     void *const *dk, void *dv, void *const *da, void *const *db, hipStream_t stream) {
+                     void *const *dk, void *dv, void *const *da, void *const *db, int wide, hipStream_t stream) {
     BwdOuts<T> o;
     for (int i = 0; i < 2; i++) {
         o.dw[i] = (T *)dw[i]; o.dq[i] = (T *)dq[i]; o.dk[i] = (T *)dk[i]; o.db[i] = (T *)db[i]; o.da[i] = (T *)da[i];
     }
     o.dv = (T *)dv;
-    if (g_bwd_split_wide) return launch_bwd<T, 1, 8>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
+    if (wide) return launch_bwd<T, 1, 8>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
     return launch_bwd<T, 2, 4>(B, T_, H, w, q, k, v, a, b, dy, s, sa, o, stream);
 }
 
@@ -368,13 +366,13 @@ int wkv_bwd_f32(int B, int T_, int H, const void *w, const void *q, const void *
 }
 int wkv_bwd_split_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                        const void *b, const void *dy, const float *s, const float *sa, void *const *dw,
-                       void *const *dq, void *const *dk, void *dv, void *const *da, void *const *db, hipStream_t st) {
-    return bwd_split<bf16_t>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, st);
+                       void *const *dq, void *const *dk, void *dv, void *const *da, void *const *db, int wide, hipStream_t st) {
+    return bwd_split<bf16_t>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, wide, st);
 }
 int wkv_bwd_split_f32(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                       const void *b, const void *dy, const float *s, const float *sa, void *const *dw, void *const *dq,
-                      void *const *dk, void *dv, void *const *da, void *const *db, hipStream_t st) {
-    return bwd_split<float>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, st);
+                      void *const *dk, void *dv, void *const *da, void *const *db, int wide, hipStream_t st) {
+    return bwd_split<float>(B, T_, H, w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db, wide, st);
 }
 
 }  // namespace rwkv7

@@ -273,16 +273,15 @@ static void launch_fwd_cw(int B, int T_, int H, const T *W, const T *Q, const T 
     }
 }
 
-static int g_fwd_force_cw = 0;  // 0 = automatic; 4 / 8 force a shape (rwkv7_debug_set_fwd_shape, tools/bench_wkv.py)
-
 template <typename T>
 static int launch_fwd(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v,
-                      const void *a, const void *b, void *y, float *s, float *sa, float *state,
+                      const void *a, const void *b, void *y, float *s, float *sa, float *state, int force_cw,
                       hipStream_t stream) {
+    // force_cw: 0 = automatic by B*H; 4 / 8 = that many state columns per lane (the *_variant entry points: A/B measurements)
     (void)hipGetLastError();  // drop any stale error left by an earlier runtime call of the host program
     const T *W = (const T *)w, *Q = (const T *)q, *K = (const T *)k, *V = (const T *)v, *A = (const T *)a,
             *Bv = (const T *)b;
-    const bool wide = g_fwd_force_cw ? g_fwd_force_cw == 4 : (long)B * H < kWideBelowHeads;
+    const bool wide = force_cw ? force_cw == 4 : (long)B * H < kWideBelowHeads;
     if (wide)
         launch_fwd_cw<T, 4>(B, T_, H, W, Q, K, V, A, Bv, (T *)y, s, sa, state, stream);
     else
@@ -290,15 +289,13 @@ static int launch_fwd(int B, int T_, int H, const void *w, const void *q, const 
     return (int)hipGetLastError();
 }
 
-void fwd_force_shape(int cw) { g_fwd_force_cw = (cw == 4 || cw == 8) ? cw : 0; }
-
 int wkv_fwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                 const void *b, void *y, float *s, float *sa, float *state, hipStream_t stream) {
-    return launch_fwd<bf16_t>(B, T_, H, w, q, k, v, a, b, y, s, sa, state, stream);
+                 const void *b, void *y, float *s, float *sa, float *state, int force_cw, hipStream_t stream) {
+    return launch_fwd<bf16_t>(B, T_, H, w, q, k, v, a, b, y, s, sa, state, force_cw, stream);
 }
 int wkv_fwd_f32(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                const void *b, void *y, float *s, float *sa, float *state, hipStream_t stream) {
-    return launch_fwd<float>(B, T_, H, w, q, k, v, a, b, y, s, sa, state, stream);
+                const void *b, void *y, float *s, float *sa, float *state, int force_cw, hipStream_t stream) {
+    return launch_fwd<float>(B, T_, H, w, q, k, v, a, b, y, s, sa, state, force_cw, stream);
 }
 
 }  // namespace rwkv7

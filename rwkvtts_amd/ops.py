@@ -93,19 +93,23 @@ def _wb_backward(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
     _lib.check(rc, "wind_backstepping.backward")
 
 
-def wkv7_backward_split(w, q, k, v, z, a, dy, s, sa):
+def wkv7_backward_split(w, q, k, v, z, a, dy, s, sa, wide=None):
     """WKV7 backward with each head split over two workgroups (rwkv7_wkv_bwd_split_*: all 256 CUs busy at B*H=128).
     Returns (dw2, dq2, dk2, dv, dz2, da2): the *2 tensors are [2, B,T,H,64] partial column sums whose sum over dim 0
-    is the gradient wind_backstepping.backward returns; dv is complete."""
+    is the gradient wind_backstepping.backward returns; dv is complete.
+    wide (bf16 only, measurements/tests): 0 / 1 selects the 256- / 512-thread shape explicitly (rwkv7_wkv_bwd_split_variant_bf16)."""
     B, T, H, C = w.shape
     sfx = _sfx([w, q, k, v, z, a, dy], "wkv7_backward_split")
     dw2, dq2, dk2, dz2, da2 = [torch.empty((2,) + tuple(w.shape), dtype=w.dtype, device=w.device) for _ in range(5)]
     dv = torch.empty_like(v)
     pair = lambda t: (ctypes.c_void_p * 2)(t[0].data_ptr(), t[1].data_ptr())
     with torch.cuda.device_of(w), _timed("wkv7_bwd", w):
-        rc = getattr(_lib.lib(), "rwkv7_wkv_bwd_split_" + sfx)(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a),
-                                                             _p(dy), _p(s), _p(sa), pair(dw2), pair(dq2), pair(dk2),
-                                                             _p(dv), pair(dz2), pair(da2), _stream(w))
+        args = (B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a), _p(dy), _p(s), _p(sa), pair(dw2), pair(dq2), pair(dk2),
+                _p(dv), pair(dz2), pair(da2))
+        if wide is None:
+            rc = getattr(_lib.lib(), "rwkv7_wkv_bwd_split_" + sfx)(*args, _stream(w))
+        else:
+            rc = getattr(_lib.lib(), "rwkv7_wkv_bwd_split_variant_" + sfx)(*args, int(wide), _stream(w))
     _lib.check(rc, "wkv7_backward_split")
     return dw2, dq2, dk2, dv, dz2, da2
 
@@ -245,7 +249,7 @@ def wkv7_chunk_prep(w, a, b):
     return tinv
 
 
-def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None):
+def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None, waves=None):
     """Chunked forward.  Returns y, and (tinv, sa, hs) when save (what the chunked backward consumes).
     seq_off: packed rows -- int32 [nseq + 1] device tensor of cumulative 32-step chunk counts over the [B][T/32] chunk
     space; sequence s owns chunks seq_off[s] .. seq_off[s+1] - 1 and starts from the zero state."""
@@ -258,9 +262,12 @@ def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None):
     sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device) if save else None
     hs = torch.empty(B, H, T // CHUNK_T, C, C, dtype=torch.float32, device=w.device) if save else None
     with torch.cuda.device_of(w), _timed("wkv7c_fwd", w):
-        rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_seq_" + sfx)(
-            B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(tinv), _p(y),
-            None if sa is None else _p(sa), None if hs is None else _p(hs), *_seq_args(seq_off), _stream(w))
+        args = (B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(tinv), _p(y),
+                None if sa is None else _p(sa), None if hs is None else _p(hs), *_seq_args(seq_off))
+        if waves is None:
+            rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_seq_" + sfx)(*args, _stream(w))
+        else:   # measurements / cross-checks: the 4-wave or the 8-wave bf16 kernel, chosen explicitly
+            rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_seq_variant_" + sfx)(*args, int(waves), _stream(w))
     _lib.check(rc, "wkv7_chunk_forward")
     return (y, tinv, sa, hs) if save else y
 

@@ -40,6 +40,7 @@ class RWKV7SpeechConfig(RWKV7Config):
 
     @classmethod
     def from_dict(cls, d):
+        d = {k: v for k, v in d.items() if k != "architectures"}
         return cls(**d)
 
 

@@ -78,3 +78,42 @@ def test_xy_and_cosy_from_base():
     assert cosy.text_embedding.weight.shape == (64, 128) and cosy.lm_head.weight.shape == (21, 128)
     assert torch.equal(cosy.text_embedding.weight[:50], base.model.embeddings.weight)
     assert torch.equal(cosy.model.layers[1].ffn.key.weight, base.model.layers[1].ffn.key.weight)
+
+
+def test_auto_map_shim_loads_through_transformers_auto_classes(tmp_path):
+    """The reference loads its Spark checkpoints with AutoModelForCausalLM.from_pretrained(dir, trust_remote_code=True) through
+    config.json's auto_map -> modeling_rwkvspeech.py (model/test/audio_rwkv.config:9-13, data/spark/modeling_rwkvspeech.py:1-6).
+    save_pretrained() writes both; the Auto classes of the installed transformers must hand back OUR classes with identical
+    weights.  Runs in a subprocess so that transformers' dynamic-module cache lives under tmp_path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f'''
+import sys, json, os, torch
+sys.path.insert(0, {root!r})
+from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
+cfg = RWKV7SpeechConfig(vocab_size=257, text_vocab_size=300, audio_global_vocab_size=64, hidden_size=128, num_hidden_layers=2,
+                        decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=32, gate_low_rank_dim=32)
+m = RWKV7ForSpeech(cfg).init_weights(1)
+d = {str(tmp_path / "ckpt")!r}
+m.save_pretrained(d)
+c = json.load(open(os.path.join(d, "config.json")))
+assert c["auto_map"]["AutoModelForCausalLM"] == "modeling_rwkvspeech.RWKV7ForSpeech" and c["architectures"] == ["RWKV7ForSpeech"]
+assert c["text_vocab_size"] == 300 and c["audio_global_vocab_size"] == 64
+from transformers import AutoConfig, AutoModelForCausalLM
+ac = AutoConfig.from_pretrained(d, trust_remote_code=True)
+assert type(ac).__name__ == "RWKV7SpeechConfig" and ac.hidden_size == 128 and ac.text_vocab_size == 300
+m2 = AutoModelForCausalLM.from_pretrained(d, trust_remote_code=True)
+assert isinstance(m2, RWKV7ForSpeech), type(m2).__mro__   # transformers may wrap the class to add its GenerationMixin
+sd, sd2 = m.state_dict(), m2.state_dict()
+assert sd.keys() == sd2.keys() and all(torch.equal(sd[k], sd2[k]) for k in sd)
+m3 = RWKV7ForSpeech.from_pretrained(d, torch_dtype=torch.bfloat16)
+assert m3.lm_head.weight.dtype == torch.bfloat16
+print("AUTO_MAP_OK")
+'''
+    env = dict(os.environ, HF_HOME=str(tmp_path / "hf"), HF_MODULES_CACHE=str(tmp_path / "hf" / "modules"), HF_HUB_OFFLINE="1",
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert out.returncode == 0 and "AUTO_MAP_OK" in out.stdout, out.stderr[-3000:]

@@ -214,7 +214,7 @@ def test_packed_sequences_equal_separate_sequences_vs_oracle(c_oracle):
 
 @pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
 def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T, H, seed):
-    """wkv7_chunk_fwd8.hip (producer / consumer split, rwkv7_debug_set_chunk_fwd_waves(8)): the same bars against the C oracle
+    """wkv7_chunk_fwd8.hip (producer / consumer split; `waves` of rwkv7_wkv_chunk_fwd_seq_variant_bf16): the same bars against the C oracle
     as the 4-wave kernel, feeding the chunked backward; and against the 4-wave kernel itself the fp32 outputs agree to
     rounding (hipcc contracts the split prologue differently: last-ulp differences of the scaled operands), also on packed
     rows."""
@@ -232,17 +232,14 @@ def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T
         if nc > 1:
             cuts.add(b * nc + (nc + b) // 2)
     seq_off = torch.tensor(sorted(cuts), dtype=torch.int32, device=DEV)
-    try:
-        lib.rwkv7_debug_set_chunk_fwd_waves(4)
-        ref = ops.wkv7_chunk_forward(*d)
-        ref_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off)
-        lib.rwkv7_debug_set_chunk_fwd_waves(8)
-        y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
-        got_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off)
-        grads = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv=tinv, ck_mode=1)
-        torch.cuda.synchronize()
-    finally:
-        lib.rwkv7_debug_set_chunk_fwd_waves(8)   # the default
+    ref = ops.wkv7_chunk_forward(*d, waves=4)
+    ref_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off, waves=4)
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d, waves=8)
+    got_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off, waves=8)
+    plain = ops.wkv7_chunk_forward(*d)                  # the plain entry point launches the 8-wave kernel
+    grads = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv=tinv, ck_mode=1)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(plain, (y, tinv, sa, hs)))
     _assert_bf16_close(y, y_o, "y")
     _assert_f32_close(sa, sa_o, "sa", 2e-3)
     for c in range(1, nc):

@@ -433,3 +433,27 @@ def test_trainer_memorises_one_batch():
         losses.append(float(tr.step(**b)))
     assert all(l == l for l in losses), losses
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+def test_auto_model_from_pretrained_round_trips_logits_and_generate(tmp_path, monkeypatch):
+    """save_pretrained -> transformers.AutoModelForCausalLM.from_pretrained(dir, trust_remote_code=True) (the reference's entry:
+    model/test/audio_rwkv.config:9-13 + data/spark/modeling_rwkvspeech.py) -> same logits bit for bit, and generate() is OUR
+    persistent-state loop (same greedy ids as the saved model)."""
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    import transformers.dynamic_module_utils as dmu
+    monkeypatch.setattr(dmu, "HF_MODULES_CACHE", str(tmp_path / "hf_modules"))
+    from transformers import AutoModelForCausalLM
+    model, p, rcfg = _spark_pair(seed=5)
+    d = str(tmp_path / "ckpt")
+    model.save_pretrained(d)
+    m2 = AutoModelForCausalLM.from_pretrained(d, trust_remote_code=True).to(DEV).eval()
+    assert isinstance(m2, RWKV7ForSpeech)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(2, 48, 128, generator=g) * 0.5).to(DEV)
+    with torch.no_grad():
+        a = model(inputs_embeds=x).logits
+        b = m2(inputs_embeds=x).logits
+    assert torch.equal(a, b)
+    ids1 = model.generate(inputs_embeds=x, max_new_tokens=12, do_sample=False, suppress_tokens=[256])
+    ids2 = m2.generate(inputs_embeds=x, max_new_tokens=12, do_sample=False, suppress_tokens=[256])
+    assert ids2.shape == (2, 12) and torch.equal(ids1, ids2)

@@ -196,12 +196,10 @@ def test_full_size_config2_properties_and_slices(c_oracle):
     assert (lhs - rhs).abs().max().item() <= 1e-4 * rhs.abs().max().item()
 
 
-@pytest.fixture(params=[1, 0], ids=["512thr", "256thr"])
+@pytest.fixture(params=[1, 0, None], ids=["512thr", "256thr", "plain-entry"])
 def bwd_shape(request):
-    from rwkvtts_amd import _lib
-    _lib.lib().rwkv7_debug_set_bwd_shape(request.param)
-    yield request.param
-    _lib.lib().rwkv7_debug_set_bwd_shape(0)
+    """explicit `wide` argument of rwkv7_wkv_bwd_split_variant_* (bf16), None = the plain entry point; no global switch"""
+    return request.param
 
 
 @pytest.mark.parametrize("B,T,H,seed", [(1, 16, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2)])
@@ -216,7 +214,9 @@ def test_row_split_backward_vs_oracle(c_oracle, bwd_shape, B, T, H, seed, dtype)
     d = [t.to(DEV) for t in ins]
     y, s, sa = torch.empty_like(d[0]), torch.empty(B, H, T // 16, 64, 64, device=DEV), torch.empty(B, T, H, 64, device=DEV)
     torch.ops.wind_backstepping.forward(*d, y, s, sa)
-    dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(*d, dy.to(DEV), s, sa)
+    if dtype != torch.bfloat16 and bwd_shape is not None:
+        pytest.skip("the shape variant entry exists for bf16 only")
+    dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(*d, dy.to(DEV), s, sa, wide=bwd_shape)
     full = [torch.empty_like(d[0]) for _ in range(6)]
     torch.ops.wind_backstepping.backward(*d, dy.to(DEV), s, sa, *full)
     # dv is a complete row sum in every shape; the instantiations may associate the fp32 terms differently
@@ -259,14 +259,22 @@ def test_forward_both_lane_shapes_vs_oracle(c_oracle, cw, dtype):
     st = st0.to(DEV).clone()
     y2 = torch.empty_like(d[0])
     f3 = lambda t: t.view(B, T, H * 64)
-    _lib.lib().rwkv7_debug_set_fwd_shape(cw)
-    try:
-        torch.ops.wind_backstepping.forward(*d, y, s, sa)
+    import ctypes
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    sfx = "bf16" if dtype == torch.bfloat16 else "f32"
+    lib = _lib.lib()
+    # explicit shape argument of the *_variant entry points (the library has no global switches)
+    rc = getattr(lib, "rwkv7_wkv_fwd_variant_" + sfx)(B, T, H, *[P(t) for t in d], P(y), P(s), P(sa), cw, None)
+    assert rc == 0
+    if dtype == torch.bfloat16:
+        rc = lib.rwkv7_wkv_state_fwd_variant_bf16(B, T, H * 64, H, P(st), P(d[1]), P(d[0]), P(d[2]), P(d[3]), P(d[4]), P(d[5]), P(y2),
+                                                  cw, None)
+        assert rc == 0
+    else:
         torch.ops.rwkv7_state_fwd_fp16.forward(B, T, H * 64, H, st, f3(d[1]), f3(d[0]), f3(d[2]), f3(d[3]), f3(d[4]),
                                                 f3(d[5]), f3(y2))
-        torch.cuda.synchronize()
-    finally:
-        _lib.lib().rwkv7_debug_set_fwd_shape(0)
+    torch.cuda.synchronize()
+    assert getattr(lib, "rwkv7_wkv_fwd_variant_" + sfx)(B, T, H, *[P(t) for t in d], P(y), P(s), P(sa), 5, None) == -4
     if dtype == torch.bfloat16:
         _assert_bf16_close(y, y_o, "y")
         _assert_bf16_close(y2, y2_o.view(B, T, H, 64), "y(state)")

@@ -68,11 +68,12 @@ def main():
     sfx = "bf16" if a.dtype == "bf16" else "f32"
     cf = lambda: getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_" + sfx)(B, T, H, P(w), P(q), P(k), P(v), P(aa), P(b), P(tinv), P(y), P(sa2), P(hs), st_)
     def shaped(cw, fn):
-        def g():
-            _lib.lib().rwkv7_debug_set_fwd_shape(cw)
-            fn()
-            _lib.lib().rwkv7_debug_set_fwd_shape(0)
-        return g
+        # explicit shape through the *_variant entry points (bf16 for the state-carrying one)
+        if fn is fwd:
+            return lambda: getattr(_lib.lib(), "rwkv7_wkv_fwd_variant_" + sfx)(B, T, H, P(w), P(q), P(k), P(v), P(aa), P(b), P(y), P(s), P(sa), cw, st_)
+        if a.dtype != "bf16":
+            return None
+        return lambda: _lib.lib().rwkv7_wkv_state_fwd_variant_bf16(B, T, H * 64, H, P(st), P(q), P(w), P(k), P(v), P(aa), P(b), P(yy), cw, st_)
     cb = (lambda: ops.wkv7_chunk_backward(w, q, k, v, aa, b, dy, s, sa)) if a.dtype == "bf16" else None
     cb_state = (lambda: ops.wkv7_chunk_bwd_state(w, q, aa, b, dy, tinv)) if a.dtype == "bf16" else None
     for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz),
@@ -81,7 +82,7 @@ def main():
                                 ("wkv7_state_fwd 8 col/lane", shaped(8, sfw), 7 * 64 * esz),
                                 ("wkv7_state_fwd 4 col/lane", shaped(4, sfw), 7 * 64 * esz), ("wkv7_bwd", bwd, 13 * 64 * esz),
                                 ("wkv7_bwd row-split 256 thr", bwd2, 13 * 64 * esz),
-                                ("wkv7_bwd row-split 512 thr", lambda: (_lib.lib().rwkv7_debug_set_bwd_shape(1), bwd2(), _lib.lib().rwkv7_debug_set_bwd_shape(0)), 13 * 64 * esz),
+                                ("wkv7_bwd row-split 512 thr", (lambda: ops.wkv7_backward_split(w, q, k, v, aa, b, dy, s, sa, wide=1)) if a.dtype == "bf16" else None, 13 * 64 * esz),
                                 ("wkv7_state_fwd", sfw, 7 * 64 * esz), ("wkv7c_prep (T inverse)", prep, 3 * 64 * esz),
                                 ("wkv7c_fwd (chunked, save)", cf, 7 * 64 * esz),
                                 ("wkv7c bwd pre+state", cb_state, 13 * 64 * esz),
