@@ -82,7 +82,7 @@ int rwkv7_wkv_bwd_split_variant_bf16(int B, int T, int H, const void *w, const v
                                      void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
                                      void *const *db, int wide, rwkv7_stream_t stream);
 int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                         const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                                         const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                                          const int *seq_chunk_off, int nseq, int waves, rwkv7_stream_t stream);
 
 /* ---- same backward with each head split over two workgroups (32 state rows each) so that 256 CUs are busy at
@@ -235,7 +235,8 @@ int rwkv7_relusq_bwd_f32(long n, const void *x, const void *dy, void *dx, rwkv7_
  * w <= -0.5, rwkv_s2s_single_ffn.py:172).  Scratch / saved tensors, all caller-allocated fp32:
  *   tinv [B,H,T/32,32,32]   (I - A_ab)^-1 per chunk, written by _prep, read by _fwd and _bwd
  *   sa   [B,T,H,64]         u_t = S_{t-1} a_t (same meaning as the scalar op's `sa`)
- *   hs   [B,H,T/32,64,64]   state at the START of each chunk, [value][key]
+ *   hs   [B,H,T/32,64,64]   state at the START of each chunk, bf16, [value][key]: the backward's checkpoint (the forward itself
+ *                           carries the state in fp32; the checkpoint is its bf16 rounding, 8 KB per chunk and head)
  * sa and hs may both be NULL in _fwd (inference).
  * ===================================================================================================== */
 #define RWKV7_CHUNK_T 32
@@ -244,10 +245,10 @@ int rwkv7_wkv_chunk_prep_bf16(int B, int T, int H, const void *w, const void *a,
 int rwkv7_wkv_chunk_prep_f32(int B, int T, int H, const void *w, const void *a, const void *b, float *tinv,
                              rwkv7_stream_t stream);
 int rwkv7_wkv_chunk_fwd_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                             const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                             const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                              rwkv7_stream_t stream);
 int rwkv7_wkv_chunk_fwd_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                            const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                            const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                             rwkv7_stream_t stream);
 /* Packed variable-length rows (fla chunk_rwkv7's `cu_seqlens`; the reference passes it for its packed Spark batches,
  * train_spark_rwkv7speech.py:238-239, data/utils/spark_dataset.py:111-162): the caller lays the sequences out 32-aligned
@@ -256,29 +257,28 @@ int rwkv7_wkv_chunk_fwd_f32(int B, int T, int H, const void *w, const void *q, c
  * starts from the zero state and gets its own workgroups, so the sequences of a row run in parallel; chunks that belong to
  * no sequence are left untouched.  seq_chunk_off == NULL: the plain ops above (one sequence per row). */
 int rwkv7_wkv_chunk_fwd_seq_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                 const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                                 const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                                  const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
 int rwkv7_wkv_chunk_fwd_seq_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                                const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                                 const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
-/* ---- chunked backward, bf16 (csrc/wkv7_chunk_bwd.hip).  With H = S^T and the chunk quantities above, the adjoint state
- *      obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
+/* ---- chunked backward, bf16 (csrc/wkv7_chunk_bwd.hip, wkv7_chunk_bwd8.hip).  With H = S^T and the chunk quantities above, the
+ *      adjoint state obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
  *   bwd_pre : parallel over chunks.  mt  = M_c^T as bf16 hi/lo planes, uint16 [B*H*T/32][2][64][64];
  *                                    np  = N'_c, fp32 [B*H*T/32][4 tiles][64 lanes][16] (MFMA accumulator layout)
  *   state   : sequential over chunks (reverse), one workgroup per (head, half of the value columns).
- *             e_kv[b,h,c][k][v] = E_{c+1} (fp32), what chunk c receives from its future. ---- */
+ *             e_vk[b,h,c][v][k] = E_{c+1}, what chunk c receives from its future, as bf16 (the recurrence itself carries
+ *             ~16 mantissa bits; the per-chunk kernel reads this rounded copy once). ---- */
 int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
                                  const void *dy, const float *tinv, void *mt, float *np, rwkv7_stream_t stream);
-int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_kv, rwkv7_stream_t stream);
-int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const float *np, float *e_kv, const int *seq_chunk_off,
+int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, void *e_vk, rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const float *np, void *e_vk, const int *seq_chunk_off,
                                    int nseq, rwkv7_stream_t stream);   /* packed rows: see rwkv7_wkv_chunk_fwd_seq_bf16 */
-/*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from the forward's saved
- *             tensors, tinv and the adjoint states of `state`.  ck_mode 0: s, sa as saved by rwkv7_wkv_fwd_bf16 (fp32
- *             checkpoints every 16 steps); ck_mode 1: s = hs of rwkv7_wkv_chunk_fwd_bf16 (state at the start of every
- *             32-step chunk, [k][v]). */
+/*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from what the chunked
+ *             forward saved (hs, sa, tinv) and the adjoint states e_vk of `state`. */
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                 const void *a, const void *b, const void *dy, const float *s, const float *sa,
-                                 const float *tinv, const float *e_kv, int ck_mode, void *dw, void *dq, void *dk, void *dv,
+                                 const void *a, const void *b, const void *dy, const void *hs, const float *sa,
+                                 const float *tinv, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
                                  void *da, void *db, rwkv7_stream_t stream);
 /* ---- head loss: softmax cross-entropy of a chunk of bf16 logits [rows,V], forward and backward in one pass
  *      (spark_llm.py:146-160, FusedLinearCrossEntropyLoss).  labels int64 [rows]; rows with label == ignore_index give 0.

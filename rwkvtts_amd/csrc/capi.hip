@@ -27,9 +27,9 @@ int wkv_bwd_split_f32(int, int, int, const void *, const void *, const void *, c
 int chunk_prep_bf16(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_prep_f32(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
-                   const float *, void *, float *, float *, const int *, int, int, hipStream_t);
+                   const float *, void *, float *, void *, const int *, int, int, hipStream_t);
 int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
-                  const float *, void *, float *, float *, const int *, int, hipStream_t);
+                  const float *, void *, float *, void *, const int *, int, hipStream_t);
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int gemv32_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
@@ -39,10 +39,10 @@ int adamw_step(long, float *, const void *, float *, float *, void *, const uint
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        float *, hipStream_t);
-int chunk_state_bf16(int, int, int, const void *, const float *, float *, const int *, int, hipStream_t);
-int chunk_bwd_out_bf16(int, int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
-                       const float *, const float *, const float *, const float *, void *, void *, void *, void *,
-                       void *, void *, hipStream_t);
+int chunk_state_bf16(int, int, int, const void *, const float *, void *, const int *, int, hipStream_t);
+int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
+                        const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *,
+                        hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int decode_layer_ptrs();
 size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
@@ -318,7 +318,7 @@ EW_DEFINE(f32, float)
         return rwkv7::chunk_prep_##SFX(B, T, H, w, a, b, tinv, (hipStream_t)stream);                                \
     }                                                                                                               \
     int rwkv7_wkv_chunk_fwd_##SFX(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,  \
-                                  const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,   \
+                                  const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,   \
                                   rwkv7_stream_t stream) {                                                          \
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
         if ((sa == nullptr) != (hs == nullptr)) return RWKV7_EINVAL;                                                \
@@ -326,7 +326,7 @@ EW_DEFINE(f32, float)
         return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, nullptr, 0, WAVES_ARG (hipStream_t)stream); \
     }                                                                                                               \
     int rwkv7_wkv_chunk_fwd_seq_##SFX(int B, int T, int H, const void *w, const void *q, const void *k, const void *v, \
-                                      const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs, \
+                                      const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs, \
                                       const int *seq_chunk_off, int nseq, rwkv7_stream_t stream) {                  \
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
         if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;    \
@@ -338,7 +338,7 @@ CHUNK_DEFINE(bf16, 8 RWKV7_COMMA)
 CHUNK_DEFINE(f32, )
 // A/B and cross-check: the 4-wave kernel (waves = 4) or the 8-wave producer/consumer kernel (8, what the plain entry launches)
 int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                         const void *a, const void *b, const float *tinv, void *y, float *sa, float *hs,
+                                         const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                                          const int *seq_chunk_off, int nseq, int waves, rwkv7_stream_t stream) {
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;
     if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;
@@ -354,27 +354,25 @@ int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void 
     if (T % 32 != 0) return RWKV7_ECHUNK;
     return rwkv7::chunk_bwd_pre_bf16(B, T, H, w, q, a, b, dy, tinv, mt, np, (hipStream_t)stream);
 }
-int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, float *e_kv, rwkv7_stream_t stream) {
-    if (BH <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_kv})) return RWKV7_EINVAL;
-    return rwkv7::chunk_state_bf16(BH, nchunks, 1, mt, np, e_kv, nullptr, 0, (hipStream_t)stream);
+int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, void *e_vk, rwkv7_stream_t stream) {
+    if (BH <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk})) return RWKV7_EINVAL;
+    return rwkv7::chunk_state_bf16(BH, nchunks, 1, mt, np, e_vk, nullptr, 0, (hipStream_t)stream);
 }
-int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const float *np, float *e_kv, const int *seq_chunk_off,
+int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const float *np, void *e_vk, const int *seq_chunk_off,
                                    int nseq, rwkv7_stream_t stream) {
-    if (B <= 0 || H <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_kv})) return RWKV7_EINVAL;
+    if (B <= 0 || H <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk})) return RWKV7_EINVAL;
     if (seq_chunk_off != nullptr && nseq <= 0) return RWKV7_EINVAL;
-    return rwkv7::chunk_state_bf16(B * H, nchunks, H, mt, np, e_kv, seq_chunk_off, nseq, (hipStream_t)stream);
+    return rwkv7::chunk_state_bf16(B * H, nchunks, H, mt, np, e_vk, seq_chunk_off, nseq, (hipStream_t)stream);
 }
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                 const void *a, const void *b, const void *dy, const float *s, const float *sa,
-                                 const float *tinv, const float *e_kv, int ck_mode, void *dw, void *dq, void *dk, void *dv,
+                                 const void *a, const void *b, const void *dy, const void *hs, const float *sa,
+                                 const float *tinv, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
                                  void *da, void *db, rwkv7_stream_t stream) {
-    if (B <= 0 || T <= 0 || H <= 0 || ck_mode < 0 || ck_mode > 1 ||
-        any_null({w, q, k, v, a, b, dy, (const void *)s, (const void *)sa, (const void *)tinv, (const void *)e_kv, dw, dq, dk,
-                  dv, da, db}))
+    if (B <= 0 || T <= 0 || H <= 0 ||
+        any_null({w, q, k, v, a, b, dy, hs, (const void *)sa, (const void *)tinv, e_vk, dw, dq, dk, dv, da, db}))
         return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
-    return rwkv7::chunk_bwd_out_bf16(B, T, H, ck_mode, w, q, k, v, a, b, dy, s, sa, tinv, e_kv, dw, dq, dk, dv, da, db,
-                                     (hipStream_t)stream);
+    return rwkv7::chunk_bwd_out8_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, tinv, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
 int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const void *bias, void *y, rwkv7_stream_t stream) {
     if (any_null({x, w, y})) return RWKV7_EINVAL;

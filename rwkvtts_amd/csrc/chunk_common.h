@@ -286,6 +286,52 @@ __device__ __forceinline__ float next32(float x, int lane) {
     return (lane & 31) == 31 ? 0.f : y;
 }
 
+// ---- state checkpoints between kernels ("q15" records) ------------------------------------------------------------------------
+// The two 64x64 states that cross kernel boundaries once per chunk -- H at the start of a chunk (forward -> backward) and the
+// adjoint E (state recurrence -> per-chunk gradient kernel) -- are stored as int16 mantissas with one fp32 scale per MFMA lane:
+// the producer holds a 32(k) x 32(v) accumulator tile per wave (lane = value column + 32 * bit 2 of k, 16 registers = 16 key
+// rows), takes the maximum of its own 16 values (no cross-lane work), and writes 16 int16 (two 16-byte stores) + one scale:
+//     record[b,h,c] = mant[vh][kt][lane][16] int16 (8 KB)  +  scale[vh][kt][lane] fp32 (1 KB)         x ~ mant * scale
+// vh = half of the value columns (the producers split a head over two workgroups), kt = key tile, register r of lane l holds
+// key k = 32 kt + (r & 3) + 8 (r >> 2) + 4 (l >> 5), value v = 32 vh + (l & 31).  9 KB per record instead of 16 KB of fp32 (and 3
+// stores per lane instead of 16 scattered 4-byte stores on the recurrence's critical waves).  The recurrences themselves never
+// see the rounded copy (they carry fp32 accumulators / hi + lo planes); the per-chunk kernel reads each record once.
+// Why not bf16: a float64 simulation of the per-chunk gradients with rounded checkpoints (tools/diag_checkpoint_precision.py)
+// gives up to 5.8 bf16 ulp of extra error on the gradients (20 on dw, where rowsum(E * H_C) cancels against the in-chunk sums)
+// for bf16 records, 0.6 (2.6) ulp for fp16, 0.05 (0.17) ulp for this format.
+constexpr int kQMant = kN * kN;            // uint16 units
+constexpr int kQRec = kQMant + 2 * 256;    // + 256 floats
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void q15_encode_tile(const f32x16 &acc, uint16_t *rec, int vh, int kt, int lane) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) m = fmaxf(m, fabsf(acc[r]));
+    const float inv = m > 0.f ? 1.f / m : 0.f;
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)   // v_cvt_pknorm_i16_f32: round(x * 32767) for x in [-1, 1], two per instruction
+        w[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(acc[2 * j] * inv, acc[2 * j + 1] * inv));
+    const int slot = (vh * 2 + kt) * 64 + lane;
+    uint4 *q = reinterpret_cast<uint4 *>(rec + slot * 16);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    reinterpret_cast<float *>(rec + kQMant)[slot] = m * (1.f / 32767.f);
+}
+// Reader side, thread = (value row v, keys k8 .. k8 + 7, k8 % 8 == 0): the 8 values are registers r0 .. r0 + 3 of lane (v & 31)
+// (keys k8 .. k8 + 3) and of lane (v & 31) + 32 (keys k8 + 4 .. k8 + 7), r0 = 4 ((k8 >> 3) & 3), tile kt = k8 >> 5.
+__device__ __forceinline__ int q15_slot(int v, int k8) { return ((v >> 5) * 2 + (k8 >> 5)) * 64 + (v & 31); }
+__device__ __forceinline__ void q15_load8(const uint16_t *rec, int v, int k8, uint2 &lo4, uint2 &hi4) {
+    const uint16_t *p = rec + q15_slot(v, k8) * 16 + 4 * ((k8 >> 3) & 3);
+    lo4 = *reinterpret_cast<const uint2 *>(p);
+    hi4 = *reinterpret_cast<const uint2 *>(p + 32 * 16);
+}
+__device__ __forceinline__ void q15_decode8(const uint2 lo4, const uint2 hi4, float s_lo, float s_hi, float (&x)[8]) {
+    x[0] = (float)(int)(int16_t)(lo4.x & 0xffffu) * s_lo; x[1] = (float)((int)lo4.x >> 16) * s_lo;
+    x[2] = (float)(int)(int16_t)(lo4.y & 0xffffu) * s_lo; x[3] = (float)((int)lo4.y >> 16) * s_lo;
+    x[4] = (float)(int)(int16_t)(hi4.x & 0xffffu) * s_hi; x[5] = (float)((int)hi4.x >> 16) * s_hi;
+    x[6] = (float)(int)(int16_t)(hi4.y & 0xffffu) * s_hi; x[7] = (float)((int)hi4.y >> 16) * s_hi;
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
                                                         const T *__restrict__ k_, const T *__restrict__ v_,
                                                         const T *__restrict__ a_, const T *__restrict__ b_,
                                                         const float *__restrict__ tinv_, T *__restrict__ y_,
-                                                        float *__restrict__ sa_, float *__restrict__ hs_,
+                                                        float *__restrict__ sa_, uint16_t *__restrict__ hs_,
                                                         const int *__restrict__ seq_off_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     float *fm = reinterpret_cast<float *>(sm + FwdSmem::end16);
@@ -398,13 +398,8 @@ __global__ __launch_bounds__(256) void wkv7c_fwd_kernel(int T_, int H, const T *
             for (int r = 0; r < 16; r++) sh_Y[d_row(r, lane) * kStageLD + (lane & 31)] = accY[r];
         } else if (wave == 1 || wave == 2) {
             const int kt = wave - 1;  // rows (key channels) [32 kt, 32 kt + 32)
-            if (SAVE) {
-                // state at the START of chunk c, hs[b,h,c][k][v] (the orientation of the scalar kernel's checkpoints):
-                // lane = v, registers = k -> 32 consecutive lanes write 128 contiguous bytes
-                float *hp = hs_ + ((long)bh * nc + c) * kN * kN + vh * VH + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; r++) hp[(long)(kt * 32 + d_row(r, lane)) * kN] = Smaster[r];
-            }
+            // state at the START of chunk c as the backward's checkpoint: a q15 record (chunk_common.h) from the fp32 tile
+            if (SAVE) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + c) * kQRec, vh, kt, lane);
             f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
             mma_gen<kC, true, true, false, true>(acc, sm + L::BHh, sm + L::BHl, LDK, kt * 32, sm + L::Uh, sm + L::Ul, LDC, 0, lane);
             mma_gen<kC, true, true, true, !VEXACT>(acc, sm + L::KHh, sm + L::KHl, LDK, kt * 32, sm + L::Vt, sm + L::Vtl, LDC, 0, lane);
@@ -488,7 +483,7 @@ static int launch_prep(int B, int T_, int H, const void *w, const void *a, const
 
 template <typename T, bool SAVE>
 static int launch_fwd_t(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                        const void *b, const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq,
+                        const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq,
                         hipStream_t st) {
     static bool attr = false;
     if (!attr) {
@@ -499,7 +494,7 @@ static int launch_fwd_t(int B, int T_, int H, const void *w, const void *q, cons
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL((wkv7c_fwd_kernel<T, SAVE>), dim3((seq_off ? nseq : B) * H * 2), dim3(256), FwdSmem::total<T>(), st, T_, H,
-                       (const T *)w, (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, tinv, (T *)y, sa, hs, seq_off);
+                       (const T *)w, (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, tinv, (T *)y, sa, (uint16_t *)hs, seq_off);
     return (int)hipGetLastError();
 }
 
@@ -512,16 +507,16 @@ int chunk_prep_f32(int B, int T_, int H, const void *w, const void *a, const voi
 // bf16 tensors run the 8-wave producer / consumer kernel (wkv7_chunk_fwd8.hip: 335 us against 495 us for this 4-wave kernel at
 // B=8, T=4096, H=16); waves == 4 (rwkv7_wkv_chunk_fwd_seq_variant_bf16) selects this one (A/B, cross-check).  fp32 tensors always run here.
 int chunk_fwd8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const float *,
-                    void *, float *, float *, const int *, int, hipStream_t);
+                    void *, float *, void *, const int *, int, hipStream_t);
 
 int chunk_fwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                   const void *b, const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq, int waves, hipStream_t st) {
+                   const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, int waves, hipStream_t st) {
     if (waves != 4) return chunk_fwd8_bf16(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st);
     return (sa && hs) ? launch_fwd_t<bf16_t, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st)
                       : launch_fwd_t<bf16_t, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, seq_off, nseq, st);
 }
 int chunk_fwd_f32(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                  const void *b, const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq, hipStream_t st) {
+                  const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, hipStream_t st) {
     return (sa && hs) ? launch_fwd_t<float, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st)
                       : launch_fwd_t<float, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, seq_off, nseq, st);
 }

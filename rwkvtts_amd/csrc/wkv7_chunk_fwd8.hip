@@ -55,7 +55,7 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                                                          const bf16_t *__restrict__ k_, const bf16_t *__restrict__ v_,
                                                          const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_,
                                                          const float *__restrict__ tinv_, bf16_t *__restrict__ y_,
-                                                         float *__restrict__ sa_, float *__restrict__ hs_,
+                                                         float *__restrict__ sa_, uint16_t *__restrict__ hs_,
                                                          const int *__restrict__ seq_off_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = F8Smem;
@@ -201,12 +201,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                     for (int r = 0; r < 16; r++) sh_Y[d_row(r, lane) * kStageLD + (lane & 31)] = accY[r];
                 } else if (wave == 1 || wave == 2) {
                     const int kt = wave - 1;  // rows (key channels) [32 kt, 32 kt + 32)
-                    if (SAVE) {
-                        // state at the START of chunk cc, hs[b,h,c][k][v]
-                        float *hp = hs_ + ((long)bh * nc + cc) * kN * kN + vh * VH + (lane & 31);
-    #pragma unroll
-                        for (int r = 0; r < 16; r++) hp[(long)(kt * 32 + d_row(r, lane)) * kN] = Smaster[r];
-                    }
+                    // state at the START of chunk cc as the backward's checkpoint: a q15 record (chunk_common.h) straight from the
+                    // fp32 accumulator tile -- 3 stores per lane (the fp32 [k][v] checkpoint: 16 scattered 4-byte stores, 16 KB)
+                    if (SAVE) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + cc) * kQRec, vh, kt, lane);
                     f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
                     mma_gen<kC, true, true, false, true>(acc, bufc + L::BHh, bufc + L::BHl, LDK, kt * 32, sm + L::Uh, sm + L::Ul, LDC, 0, lane);
                     mma_gen<kC, true, true, true, false>(acc, bufc + L::KHh, bufc + L::KHl, LDK, kt * 32, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
 }
 
 static int launch_fwd8(bool save, int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                       const void *b, const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq, hipStream_t st) {
+                       const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_fwd8_kernel<true>),
@@ -355,7 +352,7 @@ static int launch_fwd8(bool save, int B, int T_, int H, const void *w, const voi
     const dim3 grid((seq_off ? nseq : B) * H * 2), block(512);
     if (save)
         hipLaunchKernelGGL(wkv7c_fwd8_kernel<true>, grid, block, F8Smem::bytes, st, T_, H, (const bf16_t *)w, (const bf16_t *)q,
-                           (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a, (const bf16_t *)b, tinv, (bf16_t *)y, sa, hs, seq_off);
+                           (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a, (const bf16_t *)b, tinv, (bf16_t *)y, sa, (uint16_t *)hs, seq_off);
     else
         hipLaunchKernelGGL(wkv7c_fwd8_kernel<false>, grid, block, F8Smem::bytes, st, T_, H, (const bf16_t *)w, (const bf16_t *)q,
                            (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a, (const bf16_t *)b, tinv, (bf16_t *)y, nullptr, nullptr,
@@ -364,7 +361,7 @@ static int launch_fwd8(bool save, int B, int T_, int H, const void *w, const voi
 }
 
 int chunk_fwd8_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a, const void *b,
-                    const float *tinv, void *y, float *sa, float *hs, const int *seq_off, int nseq, hipStream_t st) {
+                    const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, hipStream_t st) {
     return launch_fwd8(sa && hs, B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st);
 }
 

@@ -6,9 +6,9 @@ Two levels:
     projection) through rwkv7_decode_step_bf16 (csrc/decode_step.hip): 7 grid-wide phases per layer instead of ~18
     module-level launches, either as one launch per phase (default) or as ONE persistent kernel with device-scope barriers
     between the phases (persistent=1; slower on MI355X, the barrier costs 7.4 us against ~1.5 us for a kernel boundary).
-  * GraphDecoder -- greedy loop around it: embedding lookup of the previous ids, the step, suppress/argmax and the
-    bookkeeping are recorded once into a hipGraph on static buffers and replayed per token; the ids never leave the device
-    until the end.  Models the step kernel does not cover (fp32 weights, B > 32, odd low-rank sizes) run the module-by-module
+  * GraphDecoder -- greedy or sampled (temperature / top-k / top-p, device RNG) loop around it: embedding lookup of the
+    previous ids, the step, suppress + argmax/sampling and the bookkeeping are recorded once into a hipGraph on static buffers
+    and replayed per token; the ids never leave the device until the end.  Models the step kernel does not cover (fp32 weights, B > 32, odd low-rank sizes) run the module-by-module
     step inside the same graph.
 """
 from __future__ import annotations
@@ -151,7 +151,7 @@ class GraphDecoder:
             logits = out.logits[:, -1].float()
         if self.suppress is not None:
             logits.index_fill_(1, self.suppress, float("-inf"))
-        nxt = torch.argmax(logits, dim=-1)
+        nxt = self._pick(logits)
         if self.eos is not None:
             nxt = torch.where(self.unfinished, nxt, self.pad_t)
             self.unfinished &= nxt != self.eos
@@ -159,10 +159,21 @@ class GraphDecoder:
         self.out.scatter_(1, self.pos.expand(self.B, 1), nxt.unsqueeze(1))
         self.pos += 1
 
+    def _pick(self, logits):
+        """argmax, or temperature / top-k / top-p multinomial sampling (spark_llm.sample_next: the HF warper order the reference's
+        generate runs, utils/utilities.py:101-117) -- inside the captured step too: torch's device generator is graph-safe
+        (philox seed/offset live in device memory and advance per replay), so sampled decode replays like greedy decode."""
+        from .spark_llm import sample_next
+        return sample_next(logits, self.do_sample, self.top_k, self.top_p, self.temperature)
+
     @torch.no_grad()
     def generate(self, inputs_embeds=None, input_ids=None, attention_mask=None, max_new_tokens=256,
                  eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
-                 suppress_tokens: Optional[Sequence[int]] = None):
+                 suppress_tokens: Optional[Sequence[int]] = None, do_sample: bool = False, temperature: float = 1.0,
+                 top_k: int = 0, top_p: float = 1.0, seed: Optional[int] = None):
+        self.do_sample, self.temperature, self.top_k, self.top_p = bool(do_sample), float(temperature), int(top_k or 0), float(top_p)
+        if seed is not None:
+            torch.cuda.manual_seed(seed)
         m = self.model
         dev = m.device
         B = self.B
@@ -180,7 +191,7 @@ class GraphDecoder:
         logits = o.logits[:, -1].float()
         if self.suppress is not None:
             logits.index_fill_(1, self.suppress, float("-inf"))
-        first = torch.argmax(logits, dim=-1)
+        first = self._pick(logits)
         self.ids = first.clone()
         self.out[:, 0] = first
         self.pos.fill_(1)

@@ -195,8 +195,8 @@ def tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, eps):
     return _TmixPost.apply(y, r, k, v, g, gn_weight, gn_bias, r_k.reshape(-1), eps)
 
 
-CHUNKED_WKV_BWD = True   # bf16 training: scan backward on the matrix cores (csrc/wkv7_chunk_bwd.hip)
-CHUNKED_WKV_FWD = True   # ... and the forward too (csrc/wkv7_chunk_fwd.hip); needs CHUNKED_WKV_BWD
+CHUNKED_WKV_BWD = True   # bf16 training: scan forward + backward on the matrix cores (csrc/wkv7_chunk_*.hip); the pair goes
+CHUNKED_WKV_FWD = True   # together (the backward consumes the forward's checkpoints): set BOTH False for the scalar kernels
 
 
 class _TmixCore(torch.autograd.Function):
@@ -262,9 +262,9 @@ class _TmixCore(torch.autograd.Function):
               _p(part_post), nb)
         # 2. scan: chunked MFMA backward (bf16, T % 32 == 0) or the scalar kernel with two workgroups per head
         v4 = lambda t: t.view(B, T, H, 64)
-        if ctx.chunked_fwd or (CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0):
+        if ctx.chunked_fwd:   # the chunked backward consumes what the chunked forward saved (hs bf16, sa, tinv)
             dw, dq, dk, dv, da, db = ops.wkv7_chunk_backward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(d_y), s, sa,
-                                                             tinv=tinv, ck_mode=1 if ctx.chunked_fwd else 0, seq_off=ctx.seq_start)
+                                                             tinv, seq_off=ctx.seq_start)
             dw2, dq2, dk2, da2, db2 = [(g, None) for g in (dw, dq, dk, da, db)]
         else:
             dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in),

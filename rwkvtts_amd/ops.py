@@ -236,6 +236,24 @@ def RWKV7_BATCH_OP(state, r, w, k, v, a, b):
 # chunked (MFMA) WKV7: the training fast path (csrc/chunk_common.h, wkv7_chunk_fwd.hip, wkv7_chunk_bwd.hip)
 # ------------------------------------------------------------------------------------------------
 CHUNK_T = 32
+Q15_REC = 64 * 64 + 2 * 256   # int16 units of one 64x64 state checkpoint: 4096 mantissas + 256 fp32 scales
+_Q15_IDX = None
+
+
+def q15_decode(rec):
+    """[..., Q15_REC] int16 records (csrc/chunk_common.h: what the chunked forward saves as hs and the adjoint-state kernel as
+    e_vk; mantissas in MFMA accumulator order mant[vh][kt][lane][16], one scale per lane) -> fp32 [..., 64 (value), 64 (key)]."""
+    global _Q15_IDX
+    if _Q15_IDX is None:
+        v = torch.arange(64).view(64, 1).expand(64, 64)
+        k = torch.arange(64).view(1, 64).expand(64, 64)
+        slot = ((v >> 5) * 2 + (k >> 5)) * 64 + (v & 31) + 32 * ((k >> 2) & 1)
+        r = (k & 3) + 4 * ((k >> 3) & 3)
+        _Q15_IDX = ((slot * 16 + r).reshape(-1), slot.reshape(-1))
+    mi, si = (t.to(rec.device) for t in _Q15_IDX)
+    q = rec[..., :4096].float().index_select(-1, mi)
+    sc = rec[..., 4096:].contiguous().view(torch.float32).index_select(-1, si)
+    return (q * sc).reshape(*rec.shape[:-1], 64, 64)
 
 
 def wkv7_chunk_prep(w, a, b):
@@ -250,7 +268,8 @@ def wkv7_chunk_prep(w, a, b):
 
 
 def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None, waves=None):
-    """Chunked forward.  Returns y, and (tinv, sa, hs) when save (what the chunked backward consumes).
+    """Chunked forward.  Returns y, and (tinv, sa, hs) when save (what the chunked backward consumes; hs = the state at the
+    start of every chunk as q15 records, see q15_decode).
     seq_off: packed rows -- int32 [nseq + 1] device tensor of cumulative 32-step chunk counts over the [B][T/32] chunk
     space; sequence s owns chunks seq_off[s] .. seq_off[s+1] - 1 and starts from the zero state."""
     B, T, H, C = w.shape
@@ -260,7 +279,7 @@ def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None, waves=None):
     tinv = wkv7_chunk_prep(w, a, b)
     y = torch.empty_like(v)
     sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device) if save else None
-    hs = torch.empty(B, H, T // CHUNK_T, C, C, dtype=torch.float32, device=w.device) if save else None
+    hs = torch.empty(B, H, T // CHUNK_T, Q15_REC, dtype=torch.int16, device=w.device) if save else None
     with torch.cuda.device_of(w), _timed("wkv7c_fwd", w):
         args = (B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(tinv), _p(y),
                 None if sa is None else _p(sa), None if hs is None else _p(hs), *_seq_args(seq_off))
@@ -282,7 +301,7 @@ def _seq_args(seq_off):
 
 def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off=None):
     """First two stages of the chunked backward (bf16): per-chunk M^T / N' (parallel) and the adjoint-state recurrence
-    E_c = M_c^T E_{c+1} + N'_c (sequential over chunks).  Returns (mt, np, e_kv): e_kv[b,h,c][k][v] = E_{c+1}."""
+    E_c = M_c^T E_{c+1} + N'_c (sequential over chunks).  Returns (mt, np, e_vk): e_vk[b,h,c] = E_{c+1} as q15 records."""
     B, T, H, C = w.shape
     if w.dtype != torch.bfloat16:
         raise TypeError("the chunked backward is bf16 only")
@@ -292,31 +311,31 @@ def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off=None):
     dev = w.device
     mt = torch.empty(B, H, nc, 2, C, C, dtype=torch.int16, device=dev)
     np_ = torch.empty(B, H, nc, 4, 64, 16, dtype=torch.float32, device=dev)
-    e_kv = torch.empty(B, H, nc, C, C, dtype=torch.float32, device=dev)
+    e_vk = torch.empty(B, H, nc, Q15_REC, dtype=torch.int16, device=dev)
     with torch.cuda.device_of(w):
         with _timed("wkv7c_bwd_pre", w):
             rc = _lib.lib().rwkv7_wkv_chunk_bwd_pre_bf16(B, T, H, _p(w), _p(q), _p(a), _p(b), _p(dy), _p(tinv), _p(mt), _p(np_),
                                                          _stream(w))
         _lib.check(rc, "wkv7_chunk_bwd_pre")
         with _timed("wkv7c_state", w):
-            rc = _lib.lib().rwkv7_wkv_chunk_state_seq_bf16(B, H, nc, _p(mt), _p(np_), _p(e_kv), *_seq_args(seq_off), _stream(w))
+            rc = _lib.lib().rwkv7_wkv_chunk_state_seq_bf16(B, H, nc, _p(mt), _p(np_), _p(e_vk), *_seq_args(seq_off), _stream(w))
         _lib.check(rc, "wkv7_chunk_state")
-    return mt, np_, e_kv
+    return mt, np_, e_vk
 
 
-def wkv7_chunk_backward(w, q, k, v, a, b, dy, s, sa, tinv=None, ck_mode=0, seq_off=None):
-    """Chunked (MFMA) WKV7 backward, bf16: same inputs and outputs as torch.ops.wind_backstepping.backward, T % 32 == 0.
-    ck_mode 0: s, sa = what wind_backstepping.forward saved; ck_mode 1: s = hs, sa, tinv = what wkv7_chunk_forward saved.
-    Launches: (T inverse,) M^T/N', adjoint-state recurrence, per-chunk gradients.  Returns (dw, dq, dk, dv, da, db)."""
+def wkv7_chunk_backward(w, q, k, v, a, b, dy, hs, sa, tinv, seq_off=None):
+    """Chunked (MFMA) WKV7 backward, bf16: same gradients as torch.ops.wind_backstepping.backward, T % 32 == 0, from what
+    wkv7_chunk_forward saved (hs, sa, tinv).  Launches: M^T/N', adjoint-state recurrence, per-chunk gradients.
+    Returns (dw, dq, dk, dv, da, db)."""
     B, T, H, C = w.shape
-    if tinv is None:
-        tinv = wkv7_chunk_prep(w, a, b)
-    mt, np_, e_kv = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off)
+    if hs.dtype != torch.int16 or hs.shape[-1] != Q15_REC or sa.dtype != torch.float32 or tinv.dtype != torch.float32:
+        raise TypeError("wkv7_chunk_backward takes hs (q15 records), sa and tinv (fp32) as saved by wkv7_chunk_forward")
+    mt, np_, e_vk = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off)
     del mt, np_
     grads = [torch.empty_like(w) for _ in range(6)]
     with torch.cuda.device_of(w), _timed("wkv7c_bwd_out", w):
-        rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(s), _p(sa),
-                                                     _p(tinv), _p(e_kv), ck_mode, *[_p(g) for g in grads], _stream(w))
+        rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(hs), _p(sa),
+                                                     _p(tinv), _p(e_vk), *[_p(g) for g in grads], _stream(w))
     _lib.check(rc, "wkv7_chunk_bwd_out")
     return tuple(grads)
 

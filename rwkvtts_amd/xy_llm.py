@@ -124,7 +124,17 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
                  temperature=1.0, top_k=0, top_p=1.0, eos_token_id=None, generator: Optional[torch.Generator] = None,
                  return_dict_in_generate=False, **unused):
         """CustomGenerationMixin._sample (xy_llm.py:39-146) on the persistent-state decode path.
-        input_ids [B,T,C].  do_sample=False replaces each multinomial by argmax (greedy, for parity tests)."""
+        input_ids [B,T,C].  do_sample=False replaces each multinomial by argmax (greedy, for parity tests).
+
+        Flush (xy_llm.py:104-121): a non-audio id on channel 0 starts a countdown of C-1 further rows; in all C rows channel 0
+        carries EOS (if one is configured), channel i keeps its sampled ids for i more rows and is padded afterwards, and the
+        sequence finishes with the last row.  Two places where the reference's loop cannot do what its comments say, and
+        where this loop follows the comments (tests/test_heads_gpu.py hand-steps the rules):
+          * `unfinished & ~stopping & ~(needs_additional_steps == -1)` (:140) is false for every sequence that is NOT flushing,
+            i.e. from the first step on -- the reference would emit one frame; here only a flushing sequence whose countdown
+            reached -1 finishes;
+          * with an EOS id configured, the EOS that the flush writes on channel 0 meets the EOS stopping criterion in the
+            very row that starts the countdown (:139); here the criterion is not applied to flushing sequences."""
         from .spark_llm import sample_next
         cfg = self.config
         was_training = self.training
@@ -172,7 +182,9 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
             if total is not None and input_ids.shape[1] >= total:
                 stop[:] = True
             if eos is not None:
-                stop |= torch.isin(input_ids[:, -1, 0], torch.tensor(eos, device=dev))
+                # the EOS criterion applies to sequences that are NOT flushing: the flush itself writes EOS on channel 0, and
+                # letting that end the sequence would cut the countdown after its first row (see the docstring)
+                stop |= torch.isin(input_ids[:, -1, 0], torch.tensor(eos, device=dev)) & ~is_flushing
             unfinished = unfinished & (~stop).long() & (~(needs_additional_steps == -1) | (~is_flushing)).long()
             if unfinished.max() == 0:
                 break

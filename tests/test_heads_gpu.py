@@ -216,3 +216,77 @@ def test_cosy_inference_step_kernel_vs_fp32_twin():
                 checked += 1
             x = twin.speech_embedding.weight[tok].reshape(1, 1, -1)
     assert checked >= len(a) // 2, (checked, len(a))
+
+
+def test_xy_generate_flush_stagger_eos_and_stop_at_full_channel_count(monkeypatch):
+    """CustomGenerationMixin._sample (xy_llm.py:88-146) at the real channel count and vocabularies (8 channels, V0 = 66 661,
+    1 025 per speech channel): once channel 0 leaves the audio range a C-1 = 7 step countdown starts; during its 8 rows channel 0
+    carries EOS, and channel i keeps its sampled value for i more rows (the delay pattern: RVQ-i lags i steps) before it is
+    padded; the sequence finishes when the countdown ends; finished sequences emit EOS / pad while the rest of the batch
+    continues; an EOS on channel 0 stops a sequence at once.  The sampler is scripted (channel 0 is masked to the audio range, so
+    only a scripted draw can leave it -- exactly the situation the reference's flush logic is written for) and the expectation
+    is hand-stepped from the reference's rules, not from our code.  The reference's own termination test
+    (`& ~(needs_additional_steps == -1)`, true from the first step on) would stop every sequence after ONE token; that bug is
+    not reproduced."""
+    from rwkvtts_amd import spark_llm
+    C, V0, SV, SHIFT = 8, 66661, 1025, 65536
+    cfg = RWKV7XYConfig(vocab_size=V0, speech_vocab_size=SV, num_channels=C, text_shift_size=SHIFT, **SMALL)
+    model = RWKV7XYLM(cfg).init_weights(seed=2)
+    model.zero_embs()
+    model = model.to(DEV).eval()
+    PAD, EOS = cfg.speech_pad_token, 65535          # EOS: a text id, outside the audio range
+    assert PAD == SV - 1
+    B, T0 = 3, 4
+    trigger = {0: 2, 1: 5}                           # sequence -> step at which channel 0 draws a non-audio id; sequence 2: never
+    calls = {"n": 0}
+
+    def scripted(logits, *a, **k):                   # called once per channel and step, channels in order
+        step, ch = divmod(calls["n"], C)
+        calls["n"] += 1
+        if ch == 0:
+            # what the mask must have done before the draw: only audio ids are finite
+            assert torch.isinf(logits[:, :SHIFT]).all() and torch.isinf(logits[:, SHIFT + SV:]).all()
+            assert torch.isfinite(logits[:, SHIFT:SHIFT + SV]).all()
+            out = torch.full((logits.shape[0],), SHIFT, dtype=torch.long, device=logits.device) + 10 + step
+            for s_, st_ in trigger.items():
+                if step == st_:
+                    out[s_] = 7                      # a text id
+            return out
+        return torch.full((logits.shape[0],), 100 * ch + step, dtype=torch.long, device=logits.device)
+
+    monkeypatch.setattr(spark_llm, "sample_next", scripted)
+    prompt = torch.full((B, T0, C), PAD, dtype=torch.long, device=DEV)
+    prompt[:, :, 0] = torch.arange(T0, device=DEV) + 5
+    out = model.generate(prompt, max_new_tokens=16, eos_token_id=EOS)
+    new = out[:, T0:].cpu()
+    n_steps = new.shape[1]
+    # hand-stepped expectation
+    want = torch.zeros(B, n_steps, C, dtype=torch.long)
+    for b in range(B):
+        done_after = trigger[b] + C - 1 if b in trigger else None      # last row of the flush
+        for step in range(n_steps):
+            for ch in range(C):
+                sampled = (SHIFT + 10 + step) if ch == 0 else 100 * ch + step
+                if done_after is not None and step > done_after:         # finished: EOS / pad
+                    want[b, step, ch] = EOS if ch == 0 else PAD
+                elif b in trigger and step >= trigger[b]:                # flushing rows j = step - trigger = 0..7
+                    j = step - trigger[b]
+                    want[b, step, ch] = EOS if ch == 0 else (sampled if j < ch else PAD)
+                else:
+                    want[b, step, ch] = sampled
+    assert n_steps == 16                                                 # sequence 2 never flushes: max_new_tokens ends it
+    assert torch.equal(new, want), (new - want).abs().sum(-1)
+    # without an EOS id (no EOS criterion in the reference either): channel 0 keeps what was drawn, finished rows carry 0 / pad
+    calls["n"] = 0
+    out0 = model.generate(prompt, max_new_tokens=16)[:, T0:].cpu()
+    for b in range(B):
+        for step in range(16):
+            drawn0 = 7 if trigger.get(b) == step else SHIFT + 10 + step
+            fin = b in trigger and step > trigger[b] + C - 1
+            assert int(out0[b, step, 0]) == (0 if fin else drawn0), (b, step)
+    assert torch.equal(out0[:, :, 1:], want[:, :, 1:])
+    # EOS inside the audio range (stopping criteria on channel 0, xy_llm.py:139): the sequence stops with that row
+    calls["n"] = 0
+    trigger.clear()
+    out2 = model.generate(prompt[:1], max_new_tokens=16, eos_token_id=SHIFT + 10 + 3)
+    assert out2.shape[1] == T0 + 4 and int(out2[0, -1, 0]) == SHIFT + 13

@@ -60,7 +60,7 @@ def main():
     prep = lambda: ops.wkv7_chunk_prep(w, aa, b)
     tinv = prep()
     sa2 = torch.empty(B, T, H, 64, device=dev)
-    hs = torch.empty(B, H, T // 32, 64, 64, device=dev)
+    hs = torch.empty(B, H, T // 32, ops.Q15_REC, device=dev, dtype=torch.int16)
     import ctypes
     from rwkvtts_amd import _lib
     P = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -74,7 +74,10 @@ def main():
         if a.dtype != "bf16":
             return None
         return lambda: _lib.lib().rwkv7_wkv_state_fwd_variant_bf16(B, T, H * 64, H, P(st), P(q), P(w), P(k), P(v), P(aa), P(b), P(yy), cw, st_)
-    cb = (lambda: ops.wkv7_chunk_backward(w, q, k, v, aa, b, dy, s, sa)) if a.dtype == "bf16" else None
+    hs16 = None
+    if a.dtype == "bf16":
+        _, _, sa2, hs16 = ops.wkv7_chunk_forward(w, q, k, v, aa, b)
+    cb = (lambda: ops.wkv7_chunk_backward(w, q, k, v, aa, b, dy, hs16, sa2, tinv)) if a.dtype == "bf16" else None
     cb_state = (lambda: ops.wkv7_chunk_bwd_state(w, q, aa, b, dy, tinv)) if a.dtype == "bf16" else None
     for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz),
                                 ("wkv7_fwd 8 col/lane", shaped(8, fwd), 7 * 64 * esz),
@@ -86,7 +89,7 @@ def main():
                                 ("wkv7_state_fwd", sfw, 7 * 64 * esz), ("wkv7c_prep (T inverse)", prep, 3 * 64 * esz),
                                 ("wkv7c_fwd (chunked, save)", cf, 7 * 64 * esz),
                                 ("wkv7c bwd pre+state", cb_state, 13 * 64 * esz),
-                                ("wkv7c bwd total (4 launches)", cb, 13 * 64 * esz)):
+                                ("wkv7c bwd total (3 launches)", cb, 13 * 64 * esz)):
         if fn is None:
             continue
         med, best = timeit(fn, a.iters)
