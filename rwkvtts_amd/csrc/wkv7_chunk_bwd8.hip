@@ -185,41 +185,43 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
     using L = Out8Smem;
     float *sh_gC = reinterpret_cast<float *>(sm + L::gC), *sh_dterm = reinterpret_cast<float *>(sm + L::dterm);
     const int nc = T_ / kC;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // wave and half are wave-uniform, and the compiler must know it: as plain functions of threadIdx every `if (wave == ..)` is an
+    // exec-masked region that all waves walk through, and values defined in different regions share registers -- hipcc then
+    // separated a load into v[48:51] on one path from a constant write to v[48:51] on the other with s_waitcnt vmcnt, i.e.
+    // every wave sat out a full HBM latency inside load_rows (2.3k of 19k cycles per chunk)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int pt = tid & 31, pk = (tid >> 5) * 4;                        // compute mapping: step pt, channels pk .. pk+3
-    const int half = tid >> 8, ltid = tid & 255, lt = ltid >> 3, lk = (ltid & 7) * 8;   // global mapping: step lt, channels lk .. lk+7
+    const int half = wave >> 2, ltid = tid & 255, lt = ltid >> 3, lk = (ltid & 7) * 8;   // global mapping: step lt, channels lk .. lk+7
     const long tstride = (long)H * kN;
 
     // global -> registers, one chunk ahead.  Rows: waves 0-3 fetch w, q, k, a and T^-1; waves 4-7 fetch b, v, dy and u (= sa).
     struct Rows {
-        uint4 x0, x1, x2, x3;
-        float4 f0, f1;
+        uint4 x0, x1, x2;   // waves 0-3: w, q, k          waves 4-7: b, v, dy
+        float4 f0;          //            T^-1 (4 floats)             u[0..3]
+        uint4 x3;           //            a                           u[4..7] (float bits)
         long off;
     };
     struct Mats {
         uint2 e[2], hc[2];   // q15 mantissas of (value row v = tid >> 3, keys 8 (tid & 7) .. +8): two 4-key pieces (chunk_common.h)
         float4 sc;           // threads 0-63: 4 of the 256 scales of E; threads 64-127: of H_C
     };
+    // The same five 16-byte loads in both halves, through per-half pointers (wave-uniform selects), no branch: any
+    // half-dependent control flow around a load (a field copied from another field's result, a constant written on the other
+    // path, a conditional load merged by a phi) made hipcc put s_waitcnt vmcnt + register moves right behind the loads, i.e.
+    // every wave sat out an HBM latency inside this function (2.3k of 19k cycles per chunk).
     auto load_rows = [&](int chunk) {
         const int bh = chunk / nc, c = chunk - bh * nc;
         const int bb = bh / H, hh = bh - bb * H;
         Rows r;
         r.off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + lt) * tstride + lk;
-        if (half == 0) {
-            r.x0 = *reinterpret_cast<const uint4 *>(w_ + r.off);
-            r.x1 = *reinterpret_cast<const uint4 *>(q_ + r.off);
-            r.x2 = *reinterpret_cast<const uint4 *>(k_ + r.off);
-            r.x3 = *reinterpret_cast<const uint4 *>(a_ + r.off);
-            r.f0 = *reinterpret_cast<const float4 *>(tinv_ + (long)chunk * kC * kC + ltid * 4);
-            r.f1 = r.f0;
-        } else {
-            r.x0 = *reinterpret_cast<const uint4 *>(b_ + r.off);
-            r.x1 = *reinterpret_cast<const uint4 *>(v_ + r.off);
-            r.x2 = *reinterpret_cast<const uint4 *>(dy_ + r.off);
-            r.x3 = r.x2;
-            r.f0 = *reinterpret_cast<const float4 *>(sa_ + r.off);
-            r.f1 = *reinterpret_cast<const float4 *>(sa_ + r.off + 4);
-        }
+        const bf16_t *p0 = half ? b_ : w_, *p1 = half ? v_ : q_, *p2 = half ? dy_ : k_;
+        const float *pf = half ? sa_ + r.off : tinv_ + (long)chunk * kC * kC + ltid * 4;
+        const void *p3 = half ? static_cast<const void *>(sa_ + r.off + 4) : static_cast<const void *>(a_ + r.off);
+        r.x0 = *reinterpret_cast<const uint4 *>(p0 + r.off);
+        r.x1 = *reinterpret_cast<const uint4 *>(p1 + r.off);
+        r.x2 = *reinterpret_cast<const uint4 *>(p2 + r.off);
+        r.f0 = *reinterpret_cast<const float4 *>(pf);
+        r.x3 = *reinterpret_cast<const uint4 *>(p3);
         return r;
     };
     const int st_v = tid >> 3, st_k8 = (tid & 7) * 8;   // this thread's piece of a 64x64 state: value row qv, keys qk8 .. qk8 + 7
@@ -235,6 +237,11 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
         if (tid < 64) r.sc = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(er + kQMant) + tid * 4);
         else if (tid < 128 && hasC) r.sc = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(hr + kQMant) + (tid - 64) * 4);
     };
+#if B8TIMING
+    long long *tacc_ = reinterpret_cast<long long *>(sm + L::tacc);
+    if (tid < 128) tacc_[tid] = 0;
+    lds_barrier();
+#endif
     const int chunk0 = blockIdx.x * kOut8ChunksPerWG;
     Rows cur = load_rows(chunk0);
     Mats curm;
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
                 *reinterpret_cast<uint4 *>(rs + 5 * kC * LDK + wo) = cur.x1;
                 *reinterpret_cast<uint4 *>(rs + 6 * kC * LDK + wo) = cur.x2;
                 *reinterpret_cast<float4 *>(rsu + lt * L::kStLD + lk) = cur.f0;
-                *reinterpret_cast<float4 *>(rsu + lt * L::kStLD + lk + 4) = cur.f1;
+                *reinterpret_cast<uint4 *>(rsu + lt * L::kStLD + lk + 4) = cur.x3;
             }
             lds_barrier();
             rw = *reinterpret_cast<const uint2 *>(rs + 0 * kC * LDK + ro);
@@ -338,6 +345,8 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
             put_row8(sm + L::XTh, sm + L::XTl, row * LDK + k8, x, hi, lo);
             q15_decode8(h0[0], h0[1], sH0[slot], sH0[slot + 32], x);
             put_row8(sm + L::HTh, sm + L::HTl, row * LDK + k8, x, hi, lo);
+            h0[0] = curm.hc[0];   // H_C of this chunk = H0 of the next (zeros across a head / sequence boundary on both sides);
+            h0[1] = curm.hc[1];   // copied here, while no load is in flight
             // rowsum over v (= over the 8 lanes of this wave with the same tid & 7, then over the 8 waves): transposing pair sums
             // on v_permlane{32,16}_swap -- after each step a lane keeps half of its values, summed over twice as many rows
             float s4[4], s2[2];
@@ -443,9 +452,10 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
         B8STAMP(9);
         lds_barrier();
         B8STAMP(10);
-        // the next chunk's raw rows: three phases (~4k cycles) ahead of their use
-        Rows nxt = cur;
-        if (more) nxt = load_rows(chunk + 1);
+        // the next chunk's raw rows: three phases (~4k cycles) ahead of their use.  `cur` is dead since the restaging at the top of
+        // the iteration and is overwritten in place (a second variable + copy at the loop end made hipcc wait for every
+        // outstanding load at the loop header in order to move registers)
+        if (more) cur = load_rows(chunk + 1);
         // ---- phase D --------------------------------------------------------------------------------------------------------------
         const int lnD = fresh(lane);
         if (wave <= 1) {
@@ -470,9 +480,8 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
         B8STAMP(11);
         lds_barrier();
         B8STAMP(12);
-        // the next chunk's E, H0, H_C (used ~1.5 phases into its prologue)
-        Mats nxtm = curm;
-        if (more) load_mats(chunk + 1, nxtm);
+        // the next chunk's E, H_C (used ~1.5 phases into its prologue); curm is dead since prologue 2
+        if (more) load_mats(chunk + 1, curm);
         // ---- phase F --------------------------------------------------------------------------------------------------------------
         const int lnF = fresh(lane);
         if (wave <= 1) {
@@ -535,10 +544,6 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
         B8STAMP(15);
         // no barrier here: the next chunk's first writes go to the restaging area (P / temporaries), which nobody reads any more,
         // and its first barrier comes before anything else is overwritten
-        cur = nxt;
-        h0[0] = curm.hc[0];   // H_C of this chunk = H0 of the next (zeros across a head / sequence boundary on both sides)
-        h0[1] = curm.hc[1];
-        curm = nxtm;
     }  // chunk loop
 #if B8TIMING
     lds_barrier();
