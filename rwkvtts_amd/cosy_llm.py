@@ -14,7 +14,7 @@ from typing import Callable, List, Optional
 
 import torch
 import torch.nn as nn
-from torch.nn.utils.rnn import pad_sequence, unpad_sequence
+from torch.nn.utils.rnn import pad_sequence
 
 from .backbone import Cache, ModelOutput, RWKV7Config, RWKV7Model
 from .hf_api import HFModelMixin
@@ -91,15 +91,24 @@ class RWKV7CosyLM(HFModelMixin, nn.Module):
                                   self.config.length_normalized_loss)
 
     def pad_unpad_sequence(self, sos_eos_emb, text_token, text_token_len, task_id_emb, speech_token, speech_token_len):
-        """cosy_llm.py:64-73 (note the padding VALUE -1 in the embeddings; masked positions)."""
-        device = text_token.device
-        text_token = unpad_sequence(text_token, text_token_len.cpu(), batch_first=True)
-        speech_token = unpad_sequence(speech_token, speech_token_len.cpu(), batch_first=True)
-        lm_input = [torch.concat([sos_eos_emb.squeeze(dim=0), text_token[i], task_id_emb.squeeze(dim=0), speech_token[i]],
-                                 dim=0) for i in range(len(text_token))]
-        attention_mask = [torch.ones(i.size(0), device=device, dtype=torch.int32) for i in lm_input]
-        lm_input = pad_sequence(lm_input, batch_first=True, padding_value=IGNORE_ID)
-        attention_mask = pad_sequence(attention_mask, batch_first=True, padding_value=0)
+        """Per sample [sos, text[:n_t], task_id, speech[:n_s]], right-padded to the longest sample.  Behaviour of
+        cosy_llm.py:64-73: the padding VALUE in the embedding tensor is -1 (IGNORE_ID), the mask is int32 ones over the real
+        length.  Built into preallocated tensors (one slice write per piece) rather than through unpad/pad_sequence."""
+        B, D = text_token.shape[0], text_token.shape[-1]
+        n_t = [int(n) for n in text_token_len.tolist()]
+        n_s = [int(n) for n in speech_token_len.tolist()]
+        total = [2 + a + b for a, b in zip(n_t, n_s)]
+        L = max(total)
+        lm_input = text_token.new_full((B, L, D), float(IGNORE_ID))
+        attention_mask = torch.zeros(B, L, dtype=torch.int32, device=text_token.device)
+        sos, task = sos_eos_emb.reshape(D), task_id_emb.reshape(D)
+        for i in range(B):
+            row = lm_input[i]
+            row[0] = sos
+            row[1:1 + n_t[i]] = text_token[i, :n_t[i]]
+            row[1 + n_t[i]] = task
+            row[2 + n_t[i]:total[i]] = speech_token[i, :n_s[i]]
+            attention_mask[i, :total[i]] = 1
         return lm_input, attention_mask
 
     def build_inputs(self, batch):
@@ -148,17 +157,15 @@ class RWKV7CosyLM(HFModelMixin, nn.Module):
         return self.lm_head(outs.last_hidden_state), outs.past_key_values
 
     def sampling_ids(self, weighted_scores, decoded_tokens: List, sampling: int, ignore_eos: bool = True):
-        """cosy_llm.py:162-178: resample (<= 100 times) while EOS comes out and it must be ignored."""
-        num_trials, max_trials = 0, 100
-        while True:
-            top_ids = self.sampling(weighted_scores, decoded_tokens, sampling)
-            if (not ignore_eos) or (self.speech_token_size not in top_ids):
-                break
-            num_trials += 1
-            if num_trials > max_trials:
-                raise RuntimeError(f"sampling reaches max_trials {max_trials} and still get eos when ignore_eos is True, "
-                                   "check your input!")
-        return top_ids
+        """One draw from self.sampling; while EOS must be ignored (min length not reached) a draw that contains EOS is
+        rejected and repeated, at most 100 more times (behaviour of cosy_llm.py:162-178, same error text)."""
+        eos, max_trials = self.speech_token_size, 100
+        for _ in range(max_trials + 1):
+            ids = self.sampling(weighted_scores, decoded_tokens, sampling)
+            if not ignore_eos or eos not in ids:
+                return ids
+        raise RuntimeError(f"sampling reaches max_trials {max_trials} and still get eos when ignore_eos is True, "
+                           "check your input!")
 
     @torch.inference_mode()
     def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len,
@@ -167,26 +174,20 @@ class RWKV7CosyLM(HFModelMixin, nn.Module):
         """Streaming generator of speech token ids (cosy_llm.py:180-272): prefill [sos, prompt_text+text, task_id,
         prompt_speech], then one persistent-state step per token; ids >= speech_token_size are EOS / skipped."""
         device = text.device
-        text = torch.concat([prompt_text, text], dim=1)
-        text_len = text_len + prompt_text_len
-        original_text_len = int(text_len.item())
-        end_of_prompt_id = 65531
-        idx = (text == end_of_prompt_id).nonzero()
-        content_length = text_len
-        if idx.size(0) > 0:
-            instruction_length = idx[0, 1].item()
-            content_length = text_len - (instruction_length + 1)
-            original_text_len -= (instruction_length + 1)
-        text_emb = self.text_embedding(text)
-        sos_eos_emb = self.llm_embedding.weight[self.sos_eos].reshape(1, 1, -1)
-        task_id_emb = self.llm_embedding.weight[self.task_id].reshape(1, 1, -1)
+        text = torch.cat([prompt_text, text], dim=1)
+        n_text = int((text_len + prompt_text_len).item())
+        # an instruction prefix ends at the <|endofprompt|> id (65531): it does not count towards the length budget
+        # (cosy_llm.py:195-207)
+        hits = (text[0] == 65531).nonzero()
+        n_instr = int(hits[0, 0].item()) + 1 if hits.numel() else 0
+        content_length = n_text - n_instr
+        original_text_len = n_text - n_instr
+        emb_w = self.llm_embedding.weight
+        pieces = [emb_w[self.sos_eos].view(1, 1, -1), self.text_embedding(text), emb_w[self.task_id].view(1, 1, -1)]
         if int(prompt_speech_token_len) != 0:
-            prompt_speech_token_emb = self.speech_embedding(prompt_speech_token)
-        else:
-            prompt_speech_token_emb = torch.zeros(1, 0, self.config.llm_input_size, dtype=text_emb.dtype, device=device)
-        lm_input = torch.concat([sos_eos_emb, text_emb, task_id_emb, prompt_speech_token_emb], dim=1)
-        min_len = int(content_length * min_token_text_ratio)
-        max_len = int(content_length * max_token_text_ratio)
+            pieces.append(self.speech_embedding(prompt_speech_token))
+        lm_input = torch.cat(pieces, dim=1)
+        min_len, max_len = int(content_length * min_token_text_ratio), int(content_length * max_token_text_ratio)
         out_tokens = []
         if cache is None:
             cache = Cache.zeros(self.config, 1, device, lm_input.dtype)
