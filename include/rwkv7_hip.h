@@ -240,6 +240,10 @@ int rwkv7_relusq_bwd_f32(long n, const void *x, const void *dy, void *dx, rwkv7_
  * sa and hs may both be NULL in _fwd (inference).
  * ===================================================================================================== */
 #define RWKV7_CHUNK_T 32
+/* One 64x64 fp32 matrix handed between the chunk kernels (hs, e_vk, np) as a "q15" record: 4096 int16 mantissas in MFMA
+ * accumulator order [tile][lane][16] followed by 256 fp32 scales [tile][lane] (x = mantissa * scale of its lane); see
+ * csrc/chunk_common.h.  Sizes of hs / e_vk / np buffers: RWKV7_Q15_REC uint16 per (batch, head, chunk). */
+#define RWKV7_Q15_REC (64 * 64 + 2 * 256)
 int rwkv7_wkv_chunk_prep_bf16(int B, int T, int H, const void *w, const void *a, const void *b, float *tinv,
                               rwkv7_stream_t stream);
 int rwkv7_wkv_chunk_prep_f32(int B, int T, int H, const void *w, const void *a, const void *b, float *tinv,
@@ -265,14 +269,15 @@ int rwkv7_wkv_chunk_fwd_seq_f32(int B, int T, int H, const void *w, const void *
 /* ---- chunked backward, bf16 (csrc/wkv7_chunk_bwd.hip, wkv7_chunk_bwd8.hip).  With H = S^T and the chunk quantities above, the
  *      adjoint state obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
  *   bwd_pre : parallel over chunks.  mt  = M_c^T as bf16 hi/lo planes, uint16 [B*H*T/32][2][64][64];
- *                                    np  = N'_c, fp32 [B*H*T/32][4 tiles][64 lanes][16] (MFMA accumulator layout)
+ *                                    np  = N'_c as a q15 record per chunk (int16 [4 tiles][64 lanes][16] in MFMA accumulator
+ *                                          order + fp32 scale [4][64]; RWKV7_Q15_REC uint16 units per record)
  *   state   : sequential over chunks (reverse), one workgroup per (head, half of the value columns).
  *             e_vk[b,h,c][v][k] = E_{c+1}, what chunk c receives from its future, as bf16 (the recurrence itself carries
  *             ~16 mantissa bits; the per-chunk kernel reads this rounded copy once). ---- */
 int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
-                                 const void *dy, const float *tinv, void *mt, float *np, rwkv7_stream_t stream);
-int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, void *e_vk, rwkv7_stream_t stream);
-int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const float *np, void *e_vk, const int *seq_chunk_off,
+                                 const void *dy, const float *tinv, void *mt, void *np, rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const void *np, void *e_vk, rwkv7_stream_t stream);
+int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const void *np, void *e_vk, const int *seq_chunk_off,
                                    int nseq, rwkv7_stream_t stream);   /* packed rows: see rwkv7_wkv_chunk_fwd_seq_bf16 */
 /*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from what the chunked
  *             forward saved (hs, sa, tinv) and the adjoint states e_vk of `state`. */

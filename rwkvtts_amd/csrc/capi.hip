@@ -38,8 +38,8 @@ int adamw_step(long, float *, const void *, float *, float *, void *, const uint
                float, float, float, hipStream_t);
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
-                       float *, hipStream_t);
-int chunk_state_bf16(int, int, int, const void *, const float *, void *, const int *, int, hipStream_t);
+                       void *, hipStream_t);
+int chunk_state_bf16(int, int, int, const void *, const void *, void *, const int *, int, hipStream_t);
 int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *,
                         hipStream_t);
@@ -349,16 +349,16 @@ int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, con
 
 // chunked backward (bf16): see csrc/wkv7_chunk_bwd.hip
 int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
-                                 const void *dy, const float *tinv, void *mt, float *np, rwkv7_stream_t stream) {
+                                 const void *dy, const float *tinv, void *mt, void *np, rwkv7_stream_t stream) {
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, a, b, dy, (const void *)tinv, mt, (const void *)np})) return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
     return rwkv7::chunk_bwd_pre_bf16(B, T, H, w, q, a, b, dy, tinv, mt, np, (hipStream_t)stream);
 }
-int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const float *np, void *e_vk, rwkv7_stream_t stream) {
+int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const void *np, void *e_vk, rwkv7_stream_t stream) {
     if (BH <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk})) return RWKV7_EINVAL;
     return rwkv7::chunk_state_bf16(BH, nchunks, 1, mt, np, e_vk, nullptr, 0, (hipStream_t)stream);
 }
-int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const float *np, void *e_vk, const int *seq_chunk_off,
+int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const void *np, void *e_vk, const int *seq_chunk_off,
                                    int nseq, rwkv7_stream_t stream) {
     if (B <= 0 || H <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk})) return RWKV7_EINVAL;
     if (seq_chunk_off != nullptr && nseq <= 0) return RWKV7_EINVAL;

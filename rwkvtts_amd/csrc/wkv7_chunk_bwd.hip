@@ -6,7 +6,7 @@
 //     E_c = M_c^T E_{c+1} + N'_c ,   N'_c = Q~^T dY + W^T (A_qb^T dY)              (E_c = dL/dH at the START of chunk c)
 // is the only sequential object of the backward pass (tests/chunked_proto2.py validates the algebra against the oracle).
 // Three kernels:
-//   wkv7c_bwd_pre_kernel   grid B*H*(T/32), parallel: M_c^T (bf16 hi/lo planes) and N'_c (fp32, MFMA tile layout)
+//   wkv7c_bwd_pre_kernel   grid B*H*(T/32), parallel: M_c^T (bf16 hi/lo planes) and N'_c (q15 record, MFMA tile order)
 //   wkv7c_state_kernel     grid B*H, sequential over chunks in reverse: E for every chunk (one 64x64x64 product each)
 //   wkv7c_bwd_out8_kernel  grid B*H*(T/32), parallel: dw,dq,dk,dv,da,db of a chunk from (H_c, E_{c+1}, U = sa, dY)
 //                          (wkv7_chunk_bwd8.hip)
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
                                                             const bf16_t *__restrict__ q_, const bf16_t *__restrict__ a_,
                                                             const bf16_t *__restrict__ b_, const bf16_t *__restrict__ dy_,
                                                             const float *__restrict__ tinv_, uint16_t *__restrict__ mt_,
-                                                            float *__restrict__ np_) {
+                                                            uint16_t *__restrict__ np_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = PreSmem;
     float *sh_gC = reinterpret_cast<float *>(sm + L::gC);
@@ -158,10 +158,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
             mma_xs_ye<kC, 2>(acc, sm + L::QTTh + mt * 32 * LDC, sm + L::QTTl + mt * 32 * LDC, LDC, sm + L::DYT + nt * 32 * LDC, LDC, lane);
             mma_tile3<kC, 2>(acc, sm + L::WTh + mt * 32 * LDC, sm + L::WTl + mt * 32 * LDC, LDC, sm + L::G1Th + nt * 32 * LDC,
                           sm + L::G1Tl + nt * 32 * LDC, LDC, lane);
-            float *o = np_ + (((long)chunk * 4 + wave) * 64 + lane) * 16;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                *reinterpret_cast<float4 *>(o + 4 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            // N' as a q15 record in accumulator order (chunk_common.h), tile = wave: 3 stores per lane, 9 KB instead of 16 KB fp32
+            q15_encode_tile(acc, np_ + (long)chunk * kQRec, wave >> 1, wave & 1, lane);
             // wave = (k-tile mt, plane): the four 16-byte A fragments of its 32 rows of M^T
             const uint16_t *pl = sm + ((wave & 1) ? L::MPl : L::MPh) + (mt * 32 + (lane & 31)) * LDK + (lane >> 5) * 8;
             uint16_t *mo = mt_ + ((long)chunk * 4 + wave) * 4 * 512 + lane * 8;
@@ -188,7 +186,7 @@ struct StateSmem {  // E planes of one half of the value columns, [32 v][64 k], 
 };
 }  // namespace
 
-__global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const uint16_t *__restrict__ mt_, const float *__restrict__ np_,
+__global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const uint16_t *__restrict__ mt_, const uint16_t *__restrict__ np_,
                                                           uint16_t *__restrict__ e_vk, const int *__restrict__ seq_off_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = StateSmem;
@@ -221,7 +219,8 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
 
     struct In {
         bf16x8 mh[4], ml[4];
-        float4 n[4];
+        uint4 n[2];     // N' tile: 16 int16 mantissas of this lane (q15 record, accumulator order) ...
+        float ns;       // ... and their scale
     };
     auto load = [&](int c) {
         In r;
@@ -232,9 +231,11 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
                 r.mh[i] = *reinterpret_cast<const bf16x8 *>(mp + i * 512);
                 r.ml[i] = *reinterpret_cast<const bf16x8 *>(mp + 4 * 512 + i * 512);
             }
-            const float *np = np_ + ((((long)bh * nc + c) * 4 + mt * 2 + nt) * 64 + lane) * 16;
-#pragma unroll
-            for (int j = 0; j < 4; j++) r.n[j] = *reinterpret_cast<const float4 *>(np + 4 * j);
+            const uint16_t *nrec = np_ + ((long)bh * nc + c) * kQRec;
+            const int slot = (mt * 2 + nt) * 64 + lane;
+            r.n[0] = *reinterpret_cast<const uint4 *>(nrec + slot * 16);
+            r.n[1] = *reinterpret_cast<const uint4 *>(nrec + slot * 16 + 8);
+            r.ns = reinterpret_cast<const float *>(nrec + kQMant)[slot];
         }
         return r;
     };
@@ -247,9 +248,13 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
         q15_encode_tile(E, e_vk + ((long)bh * nc + c) * kQRec, nt, mt, lane);
         const uint16_t *Eh = sm + (cur ? L::E1h : L::E0h) + (lane & 31) * LDK + (lane >> 5) * 8, *El = Eh + kC * LDK;
         f32x16 acc;
+        {
+            const uint32_t nw[8] = {in.n[0].x, in.n[0].y, in.n[0].z, in.n[0].w, in.n[1].x, in.n[1].y, in.n[1].z, in.n[1].w};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            acc[4 * j] = in.n[j].x; acc[4 * j + 1] = in.n[j].y; acc[4 * j + 2] = in.n[j].z; acc[4 * j + 3] = in.n[j].w;
+            for (int j = 0; j < 8; j++) {
+                acc[2 * j] = (float)(int)(int16_t)(nw[j] & 0xffffu) * in.ns;
+                acc[2 * j + 1] = (float)((int)nw[j] >> 16) * in.ns;
+            }
         }
         bf16x8 eh[4], el[4];
 #pragma unroll
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 int chunk_bwd_pre_bf16(int B, int T_, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
-                       const float *tinv, void *mt, float *np, hipStream_t st) {
+                       const float *tinv, void *mt, void *np, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_bwd_pre_kernel),
@@ -304,11 +309,11 @@ int chunk_bwd_pre_bf16(int B, int T_, int H, const void *w, const void *q, const
     const int total = B * H * (T_ / kC);
     hipLaunchKernelGGL(wkv7c_bwd_pre_kernel, dim3((total + kChunksPerWG - 1) / kChunksPerWG), dim3(256), PreSmem::bytes, st, T_, H,
                        total, (const bf16_t *)w, (const bf16_t *)q, (const bf16_t *)a, (const bf16_t *)b, (const bf16_t *)dy, tinv,
-                       (uint16_t *)mt, np);
+                       (uint16_t *)mt, (uint16_t *)np);
     return (int)hipGetLastError();
 }
 
-int chunk_state_bf16(int BH, int nc, int H, const void *mt, const float *np, void *e_vk, const int *seq_off, int nseq,
+int chunk_state_bf16(int BH, int nc, int H, const void *mt, const void *np, void *e_vk, const int *seq_off, int nseq,
                      hipStream_t st) {
     static bool attr = false;
     if (!attr) {
@@ -319,7 +324,7 @@ int chunk_state_bf16(int BH, int nc, int H, const void *mt, const float *np, voi
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL(wkv7c_state_kernel, dim3((seq_off ? nseq * H : BH) * 2), dim3(128), StateSmem::bytes, st, nc, H, (const uint16_t *)mt,
-                       np, (uint16_t *)e_vk, seq_off);
+                       (const uint16_t *)np, (uint16_t *)e_vk, seq_off);
     return (int)hipGetLastError();
 }
 
