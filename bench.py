@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-checkpoint", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement (BASELINE configs[4]) after the timed region")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of the N > 1 launch path on a one-GPU box: all ranks share GPU 0 and exchange over gloo "
+                         "(RCCL refuses two ranks on one device); marked in the JSON line, not a measurement")
     ap.add_argument("--scalar-wkv", action="store_true", help="A/B: scalar WKV7 kernels (reference schema fwd, row-split bwd) instead of the chunked MFMA pair")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -185,7 +188,9 @@ def main():
     from rwkvtts_amd import backbone, ops, trainer
     from rwkvtts_amd.layouts import synthetic_spark_batch, synthetic_xy_batch
 
-    rank, local_rank, world = trainer.init_distributed()
+    rank, local_rank, world = trainer.init_distributed("gloo" if a.one_device else None)
+    if a.one_device:
+        local_rank = 0
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or let bench.py launch itself)")
     torch.cuda.set_device(local_rank)
@@ -320,12 +325,15 @@ def main():
                                    f"(fwd+bwd+AdamW), B={B}/GPU L={T}, synthetic text+speech tokens, random init "
                                    f"(BASELINE.json configs[{which}])",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
-                       "grad_allreduce": "bucketed RCCL AVG, bf16, overlapped with backward" if world > 1 else "none"},
+                       "grad_allreduce": ("bucketed gloo SUM in fp32 (rehearsal)" if a.one_device else
+                                          "bucketed RCCL AVG, bf16, overlapped with backward") if world > 1 else "none"},
             "loss": round(loss_val, 4),
             "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "roofline": roof,
         }
+        if a.one_device:
+            out["rehearsal"] = f"{world} ranks sharing GPU 0, exchange over gloo: exercises the launch path, not a measurement"
         if world > 1:
             r = tr.reducer
             out["comm"] = {"rccl_ranks": world, "backend": r.backend, "bytes_allreduced_per_step": tr.flat.numel * tr.flat.flat_grad.element_size(),

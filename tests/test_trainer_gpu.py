@@ -4,8 +4,10 @@
   * one GPU, RCCL group of one rank, collectives forced on: the whole hook -> flush -> bucket all-reduce -> wait path runs with
     the in-place split weight gradients (`_grad_slot`, rwkv7_sum_slabs_bf16) and must leave exactly the parameters the
     collective-free trainer leaves;
-  * two GPUs (skipped on a one-GPU box; the driver's 8-GPU scaling run is the other user of this path): two ranks, three
-    steps, different data per rank -> replicas bit-identical, and equal (bf16 bar) to one process stepping on the mean loss.
+  * two ranks, three steps, different data per rank -> replicas bit-identical, and equal (bf16 bar) to one process stepping on
+    the mean loss.  Over RCCL on two GPUs (skipped on a one-GPU box; the driver's 8-GPU scaling run is the other user of that
+    path), and -- so that the multi-process trainer with the real model and its in-place gradients runs on every GPU box --
+    as two processes sharing GPU 0 with the bucket exchange over gloo (RCCL refuses two ranks on one device).
 """
 import os
 import socket
@@ -62,12 +64,13 @@ def test_forced_allreduce_on_one_rank_equals_plain_trainer():
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _worker(rank, world, port, q, backend, one_device):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(0 if one_device else rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from rwkvtts_amd import trainer
-    trainer.init_distributed("nccl")
-    dev = torch.device("cuda", rank)
+    trainer.init_distributed(backend)
+    dev = torch.device("cuda", 0 if one_device else rank)
+    torch.cuda.set_device(dev)
     model = _model(dev)
     tr = trainer.DataParallelTrainer(model, lr=1e-3, warmup_steps=0, total_steps=10, bucket_bytes=64 << 10)
     losses = [float(tr.step(**_batch(model, rank, step))) for step in range(3)]
@@ -77,14 +80,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_two_ranks_rccl_real_model_replicas_identical_and_equal_single_process_mean():
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs (the GPU test box has one; covered on CPU by tests/test_trainer_dist.py over gloo)")
+def _two_ranks(backend, one_device):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, one_device)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
@@ -113,3 +113,15 @@ def test_two_ranks_rccl_real_model_replicas_identical_and_equal_single_process_m
     d = (p0 - ref).abs()
     assert d.max().item() <= 3 * 2 * 1e-3 + 2e-2 * ref.abs().max().item(), d.max().item()
     assert (d > 1e-3).float().mean().item() < 0.2
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_rccl_real_model_replicas_identical_and_equal_single_process_mean():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the GPU test box has one; the same run over gloo on one GPU is the next test)")
+    _two_ranks("nccl", False)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_sharing_one_gpu_over_gloo_real_model():
+    _two_ranks("gloo", True)
