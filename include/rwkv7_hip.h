@@ -194,17 +194,6 @@ int rwkv7_add_ln_bwd_f32(long rows, int D, const void *dh, const void *d_resid, 
                          const float *rstd, const void *gamma, void *dx, float *dparams_partial, int nblocks,
                          rwkv7_stream_t stream);
 
-/* ---- low-rank branches (rwkv_s2s_single_ffn.py:172-181: w0 + tanh(xw@w1)@w2, a0 + (xa@a1)@a2, v0 + (xv@v1)@v2,
- *      sigmoid(xg@g1)@g2; rwkvfla LoRA modules *.lora.0 / *.lora.2).  The two skinny products with a [M,K] operand
- *      and a [M,R] result, bf16, fp32 accumulate on MFMA.  R in {32,64,128}, K % 64 == 0, act 0 none / 1 tanh / 2 sigmoid.
- *        down     : a_out[M,R] = act(x[M,K] @ w1[R,K]^T)                       (w1 = lora.0.weight as stored)
- *        dgrad_up : dy[M,R]    = (dz[M,K] @ w2t[R,K]^T) * act'(a)              (w2t = lora.2.weight transposed)
- *      The [M,R] x [R,K] products and the weight gradients stay with the BLAS library. ---- */
-int rwkv7_lora_down_bf16(long M, int K, int R, int act, const void *x, const void *w1, void *a_out,
-                         rwkv7_stream_t stream);
-int rwkv7_lora_dgrad_up_bf16(long M, int K, int R, int act, const void *dz, const void *w2t, const void *a, void *dy,
-                             rwkv7_stream_t stream);
-
 /* after the scan (rwkv_s2s_single_ffn.py:192-195): out = (GroupNorm_H(y; gn_w, gn_b, eps) + (sum_head r*k*r_k) v) * g.
  * r_k is [H*64] flattened.  backward partials: P = 3 (d gn_w, d gn_b, d r_k). */
 int rwkv7_tmix_post_fwd_bf16(long rows, int D, const void *y, const void *r, const void *k, const void *v,

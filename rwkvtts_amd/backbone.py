@@ -109,11 +109,6 @@ def config_1p5b(**kw):
                        v_low_rank_dim=64, gate_low_rank_dim=256, **kw)
 
 
-# bf16 low-rank branches through csrc/lora.hip.  Off by default: measured on MI355X (tools/bench_lora.py) the BLAS
-# library serves x @ w1^T at 24 us for every rank, the hand-written kernel needs 19 / 30 / 47 us at R = 32 / 64 / 128.
-FUSED_LORA = False
-
-
 class Linear(nn.Linear):
     """nn.Linear (same parameters / state_dict keys) whose weight gradient is reduced over B*T in slabs
     (fused.wgrad_splitk) when training in bf16."""
@@ -134,8 +129,6 @@ class LoRA(nn.Module):
     def forward(self, x):
         if fused.lora_decode_supported(x, self.rank) and self.lora[0].weight.dtype == torch.bfloat16:
             return fused.lora_decode(x, self.lora[0].weight, self.lora[2].weight, self.lora[2].bias, self.activation)
-        if FUSED_LORA and fused.lora_supported(x, self.rank):
-            return fused.lora(x, self.lora[0].weight, self.lora[2].weight, self.lora[2].bias, self.activation)
         return self.lora(x)  # fp32 models and decode-sized inputs: BLAS
 
 

@@ -48,8 +48,6 @@ int decode_layer_ptrs();
 size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
 int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *, const void *,
                      const void *, const void *, const void *, float *, void *, int, hipStream_t);
-int lora_down_bf16(long, int, int, int, const void *, const void *, void *, hipStream_t);
-int lora_dgrad_up_bf16(long, int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 struct bf16_t;
 template <typename T> int mix_fwd(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, hipStream_t);
 template <typename T> int mix_bwd(int, int, int, int, const void *const *, const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t);
@@ -142,22 +140,6 @@ int rwkv7_wkv_bwd_split_variant_bf16(int B, int T, int H, const void *w, const v
                                      void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
                                      void *const *db, int wide, rwkv7_stream_t stream) {
     BWD2_BODY(wkv_bwd_split_bf16, wide)
-}
-
-static bool lora_shape_ok(long M, int K, int R, int act) {
-    return M > 0 && K > 0 && K % 64 == 0 && (R == 32 || R == 64 || R == 128) && act >= 0 && act <= 2;
-}
-int rwkv7_lora_down_bf16(long M, int K, int R, int act, const void *x, const void *w1, void *a_out,
-                         rwkv7_stream_t stream) {
-    if (any_null({x, w1, a_out})) return RWKV7_EINVAL;
-    if (!lora_shape_ok(M, K, R, act)) return RWKV7_ESHAPE;
-    return rwkv7::lora_down_bf16(M, K, R, act, x, w1, a_out, (hipStream_t)stream);
-}
-int rwkv7_lora_dgrad_up_bf16(long M, int K, int R, int act, const void *dz, const void *w2t, const void *a, void *dy,
-                             rwkv7_stream_t stream) {
-    if (any_null({dz, w2t, a, dy})) return RWKV7_EINVAL;
-    if (!lora_shape_ok(M, K, R, act)) return RWKV7_ESHAPE;
-    return rwkv7::lora_dgrad_up_bf16(M, K, R, act, dz, w2t, a, dy, (hipStream_t)stream);
 }
 
 int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_bytes) {

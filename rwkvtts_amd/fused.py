@@ -299,51 +299,6 @@ def tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_
 
 
 _ACT_ID = {None: 0, "tanh": 1, "sigmoid": 2}
-LORA_MIN_ROWS = 256   # below this (decode steps) the BLAS path is as good; the skinny kernels need rows to fill the GPU
-
-
-class _LoRA(torch.autograd.Function):
-    """act(x @ W1^T) @ W2^T + bias with the two [M,D]-operand products on rwkv7_lora_down / rwkv7_lora_dgrad_up
-    (csrc/lora.hip); the [M,R]-operand products and the weight gradients are BLAS calls.  bf16 only."""
-
-    @staticmethod
-    def forward(ctx, x, w1, w2, bias, act):
-        shp = x.shape
-        K = shp[-1]
-        x2 = _c(x).view(-1, K)
-        M, R = x2.shape[0], w1.shape[0]
-        w1c = _c(w1)
-        a = torch.empty(M, R, dtype=x.dtype, device=x.device)
-        with torch.cuda.device_of(x):
-            rc = _lib.lib().rwkv7_lora_down_bf16(ctypes.c_long(M), K, R, act, _p(x2), _p(w1c), _p(a), _stream(x))
-        _lib.check(rc, "lora_down")
-        z = torch.addmm(bias, a, w2.t()) if bias is not None else torch.mm(a, w2.t())
-        ctx.save_for_backward(x2, w1c, w2, a)
-        ctx.act, ctx.has_bias, ctx.shp = act, bias is not None, shp
-        return z.view(*shp[:-1], w2.shape[0])
-
-    @staticmethod
-    def backward(ctx, dz):
-        x2, w1, w2, a = ctx.saved_tensors
-        M, K = x2.shape
-        R, N = w1.shape[0], w2.shape[0]
-        dz2 = _c(dz).view(M, N)
-        dbias = dz2.sum(0) if ctx.has_bias else None
-        dw2 = wgrad_splitk(dz2, a)
-        dy = torch.empty_like(a)
-        w2t = w2.t().contiguous()
-        with torch.cuda.device_of(dz2):
-            rc = _lib.lib().rwkv7_lora_dgrad_up_bf16(ctypes.c_long(M), N, R, ctx.act, _p(dz2), _p(w2t), _p(a), _p(dy),
-                                                     _stream(dz2))
-        _lib.check(rc, "lora_dgrad_up")
-        dw1 = wgrad_splitk(dy, x2)
-        dx = torch.mm(dy, w1).view(ctx.shp)
-        return dx, dw1, dw2, dbias, None
-
-
-def lora_supported(x, rank):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and rank in (32, 64, 128) and x.shape[-1] % 64 == 0
-            and x.numel() // x.shape[-1] >= LORA_MIN_ROWS)
 
 
 def lora_decode_supported(x, rank):
@@ -364,11 +319,6 @@ def lora_decode(x, w1, w2, bias, activation):
                                           _stream(x))
     _lib.check(rc, "lora32")
     return y.view(*x.shape[:-1], N)
-
-
-def lora(x, w1, w2, bias, activation):
-    """act(x @ w1.T) @ w2.T + bias  (rwkvfla LoRA: lora.0.weight = w1 [R,D], lora.2.weight = w2 [D_out,R])."""
-    return _LoRA.apply(x, w1, w2, bias, _ACT_ID[activation])
 
 
 # ------------------------------------------------------------------------------------------------------

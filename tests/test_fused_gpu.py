@@ -160,67 +160,6 @@ def test_shape_and_device_errors():
         fused.relu_sq(torch.zeros(8))
 
 
-@pytest.mark.parametrize("R,act", [(32, None), (64, None), (64, "tanh"), (128, "sigmoid")])
-@pytest.mark.parametrize("M", [64, 200, 1024])
-def test_lora_skinny_kernels_vs_fp32_reference(R, act, M):
-    """rwkv7_lora_down / rwkv7_lora_dgrad_up (csrc/lora.hip) against the fp32 formula of
-    rwkv_s2s_single_ffn.py:172-181 on the same bf16-rounded inputs.  Tolerance: one bf16 rounding of the result
-    (2^-8 relative) plus the fp32 accumulation-order noise."""
-    from rwkvtts_amd import _lib
-    import ctypes
-    D = 256
-    g = torch.Generator().manual_seed(R + M)
-    x = (torch.randn(M, D, generator=g) * 0.7).bfloat16()
-    w1 = (torch.randn(R, D, generator=g) * 0.08).bfloat16()
-    w2 = (torch.randn(D, R, generator=g) * 0.1).bfloat16()
-    bias = None if act == "sigmoid" else (torch.randn(D, generator=g) * 0.1).bfloat16()
-    dz = torch.randn(M, D, generator=g).bfloat16()
-    f = {None: lambda t: t, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
-    # fp32 reference with autograd
-    xr, w1r, w2r = [t.float().requires_grad_(True) for t in (x, w1, w2)]
-    br = None if bias is None else bias.float().requires_grad_(True)
-    a_ref = f(xr @ w1r.t())
-    z_ref = a_ref @ w2r.t() + (0 if br is None else br)
-    z_ref.backward(dz.float())
-    # HIP path
-    xd, w1d, w2d = [t.to(DEV).requires_grad_(True) for t in (x, w1, w2)]
-    bd = None if bias is None else bias.to(DEV).requires_grad_(True)
-    z = fused.lora(xd, w1d, w2d, bd, act)
-    z.backward(dz.to(DEV))
-    _cmp(z, z_ref, 1e-2, "z")
-    _cmp(xd.grad, xr.grad, 1.5e-2, "dx")
-    _cmp(w1d.grad, w1r.grad, 1.5e-2, "dw1")
-    _cmp(w2d.grad, w2r.grad, 1.5e-2, "dw2")
-    if bias is not None:
-        _cmp(bd.grad, br.grad, 1e-2, "dbias")
-    # the down product alone, tight: only the final bf16 rounding separates it from fp32
-    a = torch.empty(M, R, dtype=torch.bfloat16, device=DEV)
-    rc = _lib.lib().rwkv7_lora_down_bf16(ctypes.c_long(M), D, R, fused._ACT_ID[act], ctypes.c_void_p(xd.data_ptr()),
-                                         ctypes.c_void_p(w1d.data_ptr()), ctypes.c_void_p(a.data_ptr()), None)
-    assert rc == 0
-    torch.cuda.synchronize()
-    err = (a.float().cpu() - a_ref.detach()).abs()
-    assert (err <= 2.0 ** -8 * a_ref.detach().abs() + 1e-3).all(), err.max().item()
-
-
-def test_lora_module_fused_equals_blas_path():
-    from rwkvtts_amd import backbone
-    torch.manual_seed(0)
-    m = backbone.LoRA(256, 256, 64, "tanh", True).to(DEV).bfloat16()
-    x = (torch.randn(4, 128, 256, device=DEV) * 0.5).bfloat16()
-    outs = {}
-    saved = backbone.FUSED_LORA
-    for flag in (True, False):
-        backbone.FUSED_LORA = flag
-        try:
-            outs[flag] = m(x).float()
-        finally:
-            backbone.FUSED_LORA = saved
-    assert (outs[True] - outs[False]).abs().max().item() <= 2e-2 * outs[False].abs().max().item()
-    # decode-sized input and fp32 stay on BLAS
-    assert not fused.lora_supported(x[:1, :1], 64) and not fused.lora_supported(x.float(), 64)
-
-
 @pytest.mark.parametrize("N,K", [(64, 256), (256, 256), (1024, 2048)])
 def test_linear_split_wgrad_vs_fp32_reference(N, K):
     """fused.linear: forward = F.linear; backward's weight gradient is summed over row slabs in fp32."""
