@@ -257,9 +257,10 @@ int rwkv7_wkv_chunk_fwd_seq_f32(int B, int T, int H, const void *w, const void *
                                 const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
 /* ---- chunked backward, bf16 (csrc/wkv7_chunk_bwd.hip, wkv7_chunk_bwd8.hip).  With H = S^T and the chunk quantities above, the
  *      adjoint state obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
- *   bwd_pre : parallel over chunks.  mt  = M_c^T as bf16 hi/lo planes, uint16 [B*H*T/32][2][64][64];
- *                                    np  = N'_c as a q15 record per chunk (int16 [4 tiles][64 lanes][16] in MFMA accumulator
- *                                          order + fp32 scale [4][64]; RWKV7_Q15_REC uint16 units per record)
+ *   bwd_pre : parallel over chunks.  mt  = M_c^T and np = N'_c, one q15 record per chunk each (int16 [4 tiles][64 lanes][16] +
+ *                                    fp32 scale [4][64]; RWKV7_Q15_REC uint16 units per record): N' in MFMA accumulator
+ *                                    order, M^T as the A fragments the state kernel multiplies with (tile = (k-tile, k'-tile),
+ *                                    lane = (row k % 32, half h), values k' = 32 k'-tile + 16 i + 8 h + j, i = 0..1, j = 0..7)
  *   state   : sequential over chunks (reverse), one workgroup per (head, half of the value columns).
  *             e_vk[b,h,c][v][k] = E_{c+1}, what chunk c receives from its future, as bf16 (the recurrence itself carries
  *             ~16 mantissa bits; the per-chunk kernel reads this rounded copy once). ---- */

@@ -6,7 +6,7 @@
 //     E_c = M_c^T E_{c+1} + N'_c ,   N'_c = Q~^T dY + W^T (A_qb^T dY)              (E_c = dL/dH at the START of chunk c)
 // is the only sequential object of the backward pass (tests/chunked_proto2.py validates the algebra against the oracle).
 // Three kernels:
-//   wkv7c_bwd_pre_kernel   grid B*H*(T/32), parallel: M_c^T (bf16 hi/lo planes) and N'_c (q15 record, MFMA tile order)
+//   wkv7c_bwd_pre_kernel   grid B*H*(T/32), parallel: M_c^T (q15 record, A-fragment order) and N'_c (q15 record, accumulator order)
 //   wkv7c_state_kernel     grid B*H, sequential over chunks in reverse: E for every chunk (one 64x64x64 product each)
 //   wkv7c_bwd_out8_kernel  grid B*H*(T/32), parallel: dw,dq,dk,dv,da,db of a chunk from (H_c, E_{c+1}, U = sa, dY)
 //                          (wkv7_chunk_bwd8.hip)
@@ -22,11 +22,11 @@ namespace {
 constexpr int kChunksPerWG = 4;     // bwd_pre walks this many consecutive chunks per workgroup, prefetching the next one's inputs
 
 struct PreSmem {  // offsets in uint16 units
-    // phase-1 inputs, contiguous: dead after phase 1 and overlaid by G1T and the M^T planes
+    // phase-1 inputs, contiguous: dead after phase 1 and overlaid by G1T
     static constexpr int QTh = 0, QTl = QTh + kC * LDK, BHh = QTl + kC * LDK, BHl = BHh + kC * LDK;
     static constexpr int ATTh = BHl + kC * LDK, ATTl = ATTh + kN * LDC, TMh = ATTl + kN * LDC, TMl = TMh + kC * LDC;
     static constexpr int end1 = TMl + kC * LDC;
-    static constexpr int G1Th = 0, G1Tl = G1Th + kN * LDC, MPh = G1Tl + kN * LDC, MPl = MPh + kN * LDK;   // M^T[k][k'] planes
+    static constexpr int G1Th = 0, G1Tl = G1Th + kN * LDC;
     static constexpr int QTTh = end1, QTTl = QTTh + kN * LDC, BCTh = QTTl + kN * LDC, BCTl = BCTh + kN * LDC;
     static constexpr int DYT = BCTl + kN * LDC, QBTh = DYT + kN * LDC, QBTl = QBTh + kC * LDC;
     static constexpr int WTh = QBTl + kC * LDC, WTl = WTh + kN * LDC;   // W^T planes
@@ -34,15 +34,14 @@ struct PreSmem {  // offsets in uint16 units
     static constexpr int end16 = gC + 2 * kN;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
-static_assert(PreSmem::MPl + kN * LDK <= PreSmem::end1, "G1T + M^T planes must fit over the phase-1 inputs");
-static_assert(PreSmem::ATTh % 8 == 0 && PreSmem::QTTh % 8 == 0 && PreSmem::WTh % 8 == 0 && PreSmem::gC % 8 == 0 &&
-                  PreSmem::MPh % 8 == 0, "16-byte alignment");
+static_assert(PreSmem::G1Tl + kN * LDC <= PreSmem::end1, "G1T planes must fit over the phase-1 inputs");
+static_assert(PreSmem::ATTh % 8 == 0 && PreSmem::QTTh % 8 == 0 && PreSmem::WTh % 8 == 0 && PreSmem::gC % 8 == 0, "16-byte alignment");
 static_assert(PreSmem::bytes <= 80 * 1024, "two workgroups per CU");
 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// pre: M_c^T (bf16 hi/lo, in MFMA A-fragment order: [chunk][k-tile][plane][k-step][lane][8]) and N'_c
+// pre: M_c^T (q15 record whose tiles are MFMA A fragments: tile (k-tile, k'-tile) = [lane][k-steps 2 k'-tile, +1][8]) and N'_c
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int nchunks_total, const bf16_t *__restrict__ w_,
                                                             const bf16_t *__restrict__ q_, const bf16_t *__restrict__ a_,
@@ -53,7 +52,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
     using L = PreSmem;
     float *sh_gC = reinterpret_cast<float *>(sm + L::gC);
     const int nc = T_ / kC;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: role branches must not become exec-masked regions
     const int pt = tid & 31, pk = (tid >> 5) * 8;
     const long tstride = (long)H * kN;
 
@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
     for (int ci = 0; ci < kChunksPerWG; ci++) {
         const int chunk = chunk0 + ci;
         if (chunk >= nchunks_total) break;
-        In nxt = cur;
-        if (ci + 1 < kChunksPerWG && chunk + 1 < nchunks_total) nxt = load(chunk + 1);
+        // unconditional (clamped) prefetch: a conditional load makes the s_waitcnt at the top of the next iteration vmcnt(0), which
+        // also waits for this iteration's record stores; the one wasted fetch per workgroup re-reads the last chunk (an L2 hit)
+        const In nxt = load(chunk + 1 < nchunks_total && ci + 1 < kChunksPerWG ? chunk + 1 : chunk);
         // ---- prologue -----------------------------------------------------------------------------------------------
         put_tm<false>(cur.tm, sm + L::TMh, sm + L::TMl, tid);
         float lw[8], G[8];
@@ -144,14 +145,26 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
                 if (mt == nt) {
                     const int n = lane & 31;
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        if (d_row(r, lane) == n) acc[r] += sh_gC[mt * 32 + n];
+                    for (int r = 0; r < 16; r++) acc[r] += d_row(r, lane) == n ? sh_gC[mt * 32 + n] : 0.f;
                 }
-                store_T_split(acc, sm + L::MPh + nt * 32 * LDK + mt * 32, sm + L::MPl + nt * 32 * LDK + mt * 32, LDK, lane);
+                // Lane (k, half h) holds M^T[k][k'] for k' = 32 mt + 8 q + 4 h + (0..3), q = 0..3 (registers 4q..4q+3); the state
+                // kernel's A fragment of k-step i wants k' = 32 mt + 16 i + 8 h + (0..7).  v_permlane32_swap of register
+                // groups q = 2i and q = 2i + 1 between the lane halves gives exactly that: afterwards acc[8i .. 8i+7] IS the
+                // fragment of k-step 2 mt + i, and the tile goes out as a q15 record (tile = (k-tile nt, k'-tile mt)) without
+                // touching LDS.
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * i + t]), __float_as_uint(acc[8 * i + 4 + t]), false, false);
+                        acc[8 * i + t] = __uint_as_float(sw[0]);
+                        acc[8 * i + 4 + t] = __uint_as_float(sw[1]);
+                    }
+                q15_encode_tile(acc, mt_ + (long)chunk * kQRec, nt, mt, lane);
             }
         }
         lds_barrier();
-        // ---- phase 3: N' = Q~^T dY + W^T G1 (one tile per wave, MFMA register layout); M^T planes -> fragment order ---------
+        // ---- phase 3: N' = Q~^T dY + W^T G1 (one tile per wave, MFMA register layout) ----------------------------------------
         {
             const int mt = wave >> 1, nt = wave & 1;
             f32x16 acc = zero16();  // D[m = k][n = v]
@@ -160,11 +173,6 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
                           sm + L::G1Tl + nt * 32 * LDC, LDC, lane);
             // N' as a q15 record in accumulator order (chunk_common.h), tile = wave: 3 stores per lane, 9 KB instead of 16 KB fp32
             q15_encode_tile(acc, np_ + (long)chunk * kQRec, wave >> 1, wave & 1, lane);
-            // wave = (k-tile mt, plane): the four 16-byte A fragments of its 32 rows of M^T
-            const uint16_t *pl = sm + ((wave & 1) ? L::MPl : L::MPh) + (mt * 32 + (lane & 31)) * LDK + (lane >> 5) * 8;
-            uint16_t *mo = mt_ + ((long)chunk * 4 + wave) * 4 * 512 + lane * 8;
-#pragma unroll
-            for (int i = 0; i < 4; i++) *reinterpret_cast<uint4 *>(mo + i * 512) = *reinterpret_cast<const uint4 *>(pl + 16 * i);
         }
         lds_barrier();  // the next chunk's prologue overwrites what phase 3 reads
         cur = nxt;
@@ -174,7 +182,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
 // ------------------------------------------------------------------------------------------------------------------
 // state: E_c = M_c^T E_{c+1} + N'_c, c = nc-1 .. 0; writes E_{c+1} (the adjoint state chunk c sees at its end) for every c
 // as a q15 record (chunk_common.h) e_vk[b,h,c], straight from the accumulator tiles.  M^T arrives in A-fragment order and N' in accumulator
-// order, so both go from global memory straight into MFMA operands / accumulators; only E itself passes through LDS
+// order, both as q15 records (the step is bound by the bytes a CU can pull per cycle: 13.8 KB per workgroup and step instead of
+// 20.5 KB with bf16 hi/lo planes), and go from registers straight into MFMA operands / accumulators; only E itself passes through LDS
 // (accumulator layout -> B-operand planes).  The chain is one 64x64x64 product per chunk; inputs are prefetched three
 // chunks ahead in registers so that the ~2 us HBM latency is off the critical path.
 // ------------------------------------------------------------------------------------------------------------------
@@ -185,6 +194,24 @@ struct StateSmem {  // E planes of one half of the value columns, [32 v][64 k], 
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
 }  // namespace
+
+#ifdef WKV7C_TIMING
+// profiling build only (python -m rwkvtts_amd.build --timing): cycle totals of the segments of one recurrence step, workgroup
+// 0, per wave.  The stamps force the waits they measure (lgkmcnt / vmcnt), so the build is slower than the product's.
+__device__ long long g_cstate_timing[2 * 8];
+#define STSTAMP(i)                                              \
+    do {                                                        \
+        const long long now_ = __builtin_readcyclecounter();    \
+        tacc_[i] += now_ - tprev_;                              \
+        tprev_ = now_;                                          \
+    } while (0)
+#define STWAIT_LGKM __builtin_amdgcn_s_waitcnt(0xC07F)
+#define STWAIT_VM __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define STSTAMP(i) do { } while (0)
+#define STWAIT_LGKM do { } while (0)
+#define STWAIT_VM do { } while (0)
+#endif
 
 __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const uint16_t *__restrict__ mt_, const uint16_t *__restrict__ np_,
                                                           uint16_t *__restrict__ e_vk, const int *__restrict__ seq_off_) {
@@ -203,7 +230,8 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
         bh = blockIdx.x >> 1;
         nt = blockIdx.x & 1;
     }
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: role branches must not become exec-masked regions
     const int mt = wave;
     // packed rows: one workgroup pair per (sequence, head) walks only that sequence's chunks (see wkv7c_fwd_kernel)
     int c0 = 0, c1 = nc;
@@ -218,18 +246,25 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
     }
 
     struct In {
-        bf16x8 mh[4], ml[4];
+        uint4 m[4];     // M^T: the lane's A fragments of k-steps 0..3 as int16 mantissas (two q15 tiles of 16) ...
+        float ms[2];    // ... and the two tiles' scales
         uint4 n[2];     // N' tile: 16 int16 mantissas of this lane (q15 record, accumulator order) ...
         float ns;       // ... and their scale
     };
+    // Unconditional (index clamped): a load inside a conditional makes the compiler's s_waitcnt bookkeeping take the minimum
+    // over both paths at the join, i.e. wait for ALL outstanding loads -- the three-step prefetch would be waited for at the top
+    // of every iteration (measured: 1000-1270 of 2900 cycles per step went there).
     auto load = [&](int c) {
         In r;
-        if (c >= c0) {
-            const uint16_t *mp = mt_ + (((long)bh * nc + c) * 4 + mt * 2) * 4 * 512 + lane * 8;
+        c = c < c0 ? c0 : c;
+        {
+            const uint16_t *mrec = mt_ + ((long)bh * nc + c) * kQRec;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                r.mh[i] = *reinterpret_cast<const bf16x8 *>(mp + i * 512);
-                r.ml[i] = *reinterpret_cast<const bf16x8 *>(mp + 4 * 512 + i * 512);
+            for (int j = 0; j < 2; j++) {   // tile (k-tile mt, k'-tile j) = k-steps 2j, 2j + 1
+                const int ms = (mt * 2 + j) * 64 + lane;
+                r.m[2 * j] = *reinterpret_cast<const uint4 *>(mrec + ms * 16);
+                r.m[2 * j + 1] = *reinterpret_cast<const uint4 *>(mrec + ms * 16 + 8);
+                r.ms[j] = reinterpret_cast<const float *>(mrec + kQMant)[ms];
             }
             const uint16_t *nrec = np_ + ((long)bh * nc + c) * kQRec;
             const int slot = (mt * 2 + nt) * 64 + lane;
@@ -242,10 +277,16 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
     for (int i = tid; i < 2 * kC * LDK; i += 128) sm[L::E0h + i] = 0;  // E_{nc} = 0
     f32x16 E = zero16();  // this wave's tile of the current E, accumulator layout [m = k][n = v]
     int cur = 0;
+#ifdef WKV7C_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev_ = __builtin_readcyclecounter();
+#endif
     auto step = [&](int c, const In &in) {
+        STSTAMP(0);   // loop overhead + issue of the prefetch of step c - 3
         // E_{c+1}, what chunk c receives from the future, as the per-chunk kernel's checkpoint: a q15 record straight from the
         // accumulator tile (3 stores per lane; the fp32 [k][v] copy was 16 scattered 4-byte stores and twice the bytes)
         q15_encode_tile(E, e_vk + ((long)bh * nc + c) * kQRec, nt, mt, lane);
+        STSTAMP(1);   // q15 record of E
         const uint16_t *Eh = sm + (cur ? L::E1h : L::E0h) + (lane & 31) * LDK + (lane >> 5) * 8, *El = Eh + kC * LDK;
         f32x16 acc;
         {
@@ -262,35 +303,70 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
             eh[i] = *reinterpret_cast<const bf16x8 *>(Eh + 16 * i);
             el[i] = *reinterpret_cast<const bf16x8 *>(El + 16 * i);
         }
+        STWAIT_LGKM;
+        STSTAMP(2);   // E fragments from LDS
+        STWAIT_VM;
+        STSTAMP(3);   // M^T / N' of this step in registers (prefetched three steps ago)
+        // M^T fragments: int16 mantissas -> fp32 -> bf16 hi/lo pairs (the recurrence needs ~16 mantissa bits per operand)
+        bf16x8 mh[4], ml[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t mw[4] = {in.m[i].x, in.m[i].y, in.m[i].z, in.m[i].w};
+            const float sc = in.ms[i >> 1];
+            uint32_t h4[4], l4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                split_pk((float)(int)(int16_t)(mw[j] & 0xffffu) * sc, (float)((int)mw[j] >> 16) * sc, h4[j], l4[j]);
+            mh[i] = __builtin_bit_cast(bf16x8, make_uint4(h4[0], h4[1], h4[2], h4[3]));
+            ml[i] = __builtin_bit_cast(bf16x8, make_uint4(l4[0], l4[1], l4[2], l4[3]));
+        }
         // three independent accumulator chains (one per hi/lo term): this loop is the sequential critical path, and
         // back-to-back dependent MFMAs of a lone wave expose their latency (one chain 171 us, two or three 163 us)
         f32x16 acc_b = zero16(), acc_c = zero16();
 #pragma unroll
         for (int i = 0; i < 4; i++) {  // D[m = k][n = v] += sum_k' M^T[k][k'] E[k'][v]
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.mh[i], eh[i], acc, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.mh[i], el[i], acc_b, 0, 0, 0);
-            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.ml[i], eh[i], acc_c, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[i], eh[i], acc, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[i], el[i], acc_b, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml[i], eh[i], acc_c, 0, 0, 0);
         }
         E = acc + (acc_b + acc_c);
+#ifdef WKV7C_TIMING
+        asm volatile("" ::"v"(E[0]), "v"(E[15]));
+#endif
+        STSTAMP(4);   // N' decode + 12 MFMAs + sum
         uint16_t *Oh = sm + (cur ? L::E0h : L::E1h), *Ol = Oh + kC * LDK;
         store_T_split(E, Oh + mt * 32, Ol + mt * 32, LDK, lane);  // planes [v (this half)][k]
+        STWAIT_LGKM;
+        STSTAMP(5);   // hi/lo split + transposed LDS stores
         lds_barrier();
+        STSTAMP(6);   // barrier
         cur ^= 1;
     };
     In r0 = load(c1 - 1), r1 = load(c1 - 2), r2 = load(c1 - 3);
     lds_barrier();
-    for (int c = c1 - 1; c >= c0; c -= 3) {
+    int c = c1 - 1;
+    for (; c - 2 >= c0; c -= 3) {   // straight-line body: the waits count exactly the loads issued after the ones they need
+        // the sched_barriers keep each prefetch where it is written: left alone, the scheduler sinks all three to the end of the
+        // body (shorter live ranges) and the first step of the next iteration waits for a load issued a few cycles earlier
         step(c, r0);
+        __builtin_amdgcn_sched_barrier(0);
         r0 = load(c - 3);
-        if (c - 1 >= c0) {
-            step(c - 1, r1);
-            r1 = load(c - 4);
-        }
-        if (c - 2 >= c0) {
-            step(c - 2, r2);
-            r2 = load(c - 5);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        step(c - 1, r1);
+        __builtin_amdgcn_sched_barrier(0);
+        r1 = load(c - 4);
+        __builtin_amdgcn_sched_barrier(0);
+        step(c - 2, r2);
+        __builtin_amdgcn_sched_barrier(0);
+        r2 = load(c - 5);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (c >= c0) step(c, r0);
+    if (c - 1 >= c0) step(c - 1, r1);
+#ifdef WKV7C_TIMING
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; i++) g_cstate_timing[wave * 8 + i] += tacc_[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -329,3 +405,13 @@ int chunk_state_bf16(int BH, int nc, int H, const void *mt, const void *np, void
 }
 
 }  // namespace rwkv7
+
+#ifdef WKV7C_TIMING
+extern "C" int rwkv7_debug_cstate_timing(long long *out, int reset) {
+    if (reset) {
+        long long z[16] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(rwkv7::g_cstate_timing), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rwkv7::g_cstate_timing), sizeof(long long) * 16);
+}
+#endif

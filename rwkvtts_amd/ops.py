@@ -309,7 +309,7 @@ def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off=None):
         raise ValueError(f"chunked WKV7 needs T % {CHUNK_T} == 0, got T={T}")
     nc = T // CHUNK_T
     dev = w.device
-    mt = torch.empty(B, H, nc, 2, C, C, dtype=torch.int16, device=dev)
+    mt = torch.empty(B, H, nc, Q15_REC, dtype=torch.int16, device=dev)
     np_ = torch.empty(B, H, nc, Q15_REC, dtype=torch.int16, device=dev)
     e_vk = torch.empty(B, H, nc, Q15_REC, dtype=torch.int16, device=dev)
     with torch.cuda.device_of(w):

@@ -88,15 +88,18 @@ def test_chunked_backward_state_recurrence_vs_prototype():
     mt, np_, e_vk = ops.wkv7_chunk_bwd_state(w, q, a, b, dy.to(DEV), tinv)
     e_f = ops.q15_decode(e_vk)
     torch.cuda.synchronize()
-    # M^T is stored in MFMA A-fragment order [k-tile][plane][k-step][lane][8]: row = 32*tile + lane%32, col = 16*step + 8*(lane//32) + j
-    frag = mt.cpu().view(torch.bfloat16).float().reshape(B, H, T // 32, 2, 2, 4, 64, 8)
-    frag = frag[:, :, :, :, 0] + frag[:, :, :, :, 1]                      # hi + lo -> [B,H,nc,tile,step,lane,8]
+    # M^T is a q15 record whose tiles are MFMA A fragments: tile = (k-tile, k'-tile), lane = k % 32 + 32 h, value 8 i + j =
+    # M^T[k][32 k'-tile + 16 i + 8 h + j]; one fp32 scale per (tile, lane)
+    rec = mt.cpu()
+    frag = rec[..., :4096].float().view(B, H, T // 32, 2, 2, 64, 2, 8) * \
+        rec[..., 4096:].contiguous().view(torch.float32).view(B, H, T // 32, 2, 2, 64, 1, 1)
     mt = torch.zeros(B, H, T // 32, 64, 64)
-    for tile in range(2):
-        for step in range(4):
-            for half in range(2):
-                mt[:, :, :, tile * 32:(tile + 1) * 32, 16 * step + 8 * half:16 * step + 8 * half + 8] = \
-                    frag[:, :, :, tile, step, 32 * half:32 * half + 32, :]
+    for kt in range(2):
+        for kpt in range(2):
+            for i in range(2):
+                for half in range(2):
+                    c0 = 32 * kpt + 16 * i + 8 * half
+                    mt[:, :, :, kt * 32:(kt + 1) * 32, c0:c0 + 8] = frag[:, :, :, kt, kpt, 32 * half:32 * half + 32, i, :]
     nc = T // 32
     for h in range(H):
         one = [t[0, :, h].float() for t in ins]
@@ -111,7 +114,7 @@ def test_chunked_backward_state_recurrence_vs_prototype():
             E = Ms[c].T @ E + Np[c]
         for c in range(nc):
             ref = Ms[c].T
-            assert (mt[0, h, c] - ref).abs().max() <= 2e-5 * ref.abs().max(), ("M^T", h, c)
+            assert (mt[0, h, c] - ref).abs().max() <= 4e-5 * ref.abs().max(), ("M^T", h, c)   # 2^-16 of a lane group's maximum + fp32-level error
             # N' travels as a q15 record in accumulator order: tiles [mt*2+nt][lane][16], one scale per (tile, lane)
             rec = np_[0, h, c].cpu()
             tiles = rec[:4096].float().view(4, 64, 16) * rec[4096:].contiguous().view(torch.float32).view(4, 64, 1)
