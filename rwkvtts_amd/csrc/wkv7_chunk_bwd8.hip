@@ -209,33 +209,39 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
     // half-dependent control flow around a load (a field copied from another field's result, a constant written on the other
     // path, a conditional load merged by a phi) made hipcc put s_waitcnt vmcnt + register moves right behind the loads, i.e.
     // every wave sat out an HBM latency inside this function (2.3k of 19k cycles per chunk).
-    auto load_rows = [&](int chunk) {
+    // The prefetch after a workgroup's last chunk is not skipped either (`valid` = false: every lane reads offset 0 of the
+    // tensors, one cache line per wave): a load under `if (more)` is merged with the old value by a phi, and hipcc then waits
+    // with vmcnt(0) at the loop header -- for the prefetches AND the gradient stores the epilogue has just issued.
+    auto load_rows = [&](int chunk, bool valid) {
         const int bh = chunk / nc, c = chunk - bh * nc;
         const int bb = bh / H, hh = bh - bb * H;
         Rows r;
         r.off = ((long)bb * T_ * H + hh) * kN + (long)(c * kC + lt) * tstride + lk;
+        const long lo = valid ? r.off : 0, to = valid ? (long)chunk * kC * kC + ltid * 4 : 0;
         const bf16_t *p0 = half ? b_ : w_, *p1 = half ? v_ : q_, *p2 = half ? dy_ : k_;
-        const float *pf = half ? sa_ + r.off : tinv_ + (long)chunk * kC * kC + ltid * 4;
-        const void *p3 = half ? static_cast<const void *>(sa_ + r.off + 4) : static_cast<const void *>(a_ + r.off);
-        r.x0 = *reinterpret_cast<const uint4 *>(p0 + r.off);
-        r.x1 = *reinterpret_cast<const uint4 *>(p1 + r.off);
-        r.x2 = *reinterpret_cast<const uint4 *>(p2 + r.off);
+        const float *pf = half ? sa_ + lo : tinv_ + to;
+        const void *p3 = half ? static_cast<const void *>(sa_ + lo + 4) : static_cast<const void *>(a_ + lo);
+        r.x0 = *reinterpret_cast<const uint4 *>(p0 + lo);
+        r.x1 = *reinterpret_cast<const uint4 *>(p1 + lo);
+        r.x2 = *reinterpret_cast<const uint4 *>(p2 + lo);
         r.f0 = *reinterpret_cast<const float4 *>(pf);
         r.x3 = *reinterpret_cast<const uint4 *>(p3);
         return r;
     };
     const int st_v = tid >> 3, st_k8 = (tid & 7) * 8;   // this thread's piece of a 64x64 state: value row qv, keys qk8 .. qk8 + 7
-    auto load_mats = [&](int chunk, Mats &r) {
-        const int bh = chunk / nc, c = chunk - bh * nc;
-        const uint16_t *er = e_vk + (long)chunk * kQRec;
-        const uint16_t *hr = hs_ + ((long)bh * nc + c + 1) * kQRec;
-        const bool hasC = c + 1 < nc;   // E = 0 after the last chunk of a head: H_C unused there (and hs has no entry nc)
+    // Branch-free as well.  After the last chunk of a head E = 0 and H_C is unused (hs has no entry nc): the record of the
+    // head's last chunk is fetched instead and its scales are zeroed where they are consumed (prologue 1), which zeroes H_C and
+    // the next chunk's H0.  Scales: threads 0-63 those of E, every other thread those of H_C (threads 64-127 use them).
+    auto load_mats = [&](int chunk, bool valid) {
+        Mats r;
+        const int ch = valid ? chunk : 0;
+        const int bh = ch / nc, c = ch - bh * nc;
+        const uint16_t *er = e_vk + (long)ch * kQRec;
+        const uint16_t *hr = hs_ + ((long)bh * nc + (c + 1 < nc ? c + 1 : c)) * kQRec;
         q15_load8(er, st_v, st_k8, r.e[0], r.e[1]);
-        r.hc[0] = r.hc[1] = make_uint2(0u, 0u);
-        if (hasC) q15_load8(hr, st_v, st_k8, r.hc[0], r.hc[1]);
-        r.sc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < 64) r.sc = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(er + kQMant) + tid * 4);
-        else if (tid < 128 && hasC) r.sc = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(hr + kQMant) + (tid - 64) * 4);
+        q15_load8(hr, st_v, st_k8, r.hc[0], r.hc[1]);
+        r.sc = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>((tid < 64 ? er : hr) + kQMant) + (tid & 63) * 4);
+        return r;
     };
 #if B8TIMING
     long long *tacc_ = reinterpret_cast<long long *>(sm + L::tacc);
@@ -243,9 +249,8 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
     lds_barrier();
 #endif
     const int chunk0 = blockIdx.x * kOut8ChunksPerWG;
-    Rows cur = load_rows(chunk0);
-    Mats curm;
-    load_mats(chunk0, curm);
+    Rows cur = load_rows(chunk0, true);
+    Mats curm = load_mats(chunk0, true);
     // H0 of a chunk = H_C of the chunk before it: fetched once, for the first chunk of this workgroup; afterwards the H_C
     // registers (and the scale buffer) of the previous iteration are reused.  Across a head / sequence boundary both sides are
     // zero: hs[..][first chunk] is written as zeros by the forward, and H_C of a head's last chunk is forced to zero above.
@@ -310,7 +315,10 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
             for (int j = 0; j < 4; j++) sh_gC[pk + j] = gam[j];
         }
         if (tid < 64) *reinterpret_cast<float4 *>(sh_sE + tid * 4) = curm.sc;
-        else if (tid < 128) *reinterpret_cast<float4 *>(sh_sH + (ci & 1) * 256 + (tid - 64) * 4) = curm.sc;
+        else if (tid < 128) {
+            const float z = (chunk % nc) + 1 < nc ? 1.f : 0.f;   // last chunk of a head: H_C = 0
+            *reinterpret_cast<float4 *>(sh_sH + (ci & 1) * 256 + (tid - 64) * 4) = make_float4(curm.sc.x * z, curm.sc.y * z, curm.sc.z * z, curm.sc.w * z);
+        }
         {
             const int o = pt * LDK + pk;
             put_row4(sm + L::QTh, sm + L::QTl, o, qv[0] * gam[0], qv[1] * gam[1], qv[2] * gam[2], qv[3] * gam[3]);
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
         // the next chunk's raw rows: three phases (~4k cycles) ahead of their use.  `cur` is dead since the restaging at the top of
         // the iteration and is overwritten in place (a second variable + copy at the loop end made hipcc wait for every
         // outstanding load at the loop header in order to move registers)
-        if (more) cur = load_rows(chunk + 1);
+        cur = load_rows(chunk + 1, more);
         // ---- phase D --------------------------------------------------------------------------------------------------------------
         const int lnD = fresh(lane);
         if (wave <= 1) {
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
         lds_barrier();
         B8STAMP(12);
         // the next chunk's E, H_C (used ~1.5 phases into its prologue); curm is dead since prologue 2
-        if (more) load_mats(chunk + 1, curm);
+        curm = load_mats(chunk + 1, more);
         // ---- phase F --------------------------------------------------------------------------------------------------------------
         const int lnF = fresh(lane);
         if (wave <= 1) {
@@ -534,12 +542,12 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out8_kernel(
             put(0, dG[0], dG[1], dG[2], dG[3]); put(1, dQ[0], dQ[1], dQ[2], dQ[3]); put(2, dK[0], dK[1], dK[2], dK[3]);
             put(3, sV4.x, sV4.y, sV4.z, sV4.w); put(4, dA[0], dA[1], dA[2], dA[3]); put(5, dB[0], dB[1], dB[2], dB[3]);
             lds_barrier();
-            bf16_t *const outs[6] = {dw_, dq_, dk_, dv_, da_, db_};
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const int t = half * 3 + i;
-                *reinterpret_cast<uint4 *>(outs[t] + off) = *reinterpret_cast<const uint4 *>(os + t * kC * LDK + lt * LDK + lk);
-            }
+            // per-half pointer selects, not an indexed pointer array: that loses the address space and the stores become flat_store
+            bf16_t *const o0 = half ? dv_ : dw_, *const o1 = half ? da_ : dq_, *const o2 = half ? db_ : dk_;
+            const uint16_t *src = os + half * 3 * kC * LDK + lt * LDK + lk;
+            *reinterpret_cast<uint4 *>(o0 + off) = *reinterpret_cast<const uint4 *>(src);
+            *reinterpret_cast<uint4 *>(o1 + off) = *reinterpret_cast<const uint4 *>(src + kC * LDK);
+            *reinterpret_cast<uint4 *>(o2 + off) = *reinterpret_cast<const uint4 *>(src + 2 * kC * LDK);
         }
         B8STAMP(15);
         // no barrier here: the next chunk's first writes go to the restaging area (P / temporaries), which nobody reads any more,
