@@ -188,37 +188,48 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
 // chunks ahead in registers so that the ~2 us HBM latency is off the critical path.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
-struct StateSmem {  // E planes of one half of the value columns, [32 v][64 k], double buffered
+constexpr int kStatePF = 4;   // recurrence steps whose inputs the helper waves keep in flight (registers)
+struct StateSmem {  // offsets in uint16 units
+    // E planes of this half of the value columns, [32 v][64 k] hi / lo, double buffered (B operand of the step's product)
     static constexpr int E0h = 0, E0l = E0h + kC * LDK, E1h = E0l + kC * LDK, E1l = E1h + kC * LDK;
-    static constexpr int end16 = E1l + kC * LDK;
+    // what the helper waves hand to the product waves, per buffer and tile, lane-private (lane l writes what lane l reads):
+    //   MF  M^T as bf16 A fragments  [plane hi/lo][k-step 4][lane 64][8]      NF  N' as fp32 accumulators [quarter 4][lane 64][4]
+    // and what comes back:  EF  the new E tile, fp32 accumulators [quarter 4][lane 64][4] (becomes the q15 record of the next step)
+    static constexpr int MFsz = 2 * 4 * 64 * 8, NFsz = 4 * 64 * 4 * 2;
+    static constexpr int MF = E1l + kC * LDK;             // [buf 2][tile 2][MFsz]
+    static constexpr int NF = MF + 4 * MFsz;              // [buf 2][tile 2][NFsz]
+    static constexpr int EF = NF + 4 * NFsz;              // [buf 2][tile 2][NFsz]
+    static constexpr int end16 = EF + 4 * NFsz;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
+static_assert(StateSmem::MF % 8 == 0 && StateSmem::NF % 8 == 0 && StateSmem::EF % 8 == 0, "16-byte alignment");
 }  // namespace
 
 #ifdef WKV7C_TIMING
 // profiling build only (python -m rwkvtts_amd.build --timing): cycle totals of the segments of one recurrence step, workgroup
-// 0, per wave.  The stamps force the waits they measure (lgkmcnt / vmcnt), so the build is slower than the product's.
-__device__ long long g_cstate_timing[2 * 8];
+// 0, per wave (waves 0-1: product waves, 2-3: helpers).
+__device__ long long g_cstate_timing[4 * 8];
 #define STSTAMP(i)                                              \
     do {                                                        \
         const long long now_ = __builtin_readcyclecounter();    \
         tacc_[i] += now_ - tprev_;                              \
         tprev_ = now_;                                          \
     } while (0)
-#define STWAIT_LGKM __builtin_amdgcn_s_waitcnt(0xC07F)
-#define STWAIT_VM __builtin_amdgcn_s_waitcnt(0x0F70)
 #else
 #define STSTAMP(i) do { } while (0)
-#define STWAIT_LGKM do { } while (0)
-#define STWAIT_VM do { } while (0)
 #endif
 
-__global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const uint16_t *__restrict__ mt_, const uint16_t *__restrict__ np_,
+// One workgroup per (head, half of the value columns): the value columns of E never mix (E_c = M^T E + N' acts on columns).
+// Waves 0-1 ("product") own the two 32-row tiles of that half and do nothing but the chain
+//     E fragments, M^T fragments, N' from LDS -> 12 MFMAs -> sum -> E as fp32 + as hi/lo planes to LDS -> barrier;
+// waves 2-3 ("helpers", one per tile) do everything that is not on that chain, one step ahead: the global prefetch ring, the
+// decode of M^T / N' (q15 -> bf16 hi/lo fragments / fp32) and the q15 record of E (two helpers per tile measured no faster).  A lone wave issues one instruction per ~4
+// cycles, and with everything on the product wave a step was ~330 VALU instructions = 2400 cycles whatever their order (three
+// prefetch depths and MFMA-shadow scheduling all measured the same); the chain alone is ~130 issue slots.
+__global__ __launch_bounds__(256) void wkv7c_state_kernel(int nc, int H, const uint16_t *__restrict__ mt_, const uint16_t *__restrict__ np_,
                                                           uint16_t *__restrict__ e_vk, const int *__restrict__ seq_off_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = StateSmem;
-    // the value columns of E never mix (E_c = M^T E + N' acts on columns): one workgroup per (head, half of the value
-    // columns), 2 waves = the two 32-row tiles of that half -> 2 B H workgroups keep all 256 CUs streaming
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the two halves of a head get block ids g and
     // g + 8 so that they share an L2 and M_c^T is fetched from HBM once, not twice.
     int bh, nt;
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: role branches must not become exec-masked regions
-    const int mt = wave;
+    const int mt = wave & 1;
     // packed rows: one workgroup pair per (sequence, head) walks only that sequence's chunks (see wkv7c_fwd_kernel)
     int c0 = 0, c1 = nc;
     if (seq_off_) {
@@ -244,20 +255,78 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
         bh = bb * H + hh;
         if (c1 <= c0) return;
     }
+    const int nsteps = c1 - c0;
+    // E_{nc} = 0: planes of buffer 0 and the fp32 tile the first step's record is made from (EF buffer 1)
+    for (int i = tid; i < 2 * kC * LDK; i += 256) sm[L::E0h + i] = 0;
+    for (int i = tid; i < 2 * L::NFsz; i += 256) sm[L::EF + 2 * L::NFsz + i] = 0;
+#ifdef WKV7C_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev_ = __builtin_readcyclecounter();
+#endif
 
-    struct In {
-        uint4 m[4];     // M^T: the lane's A fragments of k-steps 0..3 as int16 mantissas (two q15 tiles of 16) ...
-        float ms[2];    // ... and the two tiles' scales
-        uint4 n[2];     // N' tile: 16 int16 mantissas of this lane (q15 record, accumulator order) ...
-        float ns;       // ... and their scale
-    };
-    // Unconditional (index clamped): a load inside a conditional makes the compiler's s_waitcnt bookkeeping take the minimum
-    // over both paths at the join, i.e. wait for ALL outstanding loads -- the three-step prefetch would be waited for at the top
-    // of every iteration (measured: 1000-1270 of 2900 cycles per step went there).
-    auto load = [&](int c) {
-        In r;
-        c = c < c0 ? c0 : c;
-        {
+    if (wave < 2) {
+        // ------------------------------------------------------------------------------------------ product waves
+        lds_barrier();   // helpers: fragments of the first step; zeros above
+        for (int k = 0; k < nsteps; k++) {
+            const int buf = k & 1;
+            STSTAMP(0);
+            const uint16_t *Eh = sm + (buf ? L::E1h : L::E0h) + (lane & 31) * LDK + (lane >> 5) * 8, *El = Eh + kC * LDK;
+            const uint16_t *mf = sm + L::MF + (buf * 2 + mt) * L::MFsz + lane * 8;
+            const float *nf = reinterpret_cast<const float *>(sm + L::NF + (buf * 2 + mt) * L::NFsz) + lane * 4;
+            bf16x8 eh[4], el[4], mh[4], ml[4];
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                mh[i] = *reinterpret_cast<const bf16x8 *>(mf + i * 512);
+                eh[i] = *reinterpret_cast<const bf16x8 *>(Eh + 16 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                el[i] = *reinterpret_cast<const bf16x8 *>(El + 16 * i);
+                ml[i] = *reinterpret_cast<const bf16x8 *>(mf + 4 * 512 + i * 512);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 t = *reinterpret_cast<const float4 *>(nf + q * 256);
+                acc[4 * q] = t.x; acc[4 * q + 1] = t.y; acc[4 * q + 2] = t.z; acc[4 * q + 3] = t.w;
+            }
+            STSTAMP(1);
+            // three independent accumulator chains (one per hi/lo term), the first one starting from N'
+            f32x16 acc_b = zero16(), acc_c = zero16();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {  // D[m = k][n = v] += sum_k' M^T[k][k'] E[k'][v]
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[i], eh[i], acc, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[i], el[i], acc_b, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml[i], eh[i], acc_c, 0, 0, 0);
+            }
+            const f32x16 E = acc + (acc_b + acc_c);
+#ifdef WKV7C_TIMING
+            asm volatile("" ::"v"(E[0]), "v"(E[15]));
+#endif
+            STSTAMP(2);
+            float *ef = reinterpret_cast<float *>(sm + L::EF + (buf * 2 + mt) * L::NFsz) + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) *reinterpret_cast<float4 *>(ef + q * 256) = make_float4(E[4 * q], E[4 * q + 1], E[4 * q + 2], E[4 * q + 3]);
+            uint16_t *Oh = sm + (buf ? L::E0h : L::E1h), *Ol = Oh + kC * LDK;
+            store_T_split(E, Oh + mt * 32, Ol + mt * 32, LDK, lane);  // planes [v (this half)][k]
+            STSTAMP(3);
+            lds_barrier();
+            STSTAMP(4);
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------ helper waves
+        struct In {
+            uint4 m[4];     // M^T: the lane's A fragments of k-steps 0..3 as int16 mantissas (two q15 tiles of 16) ...
+            float ms[2];    // ... and the two tiles' scales
+            uint4 n[2];     // N' tile: 16 int16 mantissas of this lane (q15 record, accumulator order) ...
+            float ns;       // ... and their scale
+        };
+        // Unconditional (index clamped): a load inside a conditional makes the compiler's s_waitcnt bookkeeping take the minimum
+        // over both paths at the join, i.e. wait for ALL outstanding loads (measured in the two-wave kernel: 1000-1270 of 2900
+        // cycles per step).
+        auto load = [&](int c) {
+            In r;
+            c = c < c0 ? c0 : c;
             const uint16_t *mrec = mt_ + ((long)bh * nc + c) * kQRec;
 #pragma unroll
             for (int j = 0; j < 2; j++) {   // tile (k-tile mt, k'-tile j) = k-steps 2j, 2j + 1
@@ -271,98 +340,77 @@ __global__ __launch_bounds__(128) void wkv7c_state_kernel(int nc, int H, const u
             r.n[0] = *reinterpret_cast<const uint4 *>(nrec + slot * 16);
             r.n[1] = *reinterpret_cast<const uint4 *>(nrec + slot * 16 + 8);
             r.ns = reinterpret_cast<const float *>(nrec + kQMant)[slot];
-        }
-        return r;
-    };
-    for (int i = tid; i < 2 * kC * LDK; i += 128) sm[L::E0h + i] = 0;  // E_{nc} = 0
-    f32x16 E = zero16();  // this wave's tile of the current E, accumulator layout [m = k][n = v]
-    int cur = 0;
-#ifdef WKV7C_TIMING
-    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tprev_ = __builtin_readcyclecounter();
-#endif
-    auto step = [&](int c, const In &in) {
-        STSTAMP(0);   // loop overhead + issue of the prefetch of step c - 3
-        // E_{c+1}, what chunk c receives from the future, as the per-chunk kernel's checkpoint: a q15 record straight from the
-        // accumulator tile (3 stores per lane; the fp32 [k][v] copy was 16 scattered 4-byte stores and twice the bytes)
-        q15_encode_tile(E, e_vk + ((long)bh * nc + c) * kQRec, nt, mt, lane);
-        STSTAMP(1);   // q15 record of E
-        const uint16_t *Eh = sm + (cur ? L::E1h : L::E0h) + (lane & 31) * LDK + (lane >> 5) * 8, *El = Eh + kC * LDK;
-        f32x16 acc;
-        {
+            return r;
+        };
+        // q15 -> what the product wave consumes, into buffer `buf`
+        auto publish = [&](const In &in, int buf) {
+            uint16_t *mf = sm + L::MF + (buf * 2 + mt) * L::MFsz + lane * 8;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {   // int16 mantissas -> fp32 -> bf16 hi/lo pairs (the recurrence needs ~16 mantissa bits per operand)
+                const uint32_t mw[4] = {in.m[i].x, in.m[i].y, in.m[i].z, in.m[i].w};
+                const float sc = in.ms[i >> 1];
+                uint32_t h4[4], l4[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    split_pk((float)(int)(int16_t)(mw[j] & 0xffffu) * sc, (float)((int)mw[j] >> 16) * sc, h4[j], l4[j]);
+                *reinterpret_cast<uint4 *>(mf + i * 512) = make_uint4(h4[0], h4[1], h4[2], h4[3]);
+                *reinterpret_cast<uint4 *>(mf + 4 * 512 + i * 512) = make_uint4(l4[0], l4[1], l4[2], l4[3]);
+            }
+            float *nf = reinterpret_cast<float *>(sm + L::NF + (buf * 2 + mt) * L::NFsz) + lane * 4;
             const uint32_t nw[8] = {in.n[0].x, in.n[0].y, in.n[0].z, in.n[0].w, in.n[1].x, in.n[1].y, in.n[1].z, in.n[1].w};
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                acc[2 * j] = (float)(int)(int16_t)(nw[j] & 0xffffu) * in.ns;
-                acc[2 * j + 1] = (float)((int)nw[j] >> 16) * in.ns;
+            for (int q = 0; q < 4; q++) {
+                float4 t;
+                t.x = (float)(int)(int16_t)(nw[2 * q] & 0xffffu) * in.ns;
+                t.y = (float)((int)nw[2 * q] >> 16) * in.ns;
+                t.z = (float)(int)(int16_t)(nw[2 * q + 1] & 0xffffu) * in.ns;
+                t.w = (float)((int)nw[2 * q + 1] >> 16) * in.ns;
+                *reinterpret_cast<float4 *>(nf + q * 256) = t;
+            }
+        };
+        // interval k (the product waves run step k = chunk c1-1-k): record of the E that ENTERS step k (what chunk c receives from
+        // its future; made by step k-1, zero for k = 0) -> e_vk[c]; fragments of step k+1 -> the other buffer
+        auto interval = [&](int k, const In &next) {
+            STSTAMP(0);
+            const int c = c1 - 1 - k;
+            const float *ef = reinterpret_cast<const float *>(sm + L::EF + ((((k & 1) ^ 1) * 2 + mt) * L::NFsz)) + lane * 4;
+            f32x16 E;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 t = *reinterpret_cast<const float4 *>(ef + q * 256);
+                E[4 * q] = t.x; E[4 * q + 1] = t.y; E[4 * q + 2] = t.z; E[4 * q + 3] = t.w;
+            }
+            q15_encode_tile(E, e_vk + ((long)bh * nc + c) * kQRec, nt, mt, lane);
+            STSTAMP(1);
+            publish(next, (k & 1) ^ 1);
+            STSTAMP(2);
+            lds_barrier();
+            STSTAMP(4);
+        };
+        In r[kStatePF];
+#pragma unroll
+        for (int i = 0; i < kStatePF; i++) r[i] = load(c1 - 1 - i);   // r[i]: inputs of step i (mod kStatePF)
+        publish(r[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+        r[0] = load(c1 - 1 - kStatePF);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+        // interval k publishes step k+1 from r[(k+1) % PF] and then refills that slot with step k+1+PF
+        int k = 0;
+        for (; k + kStatePF <= nsteps; k += kStatePF) {   // straight-line body: the waits count exactly the loads issued after the ones they need
+#pragma unroll
+            for (int i = 0; i < kStatePF; i++) {
+                interval(k + i, r[(i + 1) % kStatePF]);
+                // the sched_barriers keep each prefetch where it is written (the scheduler would sink them to the end of the body)
+                __builtin_amdgcn_sched_barrier(0);
+                r[(i + 1) % kStatePF] = load(c1 - 1 - (k + i + 1 + kStatePF));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        bf16x8 eh[4], el[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            eh[i] = *reinterpret_cast<const bf16x8 *>(Eh + 16 * i);
-            el[i] = *reinterpret_cast<const bf16x8 *>(El + 16 * i);
-        }
-        STWAIT_LGKM;
-        STSTAMP(2);   // E fragments from LDS
-        STWAIT_VM;
-        STSTAMP(3);   // M^T / N' of this step in registers (prefetched three steps ago)
-        // M^T fragments: int16 mantissas -> fp32 -> bf16 hi/lo pairs (the recurrence needs ~16 mantissa bits per operand)
-        bf16x8 mh[4], ml[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t mw[4] = {in.m[i].x, in.m[i].y, in.m[i].z, in.m[i].w};
-            const float sc = in.ms[i >> 1];
-            uint32_t h4[4], l4[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                split_pk((float)(int)(int16_t)(mw[j] & 0xffffu) * sc, (float)((int)mw[j] >> 16) * sc, h4[j], l4[j]);
-            mh[i] = __builtin_bit_cast(bf16x8, make_uint4(h4[0], h4[1], h4[2], h4[3]));
-            ml[i] = __builtin_bit_cast(bf16x8, make_uint4(l4[0], l4[1], l4[2], l4[3]));
-        }
-        // three independent accumulator chains (one per hi/lo term): this loop is the sequential critical path, and
-        // back-to-back dependent MFMAs of a lone wave expose their latency (one chain 171 us, two or three 163 us)
-        f32x16 acc_b = zero16(), acc_c = zero16();
-#pragma unroll
-        for (int i = 0; i < 4; i++) {  // D[m = k][n = v] += sum_k' M^T[k][k'] E[k'][v]
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[i], eh[i], acc, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[i], el[i], acc_b, 0, 0, 0);
-            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml[i], eh[i], acc_c, 0, 0, 0);
-        }
-        E = acc + (acc_b + acc_c);
-#ifdef WKV7C_TIMING
-        asm volatile("" ::"v"(E[0]), "v"(E[15]));
-#endif
-        STSTAMP(4);   // N' decode + 12 MFMAs + sum
-        uint16_t *Oh = sm + (cur ? L::E0h : L::E1h), *Ol = Oh + kC * LDK;
-        store_T_split(E, Oh + mt * 32, Ol + mt * 32, LDK, lane);  // planes [v (this half)][k]
-        STWAIT_LGKM;
-        STSTAMP(5);   // hi/lo split + transposed LDS stores
-        lds_barrier();
-        STSTAMP(6);   // barrier
-        cur ^= 1;
-    };
-    In r0 = load(c1 - 1), r1 = load(c1 - 2), r2 = load(c1 - 3);
-    lds_barrier();
-    int c = c1 - 1;
-    for (; c - 2 >= c0; c -= 3) {   // straight-line body: the waits count exactly the loads issued after the ones they need
-        // the sched_barriers keep each prefetch where it is written: left alone, the scheduler sinks all three to the end of the
-        // body (shorter live ranges) and the first step of the next iteration waits for a load issued a few cycles earlier
-        step(c, r0);
-        __builtin_amdgcn_sched_barrier(0);
-        r0 = load(c - 3);
-        __builtin_amdgcn_sched_barrier(0);
-        step(c - 1, r1);
-        __builtin_amdgcn_sched_barrier(0);
-        r1 = load(c - 4);
-        __builtin_amdgcn_sched_barrier(0);
-        step(c - 2, r2);
-        __builtin_amdgcn_sched_barrier(0);
-        r2 = load(c - 5);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < kStatePF - 1; i++)
+            if (k + i < nsteps) interval(k + i, r[(i + 1) % kStatePF]);
     }
-    if (c >= c0) step(c, r0);
-    if (c - 1 >= c0) step(c - 1, r1);
 #ifdef WKV7C_TIMING
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; i++) g_cstate_timing[wave * 8 + i] += tacc_[i];
@@ -399,7 +447,7 @@ int chunk_state_bf16(int BH, int nc, int H, const void *mt, const void *np, void
         attr = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(wkv7c_state_kernel, dim3((seq_off ? nseq * H : BH) * 2), dim3(128), StateSmem::bytes, st, nc, H, (const uint16_t *)mt,
+    hipLaunchKernelGGL(wkv7c_state_kernel, dim3((seq_off ? nseq * H : BH) * 2), dim3(256), StateSmem::bytes, st, nc, H, (const uint16_t *)mt,
                        (const uint16_t *)np, (uint16_t *)e_vk, seq_off);
     return (int)hipGetLastError();
 }
@@ -409,9 +457,9 @@ int chunk_state_bf16(int BH, int nc, int H, const void *mt, const void *np, void
 #ifdef WKV7C_TIMING
 extern "C" int rwkv7_debug_cstate_timing(long long *out, int reset) {
     if (reset) {
-        long long z[16] = {0};
+        long long z[32] = {0};
         return (int)hipMemcpyToSymbol(HIP_SYMBOL(rwkv7::g_cstate_timing), z, sizeof(z));
     }
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rwkv7::g_cstate_timing), sizeof(long long) * 16);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rwkv7::g_cstate_timing), sizeof(long long) * 32);
 }
 #endif

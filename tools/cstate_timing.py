@@ -20,11 +20,13 @@ for _ in range(N):
 torch.cuda.synchronize()
 ts = sorted(x.elapsed_time(e) for x, e in ops.KERNEL_TIMERS["wkv7c_state"])
 ops.KERNEL_TIMERS = None
-buf = (ctypes.c_longlong * 16)()
+buf = (ctypes.c_longlong * 32)()
 lib.rwkv7_debug_cstate_timing(buf, 0)
-names = ["loop+prefetch issue", "q15(E)", "LDS frags", "wait M^T/N'", "decode+MFMA+sum", "split+LDS store", "barrier", "-"]
 steps = T // 32
 print(f"wkv7c_state with stamps: median {ts[len(ts) // 2] * 1e3:.1f} us; cycles per step (workgroup 0):")
-for wv in range(2):
-    vals = [buf[wv * 8 + i] / N / steps for i in range(8)]
-    print(f"wave {wv}: total {sum(vals):6.0f} | " + " ".join(f"{names[i]}={vals[i]:5.0f}" for i in range(7)))
+names = {0: ["loop", "LDS reads issued", "wait + 12 MFMA + sum", "E -> LDS (fp32 + hi/lo planes)", "barrier"],
+         1: ["loop + prefetch", "E record (q15) + stores", "decode M^T, N' -> LDS", "-", "barrier"]}
+for wv in range(4):
+    vals = [buf[wv * 8 + i] / N / steps for i in range(5)]
+    nm = names[min(wv >> 1, 1)]
+    print(f"wave {wv} ({'product' if wv < 2 else 'helper'}): total {sum(vals):6.0f} | " + "  ".join(f"{nm[i]}={vals[i]:5.0f}" for i in range(5)))
