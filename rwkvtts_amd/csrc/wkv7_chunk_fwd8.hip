@@ -23,6 +23,20 @@
 
 namespace rwkv7 {
 
+#ifdef WKV7C_TIMING
+// profiling build only (python -m rwkvtts_amd.build --timing): cycle totals per interval (work, then barrier wait), workgroup 0,
+// per wave (0-3 consumer, 4-7 producer); tools/cfwd8_timing.py
+__device__ long long g_cfwd8_timing[8 * 12];
+#define F8STAMP(i)                                              \
+    do {                                                        \
+        const long long now_ = __builtin_readcyclecounter();    \
+        tacc_[i] += now_ - tprev_;                              \
+        tprev_ = now_;                                          \
+    } while (0)
+#else
+#define F8STAMP(i) do { } while (0)
+#endif
+
 namespace {
 constexpr int LDK = kN + kPad;  // planes with K = 64 columns
 constexpr int LDC = kC + kPad;  // planes with K = 32 columns
@@ -137,6 +151,10 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
     float ksL[8], bsL[8];
     float4 tmreg = make_float4(0.f, 0.f, 0.f, 0.f);
     lds_barrier();
+#ifdef WKV7C_TIMING
+    long long tacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev_ = __builtin_readcyclecounter();
+#endif
 
     // The two roles run disjoint code (separate register allocation) with the same barrier sequence: four per iteration.
     if (role == 0) {
@@ -164,7 +182,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                     store_T_split(acc, sm + L::QKh, sm + L::QKl, LDC, lane);
                 }   // wave 3: idle here (the T planes come from the producer)
             }
+            F8STAMP(0);
             lds_barrier();
+            F8STAMP(1);
             // =============================================================== interval 2
             f32x16 accY = zero16();  // consumer wave 3: the part of Y that does not need U, finished in interval 4
             if (cc >= c0) {
@@ -179,7 +199,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                     mma_gen<kC, false, true, true, false>(accY, sm + L::QKh, sm + L::QKl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
                 }
             }
+            F8STAMP(2);
             lds_barrier();
+            F8STAMP(3);
             // =============================================================== interval 3
             if (cc >= c0) {
                 if (wave == 0) {  // U = T R
@@ -192,7 +214,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                     }
                 }
             }
+            F8STAMP(4);
             lds_barrier();
+            F8STAMP(5);
             // =============================================================== interval 4
             if (cc >= c0) {
                 if (wave == 3) {
@@ -211,7 +235,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                     for (int r = 0; r < 16; r++) Smaster[r] = gCc[kt * 32 + d_row(r, lane)] * (Smaster[r] + acc[r]);
                 }
             }
+            F8STAMP(6);
             lds_barrier();
+            F8STAMP(7);
             if (cc >= c0) {
                 // y (and sa) of this chunk: thread (pt, pv) owns 4 value columns of one step
                 const long o = head_base + (long)(cc * kC + pt) * tstride + vh * VH + pv;
@@ -257,14 +283,18 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                 bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
                 vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w;
             }
+            F8STAMP(0);
             lds_barrier();
+            F8STAMP(1);
             // =============================================================== interval 2
             if (pc < c1) {
                 // inclusive cumulative log-decay over the chunk: DPP prefix sum across the 32 lanes that hold the 32 steps
     #pragma unroll
                 for (int j = 0; j < 8; j++) Gc[j] = scan32(lw[j]);
             }
+            F8STAMP(2);
             lds_barrier();
+            F8STAMP(3);
             // =============================================================== interval 3
             if (pc < c1) {
                 // scaled operands of chunk pc, split into bf16 hi/lo pairs (stored in interval 4)
@@ -292,7 +322,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                     bsL[j] = bs[j];
                 }
             }
+            F8STAMP(4);
             lds_barrier();
+            F8STAMP(5);
             // =============================================================== interval 4
             if (pc < c1) {
                 // planes of chunk pc into its buffer (the consumer reads the other one); then the next chunk's raw rows -> staging
@@ -330,10 +362,16 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
                 }
                 if (pc + 1 < c1) stage_raw();
             }
+            F8STAMP(6);
             lds_barrier();
+            F8STAMP(7);
             
         }
     }
+#ifdef WKV7C_TIMING
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 12; i++) g_cfwd8_timing[(tid >> 6) * 12 + i] += tacc_[i];
+#endif
 }
 
 static int launch_fwd8(bool save, int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
@@ -366,3 +404,13 @@ int chunk_fwd8_bf16(int B, int T_, int H, const void *w, const void *q, const vo
 }
 
 }  // namespace rwkv7
+
+#ifdef WKV7C_TIMING
+extern "C" int rwkv7_debug_cfwd8_timing(long long *out, int reset) {
+    if (reset) {
+        long long z[96] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(rwkv7::g_cfwd8_timing), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rwkv7::g_cfwd8_timing), sizeof(long long) * 96);
+}
+#endif
