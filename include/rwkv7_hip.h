@@ -300,6 +300,11 @@ int rwkv7_adamw_groups_bf16(long n, float *p32, const void *g16, float *m, float
  *      228-229, reduced over B*T in S row slabs with fp32 partials): out[n] (bf16) = (accumulate ? out[n] : 0) +
  *      sum_s parts[s][n].  out may be the parameter's slice of the flat gradient buffer.  n % 4 == 0. ---- */
 int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, rwkv7_stream_t stream);
+/*   Weight gradient of a low-rank projection (rwkv_s2s_single_ffn.py:172-184, autograd of x @ w1 / h @ w2): for y = x W^T,
+ *   parts[s][N][K] (fp32) = dy[slab s][N]^T x[slab s][K], slab = M / S consecutive rows (a multiple of 128); one of N, K is the
+ *   rank (32, 64 or 128), the other a multiple of 256.  bf16 operands, fp32 accumulation on MFMA; finish with
+ *   rwkv7_sum_slabs_bf16(N * K, S, parts, dW, 0). */
+int rwkv7_wgrad_skinny_bf16(long M, int N, int K, int S, const void *dy, const void *x, float *parts, rwkv7_stream_t stream);
 
 /* ---- decode-step linear layers: y[M,N] = x[M,K] @ w[N,K]^T (+ bias[N]), bf16, M <= 32 rows (one token per sequence and
  *      step), K % 64 == 0.  Replaces the nn.Linear calls of the per-token path (rwkv_s2s_single_ffn.py:482-506,545-549)

@@ -44,6 +44,7 @@ int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *,
                         hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
+int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
 int decode_layer_ptrs();
 size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
 int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *, const void *,
@@ -390,6 +391,13 @@ int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, lo
                           rwkv7_stream_t stream) {
     if (rows <= 0 || V <= 0 || any_null({(const void *)logits, (const void *)labels, (const void *)loss_rows})) return RWKV7_EINVAL;
     return rwkv7::ce_fwd_bwd(rows, V, logits, labels, ignore_index, scale, loss_rows, (hipStream_t)stream);
+}
+int rwkv7_wgrad_skinny_bf16(long M, int N, int K, int S, const void *dy, const void *x, float *parts, rwkv7_stream_t stream) {
+    if (any_null({dy, x, parts})) return RWKV7_EINVAL;
+    const int rank = N > K ? K : N, wide = N > K ? N : K;
+    if (M <= 0 || S <= 0 || M % S != 0 || (M / S) % 128 != 0 || wide % 256 != 0 || (rank != 32 && rank != 64 && rank != 128))
+        return RWKV7_ESHAPE;
+    return rwkv7::wgrad_skinny_bf16(M, N, K, S, dy, x, parts, (hipStream_t)stream);
 }
 int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, rwkv7_stream_t stream) {
     if (n <= 0 || S <= 0 || any_null({(const void *)parts, (const void *)out})) return RWKV7_EINVAL;

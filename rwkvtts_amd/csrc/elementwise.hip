@@ -798,9 +798,52 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(long n4, int S, const fl
     }
 }
 
+// many slabs over a short vector (the low-rank weight gradients: S = 64 slabs of 32K-128K elements): one thread per (float4
+// column, quarter of the slabs), eight loads in flight, the four quarters combined through LDS -- the kernel above would walk
+// the 64 slabs in 16 dependent rounds of loads with 64 workgroups
+__global__ __launch_bounds__(256) void sum_slabs_wide_kernel(long n4, int S, const float *__restrict__ parts, bf16_t *__restrict__ out,
+                                                             int accumulate) {
+    __shared__ float4 red[3][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        for (int s0 = g; s0 < S; s0 += 32) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int s = s0 + 4 * u;
+                t[u] = s < S ? *reinterpret_cast<const float4 *>(parts + ((long)s * n4 + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w;
+            }
+        }
+    }
+    if (g > 0) red[g - 1][c] = a;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const float4 t = red[u][c];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        if (accumulate) {
+            const float4 o = cvt4(ld4<bf16_t>(out + i * 4, true));
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        st4(out + i * 4, a);
+    }
+}
+
 int sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, hipStream_t st) {
     (void)hipGetLastError();
     const long n4 = n / 4;
+    if (S >= 16 && n4 <= 64L * 4096) {
+        hipLaunchKernelGGL(sum_slabs_wide_kernel, dim3((int)((n4 + 63) / 64)), dim3(256), 0, st, n4, S, parts, (bf16_t *)out, accumulate);
+        return (int)hipGetLastError();
+    }
     const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid), dim3(256), 0, st, n4, S, parts, (bf16_t *)out, accumulate);
     return (int)hipGetLastError();

@@ -335,6 +335,20 @@ def wgrad_splitk(dy2, x2, out=None):
     (the parameter's slice of the trainer's flat gradient buffer), else a new tensor."""
     M, N = dy2.shape
     K = x2.shape[1]
+    rank, wide = min(N, K), max(N, K)
+    if (dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and rank in (32, 64, 128) and wide % 256 == 0
+            and M >= WGRAD_MIN_ROWS and M % 512 == 0):
+        # low-rank projections: HBM-bound (the [M, wide] operand is streamed once), rwkv7_wgrad_skinny_bf16 + one reduction
+        S = M // 512
+        part = torch.empty(S, N, K, dtype=torch.float32, device=dy2.device)
+        if out is None:
+            out = torch.empty(N, K, dtype=torch.bfloat16, device=dy2.device)
+        with torch.cuda.device_of(part):
+            rc = _lib.lib().rwkv7_wgrad_skinny_bf16(ctypes.c_long(M), N, K, S, _p(dy2), _p(x2), _p(part), _stream(part))
+            _lib.check(rc, "wgrad_skinny")
+            rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(N * K), S, _p(part), _p(out), 0, _stream(part))
+        _lib.check(rc, "sum_slabs")
+        return out
     S = 8 if N * K <= 1024 * 1024 else 4
     if M < WGRAD_MIN_ROWS or M % (S * 8) != 0:
         res = torch.mm(dy2.t(), x2)

@@ -181,6 +181,37 @@ def test_linear_split_wgrad_vs_fp32_reference(N, K):
     _cmp(bd.grad, br.grad, 1e-2, "db")
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 64, 1024), (4096, 1024, 64), (8192, 32, 768), (8192, 768, 32), (4096, 128, 2048),
+                                   (4096, 2048, 128), (4608, 1024, 64), (4096, 96, 2048)])
+def test_low_rank_weight_gradient_kernel_vs_fp32_reference(M, N, K):
+    """rwkv7_wgrad_skinny_bf16 + rwkv7_sum_slabs_bf16 (fused.wgrad_splitk routes the LoRA-shaped gradients there): dW[N][K] =
+    dy^T x over M rows against the fp32 product of the same bf16 operands (autograd of rwkv_s2s_single_ffn.py:172-184).
+    Tolerance: one bf16 rounding of the fp32 sum.  The last two shapes are not served by the kernel (rows not a multiple of
+    512, rank 96) and take the batched-GEMM route: same check."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).bfloat16()
+    x = (torch.randn(M, K, generator=g) * 0.7).bfloat16()
+    want = dy.float().t() @ x.float()
+    got = fused.wgrad_splitk(dy.to(DEV), x.to(DEV))
+    assert got.shape == (N, K) and got.dtype == torch.bfloat16
+    _cmp(got, want, 2.0 ** -8 + 1e-3, "dW")
+    # into a caller-provided slice (the trainer's flat gradient buffer), and through the C-ABI argument checks
+    out = torch.full((N, K), 7.0, dtype=torch.bfloat16, device=DEV)
+    assert fused.wgrad_splitk(dy.to(DEV), x.to(DEV), out=out) is out
+    assert torch.equal(out, got)
+
+
+def test_low_rank_weight_gradient_argument_errors():
+    import ctypes
+    from rwkvtts_amd import _lib
+    one = ctypes.c_void_p(16)
+    L = _lib.lib()
+    assert L.rwkv7_wgrad_skinny_bf16(ctypes.c_long(4096), 64, 1024, 8, None, one, one, None) == -1      # null pointer
+    assert L.rwkv7_wgrad_skinny_bf16(ctypes.c_long(4096), 48, 1024, 8, one, one, one, None) == -4       # rank 48
+    assert L.rwkv7_wgrad_skinny_bf16(ctypes.c_long(4096), 64, 1000, 8, one, one, one, None) == -4       # wide side % 256
+    assert L.rwkv7_wgrad_skinny_bf16(ctypes.c_long(4096), 64, 1024, 3, one, one, one, None) == -4       # rows per slab
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("D,with_branch,with_bias", [(128, True, True), (1024, True, True), (1024, False, True), (256, True, False)])
 def test_add_layer_norm(dtype, D, with_branch, with_bias):
