@@ -193,6 +193,28 @@ int rwkv7_add_ln_bwd_bf16(long rows, int D, const void *dh, const void *d_resid,
 int rwkv7_add_ln_bwd_f32(long rows, int D, const void *dh, const void *d_resid, const void *x1, const float *mean,
                          const float *rstd, const void *gamma, void *dx, float *dparams_partial, int nblocks,
                          rwkv7_stream_t stream);
+/* ---- the two stages above in one pass each (training path without carried state): residual add + LayerNorm + token-shift
+ *      lerps, i.e. everything between a block's branch output and the inputs of the next projections
+ *      (rwkv_s2s_single_ffn.py:251-259 with :160-169 / :223-226).
+ *   fwd: x_out = x + branch ; h = LayerNorm(x_out) rounded to the tensor type ; hm = h*mask ;
+ *        out[i] = hm + (shift(hm) - hm) * params[i], out [nmix][rows][D] ; mean/rstd [rows].  branch NULL: x_out unused.
+ *   bwd: from the nmix output gradients (HOST array of device pointers) and the gradient d_resid arriving at x_out:
+ *        dx (= gradient of x and of branch) ; dparams_partial [nblocks][nmix + 2][D] fp32 = dparams[0..nmix), dgamma, dbeta.
+ *   Workgroup b walks the runs of run_len consecutive rows number b, b + nblocks, ... ---- */
+int rwkv7_add_ln_mix_fwd_bf16(int B, int T, int D, int nmix, const void *x, const void *branch, const void *gamma,
+                              const void *beta, float eps, const void *mask, const void *params, void *x_out, void *out,
+                              float *mean, float *rstd, int nblocks, int run_len, rwkv7_stream_t stream);
+int rwkv7_add_ln_mix_fwd_f32(int B, int T, int D, int nmix, const void *x, const void *branch, const void *gamma,
+                             const void *beta, float eps, const void *mask, const void *params, void *x_out, void *out,
+                             float *mean, float *rstd, int nblocks, int run_len, rwkv7_stream_t stream);
+int rwkv7_mix_add_ln_bwd_bf16(int B, int T, int D, int nmix, const void *const *grad_outs, const void *d_resid, const void *x1,
+                              const float *mean, const float *rstd, const void *gamma, const void *beta, const void *mask,
+                              const void *params, void *dx, float *dparams_partial, int nblocks, int run_len,
+                              rwkv7_stream_t stream);
+int rwkv7_mix_add_ln_bwd_f32(int B, int T, int D, int nmix, const void *const *grad_outs, const void *d_resid, const void *x1,
+                             const float *mean, const float *rstd, const void *gamma, const void *beta, const void *mask,
+                             const void *params, void *dx, float *dparams_partial, int nblocks, int run_len,
+                             rwkv7_stream_t stream);
 
 /* after the scan (rwkv_s2s_single_ffn.py:192-195): out = (GroupNorm_H(y; gn_w, gn_b, eps) + (sum_head r*k*r_k) v) * g.
  * r_k is [H*64] flattened.  backward partials: P = 3 (d gn_w, d gn_b, d r_k). */

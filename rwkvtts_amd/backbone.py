@@ -181,6 +181,13 @@ def mark_all_ones(attention_mask: torch.Tensor, all_ones: bool):
 # Training runs prepare -> scan -> post as one autograd node (fused._TmixCore: row-split scan backward, gradient sums
 # folded into the prepare backward).  False selects the three separate nodes (same forward kernels).
 FUSED_TMIX_CORE = True
+# training: residual add + LayerNorm + token-shift lerp(s) as one kernel each way (rwkv7_add_ln_mix_fwd / rwkv7_mix_add_ln_bwd).
+# Measured on MI355X (tools/bench_add_ln_mix.py, B*T = 32768, D = 1024): channel-mix side (1 lerp) forward 56 us against 79 us
+# for the two separate stages, backward equal -> on.  Time-mix side (6 lerps): forward 140 against 170 us, but the one-pass
+# backward carries 6 x 3 x 8 values per thread next to the LayerNorm backward, spills, runs at two waves per SIMD with a
+# barrier per row: 560 against 320 us -> off.
+FUSED_ADD_LN_MIX1 = True
+FUSED_ADD_LN_MIX6 = False
 # cu_seqlens batches run on the chunked kernels' sequence flags (bf16); False: always unpack into a padded masked batch
 PACKED_NATIVE = True
 
@@ -237,11 +244,20 @@ class RWKV7Attention(nn.Module):
         """x [B,T,D] (LayerNorm'ed), mask [B,T,1] or None.  Returns (out, v_first).
         With `state`, token shift and the WKV state are carried (and updated in place).
         seq_start (int32 [nseq+1] chunk offsets): packed rows, see RWKV7Model._forward_packed."""
-        B, T, D = x.shape
-        H, N = self.num_heads, self.head_dim
         x_prev = None if state is None else state.att_x_prev
-        xr, xw, xk, xv, xa, xg = fused.token_shift_mix6(x, x_prev, self.x_r, self.x_w, self.x_k, self.x_v,
-                                                        self.x_a, self.x_g, mask, self._stacked_mix(x.dtype))
+        mixed = fused.token_shift_mix6(x, x_prev, self.x_r, self.x_w, self.x_k, self.x_v,
+                                       self.x_a, self.x_g, mask, self._stacked_mix(x.dtype))
+        return self.forward_mixed(mixed, x, mask, v_first, state, seq_start)
+
+    def mix_params(self):
+        return (self.x_r, self.x_w, self.x_k, self.x_v, self.x_a, self.x_g)
+
+    def forward_mixed(self, mixed, x, mask, v_first, state: Optional[LayerState] = None, seq_start=None):
+        """The block after the token-shift lerps (`mixed` = xr, xw, xk, xv, xa, xg); x (the LayerNorm'ed input) is only read for
+        the carried state and may be None without one."""
+        xr, xw, xk, xv, xa, xg = mixed
+        B, T, D = xr.shape
+        H, N = self.num_heads, self.head_dim
         r = self.r_proj(xr)
         k = self.k_proj(xk)
         v = self.v_proj(xv)
@@ -291,6 +307,9 @@ class RWKV7FeedForward(nn.Module):
         if state is not None:
             last = x[:, -1].detach()
             state.ffn_x_prev.copy_(last * mask[:, -1] if mask is not None else last)
+        return self.forward_mixed(kx)
+
+    def forward_mixed(self, kx):
         return self.value(fused.relu_sq(self.key(kx)))
 
 
@@ -315,11 +334,20 @@ class RWKV7Block(nn.Module):
                 x = x + delta
                 delta = None
             x = fused.layer_norm(x, self.pre_norm)
-        if delta is None:
-            h = fused.layer_norm(x, self.attn_norm)
+        one_pass = fused.add_ln_mix_supported(x, state)
+        if one_pass and FUSED_ADD_LN_MIX6:
+            x, mixed = fused.add_layer_norm_mix(x, delta, self.attn_norm, mask, self.attn.mix_params())
+            att, v_first = self.attn.forward_mixed(mixed, None, mask, v_first, None, seq_start)
         else:
-            x, h = fused.add_layer_norm(x, delta, self.attn_norm)
-        att, v_first = self.attn(h, mask, v_first, state, seq_start)
+            if delta is None:
+                h = fused.layer_norm(x, self.attn_norm)
+            else:
+                x, h = fused.add_layer_norm(x, delta, self.attn_norm)
+            att, v_first = self.attn(h, mask, v_first, state, seq_start)
+        if one_pass and FUSED_ADD_LN_MIX1:
+            # training path: add + LayerNorm + token-shift lerp in one pass each way (h / dh never reach HBM)
+            x, (kx,) = fused.add_layer_norm_mix(x, att, self.ffn_norm, mask, (self.ffn.x_k,))
+            return x, self.ffn.forward_mixed(kx), v_first
         x, h = fused.add_layer_norm(x, att, self.ffn_norm)
         return x, self.ffn(h, mask, state), v_first
 

@@ -671,6 +671,242 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_bwd_kernel(long rows, in
 }
 
 // ------------------------------------------------------------------------------------------------------
+// add + LayerNorm + token-shift mix in one pass (training path, no carried state):
+//   x1 = x + branch ; h = LN(x1) ; hm = h * mask ; out_i[t] = hm[t] + (hm[t-1] - hm[t]) p_i      (rwkv_s2s_single_ffn.py:251-259, 160-169, 223-226)
+// The separate kernels write h (add_ln_fwd) and read it back (mix_fwd), and in the backward write dh (mix_bwd) and read it back
+// (add_ln_bwd): 2 of 11 / 3 of 12 tensor passes over [B*T, D].  h is rounded to the tensor type before it is mixed, as the
+// separate path stores it, so both paths produce the same values.  Rows are walked in short runs (run j of workgroup b is run
+// b + j gridDim: together the workgroups stream one contiguous window); inside a run the neighbour row is carried in registers,
+// at the start of a run it is recomputed from x1's inputs (forward) or from x1 (backward).
+// ------------------------------------------------------------------------------------------------------
+// two sums over the D/8 threads of the workgroup with ONE barrier; slots alternate (ph = 0 / 2) between consecutive calls so that
+// a fast wave cannot overwrite a slot a slow wave is still reading
+__device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[kEwMaxThreads / 8], int ph, int ngroups) {
+    a = sum8(a);
+    b = sum8(b);
+    if ((threadIdx.x & 7) == 0) {
+        red[ph][threadIdx.x >> 3] = a;
+        red[ph + 1][threadIdx.x >> 3] = b;
+    }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f;
+    for (int i = 0; i < ngroups; i++) {
+        ta += red[ph][i];
+        tb += red[ph + 1][i];
+    }
+    a = ta;
+    b = tb;
+}
+
+template <typename T, int NMIX>
+__global__ __launch_bounds__(kEwMaxThreads) void add_ln_mix_fwd_kernel(int B, int T_, int D, int run_len, const T *__restrict__ x,
+                                                                       const T *__restrict__ branch, const T *__restrict__ gamma,
+                                                                       const T *__restrict__ beta, float eps, const T *__restrict__ mask,
+                                                                       const T *__restrict__ params, T *__restrict__ x_out,
+                                                                       T *__restrict__ out, float *__restrict__ mean,
+                                                                       float *__restrict__ rstd) {
+    __shared__ float red[4][kEwMaxThreads / 8];
+    const int c = threadIdx.x * 8, ng = D / 64;
+    const long rows = (long)B * T_;
+    const float inv_d = 1.0f / (float)D;
+    float gm[8], bt[8], p[NMIX][8];
+    V8<T>::ld(gamma + c, gm);
+    if (beta) {
+        V8<T>::ld(beta + c, bt);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) bt[j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NMIX; i++) V8<T>::ld(params + (long)i * D + c, p[i]);
+    int ph = 0;
+    // hm of one row; WRITE: also x1 and the statistics (mean, then the centred squares: two barriers, as add_ln_fwd_kernel)
+    auto ln_row = [&](long row, bool write, float (&hm)[8]) {
+        const long o = row * D + c;
+        float v[8];
+        V8<T>::ld(x + o, v);
+        if (branch) {
+            float b[8];
+            V8<T>::ld(branch + o, b);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = round_to<T>(v[j] + b[j]);
+            if (write) V8<T>::st(x_out + o, v);
+        }
+        float s = 0.f, dummy = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[j];
+        block_sum2(s, dummy, red, ph, ng);
+        ph ^= 2;
+        const float mu = s * inv_d;
+        float q = 0.f;
+        dummy = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            v[j] -= mu;
+            q = fmaf(v[j], v[j], q);
+        }
+        block_sum2(q, dummy, red, ph, ng);
+        ph ^= 2;
+        const float rs = rsqrtf(q * inv_d + eps);
+        const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) hm[j] = round_to<T>(fmaf(v[j] * rs, gm[j], bt[j])) * m;
+        if (write && threadIdx.x == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    };
+    for (long r_lo = (long)blockIdx.x * run_len; r_lo < rows; r_lo += (long)gridDim.x * run_len) {
+        const long r_hi = r_lo + run_len < rows ? r_lo + run_len : rows;
+        float hp[8];
+        if ((r_lo % T_) != 0) {
+            ln_row(r_lo - 1, false, hp);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) hp[j] = 0.f;
+        }
+        for (long row = r_lo; row < r_hi; row++) {
+            float hc[8];
+            ln_row(row, true, hc);
+            if ((row % T_) == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) hp[j] = 0.f;   // first step of a sequence: shift(x) = 0
+            }
+#pragma unroll
+            for (int i = 0; i < NMIX; i++) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = fmaf(hp[j] - hc[j], p[i][j], hc[j]);
+                V8<T>::st(out + ((long)i * rows + row) * D + c, o);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) hp[j] = hc[j];
+        }
+    }
+}
+
+// dhm[t] = sum_i g_i[t] (1 - p_i) + g_i[t+1] p_i ; dh = dhm * mask ; dx = LN'(dh) + d_resid ; dp_i = sum g_i[t] (hm[t-1] - hm[t]) ;
+// dgamma = sum dh xhat ; dbeta = sum dh.   dpart [nblocks][NMIX + 2][D]: dp_0.., dgamma, dbeta.
+template <typename T, int NMIX>
+__global__ __launch_bounds__(kEwMaxThreads) void mix_add_ln_bwd_kernel(int B, int T_, int D, int run_len, MixGrads<NMIX> gs,
+                                                                       const T *__restrict__ d_resid, const T *__restrict__ x1,
+                                                                       const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                       const T *__restrict__ gamma, const T *__restrict__ beta,
+                                                                       const T *__restrict__ mask, const T *__restrict__ params,
+                                                                       T *__restrict__ dx, float *__restrict__ dpart) {
+    __shared__ float red[4][kEwMaxThreads / 8];
+    const int c = threadIdx.x * 8, ng = D / 64;
+    const long rows = (long)B * T_;
+    const float inv_d = 1.0f / (float)D;
+    float gm[8], bt[8], dg[8], db[8], p[NMIX][8], dp[NMIX][8], gn[NMIX][8];
+    V8<T>::ld(gamma + c, gm);
+    if (beta) {
+        V8<T>::ld(beta + c, bt);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) bt[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) dg[j] = db[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NMIX; i++) {
+        V8<T>::ld(params + (long)i * D + c, p[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dp[i][j] = 0.f;
+    }
+    // xhat and hm of a row, from what the forward saved
+    auto renorm = [&](long row, float (&xh)[8], float (&hm)[8], float &rs) {
+        V8<T>::ld(x1 + row * D + c, xh);
+        const float mu = mean[row];
+        rs = rstd[row];
+        const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            xh[j] = (xh[j] - mu) * rs;
+            hm[j] = round_to<T>(fmaf(xh[j], gm[j], bt[j])) * m;
+        }
+    };
+    int ph = 0;
+    for (long r_lo = (long)blockIdx.x * run_len; r_lo < rows; r_lo += (long)gridDim.x * run_len) {
+        const long r_hi = r_lo + run_len < rows ? r_lo + run_len : rows;
+        // prime the carried values with row r_hi (the row after this run), if it belongs to the same sequence
+        if (r_hi < rows && (r_hi % T_) != 0) {
+#pragma unroll
+            for (int i = 0; i < NMIX; i++) V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + r_hi * D + c, gn[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NMIX; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) gn[i][j] = 0.f;
+        }
+        float xc[8], hc[8], rs_c;
+        renorm(r_hi - 1, xc, hc, rs_c);
+        for (long row = r_hi - 1; row >= r_lo; row--) {
+            const int t = (int)(row % T_);
+            float xp[8], hp[8], rs_p = 0.f;
+            if (t > 0) {
+                renorm(row - 1, xp, hp, rs_p);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) xp[j] = hp[j] = 0.f;
+            }
+            const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+            float g[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) g[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NMIX; i++) {
+                float gc[8];
+                V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + row * D + c, gc);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    g[j] = fmaf(gc[j], 1.f - p[i][j], g[j]);
+                    g[j] = fmaf(gn[i][j], p[i][j], g[j]);     // g_i[t+1] (zero past the end of the sequence)
+                    dp[i][j] = fmaf(gc[j], hp[j] - hc[j], dp[i][j]);
+                    gn[i][j] = t > 0 ? gc[j] : 0.f;            // row-1 is the last row of the previous sequence if t == 0
+                }
+            }
+            // dh = g * mask, rounded to the tensor type as the separate mix_bwd kernel stores it
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                g[j] = round_to<T>(g[j] * m);
+                dg[j] = fmaf(g[j], xc[j], dg[j]);
+                db[j] += g[j];
+                g[j] *= gm[j];
+                s1 += g[j];
+                s2 = fmaf(g[j], xc[j], s2);
+            }
+            block_sum2(s1, s2, red, ph, ng);
+            ph ^= 2;
+            s1 *= inv_d;
+            s2 *= inv_d;
+            float r[8];
+            if (d_resid) {
+                V8<T>::ld(d_resid + row * D + c, r);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) r[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] += rs_c * (g[j] - s1 - xc[j] * s2);
+            V8<T>::st(dx + row * D + c, r);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                xc[j] = xp[j];
+                hc[j] = hp[j];
+            }
+            rs_c = rs_p;
+            if (t == 0 && row > r_lo) renorm(row - 1, xc, hc, rs_c);  // the run continues into the previous sequence
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NMIX; i++) V8<float>::st(dpart + ((long)blockIdx.x * (NMIX + 2) + i) * D + c, dp[i]);
+    V8<float>::st(dpart + ((long)blockIdx.x * (NMIX + 2) + NMIX) * D + c, dg);
+    V8<float>::st(dpart + ((long)blockIdx.x * (NMIX + 2) + NMIX + 1) * D + c, db);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // AdamW on fp32 master weights with bf16 gradients and a bf16 copy of the updated weights in one pass
 // (train_scripts/train_spark_rwkv7speech.py:178-197 builds torch.optim.AdamW / DeepSpeed FusedAdam; DeepSpeed's bf16
 // optimizer keeps fp32 masters the same way).  Update rule = torch.optim.AdamW (decoupled weight decay):
@@ -885,6 +1121,39 @@ int mix_bwd(int B, int T_, int D, int nmix, const void *const *g, const void *x,
     return finish();
 }
 template <typename T>
+int add_ln_mix_fwd(int B, int T_, int D, int nmix, const void *x, const void *branch, const void *gamma, const void *beta, float eps,
+                   const void *mask, const void *params, void *x_out, void *out, float *mean, float *rstd, int nblocks, int run_len,
+                   hipStream_t st) {
+    (void)hipGetLastError();
+    const dim3 grid(nblocks), block(D / 8);
+    if (nmix == 6)
+        hipLaunchKernelGGL((add_ln_mix_fwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, run_len, (const T *)x, (const T *)branch,
+                           (const T *)gamma, (const T *)beta, eps, (const T *)mask, (const T *)params, (T *)x_out, (T *)out, mean, rstd);
+    else
+        hipLaunchKernelGGL((add_ln_mix_fwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, run_len, (const T *)x, (const T *)branch,
+                           (const T *)gamma, (const T *)beta, eps, (const T *)mask, (const T *)params, (T *)x_out, (T *)out, mean, rstd);
+    return finish();
+}
+template <typename T>
+int mix_add_ln_bwd(int B, int T_, int D, int nmix, const void *const *g, const void *d_resid, const void *x1, const float *mean,
+                   const float *rstd, const void *gamma, const void *beta, const void *mask, const void *params, void *dx, float *dpart,
+                   int nblocks, int run_len, hipStream_t st) {
+    (void)hipGetLastError();
+    const dim3 grid(nblocks), block(D / 8);
+    if (nmix == 6) {
+        MixGrads<6> gs;
+        for (int i = 0; i < 6; i++) gs.g[i] = g[i];
+        hipLaunchKernelGGL((mix_add_ln_bwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, run_len, gs, (const T *)d_resid, (const T *)x1,
+                           mean, rstd, (const T *)gamma, (const T *)beta, (const T *)mask, (const T *)params, (T *)dx, dpart);
+    } else {
+        MixGrads<1> gs;
+        gs.g[0] = g[0];
+        hipLaunchKernelGGL((mix_add_ln_bwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, run_len, gs, (const T *)d_resid, (const T *)x1,
+                           mean, rstd, (const T *)gamma, (const T *)beta, (const T *)mask, (const T *)params, (T *)dx, dpart);
+    }
+    return finish();
+}
+template <typename T>
 int tmix_prepare_fwd(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
                      const void *v_pre, const void *v_first, const void *mask, const void *k_k, const void *k_a,
                      void *w, void *k2, void *v2, void *ain, void *bin, int nblocks, hipStream_t st) {
@@ -989,6 +1258,10 @@ int relusq_bwd(long n, const void *x, const void *dy, void *dx, hipStream_t st) 
                                float *, float *, int, hipStream_t);                                                 \
     template int add_ln_bwd<T>(long, int, const void *, const void *, const void *, const float *, const float *,    \
                                const void *, void *, float *, int, hipStream_t);                                     \
+    template int add_ln_mix_fwd<T>(int, int, int, int, const void *, const void *, const void *, const void *, float, const void *, \
+                                   const void *, void *, void *, float *, float *, int, int, hipStream_t);           \
+    template int mix_add_ln_bwd<T>(int, int, int, int, const void *const *, const void *, const void *, const float *, const float *, \
+                                   const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t); \
     template int tmix_prepare_bwd_sum<T>(long, int, const void *, const void *, const void *, const void *,          \
                                          const void *, const void *, const void *, const void *, const void *,       \
                                          const void *const *, void *, void *, void *, void *, void *, void *, void *, \

@@ -325,6 +325,7 @@ def lora_decode(x, w1, w2, bias, activation):
 # nn.Linear with a split-M weight gradient
 # ------------------------------------------------------------------------------------------------------
 WGRAD_MIN_ROWS = 4096
+SKINNY_WGRAD = True   # low-rank weight gradients through rwkv7_wgrad_skinny_bf16 (A/B switch for tools/ab_step.py)
 
 
 def wgrad_splitk(dy2, x2, out=None):
@@ -336,7 +337,7 @@ def wgrad_splitk(dy2, x2, out=None):
     M, N = dy2.shape
     K = x2.shape[1]
     rank, wide = min(N, K), max(N, K)
-    if (dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and rank in (32, 64, 128) and wide % 256 == 0
+    if (SKINNY_WGRAD and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and rank in (32, 64, 128) and wide % 256 == 0
             and M >= WGRAD_MIN_ROWS and M % 512 == 0):
         # low-rank projections: HBM-bound (the [M, wide] operand is streamed once), rwkv7_wgrad_skinny_bf16 + one reduction
         S = M // 512
@@ -503,6 +504,71 @@ class _AddLN(torch.autograd.Function):
               _p(part), nb)
         dp = part.sum(0).to(xs.dtype)
         return dx, (dx if ctx.has_branch else None), dp[0], (dp[1] if ctx.has_beta else None), None
+
+
+_ADD_LN_MIX_RUN = 4       # rows per run of the fused add + LayerNorm + token-shift kernels (one neighbour row recomputed per run)
+_ADD_LN_MIX_BLOCKS = 8192
+_ADD_LN_MIX_BWD_BLOCKS = 2048   # also the number of parameter-gradient partials
+
+
+class _AddLNMix(torch.autograd.Function):
+    """(x1, out_0 .. out_{n-1}): x1 = x + branch (or x), h = LayerNorm(x1), out_i = token-shift lerp i of h * mask -- _AddLN
+    followed by _Mix without h (forward) and dh (backward) ever touching HBM (rwkv7_add_ln_mix_fwd / rwkv7_mix_add_ln_bwd).
+    Training path only: no carried token-shift state."""
+
+    @staticmethod
+    def forward(ctx, x, branch, gamma, beta, eps, mask, params):
+        B, T, D = x.shape
+        x, params = _c(x), _c(params)
+        nmix = params.shape[0]
+        gamma_c = _c(gamma.to(x.dtype))
+        beta_c = None if beta is None else _c(beta.to(x.dtype))
+        rows = B * T
+        out = torch.empty(nmix, B, T, D, dtype=x.dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        if branch is not None:
+            branch = _c(branch)
+            x1 = torch.empty_like(x)
+        else:
+            x1 = None
+        nb = max(1, min(-(-rows // _ADD_LN_MIX_RUN), _ADD_LN_MIX_BLOCKS))
+        _call("add_ln_mix_fwd", x, B, T, D, nmix, _p(x), _p(branch), _p(gamma_c), _p(beta_c), ctypes.c_float(eps), _p(mask),
+              _p(params), _p(x1), _p(out), _p(mean), _p(rstd), nb, _ADD_LN_MIX_RUN)
+        ctx.has_branch, ctx.has_beta = branch is not None, beta is not None
+        ctx.save_for_backward(x1 if branch is not None else x, mean, rstd, gamma_c, beta_c, mask, params)
+        return (x1 if branch is not None else x,) + tuple(out[i] for i in range(nmix))
+
+    @staticmethod
+    def backward(ctx, d_x1, *gs):
+        xs, mean, rstd, gamma, beta, mask, params = ctx.saved_tensors
+        B, T, D = xs.shape
+        nmix = params.shape[0]
+        gs = [torch.zeros_like(xs) if g is None else _c(g) for g in gs]
+        d_x1 = None if d_x1 is None else _c(d_x1)
+        rows = B * T
+        nb = max(1, min(-(-rows // _ADD_LN_MIX_RUN), _ADD_LN_MIX_BWD_BLOCKS))
+        dx = torch.empty_like(xs)
+        part = torch.empty(nb, nmix + 2, D, dtype=torch.float32, device=xs.device)
+        ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])
+        _call("mix_add_ln_bwd", xs, B, T, D, nmix, ptrs, _p(d_x1), _p(xs), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(mask),
+              _p(params), _p(dx), _p(part), nb, _ADD_LN_MIX_RUN)
+        dp = part.sum(0)
+        return (dx, (dx if ctx.has_branch else None), dp[nmix].to(xs.dtype), (dp[nmix + 1].to(xs.dtype) if ctx.has_beta else None),
+                None, None, dp[:nmix].to(params.dtype))
+
+
+def add_ln_mix_supported(x, state):
+    return x.is_cuda and state is None and x.dim() == 3 and x.dtype in (torch.bfloat16, torch.float32) and torch.is_grad_enabled()
+
+
+def add_layer_norm_mix(x, branch, norm, mask, mix_params):
+    """(x + branch, [token-shift lerps of norm(x + branch) * mask]); branch may be None.  mix_params: the lerp coefficient
+    vectors (6 for the time-mix block, 1 for the channel-mix block)."""
+    D = x.shape[-1]
+    params = torch.cat([p.reshape(1, D) for p in mix_params], 0).to(x.dtype) if len(mix_params) > 1 else mix_params[0].reshape(1, D).to(x.dtype)
+    res = _AddLNMix.apply(x, branch, norm.weight, norm.bias, norm.eps, _mask_rows(mask, x), params)
+    return res[0], res[1:]
 
 
 def layer_norm(x, norm):

@@ -181,6 +181,75 @@ def test_linear_split_wgrad_vs_fp32_reference(N, K):
     _cmp(bd.grad, br.grad, 1e-2, "db")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nmix,with_branch,with_mask,D", [(6, True, True, 256), (6, False, False, 1024), (1, True, False, 1024),
+                                                          (1, True, True, 128), (6, True, False, 2048)])
+def test_add_layer_norm_mix_equals_the_two_separate_stages(dtype, nmix, with_branch, with_mask, D):
+    """rwkv7_add_ln_mix_fwd / rwkv7_mix_add_ln_bwd (one pass each way) against rwkv7_add_ln_* followed by rwkv7_mix_* (which
+    have their own checks against torch above): the same values -- h is rounded to the tensor type before it is mixed and dh
+    before it enters the LayerNorm backward, exactly as the separate path stores them.  Several sequences, a length that is not
+    a multiple of the run length, masked positions in the middle (packed rows restart the token shift that way)."""
+    B, T = 3, 45
+    g = torch.Generator().manual_seed(D + nmix)
+    x = (torch.randn(B, T, D, generator=g) * 1.3 + 0.2).to(dtype)
+    br = torch.randn(B, T, D, generator=g).to(dtype) if with_branch else None
+    norm = torch.nn.LayerNorm(D, eps=1e-5).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(D, generator=g) * 0.2 + 1.0)
+        norm.bias.copy_(torch.randn(D, generator=g) * 0.1)
+    norm = norm.to(dtype)
+    mixp = [torch.rand(D, generator=g).to(dtype).to(DEV).requires_grad_(True) for _ in range(nmix)]
+    mask = None
+    if with_mask:
+        mask = torch.ones(B, T, 1)
+        mask[0, :3] = 0
+        mask[1, 20] = 0
+        mask[2, -1] = 0
+        mask = mask.to(dtype).to(DEV)
+    gout = [torch.randn(B, T, D, generator=g).to(dtype).to(DEV) for _ in range(nmix)]
+    gx1 = torch.randn(B, T, D, generator=g).to(dtype).to(DEV)
+
+    def run(fused_path):
+        xd = x.to(DEV).requires_grad_(True)
+        bd = None if br is None else br.to(DEV).requires_grad_(True)
+        for p_ in list(norm.parameters()) + mixp:
+            p_.grad = None
+        if fused_path:
+            x1, outs = fused.add_layer_norm_mix(xd, bd, norm, mask, tuple(mixp))
+        else:
+            if bd is None:
+                x1, h = xd, fused.layer_norm(xd, norm)
+            else:
+                x1, h = fused.add_layer_norm(xd, bd, norm)
+            if nmix == 6:
+                outs = fused.token_shift_mix6(h, None, *mixp, mask)
+            else:
+                outs = (fused.token_shift_mix1(h, None, mixp[0], mask),)
+        loss = sum((o.float() * go.float()).sum() for o, go in zip(outs, gout)) + (x1.float() * gx1.float()).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return ([o.detach().clone() for o in outs], x1.detach().clone(), xd.grad.clone(), None if bd is None else bd.grad.clone(),
+                norm.weight.grad.clone(), norm.bias.grad.clone(), [p_.grad.clone() for p_ in mixp])
+
+    a, b = run(True), run(False)
+    for oa, ob in zip(a[0], b[0]):
+        assert torch.equal(oa, ob), "mixed outputs differ"
+    assert torch.equal(a[1], b[1]), "x1 differs"
+    if br is not None:
+        assert torch.equal(a[2], b[2]), "dx differs"
+        assert torch.equal(a[3], b[3])
+    else:
+        # without a branch x1 IS x: the separate path lets autograd add the residual gradient to the LayerNorm gradient (a second
+        # rounding in the tensor type), the one-pass kernel adds it in fp32 before the only rounding
+        scale = b[2].float().abs().max().item()
+        assert (a[2].float() - b[2].float()).abs().max().item() <= (1e-6 if dtype == torch.float32 else 1e-2) * scale
+    # parameter gradients: sums over rows in a different workgroup partition (fp32 partials) -> rounding-level differences
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for name, ga, gb in [("dgamma", a[4], b[4]), ("dbeta", a[5], b[5])] + [(f"dmix{i}", pa, pb) for i, (pa, pb) in enumerate(zip(a[6], b[6]))]:
+        scale = max(gb.float().abs().max().item(), 1e-6)
+        assert (ga.float() - gb.float()).abs().max().item() <= tol * scale, name
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 64, 1024), (4096, 1024, 64), (8192, 32, 768), (8192, 768, 32), (4096, 128, 2048),
                                    (4096, 2048, 128), (4608, 1024, 64), (4096, 96, 2048)])
 def test_low_rank_weight_gradient_kernel_vs_fp32_reference(M, N, K):

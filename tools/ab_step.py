@@ -1,0 +1,42 @@
+"""A/B of optional paths inside ONE process on ONE box (boxes of the pool differ by ~5 %, more than most switches are worth):
+the 0.4B Spark training step with each switch off and on, interleaved, median of the step times."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rwkvtts_amd import backbone, fused, trainer
+from rwkvtts_amd.layouts import synthetic_spark_batch
+from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
+dev = torch.device("cuda:0")
+base = backbone.config_0p4b()
+kw = {k: v for k, v in base.to_dict().items() if k in backbone.RWKV7Config.__dataclass_fields__ and k != "extra"}
+model = RWKV7ForSpeech(RWKV7SpeechConfig(**kw)).init_weights(seed=0).to(device=dev, dtype=torch.bfloat16).train()
+tr = trainer.DataParallelTrainer(model, lr=1e-4, warmup_steps=10, total_steps=1000)
+it = [0]
+
+
+def steps(n):
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.step(**synthetic_spark_batch(model, 8, 4096, seed=1234 + it[0]))
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        it[0] += 1
+    return ts
+
+
+switches = [("add+LN+mix one pass (channel-mix side)", backbone, "FUSED_ADD_LN_MIX1"),
+            ("add+LN+mix one pass (time-mix side)", backbone, "FUSED_ADD_LN_MIX6"),
+            ("low-rank weight gradients: skinny kernel", fused, "SKINNY_WGRAD")]
+steps(3)
+for name, mod, attr in switches:
+    default = getattr(mod, attr)
+    res = {False: [], True: []}
+    for rep in range(3):
+        for v in (False, True):
+            setattr(mod, attr, v)
+            steps(1)
+            res[v] += steps(4)
+    setattr(mod, attr, default)
+    med = {v: sorted(res[v])[len(res[v]) // 2] for v in res}
+    print(f"{name:45s} off {med[False]:7.2f} ms   on {med[True]:7.2f} ms   ({med[True] - med[False]:+.2f} ms; default {'on' if default else 'off'})", flush=True)
