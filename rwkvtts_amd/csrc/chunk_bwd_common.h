@@ -68,17 +68,6 @@ __device__ __forceinline__ void put_row8(uint16_t *Ph, uint16_t *Pl, int off, co
     *reinterpret_cast<uint4 *>(Ph + off) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     *reinterpret_cast<uint4 *>(Pl + off) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
-// the same 8 values into a channel-major plane pair: element j goes to row (pk + j), column pt
-__device__ __forceinline__ void put_col8(uint16_t *Ph, uint16_t *Pl, int ld, int pk, int pt, const uint32_t (&hi)[4],
-                                         const uint32_t (&lo)[4]) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int o = (pk + j) * ld + pt, sh = (j & 1) * 16;
-        Ph[o] = (uint16_t)(hi[j >> 1] >> sh);
-        Pl[o] = (uint16_t)(lo[j >> 1] >> sh);
-    }
-}
-
 // G[j] = sum_{s <= pt} lw_s[pk + j]
 __device__ __forceinline__ void chunk_cumsum(const float (&lw)[8], float (&G)[8]) {
 #pragma unroll

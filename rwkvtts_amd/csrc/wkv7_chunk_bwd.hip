@@ -22,20 +22,22 @@ namespace {
 constexpr int kChunksPerWG = 4;     // bwd_pre walks this many consecutive chunks per workgroup, prefetching the next one's inputs
 
 struct PreSmem {  // offsets in uint16 units
-    // phase-1 inputs, contiguous: dead after phase 1 and overlaid by G1T
-    static constexpr int QTh = 0, QTl = QTh + kC * LDK, BHh = QTl + kC * LDK, BHl = BHh + kC * LDK;
-    static constexpr int ATTh = BHl + kC * LDK, ATTl = ATTh + kN * LDC, TMh = ATTl + kN * LDC, TMl = TMh + kC * LDC;
-    static constexpr int end1 = TMl + kC * LDC;
-    static constexpr int G1Th = 0, G1Tl = G1Th + kN * LDC;
-    static constexpr int QTTh = end1, QTTl = QTTh + kN * LDC, BCTh = QTTl + kN * LDC, BCTl = BCTh + kN * LDC;
-    static constexpr int DYT = BCTl + kN * LDC, QBTh = DYT + kN * LDC, QBTl = QBTh + kC * LDC;
-    static constexpr int WTh = QBTl + kC * LDC, WTl = WTh + kN * LDC;   // W^T planes
-    static constexpr int gC = WTl + kN * LDC;  // 64 floats
+    // the chunk's operands, every one stored ONCE, time-major [t][.] as its rows arrive: products that contract over time fetch
+    // them with the LDS transpose read (mma_gen, operand "k-major") -- the channel-major copies of q~, a~, b^ g_C and dY cost 72
+    // two-byte scattered LDS writes per thread and chunk (26 % of the kernel's cycles on the LDS pipe)
+    static constexpr int TM1 = kC * LDK;
+    static constexpr int QTh = 0, QTl = QTh + TM1, BHh = QTl + TM1, BHl = BHh + TM1, ATh = BHl + TM1, ATl = ATh + TM1;
+    static constexpr int BCh = ATl + TM1, BCl = BCh + TM1, DY = BCl + TM1;
+    static constexpr int TMh = DY + TM1, TMl = TMh + kC * LDC;                 // T
+    static constexpr int QBTh = TMl + kC * LDC, QBTl = QBTh + kC * LDC;        // A_qb^T
+    static constexpr int WTh = QBTl + kC * LDC, WTl = WTh + kN * LDC;          // W^T [k][t]
+    static constexpr int G1Th = WTl + kN * LDC, G1Tl = G1Th + kN * LDC;        // G1^T [v][s]
+    static constexpr int gC = G1Tl + kN * LDC;  // 64 floats
     static constexpr int end16 = gC + 2 * kN;
     static constexpr size_t bytes = (size_t)end16 * 2;
 };
-static_assert(PreSmem::G1Tl + kN * LDC <= PreSmem::end1, "G1T planes must fit over the phase-1 inputs");
-static_assert(PreSmem::ATTh % 8 == 0 && PreSmem::QTTh % 8 == 0 && PreSmem::WTh % 8 == 0 && PreSmem::gC % 8 == 0, "16-byte alignment");
+static_assert(PreSmem::TMh % 8 == 0 && PreSmem::QBTh % 8 == 0 && PreSmem::WTh % 8 == 0 && PreSmem::G1Th % 8 == 0 && PreSmem::gC % 8 == 0,
+              "16-byte alignment");
 static_assert(PreSmem::bytes <= 80 * 1024, "two workgroups per CU");
 
 }  // namespace
@@ -96,24 +98,18 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
             uint32_t hi[4], lo[4];
 #pragma unroll
             for (int j = 0; j < 8; j++) x[j] = qv[j] * fast_exp(G[j]);                 // q~ = q gamma_t
-            put_row8(sm + L::QTh, sm + L::QTl, pt * LDK + pk, x, hi, lo);
-            put_col8(sm + L::QTTh, sm + L::QTTl, LDC, pk, pt, hi, lo);
+            const int o = pt * LDK + pk;
+            put_row8(sm + L::QTh, sm + L::QTl, o, x, hi, lo);
 #pragma unroll
             for (int j = 0; j < 8; j++) x[j] = bv[j] * fast_exp(-G[j]);                // b^ = b / gamma_t
-            put_row8(sm + L::BHh, sm + L::BHl, pt * LDK + pk, x, hi, lo);
+            put_row8(sm + L::BHh, sm + L::BHl, o, x, hi, lo);
 #pragma unroll
             for (int j = 0; j < 8; j++) x[j] *= sh_gC[pk + j];                          // b^ g_C (bounded by |b|)
-#pragma unroll
-            for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], hi[j], lo[j]);
-            put_col8(sm + L::BCTh, sm + L::BCTl, LDC, pk, pt, hi, lo);
+            put_row8(sm + L::BCh, sm + L::BCl, o, x, hi, lo);
 #pragma unroll
             for (int j = 0; j < 8; j++) x[j] = av[j] * fast_exp(G[j] - lw[j]);         // a~ = a gamma_{t-1}
-#pragma unroll
-            for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], hi[j], lo[j]);
-            put_col8(sm + L::ATTh, sm + L::ATTl, LDC, pk, pt, hi, lo);
-            const uint32_t dyr[4] = {cur.dy.r.x, cur.dy.r.y, cur.dy.r.z, cur.dy.r.w};  // dY is bf16: exact, one plane
-#pragma unroll
-            for (int j = 0; j < 8; j++) sm[L::DYT + (pk + j) * LDC + pt] = (uint16_t)(dyr[j >> 1] >> ((j & 1) * 16));
+            put_row8(sm + L::ATh, sm + L::ATl, o, x, hi, lo);
+            *reinterpret_cast<uint4 *>(sm + L::DY + o) = cur.dy.r;                      // dY is bf16: exact, one plane
         }
         lds_barrier();
         // ---- phase 1: A_qb^T (wave 0), W = T A~ (waves 1, 2) -----------------------------------------------------------
@@ -124,8 +120,8 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
             store_T_split(acc, sm + L::QBTh, sm + L::QBTl, LDC, lane);
         } else if (wave <= 2) {
             const int kt = wave - 1;
-            f32x16 acc = zero16();  // D[m = t][n = k] = sum_s T[t][s] a~[s][k]; stored as WT[k][t]
-            mma_tile3<kC, 2>(acc, sm + L::TMh, sm + L::TMl, LDC, sm + L::ATTh + kt * 32 * LDC, sm + L::ATTl + kt * 32 * LDC, LDC, lane);
+            f32x16 acc = zero16();  // D[m = t][n = k] = sum_s T[t][s] a~[s][k] (a~ time-major: transpose read); stored as WT[k][t]
+            mma_gen<kC, false, true, true, true, 2>(acc, sm + L::TMh, sm + L::TMl, LDC, 0, sm + L::ATh, sm + L::ATl, LDK, kt * 32, lane);
             store_T_split(acc, sm + L::WTh + kt * 32 * LDC, sm + L::WTl + kt * 32 * LDC, LDC, lane);
         }
         lds_barrier();
@@ -133,15 +129,14 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
         if (wave <= 1) {
             const int vt = wave;
             f32x16 acc = zero16();  // D[m = s][n = v] = sum_t QBT[s][t] dY[t][v]; stored as G1T[v][s]
-            mma_xs_ye<kC, 2>(acc, sm + L::QBTh, sm + L::QBTl, LDC, sm + L::DYT + vt * 32 * LDC, LDC, lane);
+            mma_gen<kC, false, true, true, false, 2>(acc, sm + L::QBTh, sm + L::QBTl, LDC, 0, sm + L::DY, sm + L::DY, LDK, vt * 32, lane);
             store_T_split(acc, sm + L::G1Th + vt * 32 * LDC, sm + L::G1Tl + vt * 32 * LDC, LDC, lane);
         } else {
             const int mt = wave - 2;  // rows k' of the product below
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
                 f32x16 acc = zero16();  // D[m = k'][n = k] = sum_t (b^ g_C)[t][k'] W[t][k]; stored as M^T[k][k']
-                mma_tile3<kC, 2>(acc, sm + L::BCTh + mt * 32 * LDC, sm + L::BCTl + mt * 32 * LDC, LDC, sm + L::WTh + nt * 32 * LDC,
-                              sm + L::WTl + nt * 32 * LDC, LDC, lane);
+                mma_gen<kC, true, true, false, true, 2>(acc, sm + L::BCh, sm + L::BCl, LDK, mt * 32, sm + L::WTh, sm + L::WTl, LDC, nt * 32, lane);
                 if (mt == nt) {
                     const int n = lane & 31;
 #pragma unroll
@@ -168,7 +163,7 @@ __global__ __launch_bounds__(256) void wkv7c_bwd_pre_kernel(int T_, int H, int n
         {
             const int mt = wave >> 1, nt = wave & 1;
             f32x16 acc = zero16();  // D[m = k][n = v]
-            mma_xs_ye<kC, 2>(acc, sm + L::QTTh + mt * 32 * LDC, sm + L::QTTl + mt * 32 * LDC, LDC, sm + L::DYT + nt * 32 * LDC, LDC, lane);
+            mma_gen<kC, true, true, true, false, 2>(acc, sm + L::QTh, sm + L::QTl, LDK, mt * 32, sm + L::DY, sm + L::DY, LDK, nt * 32, lane);
             mma_tile3<kC, 2>(acc, sm + L::WTh + mt * 32 * LDC, sm + L::WTl + mt * 32 * LDC, LDC, sm + L::G1Th + nt * 32 * LDC,
                           sm + L::G1Tl + nt * 32 * LDC, LDC, lane);
             // N' as a q15 record in accumulator order (chunk_common.h), tile = wave: 3 stores per lane, 9 KB instead of 16 KB fp32
