@@ -19,7 +19,7 @@
 namespace rwkv7 {
 
 namespace {
-constexpr int kChunksPerWG = 4;     // bwd_pre walks this many consecutive chunks per workgroup, prefetching the next one's inputs
+constexpr int kChunksPerWG = 8;     // bwd_pre walks this many consecutive chunks per workgroup, prefetching the next one's inputs
 
 struct PreSmem {  // offsets in uint16 units
     // the chunk's operands, every one stored ONCE, time-major [t][.] as its rows arrive: products that contract over time fetch
