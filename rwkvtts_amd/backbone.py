@@ -131,6 +131,10 @@ class LoRA(nn.Module):
             return fused.lora_decode(x, self.lora[0].weight, self.lora[2].weight, self.lora[2].bias, self.activation)
         return self.lora(x)  # fp32 models and decode-sized inputs: BLAS
 
+    def forward_from_hidden(self, h):
+        """The branch after its down projection (h = x @ lora.0.weight^T computed elsewhere, fused.dual_linear)."""
+        return self.lora[2](self.lora[1](h))
+
 
 class LayerState:
     """Per-layer recurrent state (reference: rwkv_asr_cuda_whisper.py:443-447; fla Cache entries
@@ -187,6 +191,7 @@ FUSED_TMIX_CORE = True
 # backward carries 6 x 3 x 8 values per thread next to the LayerNorm backward, spills, runs at two waves per SIMD with a
 # barrier per row: 560 against 320 us -> off.
 FUSED_ADD_LN_MIX1 = True
+DUAL_LINEAR_XV = True   # training: value projection + value-residual down projection as one autograd node (fused._DualLinear)
 FUSED_ADD_LN_MIX6 = False
 # cu_seqlens batches run on the chunked kernels' sequence flags (bf16); False: always unpack into a padded masked batch
 PACKED_NATIVE = True
@@ -260,11 +265,20 @@ class RWKV7Attention(nn.Module):
         H, N = self.num_heads, self.head_dim
         r = self.r_proj(xr)
         k = self.k_proj(xk)
-        v = self.v_proj(xv)
+        v_lo = None
+        if (self.layer_idx != 0 and DUAL_LINEAR_XV and self.v_proj.bias is None
+                and fused.dual_linear_supported(xv, self.v_proj.weight, self.v_lora.lora[0].weight)):
+            # xv feeds the value projection AND the value-residual branch: one autograd node, the input gradient without an add pass
+            v, v_lo = fused.dual_linear(xv, self.v_proj.weight, self.v_lora.lora[0].weight)
+        else:
+            v = self.v_proj(xv)
         w_pre = self.w_lora(xw)
         a_pre = self.a_lora(xa)
         g = self.g_lora(xg)
-        v_pre = self.v_lora(xv) if self.layer_idx != 0 else None
+        if self.layer_idx == 0:
+            v_pre = None
+        else:
+            v_pre = self.v_lora.forward_from_hidden(v_lo) if v_lo is not None else self.v_lora(xv)
         if self.layer_idx == 0:
             if mask is not None:
                 v = v * mask  # rwkv_s2s_single_ffn.py:178: v is masked before it becomes v_first

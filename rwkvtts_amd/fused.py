@@ -429,6 +429,55 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _DualLinear(torch.autograd.Function):
+    """(x W_a^T, x W_b^T) for two bias-free Linears that read the SAME input (the value projection and the down projection of the
+    value-residual LoRA both read xv, rwkv_s2s_single_ffn.py:174,180): as two autograd nodes the input gradient is two GEMMs plus
+    an [M, D] add kernel; here the second GEMM accumulates into the first one's output (beta = 1)."""
+
+    @staticmethod
+    def forward(ctx, x, wa, wb):
+        ctx.save_for_backward(x, wa, wb)
+        ctx.params = (wa, wb)
+        return torch.nn.functional.linear(x, wa), torch.nn.functional.linear(x, wb)
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        x, wa, wb = ctx.saved_tensors
+        K = x.shape[-1]
+        x2 = _c(x).view(-1, K)
+        da2 = None if dya is None else _c(dya).view(-1, wa.shape[0])
+        db2 = None if dyb is None else _c(dyb).view(-1, wb.shape[0])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if da2 is not None and db2 is not None:
+                dx = torch.mm(da2, wa)
+                dx.addmm_(db2, wb)
+            elif da2 is not None:
+                dx = torch.mm(da2, wa)
+            elif db2 is not None:
+                dx = torch.mm(db2, wb)
+            dx = None if dx is None else dx.view(x.shape)
+        grads = []
+        for i, (d2, w) in enumerate(((da2, wa), (db2, wb))):
+            g = None
+            if d2 is not None and ctx.needs_input_grad[1 + i]:
+                slot = _grad_slot(ctx.params[i])
+                g = wgrad_splitk(d2, x2, out=slot)
+                if slot is not None:
+                    g = slot.view_as(w)
+            grads.append(g)
+        return dx, grads[0], grads[1]
+
+
+def dual_linear_supported(x, wa, wb):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and wa.requires_grad and wb.requires_grad
+            and x.numel() // x.shape[-1] >= WGRAD_MIN_ROWS)
+
+
+def dual_linear(x, wa, wb):
+    return _DualLinear.apply(x, wa, wb)
+
+
 GEMV_MAX_ROWS = 32   # decode batches: rwkv7_gemv32_bf16 instead of the BLAS library
 
 

@@ -27,7 +27,8 @@ def steps(n):
 
 switches = [("add+LN+mix one pass (channel-mix side)", backbone, "FUSED_ADD_LN_MIX1"),
             ("add+LN+mix one pass (time-mix side)", backbone, "FUSED_ADD_LN_MIX6"),
-            ("low-rank weight gradients: skinny kernel", fused, "SKINNY_WGRAD")]
+            ("low-rank weight gradients: skinny kernel", fused, "SKINNY_WGRAD"),
+            ("value projection + value-residual branch as one node", backbone, "DUAL_LINEAR_XV")]
 steps(3)
 for name, mod, attr in switches:
     default = getattr(mod, attr)
