@@ -161,10 +161,12 @@ int rwkv7_tmix_prepare_bwd_f32(long rows, int D, const void *w_pre, const void *
                                rwkv7_stream_t stream);
 
 /* Same backward with the incoming gradients given as sums, added in fp32 on load (no separate add kernels): gsum is a
- * HOST array of 14 device pointers {d_w a,b; d_k2 a,b,c; d_v2 a,b; d_ain a,b; d_bin a,b; d_r a,b,c}, and
+ * HOST array of 15 device pointers {d_w a,b; d_k2 a,b,c; d_v2 a,b; d_ain a,b; d_bin a,b; d_r a,b,c; d_vfirst_in}, and
  * d_r = d_r a+b+c is written as well.  Consumes the two partial sets of rwkv7_wkv_bwd_split_* plus tmix_post's
  * contributions to k2, v2 and r.  The second partials (d_w b, d_k2 b, d_ain b, d_bin b, d_r b) may be NULL: complete
- * gradients, as the chunked backward produces them. */
+ * gradients, as the chunked backward produces them.  d_vfirst_in (may be NULL): the gradient of v_first collected by the
+ * layers after this one (v_first of layer 0 feeds every later layer, rwkv_s2s_single_ffn.py:179-182); d_vfirst = own + d_vfirst_in,
+ * so the sum over the layers is formed layer by layer inside this kernel instead of by one [rows, D] add pass per layer. */
 int rwkv7_tmix_prepare_bwd_sum_bf16(long rows, int D, const void *w_pre, const void *k, const void *v,
                                     const void *a_pre, const void *v_pre, const void *v_first, const void *mask,
                                     const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre, void *d_k,

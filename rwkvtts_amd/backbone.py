@@ -287,9 +287,9 @@ class RWKV7Attention(nn.Module):
             r = r * mask
         if seq_start is not None or (state is None and torch.is_grad_enabled() and (r.requires_grad or w_pre.requires_grad)
                                      and FUSED_TMIX_CORE):
-            y = fused.tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, self.k_k, self.k_a, self.g_norm.weight,
-                                self.g_norm.bias, self.r_k, mask, H, self.g_norm.eps, self.layer_idx == 0, seq_start)
-            return self.o_proj(y), v_first
+            y, vf_next = fused.tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, self.k_k, self.k_a, self.g_norm.weight,
+                                         self.g_norm.bias, self.r_k, mask, H, self.g_norm.eps, self.layer_idx == 0, seq_start)
+            return self.o_proj(y), (v_first if vf_next is None else vf_next)
         w, k2, v2, a_in, b_in = fused.tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, self.k_k, self.k_a, mask,
                                                    H, self.layer_idx == 0)
         if state is None:

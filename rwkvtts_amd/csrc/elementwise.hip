@@ -255,6 +255,7 @@ struct PrepBwdExtra {
     const T *d_w_b, *d_k2_b, *d_k2_c, *d_v2_b, *d_a_b, *d_b_b;  // added to d_w, d_k2, d_k2, d_v2, d_ain, d_bin
     const T *d_r_a, *d_r_b, *d_r_c;                              // d_r = a + b + c
     T *d_r;
+    const T *d_vfirst_in;   // may be NULL: what the layers after this one contributed to d v_first, added before d_vfirst is stored
 };
 
 template <typename T, bool MULTI>
@@ -365,6 +366,12 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
                 o2[j] = g2 * (vf[j] - vx[j]) * s * (1.f - s);  // d_vpre
                 o3[j] = g2 * s;                          // d_vfirst
                 sv_acc[j] += o2[j];
+            }
+            if (MULTI && ex.d_vfirst_in) {
+                float vin[8];
+                V8<T>::ld(ex.d_vfirst_in + o, vin);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o3[j] += vin[j];
             }
             V8<T>::st(d_v + o, o1);
             V8<T>::st(d_vpre + o, o2);
@@ -1177,7 +1184,7 @@ int tmix_prepare_bwd(long rows, int D, const void *w_pre, const void *k, const v
                        (T *)d_v, (T *)d_apre, (T *)d_vpre, (T *)d_vfirst, dpart, PrepBwdExtra<T>{});
     return finish();
 }
-// gsum: HOST array of 14 device pointers {d_w a,b; d_k2 a,b,c; d_v2 a,b; d_ain a,b; d_bin a,b; d_r a,b,c}
+// gsum: HOST array of 15 device pointers {d_w a,b; d_k2 a,b,c; d_v2 a,b; d_ain a,b; d_bin a,b; d_r a,b,c; d_vfirst_in}
 template <typename T>
 int tmix_prepare_bwd_sum(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
                          const void *v_pre, const void *v_first, const void *mask, const void *k_k, const void *k_a,
@@ -1185,7 +1192,7 @@ int tmix_prepare_bwd_sum(long rows, int D, const void *w_pre, const void *k, con
                          void *d_vfirst, void *d_r, float *dpart, int nblocks, hipStream_t st) {
     (void)hipGetLastError();
     const T *const *g = reinterpret_cast<const T *const *>(gsum);
-    PrepBwdExtra<T> ex{g[1], g[3], g[4], g[6], g[8], g[10], g[11], g[12], g[13], (T *)d_r};
+    PrepBwdExtra<T> ex{g[1], g[3], g[4], g[6], g[8], g[10], g[11], g[12], g[13], (T *)d_r, g[14]};
     hipLaunchKernelGGL((tmix_prepare_bwd_kernel<T, true>), dim3(nblocks), dim3(D / 8), 0, st, rows, D,
                        (const T *)w_pre, (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre,
                        (const T *)v_first, (const T *)mask, (const T *)k_k, (const T *)k_a, g[0], g[2], g[5], g[7],

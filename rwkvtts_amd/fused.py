@@ -195,6 +195,7 @@ def tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, eps):
     return _TmixPost.apply(y, r, k, v, g, gn_weight, gn_bias, r_k.reshape(-1), eps)
 
 
+CHAIN_VFIRST_GRAD = True   # v_first is handed from layer to layer through the time-mix node (its gradient is summed inside the prepare backward)
 CHUNKED_WKV_BWD = True   # bf16 training: scan forward + backward on the matrix cores (csrc/wkv7_chunk_*.hip); the pair goes
 CHUNKED_WKV_FWD = True   # together (the backward consumes the forward's checkpoints): set BOTH False for the scalar kernels
 
@@ -242,10 +243,15 @@ class _TmixCore(torch.autograd.Function):
         ctx.save_for_backward(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
                               w, k2, v2, a_in, b_in, y, s, sa, tinv)
         ctx.H, ctx.eps, ctx.chunked_fwd, ctx.seq_start = H, eps, chunked, seq_start
-        return out
+        if v_first is None or not CHAIN_VFIRST_GRAD:
+            return out
+        # v_first is handed on to the next layer THROUGH this node (a second output aliasing the input): its gradient then arrives
+        # here already summed over the later layers and is added inside rwkv7_tmix_prepare_bwd_sum -- as a plain fan-out of one
+        # tensor into 23 nodes autograd forms that sum with one [B*T, D] add kernel per layer
+        return out, v_first.view_as(v_first)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, d_vf_next=None):
         from . import ops
         (r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
          w, k2, v2, a_in, b_in, y, s, sa, tinv) = ctx.saved_tensors
@@ -274,9 +280,10 @@ class _TmixCore(torch.autograd.Function):
         d_vpre = torch.empty_like(k) if v_pre is not None else None
         d_vf = torch.empty_like(k) if v_pre is not None else None
         part = torch.empty(nb, 5, D, dtype=torch.float32, device=k.device)
+        d_vf_next = None if (d_vf_next is None or v_pre is None) else _c(d_vf_next)
         gsum = [dw2[0], dw2[1], dk2[0], dk2[1], d_k2_post, dv, d_v2_post, da2[0], da2[1], db2[0], db2[1],
-                dq2[0], dq2[1], d_r_post]
-        ptrs = (ctypes.c_void_p * 14)(*[None if t is None else t.data_ptr() for t in gsum])
+                dq2[0], dq2[1], d_r_post, d_vf_next]
+        ptrs = (ctypes.c_void_p * 15)(*[None if t is None else t.data_ptr() for t in gsum])
         _call("tmix_prepare_bwd_sum", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
               _p(mask), _p(k_k), _p(k_a), ptrs, _p(d_wpre), _p(d_k), _p(d_v), _p(d_apre), _p(d_vpre), _p(d_vf),
               _p(d_r), _p(part), nb)
@@ -294,8 +301,11 @@ def tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_
     assert k.shape[-1] == H * 64
     if is_layer0:
         v_pre = v_first = None
-    return _TmixCore.apply(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_bias, r_k.reshape(-1),
-                           _mask_rows(mask, k), H, eps, seq_start)
+    res = _TmixCore.apply(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_weight, gn_bias, r_k.reshape(-1),
+                          _mask_rows(mask, k), H, eps, seq_start)
+    if torch.is_tensor(res):
+        return res, None
+    return res   # (y, v_first for the next layer)
 
 
 _ACT_ID = {None: 0, "tanh": 1, "sigmoid": 2}

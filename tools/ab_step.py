@@ -26,9 +26,9 @@ def steps(n):
 
 
 switches = [("add+LN+mix one pass (channel-mix side)", backbone, "FUSED_ADD_LN_MIX1"),
-            ("add+LN+mix one pass (time-mix side)", backbone, "FUSED_ADD_LN_MIX6"),
             ("low-rank weight gradients: skinny kernel", fused, "SKINNY_WGRAD"),
-            ("value projection + value-residual branch as one node", backbone, "DUAL_LINEAR_XV")]
+            ("value projection + value-residual branch as one node", backbone, "DUAL_LINEAR_XV"),
+            ("v_first gradient summed layer by layer in the prepare backward", fused, "CHAIN_VFIRST_GRAD")]
 steps(3)
 for name, mod, attr in switches:
     default = getattr(mod, attr)
