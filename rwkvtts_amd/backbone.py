@@ -189,7 +189,8 @@ FUSED_TMIX_CORE = True
 # Measured on MI355X (tools/bench_add_ln_mix.py, B*T = 32768, D = 1024): channel-mix side (1 lerp) forward 56 us against 79 us
 # for the two separate stages, backward equal -> on.  Time-mix side (6 lerps): forward 140 against 170 us, but the one-pass
 # backward carries 6 x 3 x 8 values per thread next to the LayerNorm backward, spills, runs at two waves per SIMD with a
-# barrier per row: 560 against 320 us -> off.
+# barrier per row: 560 against 320 us -> off (a 4-channels-per-thread variant of that backward: 176 registers, 365 us -- still
+# behind the two separate kernels, not kept).
 FUSED_ADD_LN_MIX1 = True
 DUAL_LINEAR_XV = True   # training: value projection + value-residual down projection as one autograd node (fused._DualLinear)
 FUSED_ADD_LN_MIX6 = False

@@ -25,19 +25,24 @@ def steps(n):
     return ts
 
 
-switches = [("add+LN+mix one pass (channel-mix side)", backbone, "FUSED_ADD_LN_MIX1"),
-            ("low-rank weight gradients: skinny kernel", fused, "SKINNY_WGRAD"),
-            ("value projection + value-residual branch as one node", backbone, "DUAL_LINEAR_XV"),
-            ("v_first gradient summed layer by layer in the prepare backward", fused, "CHAIN_VFIRST_GRAD")]
+switches = [("add+LN+mix one pass (channel-mix side)", backbone, "FUSED_ADD_LN_MIX1", False, True),
+            ("low-rank weight gradients: skinny kernel", fused, "SKINNY_WGRAD", False, True),
+            ("value projection + value-residual branch as one node", backbone, "DUAL_LINEAR_XV", False, True),
+            ("v_first gradient summed layer by layer in the prepare backward", fused, "CHAIN_VFIRST_GRAD", False, True),
+            ("parameter-gradient partials 2048 -> 1024 workgroups", fused, "_BWD_BLOCKS", 2048, 1024),
+            ("mix backward runs 4 -> 8 rows", fused, "_MIX_BWD_ROWS", 4, 8),
+            ("mix backward 1024 -> 2048 workgroups", fused, "_MIX_BWD_BLOCKS", 1024, 2048)]
+if len(sys.argv) > 1:
+    switches = [s_ for s_ in switches if any(k in s_[0] for k in sys.argv[1:])]
 steps(3)
-for name, mod, attr in switches:
+for name, mod, attr, off, on in switches:
     default = getattr(mod, attr)
-    res = {False: [], True: []}
+    res = {off: [], on: []}
     for rep in range(3):
-        for v in (False, True):
+        for v in (off, on):
             setattr(mod, attr, v)
             steps(1)
             res[v] += steps(4)
     setattr(mod, attr, default)
     med = {v: sorted(res[v])[len(res[v]) // 2] for v in res}
-    print(f"{name:45s} off {med[False]:7.2f} ms   on {med[True]:7.2f} ms   ({med[True] - med[False]:+.2f} ms; default {'on' if default else 'off'})", flush=True)
+    print(f"{name:62s} {off!s:>5}: {med[off]:7.2f} ms   {on!s:>5}: {med[on]:7.2f} ms   ({med[on] - med[off]:+.2f} ms; default {default})", flush=True)
