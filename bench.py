@@ -53,6 +53,16 @@ def _free_port():
     return p
 
 
+def _device_info(torch, dev):
+    """Name / CU count / clock of the GPU the line was measured on (boxes of one pool differ by several per cent)."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        return {"name": p.name, "compute_units": p.multi_processor_count, "clock_mhz": round(getattr(p, "clock_rate", 0) / 1e3),
+                "hbm_gib": round(p.total_memory / 2**30)}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` (the form the driver uses) -> N ranks under torch.distributed.run on this node."""
     env = dict(os.environ)
@@ -330,6 +340,7 @@ def main():
             "loss": round(loss_val, 4),
             "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+            "device": _device_info(torch, dev),
             "roofline": roof,
         }
         if a.one_device:
