@@ -57,7 +57,7 @@ def _device_info(torch, dev):
     """Name / CU count / clock of the GPU the line was measured on (boxes of one pool differ by several per cent)."""
     try:
         p = torch.cuda.get_device_properties(dev)
-        return {"name": p.name, "compute_units": p.multi_processor_count, "clock_mhz": round(getattr(p, "clock_rate", 0) / 1e3),
+        return {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
                 "hbm_gib": round(p.total_memory / 2**30)}
     except Exception as e:
         return {"error": repr(e)}
