@@ -89,7 +89,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd8_kernel(int T_, int H, const bf
         vh = blockIdx.x & 1;
         bh = blockIdx.x >> 1;
     }
-    const int tid = threadIdx.x, role = tid >> 8, ltid = tid & 255, wave = ltid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, ltid = tid & 255, lane = tid & 63;
+    // scalar role / wave ids: derived from threadIdx they make every `if (wave == ..)` an exec-masked region that all waves walk
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane(ltid >> 6);
     const int nc = T_ / kC;
     int bb, hh, c0 = 0, c1 = nc;
     if (seq_off_) {  // packed rows: see wkv7c_fwd_kernel
