@@ -38,7 +38,7 @@ steps(3)
 for name, mod, attr, off, on in switches:
     default = getattr(mod, attr)
     res = {off: [], on: []}
-    for rep in range(3):
+    for rep in range(int(os.environ.get("AB_REPS", "3"))):
         for v in (off, on):
             setattr(mod, attr, v)
             steps(1)
