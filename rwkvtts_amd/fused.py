@@ -15,7 +15,7 @@ from . import _lib
 _FWD_BLOCKS = 32768  # workgroups walking the rows (D/8 threads each): one row per workgroup at B*T = 32768 beats a row loop
                      # (tools/bench_fwd_blocks.py: prepare 178 -> 165 us, post 80 -> 71, add+LayerNorm 48 -> 44.5)
 _MIX_FWD_BLOCKS = 2048   # the token-shift kernel re-reads the previous row at the start of a run: fewer, longer runs (106 -> 103 us)
-_BWD_BLOCKS = 2048   # also the number of parameter-gradient partials (1024: same step time, 512: +4 %)
+_BWD_BLOCKS = 1024   # also the number of parameter-gradient partials (round 2, same-box A/B: 2048 -> 1024 -0.6...-0.9 ms per step)
 _MIX_BWD_ROWS = 4     # rows per run in mix_bwd (neighbours carried in registers inside a run)
 _MIX_BWD_BLOCKS = 1024
 

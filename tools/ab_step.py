@@ -30,6 +30,8 @@ switches = [("add+LN+mix one pass (channel-mix side)", backbone, "FUSED_ADD_LN_M
             ("value projection + value-residual branch as one node", backbone, "DUAL_LINEAR_XV", False, True),
             ("v_first gradient summed layer by layer in the prepare backward", fused, "CHAIN_VFIRST_GRAD", False, True),
             ("parameter-gradient partials 2048 -> 1024 workgroups", fused, "_BWD_BLOCKS", 2048, 1024),
+            ("parameter-gradient partials 1024 -> 512 workgroups", fused, "_BWD_BLOCKS", 1024, 512),
+            ("one-pass backward partials 2048 -> 1024 workgroups", fused, "_ADD_LN_MIX_BWD_BLOCKS", 2048, 1024),
             ("mix backward runs 4 -> 8 rows", fused, "_MIX_BWD_ROWS", 4, 8),
             ("mix backward 1024 -> 2048 workgroups", fused, "_MIX_BWD_BLOCKS", 1024, 2048)]
 if len(sys.argv) > 1:
