@@ -335,6 +335,7 @@ def lora_decode(x, w1, w2, bias, activation):
 # nn.Linear with a split-M weight gradient
 # ------------------------------------------------------------------------------------------------------
 WGRAD_MIN_ROWS = 4096
+WGRAD_SLABS_SMALL, WGRAD_SLABS_BIG = 8, 4   # row slabs of the batched weight-gradient GEMM: outputs up to 1024 x 1024 / larger
 SKINNY_WGRAD = True   # low-rank weight gradients through rwkv7_wgrad_skinny_bf16 (A/B switch for tools/ab_step.py)
 
 
@@ -360,7 +361,7 @@ def wgrad_splitk(dy2, x2, out=None):
             rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(N * K), S, _p(part), _p(out), 0, _stream(part))
         _lib.check(rc, "sum_slabs")
         return out
-    S = 8 if N * K <= 1024 * 1024 else 4
+    S = WGRAD_SLABS_SMALL if N * K <= 1024 * 1024 else WGRAD_SLABS_BIG
     if M < WGRAD_MIN_ROWS or M % (S * 8) != 0:
         res = torch.mm(dy2.t(), x2)
         if out is not None:

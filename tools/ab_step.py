@@ -33,6 +33,14 @@ switches = [("add+LN+mix one pass (channel-mix side)", backbone, "FUSED_ADD_LN_M
             ("parameter-gradient partials 1024 -> 512 workgroups", fused, "_BWD_BLOCKS", 1024, 512),
             ("one-pass backward partials 2048 -> 1024 workgroups", fused, "_ADD_LN_MIX_BWD_BLOCKS", 2048, 1024),
             ("mix backward runs 4 -> 8 rows", fused, "_MIX_BWD_ROWS", 4, 8),
+            ("forward stages 32768 -> 16384 workgroups", fused, "_FWD_BLOCKS", 32768, 16384),
+            ("forward stages 32768 -> 8192 workgroups", fused, "_FWD_BLOCKS", 32768, 8192),
+            ("mix forward 2048 -> 4096 workgroups", fused, "_MIX_FWD_BLOCKS", 2048, 4096),
+            ("mix forward 2048 -> 1024 workgroups", fused, "_MIX_FWD_BLOCKS", 2048, 1024),
+            ("weight gradients 1024x1024: 8 -> 16 slabs", fused, "WGRAD_SLABS_SMALL", 8, 16),
+            ("weight gradients 1024x1024: 8 -> 4 slabs", fused, "WGRAD_SLABS_SMALL", 8, 4),
+            ("weight gradients 4096x1024: 4 -> 8 slabs", fused, "WGRAD_SLABS_BIG", 4, 8),
+            ("weight gradients 4096x1024: 4 -> 2 slabs", fused, "WGRAD_SLABS_BIG", 4, 2),
             ("mix backward 1024 -> 2048 workgroups", fused, "_MIX_BWD_BLOCKS", 1024, 2048)]
 if len(sys.argv) > 1:
     switches = [s_ for s_ in switches if any(k in s_[0] for k in sys.argv[1:])]
