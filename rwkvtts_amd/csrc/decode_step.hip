@@ -277,7 +277,9 @@ __device__ __forceinline__ void gemv_steps(f32x16 &acc, const uint16_t *wp, cons
 }
 
 // OUTMODE 0: fp32 partials out[ks][n][col] (+ bias);  1: KS = 1 and out is bf16 [n][col] = relu(.)^2 (the channel-mix key)
-template <int OUTMODE, int NSEG>
+// TW: columns per tile.  16: the MFMA's 32 A rows hold each of the 16 weight rows twice (the upper half of the result is
+// ignored) -- for the sweep that cannot split K (OUTMODE 1: F / 32 = 128 items would leave half of the CUs idle).
+template <int OUTMODE, int NSEG, int TW = 32>
 __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, const GemvSeg (&segs)[NSEG], int K, int KS, void *out_,
                                            int ldo, const uint16_t *bias) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -304,8 +306,8 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
             t = here ? tile - first_tile : t;
             col_base = here ? first_col : col_base;
         }
-        const int c0 = t * 32;                                  // first column of the tile inside its segment
-        const int mrow = min(c0 + (lane & 31), sg.ncols - 1);
+        const int c0 = t * TW;                                  // first column of the tile inside its segment
+        const int mrow = min(c0 + (lane & (TW - 1)), sg.ncols - 1);
         const int kbeg = ks * (K / KS) + wave * kw + (lane >> 5) * 8;
         const uint16_t *wp = sg.W + (long)mrow * K + kbeg;
         const uint16_t *xp = sg.X + (long)nrow * K + kbeg;
@@ -326,7 +328,7 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
             uint16_t *ob = (uint16_t *)out_ + (long)n * ldo + col_base + c0;
             const bool vec = (ldo & 3) == 0 && ((col_base + c0) & 3) == 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < TW / 8; j++) {
                 const int c = 8 * j + 4 * (lane >> 5);  // 4 consecutive columns of the tile
                 float v[4];
 #pragma unroll
@@ -610,8 +612,8 @@ __device__ __forceinline__ void run_phase(const DecodeDesc &d, DecSmem &sm, int 
         break;
     }
     case 5: {
-        const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WKEY], d.kx, d.F / 32, d.F}};
-        gemv_phase<1, 1>(d, sm, seg, D, 1, d.kact, d.F, nullptr);
+        const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WKEY], d.kx, d.F / 16, d.F}};
+        gemv_phase<1, 1, 16>(d, sm, seg, D, 1, d.kact, d.F, nullptr);
         break;
     }
     default: {
@@ -743,7 +745,7 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
     } else {
         // one launch per phase, each sized to its own item count
         const int N2 = 3 * D + Rw + Ra + Rv + Rg;
-        const int g_phase[7] = {B, (N2 / 32) * w.ks_qkv, H * ((B + 1) / 2), (D / 32) * w.ks_o, B, F / 32, (D / 32) * w.ks_val};
+        const int g_phase[7] = {B, (N2 / 32) * w.ks_qkv, H * ((B + 1) / 2), (D / 32) * w.ks_o, B, F / 16, (D / 32) * w.ks_val};
         for (int l = 0; l < L; l++)
             for (int ph = 0; ph < 7; ph++) {
                 const int items = l == 0 && ph == 1 ? g_phase[1] - (Rv / 32) * w.ks_qkv : g_phase[ph];
