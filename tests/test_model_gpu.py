@@ -321,6 +321,36 @@ def test_bf16_training_blocks_at_model_widths_match_oracle_autograd(dims):
     assert top[0][1] < 0.10, f"worst five {top}"
 
 
+def test_dual_linear_and_v_first_chain_equal_the_plain_graph():
+    """fused._DualLinear (xv -> value projection + value-residual down projection as one node) and the v_first hand-over through
+    the time-mix node (fused.CHAIN_VFIRST_GRAD) only change HOW gradients are summed: against the plain autograd graph (both
+    switches off) the loss is identical and every parameter gradient agrees to the rounding of the bf16 add kernels they replace."""
+    from rwkvtts_amd import backbone, fused
+    from rwkvtts_amd.layouts import synthetic_spark_batch
+    cfg = RWKV7SpeechConfig(vocab_size=257, text_vocab_size=300, audio_global_vocab_size=64, hidden_size=256, num_hidden_layers=3,
+                            decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=32, gate_low_rank_dim=64)
+    model = RWKV7ForSpeech(cfg).init_weights(seed=11).to(DEV).to(torch.bfloat16).train()
+    model.dropout.p = 0.0
+    res = {}
+    saved = (backbone.DUAL_LINEAR_XV, fused.CHAIN_VFIRST_GRAD)
+    try:
+        for flag in (False, True):
+            backbone.DUAL_LINEAR_XV = fused.CHAIN_VFIRST_GRAD = flag
+            model.zero_grad(set_to_none=True)
+            batch = synthetic_spark_batch(model, 2, 2048, seed=5, n_text=31, n_global=8)   # 4096 rows: the split weight gradients run
+            out = model(**batch)
+            out.loss.backward()
+            res[flag] = (out.loss.item(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        backbone.DUAL_LINEAR_XV, fused.CHAIN_VFIRST_GRAD = saved
+    assert res[True][0] == res[False][0]
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) > 60
+    for n, g in res[False][1].items():
+        scale = max(g.abs().max().item(), 1e-9)
+        err = (res[True][1][n] - g).abs().max().item()
+        assert err <= 2e-2 * scale, f"{n}: {err:.3e} vs scale {scale:.3e}"
+
+
 def test_fused_linear_ce_hip_kernel_bf16():
     """bf16 hidden/weight take rwkv7_ce_fwd_bwd_bf16 (loss + d logits in one pass over the bf16 logits): against fp32
     cross_entropy on the same bf16-rounded logits.  V = 8193 (odd row length, as the Spark head)."""
