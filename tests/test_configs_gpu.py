@@ -197,6 +197,43 @@ def test_config3_xy_model_8_channels_V66661_train_step_B4_L8192():
     assert math.isfinite(l2) and l2 < l0, (l0, l1, l2)
 
 
+@pytest.mark.timeout(900)
+def test_config3_xy_model_full_depth_24_layers_train_steps_B4_L8192():
+    """configs[3] at its full depth (xy_llm.py:189-257 on a 1.5B base, convert_rwkv7_to_xy.py:23-32): 24 layers, D = 2048,
+    H = 32, 8 channels, V0 = 66 661, B = 4, L = 8192, bf16, AdamW on fp32 masters -- the step bench.py --model 1.5b --layout xy
+    times (profiles/r03a_cfg3_xy_1p5b_line.txt: 494.7 ms, 142.9 GiB).  Finite loss near sum(log V_i), the loss falls over three
+    steps on one batch, gradients reach the first and the last layer, and the peak stays well inside the 288 GB of one GPU."""
+    import math
+    from rwkvtts_amd import backbone, trainer
+    from rwkvtts_amd.xy_llm import RWKV7XYConfig, RWKV7XYLM
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = backbone.config_1p5b()
+    kw = {k: v for k, v in base.to_dict().items() if k in backbone.RWKV7Config.__dataclass_fields__ and k != "extra"}
+    kw.update(vocab_size=66661)
+    assert kw["num_hidden_layers"] == 24 and kw["hidden_size"] == 2048
+    cfg = RWKV7XYConfig(speech_vocab_size=1025, num_channels=8, text_shift_size=65536, **kw)
+    model = RWKV7XYLM(cfg).init_weights(seed=0)
+    model.zero_embs()
+    model = model.to(DEV).to(torch.bfloat16).train()
+    batch = _to(L.synthetic_xy_batch(4, T1=128, T2=8057, seed=1234), DEV)
+    assert batch["input_ids"].shape == (4, 8192, 8)
+    expect = math.log(66661) + 7 * math.log(1025)
+    tr = trainer.DataParallelTrainer(model, lr=1e-3, warmup_steps=0, total_steps=10)
+    l0 = tr.step(**batch, use_cache=False).item()
+    assert math.isfinite(l0) and abs(l0 - expect) < 0.1 * expect, (l0, expect)
+    for li in (0, 23):
+        g = model.model.layers[li].attn.r_proj.weight.grad
+        assert g is not None and torch.isfinite(g.float()).all() and g.float().abs().sum().item() > 0, li
+    l1 = tr.step(**batch, use_cache=False).item()
+    l2 = tr.step(**batch, use_cache=False).item()
+    assert math.isfinite(l2) and l2 < l0, (l0, l1, l2)
+    peak = torch.cuda.max_memory_allocated()
+    assert peak < 200 * 2**30, peak / 2**30   # measured 142.9 GiB; the GPU has 288 GB
+    del tr, model
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # configs[4]
 # ---------------------------------------------------------------------------------------------------------------------
