@@ -282,7 +282,7 @@ def main():
         value = world * B * T * a.steps / dt
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items() if v}
         th = B * T * H
-        chunk_parts = [k for k in ("wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bwd_out") if k in kern]
+        chunk_parts = [k for k in ("wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bseq", "wkv7c_bwd_out") if k in kern]
         if "wkv7c_bwd_out" in kern:
             bwd_ms = sum(kern[k] for k in chunk_parts)
             bwd_name = "WKV7 backward, chunked MFMA (" + " + ".join(chunk_parts) + f", {cfg.num_hidden_layers}x per step)"

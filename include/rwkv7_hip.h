@@ -69,7 +69,8 @@ int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_b
  * argument of these `_variant` twins, never a hidden switch that changes what the plain entry points above launch.
  *   cols_per_lane : state columns per lane of the scalar forward kernel -- 0 automatic by B*H (what the plain entry does), 4, 8
  *   wide          : row-split backward -- 0 = 256 threads, 2 state rows per lane tile (plain entry); 1 = 512 threads, 1 row
- *   waves         : chunked bf16 forward -- 8 = producer/consumer kernel (plain entry), 4 = the 4-wave kernel */
+ *   waves         : chunked bf16 forward -- 9 = producer/consumer kernel, two dependent products per chunk (plain entry),
+ *                   8 = three dependent products per chunk, 4 = the 4-wave kernel */
 int rwkv7_wkv_fwd_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                const void *a, const void *b, void *y, float *s, float *sa, int cols_per_lane, rwkv7_stream_t stream);
 int rwkv7_wkv_fwd_variant_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
@@ -293,6 +294,12 @@ int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void 
 int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const void *np, void *e_vk, rwkv7_stream_t stream);
 int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const void *np, void *e_vk, const int *seq_chunk_off,
                                    int nseq, rwkv7_stream_t stream);   /* packed rows: see rwkv7_wkv_chunk_fwd_seq_bf16 */
+/*   bseq    : `bwd_pre` + `state` as ONE sequential kernel (csrc/wkv7_chunk_bseq.hip; what ops.wkv7_chunk_backward launches): the
+ *             recurrence in factored form, E_c = E' + A~^T Z + Q~^T dY with Z = (T^T B^) E' + (T^T A_qb^T) dY, E' = g_C E_{c+1} --
+ *             M_c^T and N'_c are never formed and never reach HBM.  Same e_vk records as `state`; seq_chunk_off / nseq as in
+ *             rwkv7_wkv_chunk_fwd_seq_bf16 (NULL / 0 for plain rows). */
+int rwkv7_wkv_chunk_bseq_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
+                              const float *tinv, void *e_vk, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
 /*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from what the chunked
  *             forward saved (hs, sa, tinv) and the adjoint states e_vk of `state`. */
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,

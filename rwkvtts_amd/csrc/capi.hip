@@ -40,6 +40,8 @@ int lora32_bf16(int, int, int, int, int, const void *, const void *, const void 
 int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                        void *, hipStream_t);
 int chunk_state_bf16(int, int, int, const void *, const void *, void *, const int *, int, hipStream_t);
+int chunk_bseq_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
+                    const int *, int, hipStream_t);
 int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *,
                         hipStream_t);
@@ -345,16 +347,17 @@ EW_DEFINE(f32, float)
         return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, WAVES_ARG (hipStream_t)stream); \
     }
 #define RWKV7_COMMA ,
-CHUNK_DEFINE(bf16, 8 RWKV7_COMMA)
+CHUNK_DEFINE(bf16, 9 RWKV7_COMMA)
 CHUNK_DEFINE(f32, )
-// A/B and cross-check: the 4-wave kernel (waves = 4) or the 8-wave producer/consumer kernel (8, what the plain entry launches)
+// A/B and cross-check: the 4-wave kernel (waves = 4), the 8-wave producer/consumer kernel with three dependent products per
+// chunk (8) or with two (9, what the plain entry launches)
 int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                          const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                                          const int *seq_chunk_off, int nseq, int waves, rwkv7_stream_t stream) {
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;
     if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;
     if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;
-    if (waves != 4 && waves != 8) return RWKV7_ESHAPE;
+    if (waves != 4 && waves != 8 && waves != 9) return RWKV7_ESHAPE;
     return rwkv7::chunk_fwd_bf16(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, waves, (hipStream_t)stream);
 }
 
@@ -374,6 +377,13 @@ int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, co
     if (B <= 0 || H <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk})) return RWKV7_EINVAL;
     if (seq_chunk_off != nullptr && nseq <= 0) return RWKV7_EINVAL;
     return rwkv7::chunk_state_bf16(B * H, nchunks, H, mt, np, e_vk, seq_chunk_off, nseq, (hipStream_t)stream);
+}
+int rwkv7_wkv_chunk_bseq_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
+                              const float *tinv, void *e_vk, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, a, b, dy, (const void *)tinv, (const void *)e_vk})) return RWKV7_EINVAL;
+    if (seq_chunk_off != nullptr && nseq <= 0) return RWKV7_EINVAL;
+    if (T % 32 != 0) return RWKV7_ECHUNK;
+    return rwkv7::chunk_bseq_bf16(B, T, H, w, q, a, b, dy, tinv, e_vk, seq_chunk_off, nseq, (hipStream_t)stream);
 }
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                  const void *a, const void *b, const void *dy, const void *hs, const float *sa,

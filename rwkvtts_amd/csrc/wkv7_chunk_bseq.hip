@@ -1,0 +1,315 @@
+// rwkvtts_amd/csrc/wkv7_chunk_bseq.hip -- adjoint-state recurrence of the chunked (MFMA) WKV7 backward in ONE kernel, bf16 tensors.
+//
+// Replaces wkv7c_bwd_pre_kernel + wkv7c_state_kernel (wkv7_chunk_bwd.hip; reference wkv7_cuda.cu:54-130).  Those two materialise
+// M_c^T and N'_c (two 64 x 64 matrices per chunk, 18 KB of q15 records written by one kernel and read by the next: 0.6 GB per layer
+// at B=8, T=4096, H=16) so that the sequential kernel is one product per chunk.  Here the recurrence
+//     E_c = M_c^T E_{c+1} + N'_c ,   M_c = diag(g_C)(I + B^^T T A~) ,   N'_c = Q~^T dY + (T A~)^T (A_qb^T dY)
+// is applied in factored form, the mirror image of the forward kernel wkv7c_fwd9_kernel (wkv7_chunk_fwd9.hip), chunks descending:
+//     E' = g_C E_{c+1}
+//     Z  = B" E' + X" dY        B" = T^T B^ (32 x 64),  X" = T^T A_qb^T (32 x 32)   -- no state in them: made one chunk ahead
+//     E_c = E' + A~^T Z + Q~^T dY
+// (Z_t = dL/du_t, the same Z the per-chunk gradient kernel uses).  Two dependent products per chunk, nothing but the raw rows read
+// and nothing but the E records written: 20 KB in (16 of them shared by the two workgroups of a head through L2) + 9 KB out per
+// chunk against 43 + 28.
+//     interval a   wave 0: Z = B" E' + X" dY -> Z planes
+//                  waves 4-7 (producer): b^ splits; operand planes q~, a~, b^, dY, g_C, T planes of the NEXT chunk (c - 1); raw rows
+//                                        of the chunk after it -> LDS staging; next global prefetch
+//     interval b   waves 1,2: record of E_{c+1} -> e_vk[c]; E_c (two key tiles); E' planes of the next chunk; then B" of the next chunk
+//                  wave 3: A_qb, X" of the next chunk
+//                  waves 4-7: rows of the chunk after the next in the compute mapping: exp, prefix sums, scaling, q~ / a~ splits
+// One workgroup per (head, half of the value columns): the value columns of E never mix.
+#include "chunk_common.h"
+
+namespace rwkv7 {
+
+#ifdef WKV7C_TIMING
+__device__ long long g_cbseq_timing[8 * 4];
+#define BSSTAMP(i)                                              \
+    do {                                                        \
+        const long long now_ = __builtin_readcyclecounter();    \
+        tacc_[i] += now_ - tprev_;                              \
+        tprev_ = now_;                                          \
+    } while (0)
+#else
+#define BSSTAMP(i) do { } while (0)
+#endif
+
+namespace {
+constexpr int LDK = kN + kPad;  // planes with K = 64 columns
+constexpr int LDC = kC + kPad;  // planes with K = 32 columns
+constexpr int VH = 32;          // value columns per workgroup
+
+struct BSSmem {  // offsets in uint16 units; every plane 16-byte aligned
+    static constexpr int PL = kC * LDK, PS = kC * LDC;
+    // one producer buffer: six scaled operand planes, time-major, and dY[t][v]
+    static constexpr int QTh = 0, QTl = PL, ATh = 2 * PL, ATl = 3 * PL, BHh = 4 * PL, BHl = 5 * PL, DYt = 6 * PL;
+    static constexpr int BUF = 6 * PL + PS;
+    // single: state planes E'[v][k], B"[r][k], and the 32 x 32 matrices X"[r][t], A_qb[t][s], T[t][r], Z[v][r]
+    static constexpr int Eh = 2 * BUF, El = Eh + VH * LDK;
+    static constexpr int BBh = El + VH * LDK, BBl = BBh + PL;
+    static constexpr int XPh = BBl + PL, XPl = XPh + PS, QBh = XPl + PS, QBl = QBh + PS, TMh = QBl + PS, TMl = TMh + PS;
+    static constexpr int Zh = TMl + PS, Zl = Zh + VH * LDC;
+    static constexpr int end16 = Zl + VH * LDC;
+    static constexpr int fGC = 0, fend = 2 * kN;   // fp32: g_C of both buffers
+    // raw input staging (bf16): 4 planes [32][64 + 8] and dY [32][32 + 8]
+    static constexpr int RS = kN + 8, RSV = VH + 8;
+    static constexpr size_t bytes = (size_t)end16 * 2 + (size_t)fend * 4 + (size_t)(4 * kC * RS + kC * RSV) * 2;
+};
+static_assert(BSSmem::end16 % 8 == 0 && BSSmem::BUF % 8 == 0 && BSSmem::BBh % 8 == 0 && BSSmem::XPh % 8 == 0, "16-byte alignment");
+static_assert(BSSmem::bytes <= 160 * 1024, "LDS budget");
+}  // namespace
+
+__global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_,
+                                                         const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_,
+                                                         const bf16_t *__restrict__ dy_, const float *__restrict__ tinv_,
+                                                         uint16_t *__restrict__ e_vk, const int *__restrict__ seq_off_) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
+    using L = BSSmem;
+    float *sh_gC2 = reinterpret_cast<float *>(sm + L::end16) + L::fGC;
+    bf16_t *raw = reinterpret_cast<bf16_t *>(reinterpret_cast<float *>(sm + L::end16) + L::fend);
+    constexpr int RS = L::RS, RSV = L::RSV;
+
+    // workgroup -> (head, value half): the two halves of a head get block ids g and g + 8 (same XCD, shared L2)
+    int vh, bh;
+    if ((gridDim.x & 15) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bh = (j >> 1) * 8 + xcd;
+        vh = j & 1;
+    } else {
+        vh = blockIdx.x & 1;
+        bh = blockIdx.x >> 1;
+    }
+    const int tid = threadIdx.x, ltid = tid & 255, lane = tid & 63;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane(ltid >> 6);
+    const int nc = T_ / kC;
+    int bb, hh, c0 = 0, c1 = nc;
+    if (seq_off_) {  // packed rows: one workgroup pair per (sequence, head) walks only that sequence's chunks
+        const int sq = bh / H;
+        hh = bh - sq * H;
+        const int g0 = seq_off_[sq], g1 = seq_off_[sq + 1];
+        bb = g0 / nc;
+        c0 = g0 - bb * nc;
+        c1 = c0 + (g1 - g0);
+        bh = bb * H + hh;
+        if (c1 <= c0) return;
+    } else {
+        bb = bh / H;
+        hh = bh - bb * H;
+    }
+    const long tstride = (long)H * kN;
+    const long head_base = ((long)bb * T_ * H + hh) * kN;
+    const int pt = ltid & 31, pk = (ltid >> 5) * 8, pv = (ltid >> 5) * 4;
+    const int lt = ltid >> 3, lk = (ltid & 7) * 8, lv = (ltid & 7) * 4;
+
+    for (int i = tid; i < 2 * VH * LDK; i += 512) sm[L::Eh + i] = 0;  // E after the last chunk is zero
+    using RawVec = decltype(Raw4<bf16_t>::r);
+#ifdef WKV7C_TIMING
+    long long tacc_[4] = {0, 0, 0, 0};
+    long long tprev_ = __builtin_readcyclecounter();
+#endif
+
+    // Iteration `it` (descending): the consumer works on chunk cc = it, the producer finishes chunk pc = it - 1 and starts pc - 1.
+    if (role == 0) {
+        // =================================================================================================== consumer
+        f32x16 Emaster = zero16();  // waves 1, 2: D-layout tile (32 keys x 32 value columns) of E_{cc+1}, fp32, not yet decayed
+        lds_barrier();
+        lds_barrier();
+        for (int it = c1; it >= c0; it--) {
+            const int cc = it, pc = it - 1;
+            const uint16_t *bufc = sm + (cc & 1) * L::BUF, *bufp = sm + (pc & 1) * L::BUF;
+            const float *gCc = sh_gC2 + (cc & 1) * kN, *gCp = sh_gC2 + (pc & 1) * kN;
+            // ----------------------------------------------------------------------------------------------- interval a
+            if (cc < c1 && wave == 0) {   // Z = B" E' + X" dY : D[r][v] -> Z[v][r]
+                f32x16 acc = zero16();
+                mma_tile3<kN>(acc, sm + L::BBh, sm + L::BBl, LDK, sm + L::Eh, sm + L::El, LDK, lane);
+                mma_gen<kC, false, true, true, false>(acc, sm + L::XPh, sm + L::XPl, LDC, 0, bufc + L::DYt, bufc + L::DYt, LDC, 0, lane);
+                store_T_split(acc, sm + L::Zh, sm + L::Zl, LDC, lane);
+            }
+            BSSTAMP(0);
+            lds_barrier();
+            BSSTAMP(1);
+            // ----------------------------------------------------------------------------------------------- interval b
+            if (wave == 1 || wave == 2) {
+                const int kt = wave - 1;  // key channels [32 kt, 32 kt + 32)
+                if (cc < c1) {
+                    // what chunk cc receives from its future: q15 record straight from the accumulator tile
+                    q15_encode_tile(Emaster, e_vk + ((long)bh * nc + cc) * kQRec, vh, kt, lane);
+                    f32x16 acc = zero16();  // D[m = k][n = v] = sum_r a~[r][k] Z[r][v] + sum_t q~[t][k] dY[t][v]
+                    mma_gen<kC, true, true, false, true>(acc, bufc + L::ATh, bufc + L::ATl, LDK, kt * 32, sm + L::Zh, sm + L::Zl, LDC, 0, lane);
+                    mma_gen<kC, true, true, true, false>(acc, bufc + L::QTh, bufc + L::QTl, LDK, kt * 32, bufc + L::DYt, bufc + L::DYt, LDC, 0, lane);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) Emaster[r] = gCc[kt * 32 + d_row(r, lane)] * Emaster[r] + acc[r];
+                }
+                if (pc >= c0) {
+                    // E' = g_C E for the next chunk (its g_C arrived in interval a), planes E'[v][k]
+                    f32x16 Ep;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) Ep[r] = gCp[kt * 32 + d_row(r, lane)] * Emaster[r];
+                    store_T_split(Ep, sm + L::Eh + kt * 32, sm + L::El + kt * 32, LDK, lane);
+                    // B" = T^T B^ of the next chunk: D[m = k][n = r] = sum_s b^[s][k] T[s][r] -> B"[r][k]
+                    f32x16 acc = zero16();
+                    mma_gen<kC, true, true, true, true>(acc, bufp + L::BHh, bufp + L::BHl, LDK, kt * 32, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
+                    store_T_split(acc, sm + L::BBh + kt * 32, sm + L::BBl + kt * 32, LDK, lane);
+                }
+            } else if (wave == 3 && pc >= c0) {
+                // next chunk: A_qb[t][s] (s <= t), then X"[r][t] = sum_s T[s][r] A_qb[t][s] (this wave reads back what it wrote)
+                f32x16 acc = zero16();  // D[m = s][n = t] = b^_s . q~_t
+                mma_tile3<kN, 2>(acc, bufp + L::BHh, bufp + L::BHl, LDK, bufp + L::QTh, bufp + L::QTl, LDK, lane);
+                mask_lower_T<false>(acc, lane);
+                store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
+                f32x16 acx = zero16();  // D[m = t][n = r]
+                mma_gen<kC, false, true, true, true>(acx, sm + L::QBh, sm + L::QBl, LDC, 0, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
+                store_T_split(acx, sm + L::XPh, sm + L::XPl, LDC, lane);
+            }
+            BSSTAMP(2);
+            lds_barrier();
+            BSSTAMP(3);
+        }
+    } else {
+        // =================================================================================================== producer
+        uint4 gw, gq, ga, gb;
+        Raw4<bf16_t> gdy;
+        auto issue = [&](int c) {   // unconditional: the chunk index is clamped by the caller
+            const long off = head_base + (long)(c * kC + lt) * tstride;
+            gw = *reinterpret_cast<const uint4 *>(w_ + off + lk);
+            gq = *reinterpret_cast<const uint4 *>(q_ + off + lk);
+            ga = *reinterpret_cast<const uint4 *>(a_ + off + lk);
+            gb = *reinterpret_cast<const uint4 *>(b_ + off + lk);
+            gdy = ld4<bf16_t>(dy_ + off + vh * VH + lv, true);
+        };
+        auto stage_raw = [&]() {
+            *reinterpret_cast<uint4 *>(raw + (0 * kC + lt) * RS + lk) = gw;
+            *reinterpret_cast<uint4 *>(raw + (1 * kC + lt) * RS + lk) = gq;
+            *reinterpret_cast<uint4 *>(raw + (2 * kC + lt) * RS + lk) = ga;
+            *reinterpret_cast<uint4 *>(raw + (3 * kC + lt) * RS + lk) = gb;
+            *reinterpret_cast<RawVec *>(raw + 4 * kC * RS + lt * RSV + lv) = gdy.r;
+        };
+        auto clampc = [&](int c) { return c > c0 ? c : c0; };
+        auto load_tm = [&](int c) {
+            return *reinterpret_cast<const float4 *>(tinv_ + ((long)bh * nc + clampc(c)) * kC * kC + ltid * 4);
+        };
+        float bsL[8], gamL[8];
+        uint4 pq[2], pa[2];
+        RawVec rdy;
+        auto first_half = [&]() {
+            float lw[8], Gc[8], wr[8], qv[8], av[8], bv[8];
+            {
+                const uint4 rw = *reinterpret_cast<const uint4 *>(raw + (0 * kC + pt) * RS + pk);
+                const uint4 rq = *reinterpret_cast<const uint4 *>(raw + (1 * kC + pt) * RS + pk);
+                const uint4 ra = *reinterpret_cast<const uint4 *>(raw + (2 * kC + pt) * RS + pk);
+                const uint4 rb = *reinterpret_cast<const uint4 *>(raw + (3 * kC + pt) * RS + pk);
+                rdy = *reinterpret_cast<const RawVec *>(raw + 4 * kC * RS + pt * RSV + pv);
+                auto cvt8u = [](const uint4 r, float (&f)[8]) {
+                    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+                    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+                    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+                    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+                };
+                cvt8u(rw, wr); cvt8u(rq, qv); cvt8u(ra, av); cvt8u(rb, bv);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) lw[j] = -fast_exp(wr[j]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) Gc[j] = scan32(lw[j]);
+            float qs[8], as_[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float gam = fast_exp(Gc[j]), gprev = fast_exp(Gc[j] - lw[j]), ig = fast_exp(-Gc[j]);
+                qs[j] = qv[j] * gam;
+                as_[j] = av[j] * gprev;
+                bsL[j] = bv[j] * ig;
+                gamL[j] = gam;
+            }
+            uint32_t qh[4], ql[4], ah[4], al[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                split_pk(qs[2 * j], qs[2 * j + 1], qh[j], ql[j]);
+                split_pk(as_[2 * j], as_[2 * j + 1], ah[j], al[j]);
+            }
+            pq[0] = make_uint4(qh[0], qh[1], qh[2], qh[3]); pq[1] = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+            pa[0] = make_uint4(ah[0], ah[1], ah[2], ah[3]); pa[1] = make_uint4(al[0], al[1], al[2], al[3]);
+        };
+        issue(c1 - 1);
+        stage_raw();
+        issue(clampc(c1 - 2));
+        float4 tmreg = load_tm(c1 - 1);
+        lds_barrier();
+        first_half();   // chunk c1 - 1
+        lds_barrier();  // staging is rewritten in the first interval a
+        for (int it = c1; it >= c0; it--) {
+            const int pc = it - 1;
+            uint16_t *bufp = sm + (pc & 1) * L::BUF;
+            float *gCp = sh_gC2 + (pc & 1) * kN;
+            // ----------------------------------------------------------------------------------------------- interval a
+            if (pc >= c0) {
+                uint32_t bhh[4], bl[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) split_pk(bsL[2 * j], bsL[2 * j + 1], bhh[j], bl[j]);
+                const int o = pt * LDK + pk;
+                *reinterpret_cast<uint4 *>(&bufp[L::QTh + o]) = pq[0];
+                *reinterpret_cast<uint4 *>(&bufp[L::QTl + o]) = pq[1];
+                *reinterpret_cast<uint4 *>(&bufp[L::ATh + o]) = pa[0];
+                *reinterpret_cast<uint4 *>(&bufp[L::ATl + o]) = pa[1];
+                *reinterpret_cast<uint4 *>(&bufp[L::BHh + o]) = make_uint4(bhh[0], bhh[1], bhh[2], bhh[3]);
+                *reinterpret_cast<uint4 *>(&bufp[L::BHl + o]) = make_uint4(bl[0], bl[1], bl[2], bl[3]);
+                *reinterpret_cast<RawVec *>(&bufp[L::DYt + pt * LDC + pv]) = rdy;  // bf16 dY: exact
+                if (pt == kC - 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) gCp[pk + j] = gamL[j];
+                }
+                {   // T planes Tm[t][r] of chunk pc: thread = row ltid >> 3, columns 4 (ltid & 7) .. +4
+                    uint32_t h0, l0, h1, l1;
+                    split_pk(tmreg.x, tmreg.y, h0, l0);
+                    split_pk(tmreg.z, tmreg.w, h1, l1);
+                    const int ot = (ltid >> 3) * LDC + (ltid & 7) * 4;
+                    *reinterpret_cast<uint2 *>(&sm[L::TMh + ot]) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(&sm[L::TMl + ot]) = make_uint2(l0, l1);
+                }
+            }
+            stage_raw();   // rows of chunk pc - 1 (requested one iteration ago)
+            __builtin_amdgcn_sched_barrier(0);
+            tmreg = load_tm(pc - 1);
+            issue(clampc(pc - 2));
+            __builtin_amdgcn_sched_barrier(0);
+            BSSTAMP(0);
+            lds_barrier();
+            BSSTAMP(1);
+            // ----------------------------------------------------------------------------------------------- interval b
+            if (pc - 1 >= c0) first_half();   // chunk pc - 1
+            BSSTAMP(2);
+            lds_barrier();
+            BSSTAMP(3);
+        }
+    }
+#ifdef WKV7C_TIMING
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 4; i++) g_cbseq_timing[(tid >> 6) * 4 + i] += tacc_[i];
+#endif
+}
+
+int chunk_bseq_bf16(int B, int T_, int H, const void *w, const void *q, const void *a, const void *b, const void *dy, const float *tinv,
+                    void *e_vk, const int *seq_off, int nseq, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_bseq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)BSSmem::bytes);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(wkv7c_bseq_kernel, dim3((seq_off ? nseq : B) * H * 2), dim3(512), BSSmem::bytes, st, T_, H, (const bf16_t *)w,
+                       (const bf16_t *)q, (const bf16_t *)a, (const bf16_t *)b, (const bf16_t *)dy, tinv, (uint16_t *)e_vk, seq_off);
+    return (int)hipGetLastError();
+}
+
+}  // namespace rwkv7
+
+#ifdef WKV7C_TIMING
+extern "C" int rwkv7_debug_cbseq_timing(long long *out, int reset) {
+    if (reset) {
+        long long z[32] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(rwkv7::g_cbseq_timing), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rwkv7::g_cbseq_timing), sizeof(long long) * 32);
+}
+#endif

@@ -206,12 +206,17 @@ def test_packed_sequences_equal_separate_sequences_vs_oracle(c_oracle):
                 _assert_bf16_close(g[b:b + 1, lo:hi], go, f"{n}[{b},{lo}:{hi}]", ulps=2.0)
 
 
+DEFAULT_FWD_WAVES = 9   # what the plain entry point rwkv7_wkv_chunk_fwd_seq_bf16 launches
+
+
+@pytest.mark.parametrize("waves", [8, 9])
 @pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
-def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T, H, seed):
-    """wkv7_chunk_fwd8.hip (producer / consumer split; `waves` of rwkv7_wkv_chunk_fwd_seq_variant_bf16): the same bars against the C oracle
-    as the 4-wave kernel, feeding the chunked backward; and against the 4-wave kernel itself the fp32 outputs agree to
-    rounding (hipcc contracts the split prologue differently: last-ulp differences of the scaled operands), also on packed
-    rows."""
+def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T, H, seed, waves):
+    """wkv7_chunk_fwd8.hip (producer / consumer split, three dependent products per chunk) and wkv7_chunk_fwd9.hip (W = T A~ and
+    X' = T A_ak made beside the chain, two dependent products per chunk; `waves` = 8 / 9 of rwkv7_wkv_chunk_fwd_seq_variant_bf16):
+    the same bars against the C oracle as the 4-wave kernel, feeding the chunked backward; and against the 4-wave kernel itself the
+    fp32 outputs agree to rounding (hipcc contracts the split prologue differently: last-ulp differences of the scaled operands;
+    the two-product form associates U = T(A~ S + A_ak V) as (T A~) S + (T A_ak) V), also on packed rows."""
     from rwkvtts_amd import _lib
     lib = _lib.lib()
     ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
@@ -228,12 +233,13 @@ def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T
     seq_off = torch.tensor(sorted(cuts), dtype=torch.int32, device=DEV)
     ref = ops.wkv7_chunk_forward(*d, waves=4)
     ref_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off, waves=4)
-    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d, waves=8)
-    got_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off, waves=8)
-    plain = ops.wkv7_chunk_forward(*d)                  # the plain entry point launches the 8-wave kernel
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d, waves=waves)
+    got_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off, waves=waves)
+    plain = ops.wkv7_chunk_forward(*d)
     grads = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv)
     torch.cuda.synchronize()
-    assert all(torch.equal(a_, b_) for a_, b_ in zip(plain, (y, tinv, sa, hs)))
+    if waves == DEFAULT_FWD_WAVES:
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(plain, (y, tinv, sa, hs)))
     _assert_bf16_close(y, y_o, "y")
     _assert_f32_close(sa, sa_o, "sa", 2e-3)
     hsf = ops.q15_decode(hs).transpose(-1, -2)
@@ -246,3 +252,39 @@ def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T
         _assert_bf16_close(b[0], a[0].cpu(), "y 8 vs 4", ulps=1.0)
         _assert_f32_close(b[2], a[2].cpu(), "sa 8 vs 4", 1e-4)
         _assert_f32_close(ops.q15_decode(b[3]), ops.q15_decode(a[3]).cpu(), "hs 8 vs 4", 1e-4)
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
+def test_one_kernel_adjoint_recurrence_vs_two_kernel_pair(B, T, H, seed):
+    """wkv7_chunk_bseq.hip (the factored recurrence E_c = E' + A~^T Z + Q~^T dY, what wkv7_chunk_backward launches) against
+    wkv7c_bwd_pre + wkv7c_state (M_c^T / N'_c materialised, checked against the CPU prototype above): the same E records up to
+    the q15 rounding of M^T / N' in the pair (2^-15 of a lane's maximum) and the different association of the products, plain
+    and packed rows; and the six gradients that come out of either."""
+    ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 7))).bfloat16().to(DEV)
+    d = [t.to(DEV) for t in ins]
+    w, q, k, v, a, b = d
+    nc = T // 32
+    cuts = {0, B * nc}
+    for bi in range(B):
+        cuts.add(bi * nc + nc)
+        if nc > 1:
+            cuts.add(bi * nc + (nc + bi) // 2)
+    seq_off = torch.tensor(sorted(cuts), dtype=torch.int32, device=DEV)
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
+    for so in (None, seq_off):
+        _, _, e_pair = ops.wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, so)
+        e_one = ops.wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, so)
+        torch.cuda.synchronize()
+        ep, eo = ops.q15_decode(e_pair).cpu(), ops.q15_decode(e_one)
+        for bi in range(B):
+            for hi in range(H):
+                for c in range(nc):
+                    ref = ep[bi, hi, c]
+                    err = (eo[bi, hi, c].cpu() - ref).abs().max().item()
+                    assert err <= 3e-4 * max(ref.abs().max().item(), 1e-3), (so is not None, bi, hi, c, err, ref.abs().max().item())
+    g_pair = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv, two_kernel_state=True)
+    g_one = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv)
+    torch.cuda.synchronize()
+    for n, g1, g2 in zip(NAMES, g_one, g_pair):
+        _assert_bf16_close(g1, g2.float().cpu(), f"{n}: one-kernel vs pair", ulps=1.0)
