@@ -12,11 +12,11 @@
 // and nothing but the E records written: 20 KB in (16 of them shared by the two workgroups of a head through L2) + 9 KB out per
 // chunk against 43 + 28.
 //     interval a   wave 0: Z = B" E' + X" dY -> Z planes
-//                  waves 4-7 (producer): b^ splits; operand planes q~, a~, b^, dY, g_C, T planes of the NEXT chunk (c - 1); raw rows
+//                  waves 4-7 (producer): hi/lo splits; operand planes q~, a~, b^, dY, g_C, T planes of the NEXT chunk (c - 1); raw rows
 //                                        of the chunk after it -> LDS staging; next global prefetch
-//     interval b   waves 1,2: record of E_{c+1} -> e_vk[c]; E_c (two key tiles); E' planes of the next chunk; then B" of the next chunk
-//                  wave 3: A_qb, X" of the next chunk
-//                  waves 4-7: rows of the chunk after the next in the compute mapping: exp, prefix sums, scaling, q~ / a~ splits
+//     interval b   waves 1,2: record of E_{c+1} -> e_vk[c]; E_c (two key tiles); E' planes of the next chunk
+//                  wave 0: B" of the next chunk          wave 3: A_qb, X" of the next chunk
+//                  waves 4-7: rows of the chunk after the next in the compute mapping: exp, prefix sums, scaling
 // One workgroup per (head, half of the value columns): the value columns of E never mix.
 #include "chunk_common.h"
 
@@ -146,7 +146,11 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
 #pragma unroll
                     for (int r = 0; r < 16; r++) Ep[r] = gCp[kt * 32 + d_row(r, lane)] * Emaster[r];
                     store_T_split(Ep, sm + L::Eh + kt * 32, sm + L::El + kt * 32, LDK, lane);
-                    // B" = T^T B^ of the next chunk: D[m = k][n = r] = sum_s b^[s][k] T[s][r] -> B"[r][k]
+                }
+            } else if (wave == 0 && pc >= c0) {
+                // B" = T^T B^ of the next chunk: D[m = k][n = r] = sum_s b^[s][k] T[s][r] -> B"[r][k], two key tiles
+#pragma unroll
+                for (int kt = 0; kt < 2; kt++) {
                     f32x16 acc = zero16();
                     mma_gen<kC, true, true, true, true>(acc, bufp + L::BHh, bufp + L::BHl, LDK, kt * 32, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
                     store_T_split(acc, sm + L::BBh + kt * 32, sm + L::BBl + kt * 32, LDK, lane);
@@ -188,8 +192,7 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
         auto load_tm = [&](int c) {
             return *reinterpret_cast<const float4 *>(tinv_ + ((long)bh * nc + clampc(c)) * kC * kC + ltid * 4);
         };
-        float bsL[8], gamL[8];
-        uint4 pq[2], pa[2];
+        float qsL[8], asL[8], bsL[8], gamL[8];
         RawVec rdy;
         auto first_half = [&]() {
             float lw[8], Gc[8], wr[8], qv[8], av[8], bv[8];
@@ -211,23 +214,14 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
             for (int j = 0; j < 8; j++) lw[j] = -fast_exp(wr[j]);
 #pragma unroll
             for (int j = 0; j < 8; j++) Gc[j] = scan32(lw[j]);
-            float qs[8], as_[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const float gam = fast_exp(Gc[j]), gprev = fast_exp(Gc[j] - lw[j]), ig = fast_exp(-Gc[j]);
-                qs[j] = qv[j] * gam;
-                as_[j] = av[j] * gprev;
+                qsL[j] = qv[j] * gam;
+                asL[j] = av[j] * gprev;
                 bsL[j] = bv[j] * ig;
                 gamL[j] = gam;
             }
-            uint32_t qh[4], ql[4], ah[4], al[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                split_pk(qs[2 * j], qs[2 * j + 1], qh[j], ql[j]);
-                split_pk(as_[2 * j], as_[2 * j + 1], ah[j], al[j]);
-            }
-            pq[0] = make_uint4(qh[0], qh[1], qh[2], qh[3]); pq[1] = make_uint4(ql[0], ql[1], ql[2], ql[3]);
-            pa[0] = make_uint4(ah[0], ah[1], ah[2], ah[3]); pa[1] = make_uint4(al[0], al[1], al[2], al[3]);
         };
         issue(c1 - 1);
         stage_raw();
@@ -242,16 +236,17 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
             float *gCp = sh_gC2 + (pc & 1) * kN;
             // ----------------------------------------------------------------------------------------------- interval a
             if (pc >= c0) {
-                uint32_t bhh[4], bl[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) split_pk(bsL[2 * j], bsL[2 * j + 1], bhh[j], bl[j]);
                 const int o = pt * LDK + pk;
-                *reinterpret_cast<uint4 *>(&bufp[L::QTh + o]) = pq[0];
-                *reinterpret_cast<uint4 *>(&bufp[L::QTl + o]) = pq[1];
-                *reinterpret_cast<uint4 *>(&bufp[L::ATh + o]) = pa[0];
-                *reinterpret_cast<uint4 *>(&bufp[L::ATl + o]) = pa[1];
-                *reinterpret_cast<uint4 *>(&bufp[L::BHh + o]) = make_uint4(bhh[0], bhh[1], bhh[2], bhh[3]);
-                *reinterpret_cast<uint4 *>(&bufp[L::BHl + o]) = make_uint4(bl[0], bl[1], bl[2], bl[3]);
+                auto put = [&](const float (&x)[8], int ph, int pl) {
+                    uint32_t h[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], h[j], l[j]);
+                    *reinterpret_cast<uint4 *>(&bufp[ph + o]) = make_uint4(h[0], h[1], h[2], h[3]);
+                    *reinterpret_cast<uint4 *>(&bufp[pl + o]) = make_uint4(l[0], l[1], l[2], l[3]);
+                };
+                put(qsL, L::QTh, L::QTl);
+                put(asL, L::ATh, L::ATl);
+                put(bsL, L::BHh, L::BHl);
                 *reinterpret_cast<RawVec *>(&bufp[L::DYt + pt * LDC + pv]) = rdy;  // bf16 dY: exact
                 if (pt == kC - 1) {
 #pragma unroll

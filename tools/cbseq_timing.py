@@ -1,0 +1,26 @@
+"""Per-interval cycle breakdown of wkv7c_bseq_kernel, workgroup 0, every wave (needs `python -m rwkvtts_amd.build --timing`).
+Each interval: cycles of work, then cycles waiting at the barrier that ends it."""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rwkvtts_amd import _lib, ops
+from rwkvtts_amd.synthetic import make_wkv_inputs
+B, T, H = 8, 4096, 16
+ins = make_wkv_inputs(B, T, H, 1, torch.bfloat16, "cuda:0")
+lib = _lib.lib()
+w, q, k, v, a, b = ins
+dy = torch.randn(B, T, H, 64, device="cuda:0").bfloat16()
+tinv = ops.wkv7_chunk_prep(w, a, b)
+run = lambda: ops.wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv)
+run(); torch.cuda.synchronize()
+lib.rwkv7_debug_cbseq_timing(None, 1)
+N = 5
+for _ in range(N):
+    run()
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 32)()
+lib.rwkv7_debug_cbseq_timing(buf, 0)
+chunks = T // 32 + 1
+print("cycles per chunk (workgroup 0): interval a work / barrier wait, interval b work / barrier wait")
+for wv in range(8):
+    vals = [buf[wv * 4 + i] / N / chunks for i in range(4)]
+    print(f"wave {wv} ({'consumer' if wv < 4 else 'producer'}): total {sum(vals):6.0f} | a {vals[0]:5.0f} / {vals[1]:5.0f}   b {vals[2]:5.0f} / {vals[3]:5.0f}")
