@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal of the N > 1 launch path on a one-GPU box: all ranks share GPU 0 and exchange over gloo "
                          "(RCCL refuses two ranks on one device); marked in the JSON line, not a measurement")
+    ap.add_argument("--via-reference-op", action="store_true",
+                    help="A/B: the scan through torch.ops.wind_backstepping.forward/backward (the reference's plug-in point, wkv7_op.cpp:21-29; "
+                         "for bf16 and T % 32 == 0 it launches the same chunked MFMA kernels, with `s` as their arena) instead of the direct calls")
     ap.add_argument("--scalar-wkv", action="store_true", help="A/B: scalar WKV7 kernels (reference schema fwd, row-split bwd) instead of the chunked MFMA pair")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -191,6 +194,9 @@ def main():
         from rwkvtts_amd import fused as _fused
         _fused.CHUNKED_WKV_BWD = False
         _fused.CHUNKED_WKV_FWD = False
+    if a.via_reference_op:
+        from rwkvtts_amd import fused as _fused
+        _fused.VIA_REFERENCE_OP = True
 
     from rwkvtts_amd import build
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -283,7 +289,11 @@ def main():
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items() if v}
         th = B * T * H
         chunk_parts = [k for k in ("wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bseq", "wkv7c_bwd_out") if k in kern]
-        if "wkv7c_bwd_out" in kern:
+        if "wkv7c_op_bwd" in kern:   # --via-reference-op: the op's launches are timed as one unit each way
+            bwd_ms, bwd_name = kern["wkv7c_op_bwd"], f"torch.ops.wind_backstepping.backward -> wkv7c_bseq + wkv7c_bwd_out8 ({cfg.num_hidden_layers}x per step)"
+            fwd_ms, fwd_name = kern["wkv7c_op_fwd"], "torch.ops.wind_backstepping.forward -> wkv7c_prep + wkv7c_fwd9"
+            pmc_bwd, pmc_fwd = "wkv7c_bwd", "wkv7c_fwd"
+        elif "wkv7c_bwd_out" in kern:
             bwd_ms = sum(kern[k] for k in chunk_parts)
             bwd_name = "WKV7 backward, chunked MFMA (" + " + ".join(chunk_parts) + f", {cfg.num_hidden_layers}x per step)"
             fwd_ms = kern["wkv7c_fwd"] + kern.get("wkv7c_prep", 0.0)
@@ -343,6 +353,8 @@ def main():
             "device": _device_info(torch, dev),
             "roofline": roof,
         }
+        if a.via_reference_op:
+            out["config"]["wkv_entry"] = "torch.ops.wind_backstepping.forward/backward (reference schema)"
         if a.one_device:
             out["rehearsal"] = f"{world} ranks sharing GPU 0, exchange over gloo: exercises the launch path, not a measurement"
         if world > 1:

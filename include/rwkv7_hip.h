@@ -60,6 +60,21 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
                       const void *a, const void *b, const void *dy, const float *s, const float *sa,
                       void *dw, void *dq, void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
 
+/* ---- The same pair on the matrix cores ("fast" twins; bf16, T % 32 == 0): what torch.ops.wind_backstepping.forward / .backward
+ *      launch for bf16 tensors whose T is a multiple of 32 (rwkvtts_amd/ops.py), i.e. what a maintainer who binds the reference's op
+ *      (wkv7_op.cpp:21-29) gets.  Same schema, same caller-allocated tensors, same y / sa / gradients (sa in the reference's
+ *      layout, fp32 [B,T,H,64]).  `s` -- in the reference a private forward -> backward scratch of state checkpoints (its content is
+ *      read by nothing but the backward kernel, rwkv_s2s_single_ffn.py:22-35) -- is used as an opaque arena of the SAME size:
+ *      per 32-step chunk and head 9216 B of state checkpoint (q15 record, see rwkv7_wkv_chunk_fwd_bf16) + 4096 B of
+ *      T = (I - A_ab)^-1 + 9216 B of adjoint state written by the backward = 22 528 of the 32 768 B the reference's layout has
+ *      there.  Launches: chunk_prep + chunk_fwd (forward); chunk_bseq + chunk_bwd_out (backward).  RWKV7_ECHUNK when T % 32 != 0:
+ *      fall back to rwkv7_wkv_fwd_bf16 / rwkv7_wkv_bwd_bf16 (T % 16 == 0), whose `s` holds the reference's checkpoints. ---- */
+int rwkv7_wkv_fwd_fast_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                            const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream);
+int rwkv7_wkv_bwd_fast_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                            const void *a, const void *b, const void *dy, float *s, const float *sa,
+                            void *dw, void *dq, void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream);
+
 /* Sizes of the two caller-allocated scratch tensors of the training forward/backward pair (the reference allocates
  * them in Python, rwkv_s2s_single_ffn.py:22-24): s = fp32 [B,H,T/16,64,64] state checkpoints, sa = fp32 [B,T,H,64]. */
 int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_bytes);

@@ -417,9 +417,12 @@ class RWKV7Model(nn.Module):
             past_key_values = Cache.zeros(self.config, B, x.device, x.dtype)
         stateful = past_key_values is not None and len(past_key_values) > 0
         pad = 0
-        if not stateful and T % ops.CHUNK_LEN != 0:
-            # the training kernel needs T % 16 == 0: left-pad with masked zeros (rwkv_asr_cuda_whisper.py:482-486)
-            pad = ops.CHUNK_LEN - T % ops.CHUNK_LEN
+        # the training kernels need T % 16 == 0 (reference), the chunked MFMA pair that bf16 training runs T % 32 == 0: a bf16
+        # batch is padded to 32 so that none falls back to the scalar kernels (2.7x slower scan)
+        gran = ops.CHUNK_T if x.dtype == torch.bfloat16 else ops.CHUNK_LEN
+        if not stateful and T % gran != 0:
+            # left-pad with masked zeros (rwkv_asr_cuda_whisper.py:482-486)
+            pad = gran - T % gran
             x = torch.cat([x.new_zeros(B, pad, D), x], 1)
             m = torch.ones(B, T, 1, dtype=x.dtype, device=x.device) if mask is None else mask
             mask = torch.cat([m.new_zeros(B, pad, 1), m], 1)

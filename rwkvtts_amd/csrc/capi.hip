@@ -120,6 +120,35 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
     BWD_BODY(wkv_bwd_f32)
 }
 
+// the reference-schema pair on the chunked (MFMA) kernels: `s` as an arena [hs | T^-1 | e_vk] (include/rwkv7_hip.h)
+namespace {
+constexpr size_t kArenaRec = (size_t)RWKV7_Q15_REC * 2, kArenaTinv = 32 * 32 * sizeof(float);
+}
+int rwkv7_wkv_fwd_fast_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                            const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, y, s, sa})) return RWKV7_EINVAL;
+    if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;
+    const size_t n = (size_t)B * H * (T / RWKV7_CHUNK_T);
+    char *base = reinterpret_cast<char *>(s);
+    float *tinv = reinterpret_cast<float *>(base + n * kArenaRec);
+    const int rc = rwkv7::chunk_prep_bf16(B, T, H, w, a, b, tinv, (hipStream_t)stream);
+    if (rc != 0) return rc;
+    return rwkv7::chunk_fwd_bf16(B, T, H, w, q, k, v, a, b, tinv, y, sa, base, nullptr, 0, 9, (hipStream_t)stream);
+}
+int rwkv7_wkv_bwd_fast_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                            const void *a, const void *b, const void *dy, float *s, const float *sa, void *dw,
+                            void *dq, void *dk, void *dv, void *da, void *db, rwkv7_stream_t stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db})) return RWKV7_EINVAL;
+    if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;
+    const size_t n = (size_t)B * H * (T / RWKV7_CHUNK_T);
+    char *base = reinterpret_cast<char *>(s);
+    const float *tinv = reinterpret_cast<const float *>(base + n * kArenaRec);
+    void *e_vk = base + n * (kArenaRec + kArenaTinv);
+    const int rc = rwkv7::chunk_bseq_bf16(B, T, H, w, q, a, b, dy, tinv, e_vk, nullptr, 0, (hipStream_t)stream);
+    if (rc != 0) return rc;
+    return rwkv7::chunk_bwd_out8_bf16(B, T, H, w, q, k, v, a, b, dy, base, sa, tinv, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
+}
+
 #define BWD2_BODY(IMPL, WIDE)                                                                                 \
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, dy, s, sa, dw, dq, dk, dv, da, db}))   \
         return RWKV7_EINVAL;                                                                               \

@@ -198,6 +198,8 @@ def tmix_post(y, r, k, v, g, gn_weight, gn_bias, r_k, H, eps):
 CHAIN_VFIRST_GRAD = True   # v_first is handed from layer to layer through the time-mix node (its gradient is summed inside the prepare backward)
 CHUNKED_WKV_BWD = True   # bf16 training: scan forward + backward on the matrix cores (csrc/wkv7_chunk_*.hip); the pair goes
 CHUNKED_WKV_FWD = True   # together (the backward consumes the forward's checkpoints): set BOTH False for the scalar kernels
+VIA_REFERENCE_OP = False  # A/B (bench.py --via-reference-op): the scan through torch.ops.wind_backstepping.{forward,backward}, the
+                          # reference's own plug-in point (wkv7_op.cpp:21-29), instead of the direct calls below
 
 
 class _TmixCore(torch.autograd.Function):
@@ -224,7 +226,8 @@ class _TmixCore(torch.autograd.Function):
         _call("tmix_prepare_fwd", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
               _p(mask), _p(k_k), _p(k_a), _p(w), _p(k2), _p(v2), _p(a_in), _p(b_in), min(rows, _FWD_BLOCKS))
         v4 = lambda t: t.view(B, T, H, 64)
-        chunked = CHUNKED_WKV_FWD and CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0
+        via_op = VIA_REFERENCE_OP and seq_start is None
+        chunked = CHUNKED_WKV_FWD and CHUNKED_WKV_BWD and k.dtype == torch.bfloat16 and T % ops.CHUNK_T == 0 and not via_op
         if seq_start is not None and not chunked:
             raise ValueError("packed rows (seq_start) need the chunked WKV7 kernels: bf16 tensors, T % 32 == 0")
         if chunked:
@@ -236,13 +239,16 @@ class _TmixCore(torch.autograd.Function):
             y = torch.empty_like(k)
             s = torch.empty(B, H, T // ops.CHUNK_LEN, 64, 64, dtype=torch.float32, device=k.device)
             sa = torch.empty(B, T, H, 64, dtype=torch.float32, device=k.device)
-            torch.ops.wind_backstepping.forward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(y), s, sa)
+            if via_op:   # whatever the op launches for this dtype / length; its `s` is only good for the op's own backward
+                torch.ops.wind_backstepping.forward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(y), s, sa)
+            else:
+                ops.wkv7_forward_scalar(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(y), s, sa)
         out = torch.empty_like(k)
         _call("tmix_post_fwd", k, ctypes.c_long(rows), D, _p(y), _p(r), _p(k2), _p(v2), _p(g), _p(gn_w), _p(gn_b), _p(r_k),
               ctypes.c_float(eps), _p(out), min(rows, _FWD_BLOCKS))
         ctx.save_for_backward(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
                               w, k2, v2, a_in, b_in, y, s, sa, tinv)
-        ctx.H, ctx.eps, ctx.chunked_fwd, ctx.seq_start = H, eps, chunked, seq_start
+        ctx.H, ctx.eps, ctx.chunked_fwd, ctx.seq_start, ctx.via_op = H, eps, chunked, seq_start, via_op
         if v_first is None or not CHAIN_VFIRST_GRAD:
             return out
         # v_first is handed on to the next layer THROUGH this node (a second output aliasing the input): its gradient then arrives
@@ -271,6 +277,10 @@ class _TmixCore(torch.autograd.Function):
         if ctx.chunked_fwd:   # the chunked backward consumes what the chunked forward saved (hs bf16, sa, tinv)
             dw, dq, dk, dv, da, db = ops.wkv7_chunk_backward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(d_y), s, sa,
                                                              tinv, seq_off=ctx.seq_start)
+            dw2, dq2, dk2, da2, db2 = [(g, None) for g in (dw, dq, dk, da, db)]
+        elif ctx.via_op:
+            dw, dq, dk, dv, da, db = [torch.empty_like(k).view(B, T, H, 64) for _ in range(6)]
+            torch.ops.wind_backstepping.backward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(d_y), s, sa, dw, dq, dk, dv, da, db)
             dw2, dq2, dk2, da2, db2 = [(g, None) for g in (dw, dq, dk, da, db)]
         else:
             dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in),

@@ -73,7 +73,21 @@ def _sfx(ts, what):
 # ------------------------------------------------------------------------------------------------
 # raw ops (caller allocates everything, ops mutate in place and return None)
 # ------------------------------------------------------------------------------------------------
-def _wb_forward(w, q, k, v, z, a, y, s, sa):
+# torch.ops.wind_backstepping.{forward,backward} launch the chunked (MFMA) pair whenever they can -- bf16 tensors, T % 32 == 0 --
+# with `s` (a private forward -> backward scratch in the reference, rwkv_s2s_single_ffn.py:22-35) as an opaque arena of the same
+# size (include/rwkv7_hip.h, rwkv7_wkv_fwd_fast_bf16); otherwise (fp32, T % 32 == 16) the scalar kernels, whose `s` holds the
+# reference's checkpoints.  False = always the scalar kernels (A/B).
+REFERENCE_OP_FAST = True
+
+
+def reference_op_is_fast(dtype, T):
+    """Which kernels torch.ops.wind_backstepping.* launch for tensors of this dtype and length."""
+    return bool(REFERENCE_OP_FAST and dtype == torch.bfloat16 and T % 32 == 0)
+
+
+def wkv7_forward_scalar(w, q, k, v, z, a, y, s, sa):
+    """The scalar forward kernel (rwkv7_wkv_fwd_*): s = the reference's checkpoints (fp32 [B,H,T/16,64,64], transposed), which
+    wkv7_backward_scalar / wkv7_backward_split consume."""
     B, T, H, C = w.shape
     sfx = _sfx([w, q, k, v, z, a, y], "wind_backstepping.forward")
     assert C == HEAD_SIZE and s.dtype == torch.float32 and sa.dtype == torch.float32
@@ -83,7 +97,7 @@ def _wb_forward(w, q, k, v, z, a, y, s, sa):
     _lib.check(rc, "wind_backstepping.forward")
 
 
-def _wb_backward(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
+def wkv7_backward_scalar(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
     B, T, H, C = w.shape
     sfx = _sfx([w, q, k, v, z, a, dy, dw, dq, dk, dv, dz, da], "wind_backstepping.backward")
     with torch.cuda.device_of(w), _timed("wkv7_bwd", w):
@@ -93,8 +107,39 @@ def _wb_backward(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
     _lib.check(rc, "wind_backstepping.backward")
 
 
+def _check_arena(w, s, what):
+    B, T, H, C = w.shape
+    if s.dtype != torch.float32 or not s.is_contiguous() or s.numel() < B * H * (T // CHUNK_LEN) * C * C:
+        raise ValueError(f"{what}: s must be the reference's contiguous fp32 [B,H,T/16,64,64] scratch (rwkv_s2s_single_ffn.py:23)")
+
+
+def _wb_forward(w, q, k, v, z, a, y, s, sa):
+    B, T, H, C = w.shape
+    if not reference_op_is_fast(w.dtype, T):
+        return wkv7_forward_scalar(w, q, k, v, z, a, y, s, sa)
+    _sfx([w, q, k, v, z, a, y], "wind_backstepping.forward")
+    assert C == HEAD_SIZE and sa.dtype == torch.float32
+    _check_arena(w, s, "wind_backstepping.forward")
+    with torch.cuda.device_of(w), _timed("wkv7c_op_fwd", w):
+        rc = _lib.lib().rwkv7_wkv_fwd_fast_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a), _p(y), _p(s), _p(sa), _stream(w))
+    _lib.check(rc, "wind_backstepping.forward")
+
+
+def _wb_backward(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
+    B, T, H, C = w.shape
+    if not reference_op_is_fast(w.dtype, T):
+        return wkv7_backward_scalar(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da)
+    _sfx([w, q, k, v, z, a, dy, dw, dq, dk, dv, dz, da], "wind_backstepping.backward")
+    _check_arena(w, s, "wind_backstepping.backward")
+    with torch.cuda.device_of(w), _timed("wkv7c_op_bwd", w):
+        rc = _lib.lib().rwkv7_wkv_bwd_fast_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(z), _p(a), _p(dy), _p(s), _p(sa),
+                                                _p(dw), _p(dq), _p(dk), _p(dv), _p(dz), _p(da), _stream(w))
+    _lib.check(rc, "wind_backstepping.backward")
+
+
 def wkv7_backward_split(w, q, k, v, z, a, dy, s, sa, wide=None):
-    """WKV7 backward with each head split over two workgroups (rwkv7_wkv_bwd_split_*: all 256 CUs busy at B*H=128).
+    """WKV7 backward with each head split over two workgroups (rwkv7_wkv_bwd_split_*: all 256 CUs busy at B*H=128); s, sa as
+    written by wkv7_forward_scalar.
     Returns (dw2, dq2, dk2, dv, dz2, da2): the *2 tensors are [2, B,T,H,64] partial column sums whose sum over dim 0
     is the gradient wind_backstepping.backward returns; dv is complete.
     wide (bf16 only, measurements/tests): 0 / 1 selects the 256- / 512-thread shape explicitly (rwkv7_wkv_bwd_split_variant_bf16)."""

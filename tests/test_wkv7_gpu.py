@@ -213,12 +213,12 @@ def test_row_split_backward_vs_oracle(c_oracle, bwd_shape, B, T, H, seed, dtype)
     g_o = dict(zip(NAMES, c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)))
     d = [t.to(DEV) for t in ins]
     y, s, sa = torch.empty_like(d[0]), torch.empty(B, H, T // 16, 64, 64, device=DEV), torch.empty(B, T, H, 64, device=DEV)
-    torch.ops.wind_backstepping.forward(*d, y, s, sa)
+    ops.wkv7_forward_scalar(*d, y, s, sa)   # the scalar pair: s = the reference's checkpoints (the op itself may launch the chunked pair)
     if dtype != torch.bfloat16 and bwd_shape is not None:
         pytest.skip("the shape variant entry exists for bf16 only")
     dw2, dq2, dk2, dv, da2, db2 = ops.wkv7_backward_split(*d, dy.to(DEV), s, sa, wide=bwd_shape)
     full = [torch.empty_like(d[0]) for _ in range(6)]
-    torch.ops.wind_backstepping.backward(*d, dy.to(DEV), s, sa, *full)
+    ops.wkv7_backward_scalar(*d, dy.to(DEV), s, sa, *full)
     # dv is a complete row sum in every shape; the instantiations may associate the fp32 terms differently
     if dtype == torch.bfloat16:
         _assert_bf16_close(dv, full[3].float().cpu(), "dv vs unsplit kernel", ulps=1.0)
@@ -284,3 +284,47 @@ def test_forward_both_lane_shapes_vs_oracle(c_oracle, cw, dtype):
     _assert_f32_close(s, s_o, "s", 2e-5)
     _assert_f32_close(sa, sa_o, "sa", 2e-5)
     _assert_f32_close(st, st_o, "state", 2e-5)
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2)])
+def test_reference_op_launches_the_chunked_pair_for_bf16_T32_and_the_scalar_pair_otherwise(c_oracle, B, T, H, seed):
+    """torch.ops.wind_backstepping.forward / .backward (wkv7_op.cpp:21-24, the plug-in point SURVEY 8b names): for bf16 tensors
+    with T % 32 == 0 the op runs the chunked MFMA kernels with `s` as their arena (rwkv7_wkv_fwd_fast_bf16), otherwise the scalar
+    kernels -- asserted from the launch timers -- and either way y, sa and the six gradients meet the oracle's bars."""
+    ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).bfloat16()
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    g_o = c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)
+    d = [t.to(DEV) for t in ins]
+    for fast in (True, False):
+        ops.REFERENCE_OP_FAST = fast
+        ops.KERNEL_TIMERS = {}
+        try:
+            y = torch.empty_like(d[0])
+            s = torch.empty(B, H, T // 16, 64, 64, device=DEV)
+            sa = torch.empty(B, T, H, 64, device=DEV)
+            grads = [torch.empty_like(d[0]) for _ in range(6)]
+            torch.ops.wind_backstepping.forward(*d, y, s, sa)
+            torch.ops.wind_backstepping.backward(*d, dy.to(DEV), s, sa, *grads)
+            torch.cuda.synchronize()
+            ran = set(ops.KERNEL_TIMERS)
+        finally:
+            ops.KERNEL_TIMERS, ops.REFERENCE_OP_FAST = None, True
+        assert ran == ({"wkv7c_op_fwd", "wkv7c_op_bwd"} if fast else {"wkv7_fwd", "wkv7_bwd"}), ran
+        assert ops.reference_op_is_fast(torch.bfloat16, T) and not ops.reference_op_is_fast(torch.bfloat16, T + 16) \
+            and not ops.reference_op_is_fast(torch.float32, T)
+        _assert_bf16_close(y, y_o, "y")
+        _assert_f32_close(sa, sa_o, "sa", 2e-3 if fast else 2e-5)
+        for n, g, go in zip(NAMES, grads, g_o):
+            _assert_bf16_close(g, go, n, ulps=2.0)
+    # T % 32 == 16: the op falls back to the scalar pair by itself
+    ins = make_wkv_inputs(1, 48, 2, seed, torch.bfloat16)
+    d = [t.to(DEV) for t in ins]
+    ops.KERNEL_TIMERS = {}
+    try:
+        yg, _ = _hip_fwd_bwd(ins, torch.randn(1, 48, 2, 64).bfloat16())
+        ran = set(ops.KERNEL_TIMERS)
+    finally:
+        ops.KERNEL_TIMERS = None
+    assert ran == {"wkv7_fwd", "wkv7_bwd"}, ran
+    _assert_bf16_close(yg, c_oracle.wkv7_fwd(*ins)[0], "y (T = 48)")

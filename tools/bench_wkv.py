@@ -50,8 +50,8 @@ def main():
     sa = torch.empty(B, T, H, 64, device=dev)
     grads = [torch.empty_like(w) for _ in range(6)]
     th = B * T * H
-    fwd = lambda: torch.ops.wind_backstepping.forward(w, q, k, v, aa, b, y, s, sa)
-    bwd = lambda: torch.ops.wind_backstepping.backward(w, q, k, v, aa, b, dy, s, sa, *grads)
+    fwd = lambda: ops.wkv7_forward_scalar(w, q, k, v, aa, b, y, s, sa)
+    bwd = lambda: ops.wkv7_backward_scalar(w, q, k, v, aa, b, dy, s, sa, *grads)
     bwd2 = lambda: ops.wkv7_backward_split(w, q, k, v, aa, b, dy, s, sa)
     st = torch.zeros(B, H, 64, 64, device=dev)
     f3 = lambda t: t.view(B, T, H * 64)
