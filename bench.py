@@ -309,11 +309,21 @@ def main():
         except Exception:
             pass
 
+        stale = {}
+
         def pmc_of(key):
+            """The committed PMC record of a kernel group -- only when it covers this shape AND was collected on the kernel sources
+            that are shipped now (sha256 of the files recorded by tools/pmc_distill.py): otherwise the fields are null and
+            `pmc_stale` says why."""
             d = pmc.get(key) or {}
-            if d.get("B") == B and d.get("T") == T and d.get("H") == H:
-                return d
-            return {}
+            if not (d.get("B") == B and d.get("T") == T and d.get("H") == H):
+                return {}
+            rec = d.get("sources")
+            if not rec or build.source_hashes(list(rec)) != rec:
+                stale[key] = "no source hashes in the record" if not rec else \
+                    "kernel sources changed since the PMC pass: " + ", ".join(n for n, h in build.source_hashes(list(rec)).items() if h != rec[n])
+                return {}
+            return d
 
         def traffic(d):
             return int((2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in d else None
@@ -330,6 +340,9 @@ def main():
             roof["fwd"] = {"kernel": fwd_name, "launch_ms": round(fwd_ms, 4), "achieved": round(gbs(f_bytes, fwd_ms), 1),
                            "frac": round(gbs(f_bytes, fwd_ms) * 1e9 / HBM_PEAK, 4), "traffic": traffic(pf),
                            "mfma_util": pf.get("mfma_util"), "valu_frac": pf.get("valu_frac"), "algorithmic_bytes_per_launch": f_bytes}
+        roof["pmc_stale"] = bool(stale)
+        if stale:
+            roof["pmc_stale_why"] = stale
         if fwd_ms and bwd_ms:
             both = gbs(f_bytes + b_bytes, fwd_ms + bwd_ms)
             roof["fwd_bwd"] = {"launch_ms": round(fwd_ms + bwd_ms, 4), "achieved": round(both, 1), "frac": round(both * 1e9 / HBM_PEAK, 4),

@@ -177,7 +177,11 @@ class Cache:
 def mark_all_ones(attention_mask: torch.Tensor, all_ones: bool):
     """Host-side knowledge about a mask (True: no padding anywhere; False: padded): RWKV7Model.forward then decides
     whether to apply it without reading it back from the device -- `bool(mask.all())` is a host synchronisation in the
-    middle of the training step, which delays the first gradient bucket of the previous step's overlap window."""
+    middle of the training step, which delays the first gradient bucket of the previous step's overlap window.
+    The hint rides on the tensor object: it is lost by .to() / slicing (safe: the model then reads the mask) but SURVIVES in-place
+    edits -- mark the mask after the last edit, or pass RWKV7Model.forward(attention_mask_all_ones=...) explicitly, which takes
+    precedence.  With RWKV7_CHECK_MASK_HINT=1 in the environment (tests/conftest.py sets it) every hint is checked against the
+    mask itself."""
     attention_mask._rwkv7_all_ones = bool(all_ones)
     return attention_mask
 
@@ -396,7 +400,7 @@ class RWKV7Model(nn.Module):
         self.gradient_checkpointing = False
 
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, past_key_values: Optional[Cache] = None,
-                use_cache: Optional[bool] = None, cu_seqlens=None, **kwargs):
+                use_cache: Optional[bool] = None, cu_seqlens=None, attention_mask_all_ones: Optional[bool] = None, **kwargs):
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         x = self.embeddings(input_ids) if inputs_embeds is None else inputs_embeds
@@ -410,7 +414,10 @@ class RWKV7Model(nn.Module):
             # an all-ones mask (unpadded batches, the common training case) is dropped: multiplying by it is the
             # identity and only costs HBM traffic.  Batch builders that know the answer on the host say so
             # (mark_all_ones); only an unmarked mask costs a device round trip here.
-            known = getattr(attention_mask, "_rwkv7_all_ones", None)
+            known = attention_mask_all_ones if attention_mask_all_ones is not None else getattr(attention_mask, "_rwkv7_all_ones", None)
+            if known is not None and os.environ.get("RWKV7_CHECK_MASK_HINT") == "1":
+                assert bool(attention_mask[:, -T:].all()) == bool(known), \
+                    "attention mask hint (mark_all_ones / attention_mask_all_ones) contradicts the mask: marked before an in-place edit?"
             if not (known if known is not None else bool(attention_mask[:, -T:].all())):
                 mask = attention_mask[:, -T:].to(x.dtype).unsqueeze(-1)
         if use_cache and past_key_values is None:

@@ -22,6 +22,19 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only", "
          "-Wno-unused-result", "-Wno-pass-failed"]
 
 
+def source_hashes(names):
+    """sha256 (first 16 hex digits) of kernel source files under csrc/ -- how profiles/pmc_wkv7.json records what its counters were
+    collected on and how bench.py detects that they no longer describe the shipped kernels (no .git on the GPU box)."""
+    import hashlib
+    out = {}
+    for n in names:
+        try:
+            out[n] = hashlib.sha256(open(os.path.join(CSRC, n), "rb").read()).hexdigest()[:16]
+        except OSError:
+            out[n] = None
+    return out
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 

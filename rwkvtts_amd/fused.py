@@ -249,6 +249,7 @@ class _TmixCore(torch.autograd.Function):
         ctx.save_for_backward(r, w_pre, k, v, a_pre, g, v_pre, v_first, k_k, k_a, gn_w, gn_b, r_k, mask,
                               w, k2, v2, a_in, b_in, y, s, sa, tinv)
         ctx.H, ctx.eps, ctx.chunked_fwd, ctx.seq_start, ctx.via_op = H, eps, chunked, seq_start, via_op
+        ctx.set_materialize_grads(False)   # the last layer's handed-on v_first has no consumer: None, not a [B,T,D] zero tensor
         if v_first is None or not CHAIN_VFIRST_GRAD:
             return out
         # v_first is handed on to the next layer THROUGH this node (a second output aliasing the input): its gradient then arrives
@@ -459,6 +460,7 @@ class _DualLinear(torch.autograd.Function):
     def forward(ctx, x, wa, wb):
         ctx.save_for_backward(x, wa, wb)
         ctx.params = (wa, wb)
+        ctx.set_materialize_grads(False)   # an unused output arrives as None (handled below), not as a zero tensor
         return torch.nn.functional.linear(x, wa), torch.nn.functional.linear(x, wb)
 
     @staticmethod

@@ -90,8 +90,11 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
                 # entry (data/utils/spark_dataset.py:150-158, reproduced bit for bit in layouts.process_single_batch_culens);
                 # the backbone returns zeros there, so those labels would add log(V)-sized terms with no useful gradient
                 # and inflate the valid-token count that scales the whole step -- they are ignored instead
-                pos = torch.arange(labels.shape[1], device=labels.device)
-                labels = torch.where(pos.unsqueeze(0) >= cu[-1].to(labels.device), torch.full_like(labels, ignore_index), labels)
+                # (config.strict_reference_loss = True keeps the reference's behaviour: CE on those positions, counted in the
+                # normaliser; tests/test_model_gpu.py pins both, INTEGRATION.md lists the divergence)
+                if not getattr(self.config, "strict_reference_loss", False):
+                    pos = torch.arange(labels.shape[1], device=labels.device)
+                    labels = torch.where(pos.unsqueeze(0) >= cu[-1].to(labels.device), torch.full_like(labels, ignore_index), labels)
             if fuse:
                 loss = fused_linear_cross_entropy(hidden_states, labels, self.lm_head.weight, self.lm_head.bias,
                                                   ignore_index)

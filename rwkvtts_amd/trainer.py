@@ -119,13 +119,11 @@ class FlatBuffers:
             p._grad_slot_used = False
             self.fired[i] = False
 
-    def finish_backward(self, ran_backward: bool = True):
-        """After backward (or instead of it): zero the slices that received nothing, re-attach every .grad."""
+    def finish_backward(self):
+        """After backward: zero the slices that received nothing, re-attach every .grad."""
         self.flush()
-        if not ran_backward:
-            self.flat_grad.zero_()
         for i, p in enumerate(self.params):
-            if ran_backward and not self.fired[i]:
+            if not self.fired[i]:
                 self.views[i].zero_()
             p.grad = self.views[i]
             p._grad_slot_used = True
@@ -184,9 +182,10 @@ class BucketedAllReduce:
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
             view.copy_((tmp / self.world).to(view.dtype))
 
-    def finish(self, ran_backward: bool = True):
-        """Wait for every bucket (also launches buckets whose hooks never fired, e.g. unused params)."""
-        self.flat.finish_backward(ran_backward)
+    def finish(self):
+        """Wait for every bucket (also launches buckets whose hooks never fired, e.g. unused params).  Backward always runs: a
+        NaN step backpropagates like any other and the optimizer kernel substitutes a zero gradient (DataParallelTrainer.step)."""
+        self.flat.finish_backward()
         if not self.enabled:
             return
         for b, left in enumerate(self.pending):
@@ -250,9 +249,12 @@ def reference_param_groups(model: torch.nn.Module, weight_decay: float):
 
 
 class DataParallelTrainer:
-    """param_groups: None = one group (train_spark_rwkv7speech.py:178-197: every parameter lr x 1, `weight_decay` on all);
-    "reference" = reference_param_groups(model, weight_decay) (the Cosy trainer's lr_2x / lr_decay split); or a list of
-    (name, lr scale, weight decay), one per trainable parameter.  schedule: "linear" (Spark trainer) or "cosine" (Cosy)."""
+    """param_groups: None = the Spark trainer's single group (train_spark_rwkv7speech.py:178-197: every parameter lr x 1 and an
+    explicit "weight_decay": 0.0 at :188, which overrides the optimizer default -- the reference decays NOTHING there, whatever
+    args.weight_decay says; so does this mode: `weight_decay` is ignored); "all" = one group with `weight_decay` on every tensor
+    (explicit opt-in; not what either reference trainer does); "reference" = reference_param_groups(model, weight_decay) (the
+    Cosy trainer's lr_2x / lr_decay split); or a list of (name, lr scale, weight decay), one per trainable parameter.
+    schedule: "linear" (Spark trainer) or "cosine" (Cosy)."""
 
     def __init__(self, model: torch.nn.Module, lr=1e-4, lr_final=1e-5, warmup_steps=100, total_steps=100000,
                  weight_decay=0.0, betas=(0.9, 0.95), eps=1e-18, bucket_bytes=32 << 20, nan_guard=True,
@@ -267,6 +269,8 @@ class DataParallelTrainer:
         if param_groups == "reference":
             param_groups = reference_param_groups(model, weight_decay)
         if param_groups is None:
+            param_groups = [("all", 1.0, 0.0)] * len(self.flat.params)
+        elif param_groups == "all":
             param_groups = [("all", 1.0, float(weight_decay))] * len(self.flat.params)
         assert len(param_groups) == len(self.flat.params), "one (name, lr scale, weight decay) per trainable parameter"
         self.group_defs = []          # distinct (name, lr scale, weight decay)
@@ -296,7 +300,6 @@ class DataParallelTrainer:
             self.group_tab = torch.tensor([[g[1], g[2]] for g in self.group_defs], dtype=torch.float32).to(dev)
         else:
             # CPU (gloo tests) / fp32 models: the same update rule in torch, group by group on runs of the flat buffers
-            self.master_grad = torch.zeros_like(self.master) if self.master is not self.flat.flat_param else None
             self.runs = []   # (start, end, group index): consecutive parameters of one group merged
             ends = self.flat.offsets[1:] + [self.flat.numel]
             for o, e, gi in zip(self.flat.offsets, ends, self.param_group_idx):

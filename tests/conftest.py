@@ -10,6 +10,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("RWKV7_CHECK_MASK_HINT", "1")   # backbone: every mark_all_ones / attention_mask_all_ones hint is checked against the mask
 
 
 def pytest_configure(config):

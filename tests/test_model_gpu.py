@@ -586,3 +586,51 @@ def test_bf16_training_batch_with_T_16_mod_32_stays_on_the_chunked_kernels():
           f"scalar vs oracle {e_orc_s / go.norm().item():.3e}")
     assert torch.isfinite(gd).all()
     assert e_orc < 1.25 * e_orc_s + 1e-3 * go.norm().item(), (e_orc, e_orc_s)   # no further from the oracle than the scalar kernels are
+
+
+def test_packed_overflow_labels_ignored_by_default_and_counted_with_strict_reference_loss():
+    """A packed Spark row whose last sample overflowed max_cu_seqlens carries positions beyond cu_seqlens[-1]
+    (data/utils/spark_dataset.py:150-158).  The backbone returns zeros there.  Default: their labels are ignored (loss and its
+    normaliser over the packed sequences only).  config.strict_reference_loss = True: the reference's behaviour -- CE on those
+    positions too (spark_llm.py:139-160 has no notion of them), counted in the normaliser.  Both pinned against F.cross_entropy of
+    the materialised logits; the divergence is listed in INTEGRATION.md."""
+    model, p, rcfg = _spark_pair(seed=13)
+    lens, extra = [40, 24], 8
+    total = sum(lens)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(1, total + extra, 128, generator=g) * 0.5).to(DEV)
+    labels = torch.randint(0, 256, (1, total + extra), generator=g).to(DEV)
+    cu = torch.tensor([0, lens[0], total], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        out = model(inputs_embeds=x, labels=labels, cu_seqlens=cu)
+        shifted = torch.cat((labels[:, 1:], torch.full_like(labels[:, :1], -100)), 1)
+        lg = out.logits.float()
+        keep = shifted.clone()
+        keep[:, total:] = -100
+        want_default = torch.nn.functional.cross_entropy(lg.view(-1, lg.shape[-1]), keep.view(-1), ignore_index=-100)
+        want_strict = torch.nn.functional.cross_entropy(lg.view(-1, lg.shape[-1]), shifted.view(-1), ignore_index=-100)
+        assert abs(out.loss.item() - want_default.item()) < 1e-4
+        model.config.strict_reference_loss = True
+        try:
+            strict = model(inputs_embeds=x, labels=labels, cu_seqlens=cu)
+        finally:
+            model.config.strict_reference_loss = False
+        assert abs(strict.loss.item() - want_strict.item()) < 1e-4
+        assert abs(want_strict.item() - want_default.item()) > 1e-3   # the two really differ on this batch
+
+
+def test_mask_hint_is_checked_and_the_explicit_kwarg_takes_precedence():
+    """backbone.mark_all_ones rides on the tensor object and survives in-place edits: with RWKV7_CHECK_MASK_HINT=1 (set by
+    tests/conftest.py) a stale hint is an assertion, not a silently dropped mask; attention_mask_all_ones= overrides the attribute."""
+    from rwkvtts_amd import backbone
+    model, p, rcfg = _spark_pair(seed=17)
+    x = (torch.randn(2, 32, 128, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV)
+    mask = backbone.mark_all_ones(torch.ones(2, 32, dtype=torch.long, device=DEV), True)
+    with torch.no_grad():
+        a = model.model(inputs_embeds=x, attention_mask=mask).last_hidden_state
+        mask[1, :3] = 0   # edited after marking
+        with pytest.raises(AssertionError):
+            model.model(inputs_embeds=x, attention_mask=mask)
+        b = model.model(inputs_embeds=x, attention_mask=mask, attention_mask_all_ones=False).last_hidden_state
+        c = model.model(inputs_embeds=x, attention_mask=mask.clone()).last_hidden_state   # no hint: the model reads the mask
+    assert torch.equal(b, c) and not torch.equal(a[1], b[1])

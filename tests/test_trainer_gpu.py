@@ -125,3 +125,37 @@ def test_two_ranks_rccl_real_model_replicas_identical_and_equal_single_process_m
 @pytest.mark.timeout(600)
 def test_two_ranks_sharing_one_gpu_over_gloo_real_model():
     _two_ranks("gloo", True)
+
+
+DEV = "cuda:0"
+
+
+def test_nan_loss_step_on_the_hip_model_leaves_parameters_unchanged():
+    """train_spark_rwkv7speech.py:664-687: a NaN loss makes every rank step on a zero gradient.  Here backward runs on the NaN
+    activations (nothing waits for the flag on the host) and rwkv7_adamw_groups_bf16 reads the flag on the device: the HIP kernels
+    see NaN inputs, the parameters and the fp32 masters must come out exactly as after a zero-gradient step, and the next clean
+    step must train."""
+    from rwkvtts_amd import trainer
+    from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
+    cfg = RWKV7SpeechConfig(hidden_size=128, num_hidden_layers=2, vocab_size=257, text_vocab_size=300, audio_global_vocab_size=64,
+                            decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=16, gate_low_rank_dim=32)
+    model = RWKV7ForSpeech(cfg).init_weights(seed=0).to(DEV).to(torch.bfloat16).train()
+    tr = trainer.DataParallelTrainer(model, lr=1e-3, warmup_steps=0, total_steps=10)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(2, 64, 128, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    labels = torch.randint(0, 256, (2, 64), generator=g).to(DEV)
+    l0 = tr.step(inputs_embeds=x, labels=labels)
+    assert torch.isfinite(l0)
+    before, m_before = tr.flat.flat_param.clone(), tr.master.clone()
+    ea, eq = tr.exp_avg.clone(), tr.exp_avg_sq.clone()
+    xn = x.clone()
+    xn[0, 5, 7] = float("nan")
+    ln = tr.step(inputs_embeds=xn, labels=labels)
+    assert not torch.isfinite(ln)
+    assert torch.isfinite(tr.flat.flat_param.float()).all() and torch.isfinite(tr.master).all()
+    assert torch.isfinite(tr.exp_avg).all() and torch.isfinite(tr.exp_avg_sq).all()
+    # a zero-gradient AdamW step: moments decay, parameters move only by the (bias-corrected) momentum of the first step
+    b1, b2 = tr.betas
+    assert torch.allclose(tr.exp_avg, ea * b1, rtol=1e-6, atol=0) and torch.allclose(tr.exp_avg_sq, eq * b2, rtol=1e-6, atol=0)
+    l2 = tr.step(inputs_embeds=x, labels=labels)
+    assert torch.isfinite(l2) and torch.isfinite(tr.flat.flat_param.float()).all()

@@ -15,6 +15,10 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rwkvtts_amd.build import source_hashes  # noqa: E402
+
+COMMON = ["chunk_common.h", "wkv7_common.h"]
 
 
 def parse(path):
@@ -37,7 +41,7 @@ def find(tab, needle):
     return tab[hits[0]], hits[0]
 
 
-def group(tab, needles, B, T, H, source):
+def group(tab, needles, B, T, H, source, files):
     parts, fetch, write, busy, valu, cyc = {}, 0.0, 0.0, 0.0, 0.0, 0.0
     for n in needles:
         c, name = find(tab, n)
@@ -48,7 +52,10 @@ def group(tab, needles, B, T, H, source):
         valu += 4.0 * c["SQ_ACTIVE_INST_VALU"]
         cyc += 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
     return {"kernel": " + ".join(parts), "B": B, "T": T, "H": H, "dtype": "bf16", "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
-            "mfma_util": round(busy / cyc, 4), "valu_frac": round(valu / cyc, 4), "parts": parts, "source": source}
+            "mfma_util": round(busy / cyc, 4), "valu_frac": round(valu / cyc, 4), "parts": parts, "source": source,
+            # sha256 of the kernel sources the counters were collected on: bench.py reports pmc_stale (and nulls traffic / mfma_util /
+            # valu_frac) when the shipped sources differ
+            "sources": source_hashes(files)}
 
 
 def main():
@@ -60,10 +67,12 @@ def main():
                        "runs per counter group, no tracing). KiB per launch; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: "
                        "FETCH_SIZE counts half of a wide coalesced read stream, MI355X_MICROARCH.md). wkv7c_* = what bf16 training "
                        "launches; wkv7_* = the scalar reference-schema kernels.",
-           "wkv7c_bwd": group(tab, ["wkv7c_bwd_pre_kernel", "wkv7c_state_kernel", "wkv7c_bwd_out8_kernel"], B, T, H, src),
-           "wkv7c_fwd": group(tab, ["wkv7c_prep_kernel", "wkv7c_fwd8_kernel"], B, T, H, src),
-           "wkv7_bwd": group(tab, ["wkv7_bwd_kernel<rwkv7::bf16_t, 2, 4>"], B, T, H, src),
-           "wkv7_fwd": group(tab, ["wkv7_fwd_kernel<rwkv7::bf16_t, true, false, 4>"], B, T, H, src)}
+           "wkv7c_bwd": group(tab, ["wkv7c_bseq_kernel", "wkv7c_bwd_out8_kernel"], B, T, H, src,
+                              ["wkv7_chunk_bseq.hip", "wkv7_chunk_bwd8.hip", "chunk_bwd_common.h"] + COMMON),
+           "wkv7c_fwd": group(tab, ["wkv7c_prep_kernel", "wkv7c_fwd9_kernel"], B, T, H, src,
+                              ["wkv7_chunk_fwd.hip", "wkv7_chunk_fwd9.hip"] + COMMON),
+           "wkv7_bwd": group(tab, ["wkv7_bwd_kernel<rwkv7::bf16_t, 2, 4>"], B, T, H, src, ["wkv7_bwd.hip", "wkv7_common.h"]),
+           "wkv7_fwd": group(tab, ["wkv7_fwd_kernel<rwkv7::bf16_t, true, false, 4>"], B, T, H, src, ["wkv7_fwd.hip", "wkv7_common.h"])}
     with open(os.path.join(ROOT, "profiles", "pmc_wkv7.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k in ("wkv7c_bwd", "wkv7c_fwd"):
