@@ -66,8 +66,8 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
  *      layout, fp32 [B,T,H,64]).  `s` -- in the reference a private forward -> backward scratch of state checkpoints (its content is
  *      read by nothing but the backward kernel, rwkv_s2s_single_ffn.py:22-35) -- is used as an opaque arena of the SAME size:
  *      per 32-step chunk and head 9216 B of state checkpoint (q15 record, see rwkv7_wkv_chunk_fwd_bf16) + 4096 B of
- *      T = (I - A_ab)^-1 + 9216 B of adjoint state written by the backward = 22 528 of the 32 768 B the reference's layout has
- *      there.  Launches: chunk_prep + chunk_fwd (forward); chunk_bseq + chunk_bwd_out (backward).  RWKV7_ECHUNK when T % 32 != 0:
+ *      T = (I - A_ab)^-1 + 9216 B of adjoint state and 8192 B of Z written by the backward = 30 720 of the 32 768 B the
+ *      reference's layout has there.  Launches: chunk_prep + chunk_fwd (forward); chunk_bseq + chunk_bwd_out_z (backward).  RWKV7_ECHUNK when T % 32 != 0:
  *      fall back to rwkv7_wkv_fwd_bf16 / rwkv7_wkv_bwd_bf16 (T % 16 == 0), whose `s` holds the reference's checkpoints. ---- */
 int rwkv7_wkv_fwd_fast_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                             const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream);
@@ -314,7 +314,14 @@ int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, co
  *             M_c^T and N'_c are never formed and never reach HBM.  Same e_vk records as `state`; seq_chunk_off / nseq as in
  *             rwkv7_wkv_chunk_fwd_seq_bf16 (NULL / 0 for plain rows). */
 int rwkv7_wkv_chunk_bseq_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
-                              const float *tinv, void *e_vk, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
+                              const float *tinv, void *e_vk, float *z, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
+/*             z (may be NULL): fp32 [B,T,H,64], Z_t = dL/du_t (u = sa), which the recurrence forms anyway.  With it the per-chunk
+ *             gradient kernel needs neither T^-1 nor the A_qb -> G1 -> Z chain: rwkv7_wkv_chunk_bwd_out_z_bf16 (two matrix
+ *             phases instead of five; csrc/wkv7_chunk_bwd9.hip). */
+int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                                   const void *a, const void *b, const void *dy, const void *hs, const float *sa,
+                                   const float *z, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
+                                   void *da, void *db, rwkv7_stream_t stream);
 /*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from what the chunked
  *             forward saved (hs, sa, tinv) and the adjoint states e_vk of `state`. */
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,

@@ -41,7 +41,9 @@ int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, 
                        void *, hipStream_t);
 int chunk_state_bf16(int, int, int, const void *, const void *, void *, const int *, int, hipStream_t);
 int chunk_bseq_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
-                    const int *, int, hipStream_t);
+                    float *, const int *, int, hipStream_t);
+int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
+                        const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *,
                         hipStream_t);
@@ -144,9 +146,10 @@ int rwkv7_wkv_bwd_fast_bf16(int B, int T, int H, const void *w, const void *q, c
     char *base = reinterpret_cast<char *>(s);
     const float *tinv = reinterpret_cast<const float *>(base + n * kArenaRec);
     void *e_vk = base + n * (kArenaRec + kArenaTinv);
-    const int rc = rwkv7::chunk_bseq_bf16(B, T, H, w, q, a, b, dy, tinv, e_vk, nullptr, 0, (hipStream_t)stream);
+    float *z = reinterpret_cast<float *>(base + n * (2 * kArenaRec + kArenaTinv));   // fp32 [B,T,H,64]: 8192 B per chunk and head
+    const int rc = rwkv7::chunk_bseq_bf16(B, T, H, w, q, a, b, dy, tinv, e_vk, z, nullptr, 0, (hipStream_t)stream);
     if (rc != 0) return rc;
-    return rwkv7::chunk_bwd_out8_bf16(B, T, H, w, q, k, v, a, b, dy, base, sa, tinv, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
+    return rwkv7::chunk_bwd_out9_bf16(B, T, H, w, q, k, v, a, b, dy, base, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
 
 #define BWD2_BODY(IMPL, WIDE)                                                                                 \
@@ -408,11 +411,21 @@ int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, co
     return rwkv7::chunk_state_bf16(B * H, nchunks, H, mt, np, e_vk, seq_chunk_off, nseq, (hipStream_t)stream);
 }
 int rwkv7_wkv_chunk_bseq_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
-                              const float *tinv, void *e_vk, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream) {
+                              const float *tinv, void *e_vk, float *z, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream) {
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, a, b, dy, (const void *)tinv, (const void *)e_vk})) return RWKV7_EINVAL;
     if (seq_chunk_off != nullptr && nseq <= 0) return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
-    return rwkv7::chunk_bseq_bf16(B, T, H, w, q, a, b, dy, tinv, e_vk, seq_chunk_off, nseq, (hipStream_t)stream);
+    return rwkv7::chunk_bseq_bf16(B, T, H, w, q, a, b, dy, tinv, e_vk, z, seq_chunk_off, nseq, (hipStream_t)stream);
+}
+int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
+                                   const void *a, const void *b, const void *dy, const void *hs, const float *sa,
+                                   const float *z, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
+                                   void *da, void *db, rwkv7_stream_t stream) {
+    if (B <= 0 || T <= 0 || H <= 0 ||
+        any_null({w, q, k, v, a, b, dy, hs, (const void *)sa, (const void *)z, e_vk, dw, dq, dk, dv, da, db}))
+        return RWKV7_EINVAL;
+    if (T % 32 != 0) return RWKV7_ECHUNK;
+    return rwkv7::chunk_bwd_out9_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
 int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                  const void *a, const void *b, const void *dy, const void *hs, const float *sa,

@@ -50,7 +50,7 @@ struct BSSmem {  // offsets in uint16 units; every plane 16-byte aligned
     static constexpr int XPh = BBl + PL, XPl = XPh + PS, QBh = XPl + PS, QBl = QBh + PS, TMh = QBl + PS, TMl = TMh + PS;
     static constexpr int Zh = TMl + PS, Zl = Zh + VH * LDC;
     static constexpr int end16 = Zl + VH * LDC;
-    static constexpr int fGC = 0, fend = 2 * kN;   // fp32: g_C of both buffers
+    static constexpr int fGC = 0, fZ = 2 * kN, fend = fZ + kC * 36;   // fp32: g_C of both buffers; Z staging tile [32][36]
     // raw input staging (bf16): 4 planes [32][64 + 8] and dY [32][32 + 8]
     static constexpr int RS = kN + 8, RSV = VH + 8;
     static constexpr size_t bytes = (size_t)end16 * 2 + (size_t)fend * 4 + (size_t)(4 * kC * RS + kC * RSV) * 2;
@@ -62,10 +62,12 @@ static_assert(BSSmem::bytes <= 160 * 1024, "LDS budget");
 __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_,
                                                          const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_,
                                                          const bf16_t *__restrict__ dy_, const float *__restrict__ tinv_,
-                                                         uint16_t *__restrict__ e_vk, const int *__restrict__ seq_off_) {
+                                                         uint16_t *__restrict__ e_vk, float *__restrict__ z_,
+                                                         const int *__restrict__ seq_off_) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     using L = BSSmem;
-    float *sh_gC2 = reinterpret_cast<float *>(sm + L::end16) + L::fGC;
+    float *sh_gC2 = reinterpret_cast<float *>(sm + L::end16) + L::fGC, *sh_Z = reinterpret_cast<float *>(sm + L::end16) + L::fZ;
+    constexpr int kStageLD = 36;
     bf16_t *raw = reinterpret_cast<bf16_t *>(reinterpret_cast<float *>(sm + L::end16) + L::fend);
     constexpr int RS = L::RS, RSV = L::RSV;
 
@@ -119,11 +121,17 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
             const uint16_t *bufc = sm + (cc & 1) * L::BUF, *bufp = sm + (pc & 1) * L::BUF;
             const float *gCc = sh_gC2 + (cc & 1) * kN, *gCp = sh_gC2 + (pc & 1) * kN;
             // ----------------------------------------------------------------------------------------------- interval a
+            if (z_ && cc + 1 < c1) {
+                // Z of the previous chunk (staged in its interval b) -> HBM, fp32 [B,T,H,64] like sa: thread (pt, pv) owns 4 value
+                // columns of one step.  The per-chunk gradient kernel reads it instead of rebuilding A_qb, G1 and Z.
+                const long o = head_base + (long)((cc + 1) * kC + pt) * tstride + vh * VH + pv;
+                *reinterpret_cast<float4 *>(z_ + o) = *reinterpret_cast<const float4 *>(&sh_Z[pt * kStageLD + pv]);
+            }
+            f32x16 accZ = zero16();
             if (cc < c1 && wave == 0) {   // Z = B" E' + X" dY : D[r][v] -> Z[v][r]
-                f32x16 acc = zero16();
-                mma_tile3<kN>(acc, sm + L::BBh, sm + L::BBl, LDK, sm + L::Eh, sm + L::El, LDK, lane);
-                mma_gen<kC, false, true, true, false>(acc, sm + L::XPh, sm + L::XPl, LDC, 0, bufc + L::DYt, bufc + L::DYt, LDC, 0, lane);
-                store_T_split(acc, sm + L::Zh, sm + L::Zl, LDC, lane);
+                mma_tile3<kN>(accZ, sm + L::BBh, sm + L::BBl, LDK, sm + L::Eh, sm + L::El, LDK, lane);
+                mma_gen<kC, false, true, true, false>(accZ, sm + L::XPh, sm + L::XPl, LDC, 0, bufc + L::DYt, bufc + L::DYt, LDC, 0, lane);
+                store_T_split(accZ, sm + L::Zh, sm + L::Zl, LDC, lane);
             }
             BSSTAMP(0);
             lds_barrier();
@@ -147,13 +155,19 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
                     for (int r = 0; r < 16; r++) Ep[r] = gCp[kt * 32 + d_row(r, lane)] * Emaster[r];
                     store_T_split(Ep, sm + L::Eh + kt * 32, sm + L::El + kt * 32, LDK, lane);
                 }
-            } else if (wave == 0 && pc >= c0) {
+            } else if (wave == 0) {
+                if (z_ && cc < c1) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) sh_Z[d_row(r, lane) * kStageLD + (lane & 31)] = accZ[r];
+                }
+                if (pc >= c0) {
                 // B" = T^T B^ of the next chunk: D[m = k][n = r] = sum_s b^[s][k] T[s][r] -> B"[r][k], two key tiles
 #pragma unroll
                 for (int kt = 0; kt < 2; kt++) {
                     f32x16 acc = zero16();
                     mma_gen<kC, true, true, true, true>(acc, bufp + L::BHh, bufp + L::BHl, LDK, kt * 32, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
                     store_T_split(acc, sm + L::BBh + kt * 32, sm + L::BBl + kt * 32, LDK, lane);
+                }
                 }
             } else if (wave == 3 && pc >= c0) {
                 // next chunk: A_qb[t][s] (s <= t), then X"[r][t] = sum_s T[s][r] A_qb[t][s] (this wave reads back what it wrote)
@@ -168,6 +182,10 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
             BSSTAMP(2);
             lds_barrier();
             BSSTAMP(3);
+        }
+        if (z_) {   // Z of the last chunk processed (c0)
+            const long o = head_base + (long)(c0 * kC + pt) * tstride + vh * VH + pv;
+            *reinterpret_cast<float4 *>(z_ + o) = *reinterpret_cast<const float4 *>(&sh_Z[pt * kStageLD + pv]);
         }
     } else {
         // =================================================================================================== producer
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
 }
 
 int chunk_bseq_bf16(int B, int T_, int H, const void *w, const void *q, const void *a, const void *b, const void *dy, const float *tinv,
-                    void *e_vk, const int *seq_off, int nseq, hipStream_t st) {
+                    void *e_vk, float *z, const int *seq_off, int nseq, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_bseq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -293,7 +311,7 @@ int chunk_bseq_bf16(int B, int T_, int H, const void *w, const void *q, const vo
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL(wkv7c_bseq_kernel, dim3((seq_off ? nseq : B) * H * 2), dim3(512), BSSmem::bytes, st, T_, H, (const bf16_t *)w,
-                       (const bf16_t *)q, (const bf16_t *)a, (const bf16_t *)b, (const bf16_t *)dy, tinv, (uint16_t *)e_vk, seq_off);
+                       (const bf16_t *)q, (const bf16_t *)a, (const bf16_t *)b, (const bf16_t *)dy, tinv, (uint16_t *)e_vk, z, seq_off);
     return (int)hipGetLastError();
 }
 

@@ -368,40 +368,51 @@ def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off=None):
     return mt, np_, e_vk
 
 
-def wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off=None):
+def wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off=None, want_z=False):
     """The adjoint-state recurrence of the chunked backward as ONE sequential kernel (csrc/wkv7_chunk_bseq.hip): the factored
     form E_c = E' + A~^T Z + Q~^T dY, Z = (T^T B^) E' + (T^T A_qb^T) dY -- M_c^T / N'_c are not materialised.  Returns e_vk
-    (e_vk[b,h,c] = E_{c+1} as q15 records), the same records wkv7_chunk_bwd_state returns."""
+    (e_vk[b,h,c] = E_{c+1} as q15 records), the same records wkv7_chunk_bwd_state returns; with want_z also Z (fp32 [B,T,H,64],
+    Z_t = dL/du_t) as (e_vk, z)."""
     B, T, H, C = w.shape
     if w.dtype != torch.bfloat16:
         raise TypeError("the chunked backward is bf16 only")
     if T % CHUNK_T != 0:
         raise ValueError(f"chunked WKV7 needs T % {CHUNK_T} == 0, got T={T}")
     e_vk = torch.empty(B, H, T // CHUNK_T, Q15_REC, dtype=torch.int16, device=w.device)
+    # packed rows leave the positions behind the last sequence untouched: zeros there (the gradient kernel reads every chunk)
+    z = (torch.empty if seq_off is None else torch.zeros)(B, T, H, C, dtype=torch.float32, device=w.device) if want_z else None
     with torch.cuda.device_of(w), _timed("wkv7c_bseq", w):
-        rc = _lib.lib().rwkv7_wkv_chunk_bseq_bf16(B, T, H, _p(w), _p(q), _p(a), _p(b), _p(dy), _p(tinv), _p(e_vk), *_seq_args(seq_off),
-                                                  _stream(w))
+        rc = _lib.lib().rwkv7_wkv_chunk_bseq_bf16(B, T, H, _p(w), _p(q), _p(a), _p(b), _p(dy), _p(tinv), _p(e_vk), _p(z),
+                                                  *_seq_args(seq_off), _stream(w))
     _lib.check(rc, "wkv7_chunk_bseq")
-    return e_vk
+    return (e_vk, z) if want_z else e_vk
 
 
-def wkv7_chunk_backward(w, q, k, v, a, b, dy, hs, sa, tinv, seq_off=None, two_kernel_state=False):
+def wkv7_chunk_backward(w, q, k, v, a, b, dy, hs, sa, tinv, seq_off=None, two_kernel_state=False, from_z=True):
     """Chunked (MFMA) WKV7 backward, bf16: same gradients as torch.ops.wind_backstepping.backward, T % 32 == 0, from what
-    wkv7_chunk_forward saved (hs, sa, tinv).  Launches: adjoint-state recurrence (one kernel; two_kernel_state=True: the
-    M^T/N' kernel + the one-product recurrence, kept for A/B and cross-checks), per-chunk gradients.
+    wkv7_chunk_forward saved (hs, sa, tinv).  Launches: adjoint-state recurrence (one kernel, which also writes Z = dL/du;
+    two_kernel_state=True: the M^T/N' kernel + the one-product recurrence, kept for A/B and cross-checks), per-chunk gradients
+    (from Z: two matrix phases; from_z=False or two_kernel_state: the kernel that rebuilds Z from T^-1 itself, five phases).
     Returns (dw, dq, dk, dv, da, db)."""
     B, T, H, C = w.shape
     if hs.dtype != torch.int16 or hs.shape[-1] != Q15_REC or sa.dtype != torch.float32 or tinv.dtype != torch.float32:
         raise TypeError("wkv7_chunk_backward takes hs (q15 records), sa and tinv (fp32) as saved by wkv7_chunk_forward")
+    z = None
     if two_kernel_state:
         mt, np_, e_vk = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off)
         del mt, np_
+    elif from_z:
+        e_vk, z = wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off, want_z=True)
     else:
         e_vk = wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off)
     grads = [torch.empty_like(w) for _ in range(6)]
     with torch.cuda.device_of(w), _timed("wkv7c_bwd_out", w):
-        rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(hs), _p(sa),
-                                                     _p(tinv), _p(e_vk), *[_p(g) for g in grads], _stream(w))
+        if z is not None:
+            rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_z_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(hs), _p(sa),
+                                                           _p(z), _p(e_vk), *[_p(g) for g in grads], _stream(w))
+        else:
+            rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(hs), _p(sa),
+                                                         _p(tinv), _p(e_vk), *[_p(g) for g in grads], _stream(w))
     _lib.check(rc, "wkv7_chunk_bwd_out")
     return tuple(grads)
 

@@ -284,7 +284,9 @@ def test_one_kernel_adjoint_recurrence_vs_two_kernel_pair(B, T, H, seed):
                     err = (eo[bi, hi, c].cpu() - ref).abs().max().item()
                     assert err <= 3e-4 * max(ref.abs().max().item(), 1e-3), (so is not None, bi, hi, c, err, ref.abs().max().item())
     g_pair = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv, two_kernel_state=True)
-    g_one = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv)
+    g_one = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv, from_z=False)
+    g_z = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv)      # default: Z from the recurrence kernel, two-phase gradient kernel
     torch.cuda.synchronize()
-    for n, g1, g2 in zip(NAMES, g_one, g_pair):
+    for n, g1, g2, g3 in zip(NAMES, g_one, g_pair, g_z):
         _assert_bf16_close(g1, g2.float().cpu(), f"{n}: one-kernel vs pair", ulps=1.0)
+        _assert_bf16_close(g3, g2.float().cpu(), f"{n}: from Z vs pair", ulps=1.0)
