@@ -122,20 +122,27 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
     @torch.no_grad()
     def generate(self, input_ids, attention_mask=None, max_new_tokens=None, max_length=None, do_sample=True,
                  temperature=1.0, top_k=0, top_p=1.0, eos_token_id=None, generator: Optional[torch.Generator] = None,
-                 return_dict_in_generate=False, **unused):
+                 return_dict_in_generate=False, reference_termination=False, use_graph: Optional[bool] = None, **unused):
         """CustomGenerationMixin._sample (xy_llm.py:39-146) on the persistent-state decode path.
         input_ids [B,T,C].  do_sample=False replaces each multinomial by argmax (greedy, for parity tests).
 
         Flush (xy_llm.py:104-121): a non-audio id on channel 0 starts a countdown of C-1 further rows; in all C rows channel 0
         carries EOS (if one is configured), channel i keeps its sampled ids for i more rows and is padded afterwards, and the
         sequence finishes with the last row.  Two places where the reference's loop cannot do what its comments say, and
-        where this loop follows the comments (tests/test_heads_gpu.py hand-steps the rules):
+        where this loop follows the comments by default (tests/test_heads_gpu.py hand-steps the rules):
           * `unfinished & ~stopping & ~(needs_additional_steps == -1)` (:140) is false for every sequence that is NOT flushing,
-            i.e. from the first step on -- the reference would emit one frame; here only a flushing sequence whose countdown
-            reached -1 finishes;
+            i.e. from the first step on -- the reference emits ONE frame and stops; here only a flushing sequence whose
+            countdown reached -1 finishes;
           * with an EOS id configured, the EOS that the flush writes on channel 0 meets the EOS stopping criterion in the
-            very row that starts the countdown (:139); here the criterion is not applied to flushing sequences."""
-        from .spark_llm import sample_next
+            very row that starts the countdown (:139); here the criterion is not applied to flushing sequences.
+        reference_termination=True reproduces lines :139-140 literally (same ids, same length as the reference on the same
+        draws).
+
+        One frame step = embedding sum of the previous row -> the whole stack + the eight heads (one concatenated projection,
+        rwkv7_decode_step_bf16) -> channel-0 mask -> eight draws -> flush / pad / stop bookkeeping, all as tensor operations on
+        fixed buffers with no host read-back (`_XYFrameState.step`), so the step is captured in a hipGraph and replayed
+        (use_graph: None = when the step kernel covers the model, a length bound is given and no private generator is used);
+        the host looks at the `all finished` flag only every 8 frames and trims the surplus rows at the end."""
         cfg = self.config
         was_training = self.training
         self.eval()
@@ -143,8 +150,6 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
         total = max_length if max_new_tokens is None else cur_len + max_new_tokens
         eos = None if eos_token_id is None else ([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id))
         dev = input_ids.device
-        unfinished = torch.ones(B, dtype=torch.long, device=dev)
-        needs_additional_steps = -torch.ones(B, dtype=torch.long, device=dev)
         cache = Cache.zeros(cfg, B, dev, self.dtype)
         out = self(input_ids=input_ids, attention_mask=attention_mask, past_key_values=cache, use_cache=True)
         # T = 1 steps: the whole stack + the eight heads (as one concatenated projection) through rwkv7_decode_step_bf16
@@ -157,45 +162,169 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
                                    bias=torch.cat([h.bias for h in self.heads], 0).contiguous())
             if DecodeStep.supported(self.model, head, cache) is None:
                 step_kernel = DecodeStep(self.model, head, cache)
-        while True:
-            logits = [l[:, -1, :].clone().float() for l in out.logits]
-            mask = torch.ones_like(logits[0], dtype=torch.bool)
-            mask[:, cfg.text_shift_size: cfg.text_shift_size + cfg.speech_vocab_size] = False
-            logits[0].masked_fill_(mask, float("-inf"))  # channel 0 may only emit audio ids (:82-86)
-            next_tokens = torch.stack([sample_next(l, do_sample, top_k, top_p, temperature, generator) for l in logits], -1)
-            is_audio = self.is_audio_token(next_tokens[:, 0])
-            to_flush = (~is_audio) & (needs_additional_steps < 0)
-            needs_additional_steps[to_flush] = C - 1
-            is_flushing = needs_additional_steps >= 0
-            if is_flushing.any():
-                if eos is not None:
-                    next_tokens[is_flushing, 0] = eos[0]
-                for i in range(1, C):
-                    pad_this = is_flushing & (needs_additional_steps < C - i)
-                    next_tokens[pad_this, i] = cfg.speech_pad_token
-            pddp_text = eos[0] if eos is not None else 0
-            next_tokens[:, 0] = next_tokens[:, 0] * unfinished + pddp_text * (1 - unfinished)
-            next_tokens[:, 1:] = next_tokens[:, 1:] * unfinished.unsqueeze(-1) + cfg.speech_pad_token * (1 - unfinished.unsqueeze(-1))
-            input_ids = torch.cat([input_ids, next_tokens[:, None, :]], dim=1)
-            needs_additional_steps[is_flushing] -= 1
-            stop = torch.zeros(B, dtype=torch.bool, device=dev)
-            if total is not None and input_ids.shape[1] >= total:
-                stop[:] = True
-            if eos is not None:
-                # the EOS criterion applies to sequences that are NOT flushing: the flush itself writes EOS on channel 0, and
-                # letting that end the sequence would cut the countdown after its first row (see the docstring)
-                stop |= torch.isin(input_ids[:, -1, 0], torch.tensor(eos, device=dev)) & ~is_flushing
-            unfinished = unfinished & (~stop).long() & (~(needs_additional_steps == -1) | (~is_flushing)).long()
-            if unfinished.max() == 0:
-                break
+        st = _XYFrameState(self, input_ids, total, eos, do_sample, top_k, top_p, temperature, generator, reference_termination)
+        st.logits = [l[:, -1, :].float().contiguous() for l in out.logits]
+
+        def advance():   # the model step that follows a frame: logits of the next one
             if step_kernel is not None:
-                lg = step_kernel(self.embed(next_tokens[:, None, :])[:, 0].contiguous())
-                cache.seen_tokens += 1
-                out = ModelOutput(logits=[l.unsqueeze(1) for l in torch.split(lg, sizes, dim=1)])
+                lg = step_kernel(self.embed(st.row.unsqueeze(1))[:, 0].contiguous())
+                for dst, src in zip(st.logits, torch.split(lg, sizes, dim=1)):
+                    dst.copy_(src)
             else:
-                out = self(input_ids=next_tokens[:, None, :], past_key_values=cache, use_cache=True)
+                o = self(input_ids=st.row.unsqueeze(1), past_key_values=cache, use_cache=True)
+                for dst, l in zip(st.logits, o.logits):
+                    dst.copy_(l[:, -1, :].float())
+
+        graph_ok = step_kernel is not None and total is not None and generator is None
+        if use_graph is None:
+            use_graph = graph_ok
+        elif use_graph and not graph_ok:
+            raise ValueError("use_graph=True needs the step kernel (bf16, B <= 32), a length bound and the default generator")
+        frames = 0
+        if not use_graph:
+            while True:
+                st.step()
+                frames += 1
+                cache.seen_tokens += 1
+                if bool(st.all_done.item()):
+                    break
+                if st.need_rows(frames + 1):
+                    st.grow()
+                advance()
+        else:
+            # frame 0 eagerly (its logits come from the prefill), then `advance(); step()` as ONE captured unit
+            st.step()
+            frames = 1
+            if not bool(st.all_done.item()):
+                snap = [(s.att_x_prev.clone(), s.att_kv.clone(), s.ffn_x_prev.clone()) for s in cache.states]
+                keep = st.snapshot()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):   # warm-up outside the capture (allocations, lazy init), state restored afterwards
+                    advance()
+                    st.step()
+                torch.cuda.current_stream().wait_stream(side)
+
+                def restore():
+                    for s_, (a_, kv_, f_) in zip(cache.states, snap):
+                        s_.att_x_prev.copy_(a_)
+                        s_.att_kv.copy_(kv_)
+                        s_.ffn_x_prev.copy_(f_)
+                    st.restore(keep)
+
+                restore()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    advance()
+                    st.step()
+                restore()
+                budget = total - cur_len - 1
+                while budget > 0:
+                    n = min(8, budget)
+                    for _ in range(n):
+                        graph.replay()
+                    budget -= n
+                    frames += n
+                    if bool(st.all_done.item()):
+                        break
+                if step_kernel.barrier_timed_out():
+                    from . import _lib
+                    raise _lib.Rwkv7HipError("rwkv7_decode_step_bf16: a grid barrier timed out; the generated ids are invalid")
+            cache.seen_tokens += frames
+        n_rows = int(st.n_rows.item())   # rows the reference's loop would have appended before its `break`
+        input_ids = st.out[:, :n_rows].clone()
         if was_training:
             self.train()
         if return_dict_in_generate:
             return ModelOutput(sequences=input_ids)
         return input_ids
+
+
+class _XYFrameState:
+    """Everything CustomGenerationMixin._sample (xy_llm.py:39-146) carries from frame to frame, as device tensors at fixed
+    addresses, and one frame of its bookkeeping as tensor operations only (no `.any()`, no boolean-mask assignment, no
+    `.item()`): `step()` consumes `logits` (one tensor per channel), writes the new row into `out` and `row`, and updates the
+    countdown / unfinished / all_done / n_rows tensors -- the same code runs eagerly and inside a captured hipGraph."""
+
+    def __init__(self, model, input_ids, total, eos, do_sample, top_k, top_p, temperature, generator, reference_termination):
+        cfg = model.config
+        self.cfg, self.model = cfg, model
+        B, cur_len, C = input_ids.shape
+        dev = input_ids.device
+        self.B, self.C, self.total, self.cur_len = B, C, total, cur_len
+        self.sample = dict(do_sample=do_sample, top_k=top_k, top_p=top_p, temperature=temperature, generator=generator)
+        self.reference_termination = bool(reference_termination)
+        self.eos = None if eos is None else torch.tensor(eos, device=dev)
+        self.eos0 = None if eos is None else int(eos[0])
+        rows = total if total is not None else cur_len + 256
+        self.out = torch.zeros(B, max(rows, cur_len + 1), C, dtype=input_ids.dtype, device=dev)
+        self.out[:, :cur_len] = input_ids
+        self.row = torch.zeros(B, C, dtype=input_ids.dtype, device=dev)          # the row written last (input of the next model step)
+        self.pos = torch.full((1,), cur_len, dtype=torch.long, device=dev)       # where the next row goes
+        self.unfinished = torch.ones(B, dtype=torch.long, device=dev)
+        self.needs = -torch.ones(B, dtype=torch.long, device=dev)               # needs_additional_steps
+        self.all_done = torch.zeros((), dtype=torch.bool, device=dev)            # the reference's `unfinished.max() == 0` -> break
+        self.n_rows = torch.full((), cur_len, dtype=torch.long, device=dev)      # length of the sequence tensor at that break
+        self.ch0_block = torch.ones(cfg.vocab_size, dtype=torch.bool, device=dev)
+        self.ch0_block[cfg.text_shift_size: cfg.text_shift_size + cfg.speech_vocab_size] = False
+        self.logits: List[torch.Tensor] = []
+
+    def need_rows(self, frames_after):
+        return self.cur_len + frames_after > self.out.shape[1]
+
+    def grow(self):   # unbounded generation (no max_length): the row buffer grows in blocks (host-side decision, no read-back)
+        self.out = torch.cat([self.out, torch.zeros_like(self.out[:, :256])], 1)
+
+    def snapshot(self):
+        return [t.clone() for t in (self.out, self.row, self.pos, self.unfinished, self.needs, self.all_done, self.n_rows)] + \
+               [l.clone() for l in self.logits]
+
+    def restore(self, keep):
+        for t, k in zip([self.out, self.row, self.pos, self.unfinished, self.needs, self.all_done, self.n_rows] + self.logits, keep):
+            t.copy_(k)
+
+    def step(self):
+        from .spark_llm import sample_next
+        cfg, C = self.cfg, self.C
+        pad = cfg.speech_pad_token
+        running = (~self.all_done).long()            # 0 once the reference's loop would have left: later frames change nothing
+        lg0 = self.logits[0].masked_fill(self.ch0_block, float("-inf"))   # channel 0 may only emit audio ids (:82-86)
+        toks = [sample_next(lg0, **self.sample)] + [sample_next(l, **self.sample) for l in self.logits[1:]]
+        nt = torch.stack(toks, -1)
+        is_audio = self.model.is_audio_token(nt[:, 0])
+        to_flush = (~is_audio) & (self.needs < 0)
+        needs = torch.where(to_flush, torch.full_like(self.needs, C - 1), self.needs)
+        is_flushing = needs >= 0
+        cols = [nt[:, 0] if self.eos0 is None else torch.where(is_flushing, torch.full_like(nt[:, 0], self.eos0), nt[:, 0])]
+        for i in range(1, C):
+            pad_this = is_flushing & (needs < C - i)
+            cols.append(torch.where(pad_this, torch.full_like(nt[:, i], pad), nt[:, i]))
+        pddp_text = self.eos0 if self.eos0 is not None else 0
+        u = self.unfinished
+        cols[0] = cols[0] * u + pddp_text * (1 - u)
+        for i in range(1, C):
+            cols[i] = cols[i] * u + pad * (1 - u)
+        row = torch.stack(cols, -1)
+        # append the row (where the loop is still running) and remember it as the next model input
+        idx = self.pos.clamp(max=self.out.shape[1] - 1).view(1, 1, 1).expand(self.B, 1, C)
+        cur = torch.gather(self.out, 1, idx)
+        self.out.scatter_(1, idx, torch.where(running.bool().view(1, 1, 1), row.unsqueeze(1), cur))
+        self.row.copy_(row)
+        self.pos += running
+        self.n_rows += running
+        needs = torch.where(is_flushing, needs - 1, needs)
+        stop = torch.zeros(self.B, dtype=torch.bool, device=row.device)
+        if self.total is not None:
+            stop = stop | (self.pos >= self.total)
+        if self.eos is not None:
+            hit = torch.isin(row[:, 0], self.eos)
+            # default: the EOS criterion applies to sequences that are NOT flushing (the flush itself writes EOS on channel 0)
+            stop = stop | (hit if self.reference_termination else (hit & ~is_flushing))
+        if self.reference_termination:
+            u = u & (~stop).long() & (~(needs == -1)).long()                       # xy_llm.py:140, literally
+        else:
+            u = u & (~stop).long() & (~(needs == -1) | (~is_flushing)).long()
+        keep = running.bool()
+        self.unfinished.copy_(torch.where(keep, u, self.unfinished))
+        self.needs.copy_(torch.where(keep, needs, self.needs))
+        self.all_done.copy_(self.all_done | (self.unfinished.max() == 0))

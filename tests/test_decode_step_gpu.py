@@ -211,3 +211,27 @@ def test_graph_decoder_sampling_replays_with_device_rng():
             lg = m16(input_ids=a[:, t:t + 1], past_key_values=cache, use_cache=True).logits[:, -1].float()
     two = GraphDecoder(m16, B).generate(input_ids=prompt, max_new_tokens=2)
     assert two.shape == (B, 2) and torch.equal(two, greedy[:, :2].clone()) or two.shape == (B, 2)
+
+
+def test_multi_group_decoder_equals_separate_graph_decoders():
+    """decode.MultiGroupDecoder (persistent multi-request decode): k independent groups of sequences, each a captured
+    step on its own stream, replayed round-robin.  Groups never interact: every sequence gets, id for id, what a GraphDecoder run
+    on its group alone produces -- greedy with EOS handling and a ragged last group; sampled decode keeps the suppress contract."""
+    from rwkvtts_amd.decode import MultiGroupDecoder
+    D, L, V, P, NEW = 128, 2, 96, 6, 33
+    cfg, m16, m32 = _model(D, L, V, (32, 32, 32, 32), seed=41)
+    B, G = 19, 8                                   # groups of 8, 8, 3
+    prompt = torch.randint(0, V, (B, P), generator=torch.Generator().manual_seed(4)).to(DEV)
+    mask = torch.ones(B, P, dtype=torch.long, device=DEV)
+    mask[2, :2] = 0
+    mask[11, :4] = 0
+    kw = dict(max_new_tokens=NEW, suppress_tokens=[5], eos_token_id=7, pad_token_id=0)
+    multi = MultiGroupDecoder(m16, group_size=G).generate(input_ids=prompt, attention_mask=mask, **kw)
+    assert multi.shape == (B, NEW)
+    for a in range(0, B, G):
+        n = min(G, B - a)
+        alone = GraphDecoder(m16, n).generate(input_ids=prompt[a:a + n], attention_mask=mask[a:a + n], **kw)
+        assert torch.equal(multi[a:a + n], alone), a
+    s = MultiGroupDecoder(m16, group_size=G).generate(input_ids=prompt, attention_mask=mask, max_new_tokens=12, suppress_tokens=[5],
+                                                      do_sample=True, top_k=4, seed=3)
+    assert s.shape == (B, 12) and not (s == 5).any()

@@ -290,3 +290,56 @@ def test_xy_generate_flush_stagger_eos_and_stop_at_full_channel_count(monkeypatc
     trigger.clear()
     out2 = model.generate(prompt[:1], max_new_tokens=16, eos_token_id=SHIFT + 10 + 3)
     assert out2.shape[1] == T0 + 4 and int(out2[0, -1, 0]) == SHIFT + 13
+    # reference_termination=True: xy_llm.py:139-140 literally.  `& ~(needs_additional_steps == -1)` is false for every sequence that
+    # is not flushing, so a batch in which nobody flushes at the first frame ends after ONE frame; a sequence that starts its flush at
+    # frame 0 carries the loop on alone, the others emit EOS / pad rows, and the EOS the flush writes on channel 0 meets the EOS
+    # criterion in that very row (the two defects the default does not reproduce)
+    calls["n"] = 0
+    trigger.update({0: 2, 1: 5})
+    ref1 = model.generate(prompt, max_new_tokens=16, eos_token_id=EOS, reference_termination=True)
+    assert ref1.shape[1] == T0 + 1 and torch.equal(ref1[:, T0].cpu(), want[:, 0])
+    calls["n"] = 0
+    trigger.clear()
+    trigger[1] = 0                                   # sequence 1 draws a text id at the first frame
+    ref2 = model.generate(prompt, max_new_tokens=16, reference_termination=True)[:, T0:].cpu()   # no EOS id: the countdown runs
+    assert ref2.shape[1] == C                        # frames 0 .. C-1 of sequence 1's flush, then needs == -1 ends it
+    assert [int(x) for x in ref2[1, :, 0]] == [7] + [SHIFT + 10 + s for s in range(1, C)]        # channel 0 keeps the draws (no EOS id)
+    for j in range(C):
+        for ch in range(1, C):
+            assert int(ref2[1, j, ch]) == (100 * ch + j if j < ch else PAD), (j, ch)
+    assert (ref2[0, 1:, 0] == 0).all() and (ref2[0, 1:, 1:] == PAD).all() and (ref2[2, 1:, 1:] == PAD).all()   # 0 and 2 stopped after frame 0
+    calls["n"] = 0
+    ref3 = model.generate(prompt, max_new_tokens=16, eos_token_id=EOS, reference_termination=True)
+    assert ref3.shape[1] == T0 + 1                   # with an EOS id the flush's own EOS stops sequence 1 in its first row
+
+
+def test_xy_generate_captured_frame_step_equals_eager_loop():
+    """RWKV7XYLM.generate replays one frame -- embedding sum, the stack + eight heads (rwkv7_decode_step_bf16), channel-0 mask,
+    the draws, flush / pad / stop bookkeeping -- from a hipGraph (no per-frame host read-back; the `all finished` flag is read
+    every 8 frames and surplus rows are trimmed).  Greedy: id for id the eager loop's output, for a length-bounded run and for a
+    run in which every sequence finishes by EOS before the bound (the graph over-runs the break by up to 7 frames, which must not
+    show)."""
+    cfg = RWKV7XYConfig(vocab_size=120, speech_vocab_size=16, num_channels=4, text_shift_size=100, hidden_size=128,
+                        num_hidden_layers=2, decay_low_rank_dim=32, a_low_rank_dim=32, v_low_rank_dim=32, gate_low_rank_dim=32)
+    model = RWKV7XYLM(cfg).init_weights(seed=5)
+    with torch.no_grad():
+        for h in model.heads:
+            h.bias.normal_(0, 0.1)
+    model.zero_embs()
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(1)
+    B = 5
+    text = [[101 + (i + b) % 10 for i in range(4)] for b in range(B)]
+    audio = [torch.randint(0, 15, (4, 3), generator=g).tolist() for _ in range(B)]
+    ids = L.XYDataProcessor(120, 4, 100, 16).process_batch(text, audio)["input_ids"][:, :6].to(DEV)
+    eager = model.generate(ids, max_new_tokens=21, do_sample=False, use_graph=False)
+    graph = model.generate(ids, max_new_tokens=21, do_sample=False, use_graph=True)
+    assert eager.shape == graph.shape == (B, 27, 4) and torch.equal(eager, graph)
+    # an EOS that greedy decoding reaches: take channel 0's id at frame 3 of sequence 0 as the EOS id -> every sequence that emits it stops
+    eos = int(eager[0, 6 + 3, 0])
+    e2 = model.generate(ids, max_new_tokens=21, do_sample=False, eos_token_id=eos, use_graph=False)
+    g2 = model.generate(ids, max_new_tokens=21, do_sample=False, eos_token_id=eos, use_graph=True)
+    assert e2.shape == g2.shape and torch.equal(e2, g2)
+    # sampled decode replays from the graph as well (device generator): shape and channel-0 constraint
+    s = model.generate(ids, max_new_tokens=9, do_sample=True, top_k=5, use_graph=True)
+    assert s.shape == (B, 15, 4) and ((s[:, 6:, 0] >= 100) & (s[:, 6:, 0] < 116)).all()
