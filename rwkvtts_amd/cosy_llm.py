@@ -59,6 +59,35 @@ def ras_sampling(weighted_scores, decoded_tokens, sampling, top_p=0.8, top_k=25,
     return top_ids
 
 
+def ras_sampling_device(logp, recent, ignore_eos, eos: int, top_p=0.8, top_k=25, win_size=10, tau_r=0.1):
+    """ras_sampling + the EOS rejection of sampling_ids (cosyvoice/utils/common.py:109-137, llm.py:160-176) as tensor operations
+    only -- no `.item()`, no data-dependent slicing -- so that the draw can live inside a captured decode step:
+      nucleus  : the sorted prefix with cum_prob (before adding) < top_p and rank < top_k, sampled by multinomial over the masked
+                 probabilities (the same distribution as multinomial over the slice);
+      repeat   : count of the candidate in the last win_size emitted ids (`recent`, a device ring filled with -1), and if it is
+                 >= win_size * tau_r the draw from the full distribution instead (both draws are always made; one is selected);
+      EOS      : while `ignore_eos` (device bool) the reference rejects draws that are EOS and draws again -- the distribution of
+                 the accepted draw is the candidate set's distribution with EOS removed, which is what is sampled here directly
+                 (if the nucleus is EOS alone: the full distribution without EOS, where the reference would give up after 100
+                 rejections).
+    Same distribution as the host functions, different consumption of the random stream (the pinned id-for-id comparison with
+    the reference's functions, tests/test_sampling.py, is on the host pair)."""
+    probs = logp.softmax(dim=0)
+    sv, si = probs.sort(descending=True, stable=True)
+    cum_before = torch.cumsum(sv, 0) - sv
+    rank = torch.arange(sv.numel(), device=sv.device)   # (no host-built tensors in here: the function runs under graph capture)
+    keep = ((cum_before < top_p) & (rank < top_k)).long().cumprod(0).to(sv.dtype)
+    is_eos = si == eos
+    pk = sv * keep
+    pk_no = pk.masked_fill(is_eos, 0.0)
+    pk_no = torch.where(pk_no.sum() > 0, pk_no, sv.masked_fill(is_eos, 0.0))
+    cand = si[torch.where(ignore_eos, pk_no, pk).multinomial(1, replacement=True)]
+    full_p = torch.where(ignore_eos, probs.masked_fill(rank == eos, 0.0), probs)
+    full = full_p.multinomial(1, replacement=True)
+    rep = (recent == cand).sum()
+    return torch.where(rep >= win_size * tau_r, full, cand)
+
+
 def nucleus_sampling(weighted_scores, top_p=0.8, top_k=25, generator=None):
     sorted_value, sorted_idx = weighted_scores.softmax(dim=0).sort(descending=True, stable=True)
     # keep while cum_prob (before adding) < top_p and fewer than top_k kept (common.py:121-128), vectorised
@@ -192,30 +221,88 @@ class RWKV7CosyLM(HFModelMixin, nn.Module):
         if cache is None:
             cache = Cache.zeros(self.config, 1, device, lm_input.dtype)
         step_kernel = None   # T = 1 steps through rwkv7_decode_step_bf16 once the prompt is in (bf16 models)
+        graph = None         # ... and, with the stock sampler, the whole step incl. the draw replayed from a hipGraph
+        self.last_inference_used_graph = False
+        eos = self.speech_token_size
         for i in range(max_len):
-            if step_kernel is not None and lm_input.shape[1] == 1:
-                logits = step_kernel(lm_input[:, 0].contiguous()).unsqueeze(1)
+            if graph is not None:
+                # embedding of the previous id -> stack + head -> log-softmax -> repetition-aware draw -> ring / counter update: one
+                # replay; the id crosses to the host once, because a streaming generator has to yield it
+                graph.replay()
                 cache.seen_tokens += 1
+                top_ids = int(g_tok.item())
             else:
-                masks = torch.ones((1, lm_input.shape[1], lm_input.shape[1]), device=device, dtype=torch.bool)
-                logits, cache = self.forward_one_step(lm_input, masks=masks, cache=cache)
-                if getattr(self, "use_step_kernel", True) and step_kernel is None:
-                    from .decode import DecodeStep
-                    if DecodeStep.supported(self.model, self.lm_head, cache) is None:
-                        step_kernel = DecodeStep(self.model, self.lm_head, cache)
-            logp = logits[:, -1].float().log_softmax(dim=-1)
-            top_ids = int(self.sampling_ids(logp.squeeze(dim=0), out_tokens, sampling,
-                                            ignore_eos=(i + original_text_len < min_len)).item())
-            if top_ids == self.speech_token_size:
+                if step_kernel is not None and lm_input.shape[1] == 1:
+                    logits = step_kernel(lm_input[:, 0].contiguous()).unsqueeze(1)
+                    cache.seen_tokens += 1
+                else:
+                    masks = torch.ones((1, lm_input.shape[1], lm_input.shape[1]), device=device, dtype=torch.bool)
+                    logits, cache = self.forward_one_step(lm_input, masks=masks, cache=cache)
+                    if getattr(self, "use_step_kernel", True) and step_kernel is None:
+                        from .decode import DecodeStep
+                        if DecodeStep.supported(self.model, self.lm_head, cache) is None:
+                            step_kernel = DecodeStep(self.model, self.lm_head, cache)
+                logp = logits[:, -1].float().log_softmax(dim=-1)
+                top_ids = int(self.sampling_ids(logp.squeeze(dim=0), out_tokens, sampling,
+                                                ignore_eos=(i + original_text_len < min_len)).item())
+            if top_ids == eos:
                 for st in cache.states:  # cosy_llm.py:247-251: token-shift states are zeroed at end of utterance
-                    st.att_x_prev = torch.zeros_like(st.att_x_prev)
-                    st.ffn_x_prev = torch.zeros_like(st.ffn_x_prev)
+                    if graph is not None:   # the captured step holds these addresses
+                        st.att_x_prev.zero_()
+                        st.ffn_x_prev.zero_()
+                    else:
+                        st.att_x_prev = torch.zeros_like(st.att_x_prev)
+                        st.ffn_x_prev = torch.zeros_like(st.ffn_x_prev)
                 break
-            if top_ids > self.speech_token_size:
+            if top_ids > eos:
                 continue
             yield top_ids
             out_tokens.append(top_ids)
             lm_input = self.speech_embedding.weight[top_ids].reshape(1, 1, -1)
+            if (graph is None and step_kernel is not None and getattr(self, "use_graph", True) and self.sampling is ras_sampling
+                    and self.lm_head.weight.shape[0] == eos + 1):
+                # capture the step on fixed buffers: g_tok (previous / new id), g_recent (last 10 emitted ids), g_i (step index)
+                win = 10
+                g_tok = torch.tensor([top_ids], device=device)
+                g_recent = torch.full((win,), -1, dtype=torch.long, device=device)
+                tail = out_tokens[-win:]
+                g_recent[:len(tail)] = torch.tensor(tail, device=device)
+                g_ptr = torch.tensor([len(tail) % win], device=device)
+                g_i = torch.tensor(i + 1, device=device)
+                n_ignore = min_len - original_text_len   # ignore_eos while step index < n_ignore
+
+                def captured():
+                    x = self.speech_embedding.weight[g_tok]                      # [1, D]
+                    logp_ = step_kernel(x.contiguous())[0].float().log_softmax(dim=-1)
+                    new = ras_sampling_device(logp_, g_recent, g_i < n_ignore, eos, top_k=sampling)
+                    g_tok.copy_(new)
+                    keep_ = new != eos                                           # the reference appends emitted ids only
+                    g_recent.scatter_(0, g_ptr, torch.where(keep_, new, g_recent.gather(0, g_ptr)))
+                    g_ptr.copy_(torch.where(keep_, (g_ptr + 1) % win, g_ptr))
+                    g_i.add_(1)
+
+                snap = [(s_.att_x_prev.clone(), s_.att_kv.clone(), s_.ffn_x_prev.clone()) for s_ in cache.states]
+                keep = [t.clone() for t in (g_tok, g_recent, g_ptr, g_i)]
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    captured()   # warm-up outside the capture; the state it advanced is restored below
+                torch.cuda.current_stream().wait_stream(side)
+
+                def restore():
+                    for s_, (a_, kv_, f_) in zip(cache.states, snap):
+                        s_.att_x_prev.copy_(a_)
+                        s_.att_kv.copy_(kv_)
+                        s_.ffn_x_prev.copy_(f_)
+                    for t, k_ in zip((g_tok, g_recent, g_ptr, g_i), keep):
+                        t.copy_(k_)
+
+                restore()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    captured()
+                restore()
+                self.last_inference_used_graph = True
 
 
 class RWKV7LM(nn.Module):

@@ -343,3 +343,31 @@ def test_xy_generate_captured_frame_step_equals_eager_loop():
     # sampled decode replays from the graph as well (device generator): shape and channel-0 constraint
     s = model.generate(ids, max_new_tokens=9, do_sample=True, top_k=5, use_graph=True)
     assert s.shape == (B, 15, 4) and ((s[:, 6:, 0] >= 100) & (s[:, 6:, 0] < 116)).all()
+
+
+def test_cosy_streaming_inference_replays_the_step_from_a_graph_with_the_stock_sampler():
+    """bf16 Cosy model, stock repetition-aware sampler: after the prompt and the first id, every further token is ONE graph replay
+    (embedding -> rwkv7_decode_step_bf16 -> log-softmax -> ras_sampling_device -> ring / counter update) and one 8-byte read-back
+    for the generator's yield (the host path: three read-backs per token).  Contract: ids are speech tokens, EOS never before the
+    minimum length, the run ends by EOS or at the maximum length, a seed fixes the sequence, and the greedy prefix logic is shared
+    with the host path (same first id under the same seed: it is drawn before the capture)."""
+    cfg = RWKV7CosyConfig(vocab_size=200, speech_token_size=50, hidden_size=128, num_hidden_layers=2, decay_low_rank_dim=32,
+                          a_low_rank_dim=32, v_low_rank_dim=32, gate_low_rank_dim=32)
+    model = RWKV7CosyLM(cfg).init_weights(seed=4).to(DEV).to(torch.bfloat16).eval()
+    text = torch.tensor([[5, 6, 7, 8, 9, 10]], device=DEV)
+    z = torch.zeros(1, 0, dtype=torch.long, device=DEV)
+
+    def run(seed, graph=True):
+        model.use_graph = graph
+        torch.manual_seed(seed)
+        ids = list(model.inference(text, torch.tensor([6], device=DEV), z, torch.tensor([0], device=DEV), z, torch.tensor([0], device=DEV),
+                                   max_token_text_ratio=8, min_token_text_ratio=3))
+        return ids, model.last_inference_used_graph
+
+    a, used = run(7)
+    assert used and 18 <= len(a) <= 48 and all(0 <= t < 50 for t in a)     # min_len = 18: no EOS before it; max_len = 48
+    b, _ = run(7)
+    c, _ = run(8)
+    assert a == b and a != c
+    h, used_h = run(7, graph=False)
+    assert not used_h and h[0] == a[0] and all(0 <= t < 50 for t in h)

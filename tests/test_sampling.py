@@ -57,3 +57,32 @@ def test_spark_sampling_filter_matches_hf_warpers():
         got = sample_next(logits.clone(), True, k, p, temp)
         assert torch.equal(got, want), (V, temp, k, p)
     assert torch.equal(sample_next(torch.tensor([[1.0, 3.0, 3.0, 2.0]])), torch.tensor([1]))   # greedy: first max
+
+
+def test_device_ras_sampling_has_the_distribution_of_the_host_functions():
+    """cosy_llm.ras_sampling_device (tensor-only, lives inside the captured Cosy decode step) against ras_sampling + the EOS rejection
+    loop of sampling_ids (the pair pinned id for id against cosyvoice/utils/common.py above): same distribution over 4000 draws --
+    nucleus branch, repetition branch (full-distribution resample), and EOS ignored / allowed."""
+    from rwkvtts_amd.cosy_llm import ras_sampling, ras_sampling_device
+    g = torch.Generator().manual_seed(0)
+    V, EOS, N = 24, 23, 4000
+    logp = (torch.randn(V, generator=g) * 1.5).log_softmax(0)
+    logp[EOS] = logp.max() + 0.3          # EOS is the most likely id: the rejection matters
+    logp = logp.log_softmax(0)
+
+    def host(decoded, ignore_eos):
+        while True:
+            t = int(ras_sampling(logp, decoded, 25, top_p=0.8, top_k=6))
+            if not ignore_eos or t != EOS:
+                return t
+
+    for decoded, ignore in (([], False), ([], True), ([3, 3, 5], True), ([int(logp[:EOS].argmax())] * 4, True)):
+        recent = torch.full((10,), -1, dtype=torch.long)
+        recent[:len(decoded[-10:])] = torch.tensor(decoded[-10:], dtype=torch.long) if decoded else recent[:0]
+        torch.manual_seed(1)
+        a = torch.bincount(torch.tensor([host(decoded, ignore) for _ in range(N)]), minlength=V).float() / N
+        b = torch.bincount(torch.cat([ras_sampling_device(logp, recent, torch.tensor(ignore), EOS, top_p=0.8, top_k=6) for _ in range(N)]),
+                           minlength=V).float() / N
+        assert (a - b).abs().max().item() < 0.035, (decoded, ignore, (a - b).abs().max().item())
+        if ignore:
+            assert b[EOS] == 0
