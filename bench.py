@@ -151,6 +151,29 @@ def decode_rate(model, dev, B=32, P=128, n1=256, n2=2048):
     t1, _ = run(n1)
     t2, kernel = run(n2)
     step = (t2 - t1) / (n2 - n1)
+    # more requests than one 32-sequence group: k groups, each its own captured step, replayed round-robin on k streams
+    # (decode.MultiGroupDecoder) -- the launch-latency-bound step of one group leaves most of the chip idle
+    multi = None
+    try:
+        from rwkvtts_amd.decode import MultiGroupDecoder
+        G = 4
+        embG, maskG = emb.repeat(G, 1, 1), mask.repeat(G, 1)
+
+        def run_multi(n):
+            dec = MultiGroupDecoder(model, group_size=B)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec.generate(inputs_embeds=embG, attention_mask=maskG, max_new_tokens=n, suppress_tokens=[eos])
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        run_multi(8)
+        m1, m2 = run_multi(64), run_multi(448)
+        mstep = (m2 - m1) / (448 - 64)
+        multi = {"groups": G, "sequences": G * B, "ms_per_step_all_groups": round(mstep * 1e3, 4), "value": round(G * B / mstep, 1),
+                 "unit": "tokens/s", "note": "decode.MultiGroupDecoder: independent 32-sequence groups on separate streams"}
+    except Exception as e:
+        multi = {"error": repr(e)}
     if was_training:
         model.train()
     # streaming bound of one step: every bf16 weight of the stack + head once, the fp32 state read and written
@@ -162,7 +185,8 @@ def decode_rate(model, dev, B=32, P=128, n1=256, n2=2048):
             "value": round(B / step, 1), "unit": "tokens/s", "ms_per_step": round(step * 1e3, 4), "batch": B, "prompt": P,
             "new_tokens": n2, "total_s_incl_prefill_capture": round(t2, 3),
             "bytes_per_step": wbytes + sbytes, "hbm_floor_ms": round(floor * 1e3, 4), "frac_of_hbm_bound": round(floor / step, 4),
-            "path": "rwkv7_decode_step_bf16, one launch per phase, hipGraph replay" if kernel else "module by module, hipGraph replay"}
+            "path": "rwkv7_decode_step_bf16, one launch per phase, hipGraph replay" if kernel else "module by module, hipGraph replay",
+            "multi_group": multi}
 
 
 def main():
@@ -181,6 +205,9 @@ def main():
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal of the N > 1 launch path on a one-GPU box: all ranks share GPU 0 and exchange over gloo "
                          "(RCCL refuses two ranks on one device); marked in the JSON line, not a measurement")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1: gradient pieces reduced to slab owners, AdamW on 1/N of the flat buffers per rank, parameter slabs "
+                         "broadcast (trainer.DataParallelTrainer(shard_optimizer=True), SURVEY H6) instead of all-reduce + replicated AdamW")
     ap.add_argument("--via-reference-op", action="store_true",
                     help="A/B: the scan through torch.ops.wind_backstepping.forward/backward (the reference's plug-in point, wkv7_op.cpp:21-29; "
                          "for bf16 and T % 32 == 0 it launches the same chunked MFMA kernels, with `s` as their arena) instead of the direct calls")
@@ -230,7 +257,7 @@ def main():
     model = model.to(device=dev, dtype=torch.bfloat16).train()
     if a.grad_checkpoint:
         model.gradient_checkpointing_enable()
-    tr = trainer.DataParallelTrainer(model, lr=1e-4, warmup_steps=10, total_steps=1000)
+    tr = trainer.DataParallelTrainer(model, lr=1e-4, warmup_steps=10, total_steps=1000, shard_optimizer=a.shard_optimizer)
     H = cfg.num_heads
 
     if a.layout == "spark":
@@ -358,8 +385,9 @@ def main():
                                    f"(fwd+bwd+AdamW), B={B}/GPU L={T}, synthetic text+speech tokens, random init "
                                    f"(BASELINE.json configs[{which}])",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
-                       "grad_allreduce": ("bucketed gloo SUM in fp32 (rehearsal)" if a.one_device else
-                                          "bucketed RCCL AVG, bf16, overlapped with backward") if world > 1 else "none"},
+                       "grad_allreduce": (("bucketed gloo SUM in fp32 (rehearsal)" if a.one_device else
+                                           "bucketed RCCL AVG, bf16, overlapped with backward") if not tr.shard_optimizer else
+                                          "bucket pieces reduced to slab owners + sharded AdamW + parameter broadcast") if world > 1 else "none"},
             "loss": round(loss_val, 4),
             "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},

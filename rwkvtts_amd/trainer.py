@@ -132,11 +132,16 @@ class FlatBuffers:
 class BucketedAllReduce:
     """Gradient all-reduce in buckets, launched from backward hooks as soon as a bucket is complete."""
 
-    def __init__(self, flat: FlatBuffers, bucket_bytes: int = 32 << 20, group=None, force: bool = False):
+    def __init__(self, flat: FlatBuffers, bucket_bytes: int = 32 << 20, group=None, force: bool = False, shard: bool = False):
         """force: run the collectives even in a group of one rank (tests: the whole hook -> flush -> RCCL -> wait path on a
-        single GPU, where the exchange is the identity)."""
+        single GPU, where the exchange is the identity).
+        shard: every rank owns one contiguous 1/N slab of the flat buffers (`slab(r)`); a bucket's pieces are REDUCED to their
+        owners instead of all-reduced (half the bytes on the wire per step; the other half is the parameter broadcast after the
+        owners' optimizer step, DataParallelTrainer) -- SURVEY H6's fallback for an exposed all-reduce tail."""
         self.flat, self.group = flat, group
+        self.shard = bool(shard)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         esz = flat.flat_grad.element_size()
         # buckets follow backward order: last parameters first
@@ -158,6 +163,12 @@ class BucketedAllReduce:
         if self.enabled:
             flat.on_ready = self._ready
 
+    def slab(self, r):
+        """[start, end) of rank r's slab of the flat buffers (128-element aligned, the last one may be shorter or empty)."""
+        n = self.flat.numel
+        size = -(-n // (self.world * 128)) * 128
+        return min(r * size, n), min((r + 1) * size, n)
+
     def _ready(self, i):
         b = self.param_bucket[i]
         self.pending[b] -= 1
@@ -167,6 +178,24 @@ class BucketedAllReduce:
     def _launch(self, b):
         self.flat.flush()   # the bucket's slices must hold the final gradients
         s, e, _ = self.buckets[b]
+        if self.shard:
+            for r in range(self.world):   # the bucket's intersection with every rank's slab goes to that rank only
+                lo, hi = self.slab(r)
+                lo, hi = max(lo, s), min(hi, e)
+                if lo >= hi:
+                    continue
+                piece = self.flat.flat_grad[lo:hi]
+                if self.backend == "nccl":
+                    self.works.append(dist.reduce(piece, dst=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                                  op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    if r == self.rank:
+                        self.summed.append((lo, hi))
+                else:   # gloo (CPU tests): fp32, synchronous
+                    tmp = piece.float()
+                    dist.reduce(tmp, dst=r, op=dist.ReduceOp.SUM, group=self.group)
+                    if r == self.rank:
+                        piece.copy_((tmp / self.world).to(piece.dtype))
+            return
         view = self.flat.flat_grad[s:e]
         if self.backend == "nccl":
             if self.use_avg:
@@ -258,10 +287,16 @@ class DataParallelTrainer:
 
     def __init__(self, model: torch.nn.Module, lr=1e-4, lr_final=1e-5, warmup_steps=100, total_steps=100000,
                  weight_decay=0.0, betas=(0.9, 0.95), eps=1e-18, bucket_bytes=32 << 20, nan_guard=True,
-                 master_fp32=True, param_groups=None, schedule="linear", force_allreduce=False):
+                 master_fp32=True, param_groups=None, schedule="linear", force_allreduce=False, shard_optimizer=False):
+        """shard_optimizer: every rank reduces the gradient pieces of ITS 1/N slab only, steps AdamW on that slab and broadcasts
+        the slab's new bf16 parameters (reduce-scatter + sharded optimizer + all-gather, ZeRO-1 style: the reference's DeepSpeed
+        ZeRO-2 engine does the same exchange, train_spark_rwkv7speech.py:483-516).  Same parameters after every step as the
+        default (all-reduce + replicated AdamW) up to the rounding of the reduction; the optimizer pass is 1/N as long.  One flag:
+        for the case that the 8-GPU scaling run shows an exposed all-reduce tail."""
         self.model = model
         self.flat = FlatBuffers(model)
-        self.reducer = BucketedAllReduce(self.flat, bucket_bytes, force=force_allreduce)
+        self.reducer = BucketedAllReduce(self.flat, bucket_bytes, force=force_allreduce, shard=shard_optimizer)
+        self.shard_optimizer = bool(shard_optimizer) and self.reducer.enabled
         self.world = self.reducer.world
         self.master = self.flat.flat_param.float() if master_fp32 and self.flat.flat_param.dtype != torch.float32 \
             else self.flat.flat_param
@@ -329,7 +364,11 @@ class DataParallelTrainer:
         b1, b2 = self.betas
         t = self.step_idx + 1
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+        lo_s, hi_s = self.reducer.slab(self.reducer.rank) if self.shard_optimizer else (0, self.flat.numel)
         for s, e, gi in self.runs:
+            s, e = max(s, lo_s), min(e, hi_s)   # sharded: this rank's slab only
+            if s >= e:
+                continue
             _, scale, wd = self.group_defs[gi]
             p, m, v = self.master[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e]
             g = g_all[s:e].to(p.dtype)
@@ -340,7 +379,28 @@ class DataParallelTrainer:
             v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
             p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(self.eps), value=-lr_g / bc1)
         if self.master is not self.flat.flat_param:
-            self.flat.flat_param.copy_(self.master)
+            self.flat.flat_param[lo_s:hi_s].copy_(self.master[lo_s:hi_s])
+
+    def _broadcast_slabs(self):
+        """Sharded mode: every rank's freshly stepped parameter slab to everybody (an all-gather written as N broadcasts: the
+        slabs need not be equally long), and the fp32 masters of the foreign slabs re-derived from it are not needed -- a rank
+        only ever steps its own slab."""
+        r_ = self.reducer
+        works = []
+        for r in range(r_.world):
+            lo, hi = r_.slab(r)
+            if lo >= hi:
+                continue
+            piece = self.flat.flat_param[lo:hi]
+            src = dist.get_global_rank(r_.group, r) if r_.group is not None else r
+            if r_.backend == "nccl":
+                works.append(dist.broadcast(piece, src=src, group=r_.group, async_op=True))
+            else:
+                tmp = piece.float()
+                dist.broadcast(tmp, src=src, group=r_.group)
+                piece.copy_(tmp.to(piece.dtype))
+        for w in works:
+            w.wait()
 
     def step(self, **batch):
         """One optimisation step on this rank's shard of the batch.  Returns the (detached) loss tensor.
@@ -371,15 +431,19 @@ class DataParallelTrainer:
             from . import _lib
             P = lambda t: ctypes.c_void_p(t.data_ptr())
             f = ctypes.c_float
+            lo, hi = self.reducer.slab(self.reducer.rank) if self.shard_optimizer else (0, self.flat.numel)
             with torch.cuda.device_of(self.master):
-                rc = _lib.lib().rwkv7_adamw_groups_bf16(
-                    ctypes.c_long(self.flat.numel), P(self.master), P(self.flat.flat_grad), P(self.exp_avg), P(self.exp_avg_sq),
-                    P(self.flat.flat_param), P(self.slab_group), P(self.group_tab), len(self.group_defs), P(self.nan_flag),
+                rc = 0 if hi <= lo else _lib.lib().rwkv7_adamw_groups_bf16(
+                    ctypes.c_long(hi - lo), P(self.master[lo:hi]), P(self.flat.flat_grad[lo:hi]), P(self.exp_avg[lo:hi]),
+                    P(self.exp_avg_sq[lo:hi]), P(self.flat.flat_param[lo:hi]), P(self.slab_group[lo // 128:hi // 128]), P(self.group_tab),
+                    len(self.group_defs), P(self.nan_flag),
                     f(lr), f(self.betas[0]), f(self.betas[1]), f(self.eps), self.step_idx + 1,
                     ctypes.c_void_p(torch.cuda.current_stream(self.master.device).cuda_stream))
             _lib.check(rc, "adamw")
         else:
             self._torch_adamw(lr, self.nan_flag)
+        if self.shard_optimizer:
+            self._broadcast_slabs()
         for m in self._param_caches:
             m._mix_key = None
         self.step_idx += 1

@@ -48,13 +48,17 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shard=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     trainer.init_distributed("gloo")
     torch.set_num_threads(1)
     model = Toy()
-    tr = trainer.DataParallelTrainer(model, lr=1e-2, warmup_steps=0, total_steps=100, bucket_bytes=4096)
+    tr = trainer.DataParallelTrainer(model, lr=1e-2, warmup_steps=0, total_steps=100, bucket_bytes=4096, shard_optimizer=shard)
+    if shard:   # the two slabs tile the flat buffer, and a bucket really is split between the owners
+        (a0, a1), (b0, b1) = tr.reducer.slab(0), tr.reducer.slab(1)
+        assert a0 == 0 and a1 == b0 and b1 == tr.flat.numel and a1 % 128 == 0
+        assert any(s < a1 < e for s, e, _ in tr.reducer.buckets)
     assert len(tr.reducer.buckets) > 2  # several buckets -> hooks fire in backward order
     losses = []
     for step in range(3):
@@ -69,11 +73,15 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_two_rank_gloo_matches_single_process_average():
+@pytest.mark.parametrize("shard", [False, True])
+def test_two_rank_gloo_matches_single_process_average(shard):
+    """shard=False: bucketed all-reduce + replicated AdamW.  shard=True (DataParallelTrainer(shard_optimizer=True), SURVEY H6's
+    fallback): gradient pieces reduced to the slab owners, AdamW on the own slab only, parameter slabs broadcast -- the replicas
+    must come out identical to each other and to the single-process reference in both modes, NaN step included."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, shard)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=150) for _ in range(2)], key=lambda t: t[0])

@@ -42,14 +42,19 @@ def _batch(model, rank, step, B=2, T=2048):
     return synthetic_spark_batch(model, B, T, seed=100 * step + rank, n_text=31, n_global=8)   # 4096 rows: split weight gradients
 
 
-def test_forced_allreduce_on_one_rank_equals_plain_trainer():
+@pytest.mark.parametrize("shard", [False, True])
+def test_forced_allreduce_on_one_rank_equals_plain_trainer(shard):
+    """shard=True: the sharded-optimizer exchange (RCCL reduce of every bucket piece to its slab owner, AdamW kernel on the own
+    slab through offset pointers, broadcast of the parameter slabs) in a group of one rank, where it must be the identity."""
     from rwkvtts_amd import trainer
     dev = torch.device("cuda:0")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         m1, m2 = _model(dev), _model(dev)
-        t1 = trainer.DataParallelTrainer(m1, lr=1e-3, warmup_steps=0, total_steps=10, bucket_bytes=64 << 10, force_allreduce=True)
+        t1 = trainer.DataParallelTrainer(m1, lr=1e-3, warmup_steps=0, total_steps=10, bucket_bytes=64 << 10, force_allreduce=True,
+                                         shard_optimizer=shard)
+        assert t1.shard_optimizer == shard
         t2 = trainer.DataParallelTrainer(m2, lr=1e-3, warmup_steps=0, total_steps=10)
         t2.reducer.enabled = False
         assert t1.reducer.enabled and len(t1.reducer.buckets) > 4 and t1.reducer.backend == "nccl"
@@ -64,7 +69,7 @@ def test_forced_allreduce_on_one_rank_equals_plain_trainer():
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, q, backend, one_device):
+def _worker(rank, world, port, q, backend, one_device, shard=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(0 if one_device else rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from rwkvtts_amd import trainer
@@ -72,7 +77,7 @@ def _worker(rank, world, port, q, backend, one_device):
     dev = torch.device("cuda", 0 if one_device else rank)
     torch.cuda.set_device(dev)
     model = _model(dev)
-    tr = trainer.DataParallelTrainer(model, lr=1e-3, warmup_steps=0, total_steps=10, bucket_bytes=64 << 10)
+    tr = trainer.DataParallelTrainer(model, lr=1e-3, warmup_steps=0, total_steps=10, bucket_bytes=64 << 10, shard_optimizer=shard)
     losses = [float(tr.step(**_batch(model, rank, step))) for step in range(3)]
     torch.cuda.synchronize()
     q.put((rank, tr.flat.flat_param.float().cpu().numpy().copy(), losses))
@@ -80,11 +85,11 @@ def _worker(rank, world, port, q, backend, one_device):
     dist.destroy_process_group()
 
 
-def _two_ranks(backend, one_device):
+def _two_ranks(backend, one_device, shard=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, one_device)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, one_device, shard)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
@@ -123,8 +128,11 @@ def test_two_ranks_rccl_real_model_replicas_identical_and_equal_single_process_m
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_sharing_one_gpu_over_gloo_real_model():
-    _two_ranks("gloo", True)
+@pytest.mark.parametrize("shard", [False, True])
+def test_two_ranks_sharing_one_gpu_over_gloo_real_model(shard):
+    """shard=True: each of the two processes steps the AdamW kernel on its half of the flat buffers only and receives the other
+    half by broadcast."""
+    _two_ranks("gloo", True, shard)
 
 
 DEV = "cuda:0"
