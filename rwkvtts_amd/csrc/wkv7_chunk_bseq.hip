@@ -18,6 +18,11 @@
 //                  wave 0: B" of the next chunk          wave 3: A_qb, X" of the next chunk
 //                  waves 4-7: rows of the chunk after the next in the compute mapping: exp, prefix sums, scaling
 // One workgroup per (head, half of the value columns): the value columns of E never mix.
+// Measured (tools/cbseq_timing.py, B=8, T=4096, H=16): 3.8k cycles per chunk = 1.9k + 1.9k, 0.21 ms (0.22-0.24 with the Z store)
+// against 0.29 ms for the pair it replaces.  Tried and dropped: eight producer waves (768 threads, 4 channels per producer thread,
+// three waves per SIMD, K = 64 products in two halves to stay inside 168 registers) -- the producer's share of each interval
+// shrinks (1.5-1.9k -> 1.1-1.7k) but the chain waves, now sharing their SIMD with two producer waves, slow down by as much:
+// 3.9k cycles per chunk; B" on the waves that compute E_c instead of wave 0: no change.
 #include "chunk_common.h"
 
 namespace rwkv7 {
@@ -127,6 +132,9 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
                 const long o = head_base + (long)((cc + 1) * kC + pt) * tstride + vh * VH + pv;
                 *reinterpret_cast<float4 *>(z_ + o) = *reinterpret_cast<const float4 *>(&sh_Z[pt * kStageLD + pv]);
             }
+            // what chunk cc receives from its future: q15 record straight from the accumulator tile (here, not in interval b: waves
+            // 1 and 2 have nothing else to do while wave 0 forms Z, and the record is not on the chain)
+            if (cc < c1 && (wave == 1 || wave == 2)) q15_encode_tile(Emaster, e_vk + ((long)bh * nc + cc) * kQRec, vh, wave - 1, lane);
             f32x16 accZ = zero16();
             if (cc < c1 && wave == 0) {   // Z = B" E' + X" dY : D[r][v] -> Z[v][r]
                 mma_tile3<kN>(accZ, sm + L::BBh, sm + L::BBl, LDK, sm + L::Eh, sm + L::El, LDK, lane);
@@ -140,8 +148,6 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
             if (wave == 1 || wave == 2) {
                 const int kt = wave - 1;  // key channels [32 kt, 32 kt + 32)
                 if (cc < c1) {
-                    // what chunk cc receives from its future: q15 record straight from the accumulator tile
-                    q15_encode_tile(Emaster, e_vk + ((long)bh * nc + cc) * kQRec, vh, kt, lane);
                     f32x16 acc = zero16();  // D[m = k][n = v] = sum_r a~[r][k] Z[r][v] + sum_t q~[t][k] dY[t][v]
                     mma_gen<kC, true, true, false, true>(acc, bufc + L::ATh, bufc + L::ATl, LDK, kt * 32, sm + L::Zh, sm + L::Zl, LDC, 0, lane);
                     mma_gen<kC, true, true, true, false>(acc, bufc + L::QTh, bufc + L::QTl, LDK, kt * 32, bufc + L::DYt, bufc + L::DYt, LDC, 0, lane);

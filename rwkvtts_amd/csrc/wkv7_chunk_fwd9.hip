@@ -160,11 +160,15 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
                     mma_gen<kC, false, true, true, false>(accA, sm + L::XPh, sm + L::XPl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
                     store_T_split(accA, sm + L::Uh, sm + L::Ul, LDC, lane);
                 } else if (wave == 1) {  // D[m = s][n = t] = b^_s . q~_t = A_qb[t][s], s <= t
+                    // state at the START of chunk cc = the backward's checkpoint: q15 record straight from the accumulator tile
+                    // (in this interval: the record is not on the chain, and waves 1, 2 finish before the producer here)
+                    if (SAVE) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + cc) * kQRec, vh, 0, lane);
                     f32x16 acc = zero16();
                     mma_tile3<kN>(acc, bufc + L::BHh, bufc + L::BHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
                     mask_lower_T<false>(acc, lane);
                     store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
                 } else if (wave == 2) {  // k^_s . q~_t = A_qk[t][s], s <= t
+                    if (SAVE) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + cc) * kQRec, vh, 1, lane);
                     f32x16 acc = zero16();
                     mma_tile3<kN>(acc, bufc + L::KHh, bufc + L::KHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
                     mask_lower_T<false>(acc, lane);
@@ -180,8 +184,6 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
             if (cc >= c0) {
                 if (wave == 1 || wave == 2) {
                     const int kt = wave - 1;  // key channels [32 kt, 32 kt + 32)
-                    // state at the START of chunk cc = the backward's checkpoint: q15 record straight from the accumulator tile
-                    if (SAVE) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + cc) * kQRec, vh, kt, lane);
                     f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
                     mma_gen<kC, true, true, false, true>(acc, bufc + L::BHh, bufc + L::BHl, LDK, kt * 32, sm + L::Uh, sm + L::Ul, LDC, 0, lane);
                     mma_gen<kC, true, true, true, false>(acc, bufc + L::KHh, bufc + L::KHl, LDK, kt * 32, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
