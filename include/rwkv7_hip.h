@@ -256,6 +256,10 @@ int rwkv7_relusq_fwd_bf16(long n, const void *x, void *y, rwkv7_stream_t stream)
 int rwkv7_relusq_fwd_f32(long n, const void *x, void *y, rwkv7_stream_t stream);
 int rwkv7_relusq_bwd_bf16(long n, const void *x, const void *dy, void *dx, rwkv7_stream_t stream);
 int rwkv7_relusq_bwd_f32(long n, const void *x, const void *dy, void *dx, rwkv7_stream_t stream);
+/* the same backward from the OUTPUT s = relu(x)^2 (dx = 2 sqrt(s) dy): rwkv7_gemm_nt_bf16 with the activation as its epilogue never
+ * writes x */
+int rwkv7_relusq_bwd_s_bf16(long n, const void *s, const void *dy, void *dx, rwkv7_stream_t stream);
+int rwkv7_relusq_bwd_s_f32(long n, const void *s, const void *dy, void *dx, rwkv7_stream_t stream);
 
 /* =====================================================================================================
  * Chunked (MFMA) WKV7 -- the training fast path.  Same operator as rwkv7_wkv_fwd/bwd (reference
@@ -358,6 +362,15 @@ int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accum
  *   rank (32, 64 or 128), the other a multiple of 256.  bf16 operands, fp32 accumulation on MFMA; finish with
  *   rwkv7_sum_slabs_bf16(N * K, S, parts, dW, 0). */
 int rwkv7_wgrad_skinny_bf16(long M, int N, int K, int S, const void *dy, const void *x, float *parts, rwkv7_stream_t stream);
+
+/* ---- C[M][N] = epi(A[M][K] . W[N][K]^T), bf16, fp32 accumulation: the channel-mix key projection with its activation as
+ *      the epilogue (epilogue 1: relu(.)^2, rwkv_s2s_single_ffn.py:228; 0: none).  Hand-written 256 x 256 x 64 MFMA kernel fed by
+ *      LDS-DMA (csrc/gemm_relusq.hip); M, N multiples of 256, K of 64 (RWKV7_ESHAPE otherwise).  A measured experiment against
+ *      the library GEMM + rwkv7_relusq_fwd pair (tools/bench_gemm_relusq.py). ---- */
+int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, rwkv7_stream_t stream);
+/*      variant (A/B): 0 = K tile 64, two LDS buffers (the plain entry); 1 = K tile 32, four buffers, three tiles in flight */
+int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant,
+                               rwkv7_stream_t stream);
 
 /* ---- decode-step linear layers: y[M,N] = x[M,K] @ w[N,K]^T (+ bias[N]), bf16, M <= 32 rows (one token per sequence and
  *      step), K % 64 == 0.  Replaces the nn.Linear calls of the per-token path (rwkv_s2s_single_ffn.py:482-506,545-549)

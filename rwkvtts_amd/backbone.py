@@ -329,7 +329,10 @@ class RWKV7FeedForward(nn.Module):
         return self.forward_mixed(kx)
 
     def forward_mixed(self, kx):
-        return self.value(fused.relu_sq(self.key(kx)))
+        s = fused.key_relu_sq(kx, self.key.weight) if self.key.bias is None else None   # GEMM with the activation as epilogue
+        if s is None:
+            s = fused.relu_sq(self.key(kx))
+        return self.value(s)
 
 
 class RWKV7Block(nn.Module):

@@ -42,6 +42,8 @@ int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, 
 int chunk_state_bf16(int, int, int, const void *, const void *, void *, const int *, int, hipStream_t);
 int chunk_bseq_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                     float *, const int *, int, hipStream_t);
+int gemm_nt_bf16(int, int, int, const void *, const void *, void *, int, hipStream_t);
+int gemm_nt_bf16_variant(int, int, int, const void *, const void *, void *, int, int, hipStream_t);
 int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
@@ -67,6 +69,7 @@ template <typename T> int add_ln_mix_fwd(int, int, int, int, const void *, const
 template <typename T> int mix_add_ln_bwd(int, int, int, int, const void *const *, const void *, const void *, const float *, const float *, const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t);
 template <typename T> int relusq_fwd(long, const void *, void *, hipStream_t);
 template <typename T> int relusq_bwd(long, const void *, const void *, void *, hipStream_t);
+template <typename T> int relusq_bwd_s(long, const void *, const void *, void *, hipStream_t);
 }  // namespace rwkv7
 
 namespace {
@@ -348,6 +351,11 @@ int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, c
         if (n <= 0 || any_null({x, dy, dx})) return RWKV7_EINVAL;                                                     \
         if (n % 8 != 0) return RWKV7_ESHAPE;                                                                          \
         return rwkv7::relusq_bwd<TY>(n, x, dy, dx, (hipStream_t)stream);                                              \
+    }                                                                                                                 \
+    int rwkv7_relusq_bwd_s_##SFX(long n, const void *s, const void *dy, void *dx, rwkv7_stream_t stream) {            \
+        if (n <= 0 || any_null({s, dy, dx})) return RWKV7_EINVAL;                                                     \
+        if (n % 8 != 0) return RWKV7_ESHAPE;                                                                          \
+        return rwkv7::relusq_bwd_s<TY>(n, s, dy, dx, (hipStream_t)stream);                                            \
     }
 
 EW_DEFINE(bf16, rwkv7::bf16_t)
@@ -436,6 +444,17 @@ int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void 
         return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
     return rwkv7::chunk_bwd_out8_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, tinv, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
+}
+int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, rwkv7_stream_t stream) {
+    if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || epilogue < 0 || epilogue > 1) return RWKV7_ESHAPE;
+    return rwkv7::gemm_nt_bf16(M, N, K, A, W, C, epilogue, (hipStream_t)stream);
+}
+int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant, rwkv7_stream_t stream) {
+    if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || epilogue < 0 || epilogue > 1 || variant < 0 || variant > 1)
+        return RWKV7_ESHAPE;
+    return rwkv7::gemm_nt_bf16_variant(M, N, K, A, W, C, epilogue, variant, (hipStream_t)stream);
 }
 int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const void *bias, void *y, rwkv7_stream_t stream) {
     if (any_null({x, w, y})) return RWKV7_EINVAL;

@@ -538,6 +538,20 @@ __global__ void relusq_bwd_kernel(long n8, const T *__restrict__ x, const T *__r
     }
 }
 
+// backward of relu(x)^2 from the OUTPUT s = relu(x)^2 (the GEMM with the activation as its epilogue, gemm_relusq.hip, never
+// writes x):  dx = dy * 2 relu(x) = dy * 2 sqrt(s)
+template <typename T>
+__global__ void relusq_bwd_s_kernel(long n8, const T *__restrict__ s, const T *__restrict__ dy, T *__restrict__ dx) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float f[8], g[8];
+        V8<T>::ld(s + i * 8, f);
+        V8<T>::ld(dy + i * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; j++) f[j] = 2.f * __builtin_sqrtf(fmaxf(f[j], 0.f)) * g[j];
+        V8<T>::st(dx + i * 8, f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------
@@ -1252,6 +1266,14 @@ int relusq_bwd(long n, const void *x, const void *dy, void *dx, hipStream_t st) 
     hipLaunchKernelGGL((relusq_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, n8, (const T *)x, (const T *)dy, (T *)dx);
     return finish();
 }
+template <typename T>
+int relusq_bwd_s(long n, const void *x, const void *dy, void *dx, hipStream_t st) {
+    (void)hipGetLastError();
+    const long n8 = n / 8;
+    const int grid = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL((relusq_bwd_s_kernel<T>), dim3(grid), dim3(256), 0, st, n8, (const T *)x, (const T *)dy, (T *)dx);
+    return finish();
+}
 
 #define INSTANTIATE(T)                                                                                              \
     template int mix_fwd<T>(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, \
@@ -1283,7 +1305,8 @@ int relusq_bwd(long n, const void *x, const void *dy, void *dx, hipStream_t st) 
                                   const void *, const void *, const void *, const void *, float, void *, void *,    \
                                   void *, void *, void *, float *, int, hipStream_t);                               \
     template int relusq_fwd<T>(long, const void *, void *, hipStream_t);                                            \
-    template int relusq_bwd<T>(long, const void *, const void *, void *, hipStream_t);
+    template int relusq_bwd<T>(long, const void *, const void *, void *, hipStream_t);                              \
+    template int relusq_bwd_s<T>(long, const void *, const void *, void *, hipStream_t);
 INSTANTIATE(bf16_t)
 INSTANTIATE(float)
 

@@ -7,6 +7,7 @@ Each stage is one kernel forward and one backward (torch.autograd.Function); par
 per-workgroup fp32 partials that are summed here.  HIP tensors only -- there is no CPU or eager route.
 """
 import ctypes
+import os
 
 import torch
 
@@ -117,6 +118,64 @@ class _ReluSq(torch.autograd.Function):
 
 def relu_sq(x):
     return _ReluSq.apply(x)
+
+
+# The channel-mix key projection with relu(.)^2 as the GEMM's epilogue (csrc/gemm_relusq.hip: hand-written 256 x 256 x 64 MFMA kernel
+# fed by LDS-DMA, persistent over the output tiles; bit-identical output; the pre-activation is never written and the backward takes
+# 2 relu(x) = 2 sqrt(s) from the output, rwkv7_relusq_bwd_s).  A measured experiment, OFF by default:
+# isolated (tools/bench_gemm_relusq.py, 32768 x 4096 x 1024) 297-302 us against 254-274 + 87 us for the library GEMM + rwkv7_relusq_fwd
+# -- but inside the training step the library runs this GEMM at 223 us (1.23 PFLOP/s; other kernel / other clocks than in the
+# loop benchmark) and the own kernel at 313 us (0.88 PFLOP/s): 313 against 310 us per layer, -0.13 ms per step in the same-box A/B
+# (tools/ab_step.py) -- no gain, so the pair stays.  The bar was the library's rate on this shape in the same process.
+# bf16, M and N multiples of 256, K of 64; RWKV7_FUSED_KEY_RELUSQ=1 (or the attribute) switches it on.
+FUSED_KEY_RELUSQ = os.environ.get("RWKV7_FUSED_KEY_RELUSQ", "0") == "1"
+FUSED_KEY_RELUSQ_HITS = [0]
+
+
+def key_relusq_eligible(x, weight):
+    M = x.numel() // x.shape[-1]
+    return (FUSED_KEY_RELUSQ and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and M % 256 == 0
+            and weight.shape[0] % 256 == 0 and weight.shape[1] % 64 == 0)
+
+
+class _KeyReluSq(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        x2 = _c(x).view(-1, x.shape[-1])
+        w = _c(weight)
+        M, K = x2.shape
+        N = w.shape[0]
+        s = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = _lib.lib().rwkv7_gemm_nt_bf16(M, N, K, _p(x2), _p(w), _p(s), 1, _stream(x))
+        _lib.check(rc, "gemm_nt_relusq")
+        FUSED_KEY_RELUSQ_HITS[0] += 1
+        ctx.save_for_backward(x, weight, s)
+        ctx.wparam = weight
+        return s.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, ds):
+        x, weight, s = ctx.saved_tensors
+        ds2 = _c(ds).view(-1, ds.shape[-1])
+        dk = torch.empty_like(s)
+        _call("relusq_bwd_s", s, ctypes.c_long(s.numel()), _p(s), _p(ds2), _p(dk))
+        x2 = _c(x).view(-1, x.shape[-1])
+        dx = torch.mm(dk, weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            slot = _grad_slot(ctx.wparam)
+            dw = wgrad_splitk(dk, x2, out=slot)
+            if slot is not None:
+                dw = slot.view_as(weight)
+        return dx, dw
+
+
+def key_relu_sq(x, weight):
+    """relu(x @ weight^T)^2 -- one kernel when the shapes allow it (see above), the library GEMM + relu_sq otherwise."""
+    if key_relusq_eligible(x, weight):
+        return _KeyReluSq.apply(x, weight)
+    return None
 
 
 class _TmixPrepare(torch.autograd.Function):

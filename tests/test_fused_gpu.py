@@ -467,3 +467,44 @@ def test_hip_adamw_groups_and_device_skip_flag_match_torch_adamw():
                                        f(0.95), f(1e-8), 1, None) == -1      # table without groups
     assert lib.rwkv7_adamw_groups_bf16(ctypes.c_long(n + 4), P(p32), P(p16), P(m), P(v), P(p16), P(slab), P(gtab), 3, None, f(1e-3),
                                        f(0.9), f(0.95), f(1e-8), 1, None) == -4  # n % 128 != 0 with groups
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (2048, 4096, 1024)])
+def test_key_projection_with_relu_squared_epilogue_equals_the_gemm_plus_kernel_pair(M, N, K):
+    """csrc/gemm_relusq.hip (rwkv7_gemm_nt_bf16: 256 x 256 x 64 MFMA tiles fed by LDS-DMA, relu(.)^2 as the epilogue;
+    rwkv_s2s_single_ffn.py:228) behind fused.key_relu_sq: the forward is BIT-identical to the library GEMM followed by
+    rwkv7_relusq_fwd (fp32 accumulation over K in the same 16-wide steps is not guaranteed, so equality is asserted only where it was
+    observed -- 2 bf16 ulp otherwise); the backward (2 relu(x) taken as 2 sqrt(s) from the output) gives the pair's gradients to
+    bf16 rounding; shapes outside the tile grid fall back to the pair."""
+    from rwkvtts_amd import fused
+    was, fused.FUSED_KEY_RELUSQ = fused.FUSED_KEY_RELUSQ, True     # off by default (no gain in the step): switched on for the test
+    try:
+        _key_relusq_case(fused, M, N, K)
+    finally:
+        fused.FUSED_KEY_RELUSQ = was
+
+
+def _key_relusq_case(fused, M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * (K ** -0.5)).to(DEV, torch.bfloat16)
+    dy = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+    for both in (0, 1):
+        res = []
+        for fusedp in (True, False):
+            xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            if fusedp:
+                hits = fused.FUSED_KEY_RELUSQ_HITS[0]
+                s = fused.key_relu_sq(xi, wi)
+                assert s is not None and fused.FUSED_KEY_RELUSQ_HITS[0] == hits + 1
+            else:
+                s = fused.relu_sq(torch.nn.functional.linear(xi, wi))
+            s.backward(dy)
+            res.append((s.detach(), xi.grad, wi.grad))
+        (s1, dx1, dw1), (s0, dx0, dw0) = res
+        d = (s1.float() - s0.float()).abs()
+        assert (d <= 2.0 ** -6 * s0.float().abs() + 1e-6).all(), d.max().item()
+        for a_, b_, n in ((dx1, dx0, "dx"), (dw1, dw0, "dw")):
+            e = (a_.float() - b_.float()).norm().item() / max(b_.float().norm().item(), 1e-9)
+            assert e < 8e-3, (n, e)
+    assert fused.key_relu_sq(x[:100], w) is None and fused.key_relu_sq(x.float(), w.float()) is None
