@@ -390,11 +390,11 @@ int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const v
  *      workspace: rwkv7_decode_workspace_bytes() bytes, 256-byte aligned, owned by the caller, reused step after step;
  *      its first 8 bytes are the barrier words {arrivals, timeout flag}: flag != 0 after a step means a grid barrier was not
  *      met within ~0.1 s (the kernel then exits instead of hanging; the step's results are invalid).
- *      persistent = 0: 7 L + 2 ordinary launches, one per phase (the default of the Python host: 1.16 ms per step at
+ *      persistent = 0: 7 L + 2 ordinary launches, one kernel per phase (the default of the Python host: 1.05 ms per step at
  *      BASELINE configs[4], a stream-ordered kernel boundary costs ~1.5 us); 1: ONE launch, the same phase bodies separated by
  *      7 L + 1 device-scope barriers (measured 7.4 us per barrier on MI355X -- 3.9 us of arrivals/polling on one counter plus
  *      1.8 us L2 write-back and 1.6 us invalidate, the XCD L2s not being coherent -- so it is the slower mode: 2.4 ms).
- *      Errors: RWKV7_ESHAPE unless B in [1,32], D = 64 H <= 4096, F % 64 == 0, every rank a multiple of 32, ranks sum <= 512. */
+ *      Errors: RWKV7_ESHAPE unless B in [1,32], D = 64 H <= 4096, F % 64 == 0, every rank a multiple of 32 and <= 256, ranks sum <= 512. */
 enum {
     RWKV7_DEC_LN0_W, RWKV7_DEC_LN0_B, RWKV7_DEC_LN1_W, RWKV7_DEC_LN1_B, RWKV7_DEC_LN2_W, RWKV7_DEC_LN2_B,
     RWKV7_DEC_XR, RWKV7_DEC_XW, RWKV7_DEC_XK, RWKV7_DEC_XV, RWKV7_DEC_XA, RWKV7_DEC_XG,

@@ -24,9 +24,10 @@
 // vectors, up-projection rows) before it reads the activations, and sums partials with all loads of a round in flight.
 //
 // Two ways to run the phases (same bodies, bit-identical results, tests/test_decode_step_gpu.py):
-//   persistent = 0  one launch per phase (7 L + 2), each sized to its item count.  Measured at configs[4] (0.4B, B = 32,
-//                   tools/decode_phase_profile.py): row phases 4.9 us, GEMV phases 5-8 us, head phase 13 us, 1.18 ms per
-//                   step in the replayed graph = 27 k tokens/s (module path: 4.0 ms, 8 k tokens/s).
+//   persistent = 0  one launch per phase (7 L + 2), one kernel per phase, each sized to its item count.  Measured at configs[4]
+//                   (0.4B, B = 32, tools/decode_phase_profile.py): row phases 3.1-3.6 us at best, GEMV phases 3.5-6.6 us, head
+//                   phase 7.4-8.5 us (round 2: 13 us -- see head_phase), 1.05 ms per step in the replayed graph = 30.5 k
+//                   tokens/s (module path: 4.0 ms, 8 k tokens/s).
 //   persistent = 1  ONE launch of 256 resident workgroups that meet at a device-scope barrier between phases.  Measured:
 //                   7.4 us per barrier -- 3.9 us for 256 arrivals + polling on one counter, 1.8 us for the agent-scope
 //                   release (L2 write-back) and 1.6 us for the acquire (invalidate); the XCDs' L2s are not coherent with
@@ -87,7 +88,7 @@ constexpr int kMaxR = 512;                 // Rw + Ra + Rv + Rg
 constexpr unsigned kSpinLimit = 1u << 21;  // ~0.1 s: a barrier that is not met by then raises the flag instead of hanging the GPU
 
 constexpr int kHidLD = kMaxR + 8;          // bf16 hidden rows, padded
-constexpr int kUpFrags = 24;               // 16-wide k-steps of the two up-projection jobs of a wave: (Rw + Rv) / 16, (Ra + Rg) / 16
+constexpr int kUpFrags = 16;               // 16-wide k-steps of one up-projection job (a rank of 256)
 struct HeadSm {
     __attribute__((aligned(16))) uint16_t hid[2][kHidLD];   // activated low-rank hidden vectors, bf16 like the reference's tensors
     float rkv[3][2][64];
@@ -120,6 +121,20 @@ __device__ __forceinline__ float block_sum256(float v, float *red) {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
+// Pointers read from the layer table are generic: loads through them are flat_load, which counts on BOTH memory counters and
+// may return out of order -- the compiler then waits with vmcnt(0) lgkmcnt(0) everywhere (LDS reads behind state loads).  The
+// table holds device-memory addresses only.
+typedef const uint16_t __attribute__((address_space(1))) *gu16;
+typedef float __attribute__((address_space(1))) *gf32;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define G_U16(p) ((gu16)(p))
+#define G_F32(p) ((gf32)(p))
+// an opaque copy of a scalar: conditions derived from it cannot be hoisted out of the item loop (24 + 24 + 24 loop-invariant
+// guards kept as SGPR pairs were 245 spilled SGPRs in the head phase)
+__device__ __forceinline__ int fresh_s(int x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
 __device__ __forceinline__ float softplus_d(float u) { return u > 20.f ? u : log1pf(__expf(u)); }
 
 // One agent-scope release (L2 write-back) on arrival, a relaxed spin, one agent-scope acquire (cache invalidate) on exit: an
@@ -359,10 +374,22 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
 
 // ---------------------------------------------------------------------------------------------------------------------
 // head phase: everything between the projections and the output projection, for one head and two sequences.
-// What does not depend on this step's activations -- the state rows, the up-projection rows (as MFMA fragments), the
-// per-channel parameters -- is requested before the partial sums are read, so the phase pays two load latencies, not five.
+// Every load of the phase is issued at its top, in the order of use (partial sums, up-projection rows as MFMA fragments,
+// per-channel parameters, state rows), so the phase pays ONE memory latency (3.8k of its 10.9k cycles; tools/decode_head_timing.py).
+// Round 2's form of this phase took 22.3k cycles for the same arithmetic; what the ISA showed (round 3):
+//   * the wave id was a VGPR value, so the per-wave job sizes were divergent and each of the 24 guarded fragment loads / LDS reads /
+//     MFMAs was an exec-masked region of its own;
+//   * a guarded load (`if (i < n) x[i] = load`) is merged with "no value" by a phi and waited for right behind its issue: the
+//     fragment loads and, in step B, every LDS read in front of its MFMA, were serialised latencies.  Now all loads are
+//     unconditional with clamped slots (NF1 / NF2 template slots), only register-only work sits behind scalar branches;
+//   * the layer's pointers were read inside the item loop, i.e. behind the kernel's stores: vector loads in the data's in-order
+//     queue (partial sums -> wait -> pointers -> wait -> rows), and generic pointers, so the rows came through flat_load, which
+//     ties the LDS counter to the global one.  Now scalar loads before the loop, cast to the global address space;
+//   * one kernel held all nine phase bodies: 245 spilled SGPRs in this phase.  Now one kernel per phase.
 // ---------------------------------------------------------------------------------------------------------------------
-template <class LP>
+// NF1, NF2: fragment slots of a wave's two jobs (NF1 >= max(Rw, Ra) / 16, NF2 >= max(Rv, Rg) / 16; the host picks the smallest
+// instantiation)
+template <int NF1, int NF2, class LP>
 __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, int l, const LP &lp) {
     HeadSm &sm = smu.h;
     const int tid = threadIdx.x, D = d.D, H = d.H;
@@ -370,95 +397,121 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
     const int Rtot = d.Rw + d.Ra + d.Rv + d.Rg;
     const int oA = d.Rw, oV = d.Rw + d.Ra, oG = d.Rw + d.Ra + d.Rv;
     const int npair = (d.B + 1) / 2, nitems = H * npair;
-    const uint16_t *w2 = (const uint16_t *)lp[DP_W2], *w0 = (const uint16_t *)lp[DP_W0];
-    const uint16_t *a2 = (const uint16_t *)lp[DP_A2], *a0 = (const uint16_t *)lp[DP_A0];
-    const uint16_t *v2w = (const uint16_t *)lp[DP_V2], *v0 = (const uint16_t *)lp[DP_V0];
-    const uint16_t *g2 = (const uint16_t *)lp[DP_G2];
-    const uint16_t *k_k = (const uint16_t *)lp[DP_KK], *k_a = (const uint16_t *)lp[DP_KA], *r_k = (const uint16_t *)lp[DP_RK];
-    const uint16_t *gnw = (const uint16_t *)lp[DP_GNW], *gnb = (const uint16_t *)lp[DP_GNB];
-    float *kv_all = (float *)lp[DP_ATT_KV];
     const bool first = l == 0;
     // thread roles: B (up projections on MFMA): wave 0/1 = 32-channel tile 0/1 of the w and v branches, wave 2/3 = tile 0/1 of
     // the a and g branches; C/E: waves 0,1 = sequence, lane = channel; D (state): 128 threads per sequence, 16 lanes x float4
-    // = one state row, 8 rows per pass
-    const int wave = tid >> 6, lane = tid & 63;
-    const int bbD = tid >> 7, tt = tid & 127, k4 = (tt & 15) * 4, vr = tt >> 4;
-    const int total = 2 * Rtot + 3 * 2 * 64;
+    // = one state row, 8 rows per pass.  The wave id is made a scalar (readfirstlane): the wave's job sizes are then scalars and
+    // everything that depends on them is scalar control flow.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int bbD = wave >> 1, tt = tid & 127, k4 = (tt & 15) * 4, vr = tt >> 4;
     const int tileB = wave & 1;
-    const int R1 = wave < 2 ? d.Rw : d.Ra, R2 = wave < 2 ? (first ? 0 : d.Rv) : d.Rg;     // the wave's two jobs
-    const int off1 = wave < 2 ? 0 : oA, off2 = wave < 2 ? oV : oG;
-    const int n1 = R1 >> 4, n2 = R2 >> 4;
+    const bool wv = wave < 2;
+    const int R1 = wv ? d.Rw : d.Ra, R2 = wv ? d.Rv : d.Rg;     // the wave's two jobs (layer 0 has no v branch: n2 = 0)
+    const int off1 = wv ? 0 : oA, off2 = wv ? oV : oG;
+    const int n1 = R1 >> 4, n2 = (wv && first) ? 0 : R2 >> 4;
+    const int nhid = 2 * Rtot;   // activated hidden values of the item (<= 1024: four per thread)
+    // The layer's pointers, read here -- before the first store of the kernel -- so that they are scalar loads (behind a store the
+    // compiler must assume the table may have changed and reads it with vector loads, in the same in-order queue as the data).
+    gu16 p_w2 = G_U16(lp[DP_W2]), p_a2 = G_U16(lp[DP_A2]);
+    gu16 p_v2 = G_U16(lp[DP_V2]), p_g2 = G_U16(lp[DP_G2]);
+    gu16 k_k = G_U16(lp[DP_KK]), k_a = G_U16(lp[DP_KA]), r_k = G_U16(lp[DP_RK]);
+    gu16 gnw = G_U16(lp[DP_GNW]), gnb = G_U16(lp[DP_GNB]);
+    gu16 w0 = G_U16(lp[DP_W0]), a0 = G_U16(lp[DP_A0]), p_v0 = G_U16(lp[DP_V0]);
+    gf32 kv_all = G_F32(lp[DP_ATT_KV]);
+    gu16 up1 = wv ? p_w2 : p_a2;
+    gu16 up2 = wv ? (first ? p_w2 : p_v2) : p_g2;   // layer 0: null v pointers, never dereferenced
+    gu16 v0 = first ? w0 : p_v0;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int h = item % H, bp = item / H;
-        const int b0 = 2 * bp;
+        const int b0 = 2 * bp, b1 = min(b0 + 1, d.B - 1);
+        // opaque copies: the guards below must not be hoisted out of the item loop as 2 x 24 live SGPR pairs
+        const int m1 = fresh_s(n1), m2 = fresh_s(n2);
         DSTAMP_INIT;
-        // ---- requests that do not wait for this step's activations
-        // up-projection rows as MFMA A fragments: lane = channel 32 tile + (lane & 31), k = 16 i + 8 (lane >> 5)
-        bf16x8 wf[kUpFrags];
+        // ---- loads in the order of their use, all of them unconditional (clamped addresses): a guarded load is merged with "no
+        // value" by a phi, and the compiler waits for it right behind its issue.
+        // A: K-split partial sums of this head's r, k, v (384 values: e = tid and 256 + (tid & 127)) and of the low-rank hidden
+        // vectors (idx = tid + 256 j < 2 Rtot)
+        long addr[6];
         {
-            const int chB = h * 64 + tileB * 32 + (lane & 31);
-            const uint16_t *row1 = (wave < 2 ? w2 : a2) + (long)chB * R1 + (lane >> 5) * 8;
-            const uint16_t *row2 = (wave < 2 ? v2w : g2) + (long)chB * (wave < 2 ? d.Rv : d.Rg) + (lane >> 5) * 8;
+            const int e0 = tid, e1 = 256 + (tid & 127);
+            addr[0] = (long)(((e0 >> 6) & 1) ? b1 : b0) * N2 + (e0 >> 7) * D + h * 64 + (e0 & 63);
+            addr[1] = (long)(((e1 >> 6) & 1) ? b1 : b0) * N2 + (e1 >> 7) * D + h * 64 + (e1 & 63);
 #pragma unroll
-            for (int i = 0; i < kUpFrags; i++) {
-                if (i < n1) wf[i] = *reinterpret_cast<const bf16x8 *>(row1 + 16 * i);
-                else if (i < n1 + n2) wf[i] = *reinterpret_cast<const bf16x8 *>(row2 + 16 * (i - n1));
+            for (int j = 0; j < 4; j++) {
+                const int idx = min(tid + kDecThreads * j, nhid - 1);
+                const int bb = idx >= Rtot, r = idx - (bb ? Rtot : 0);
+                addr[2 + j] = (long)(bb ? b1 : b0) * N2 + 3 * D + r;
             }
         }
+        float accA[6];
+        const float *pp = d.p_qkv;
+        const long ps = (long)kRows * N2;
+        const bool two = d.ks_qkv > 1;
+        const long ps1 = two ? ps : 0;   // one split: the second load repeats the first and is dropped below
+        float t0[6], t1[6];
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            t0[it] = pp[addr[it]];
+            t1[it] = pp[ps1 + addr[it]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // B: up-projection rows as MFMA A fragments: lane = channel 32 tile + (lane & 31), k = 16 i + 8 (lane >> 5); slots beyond
+        // the job's fragments repeat fragment 0
+        bf16x8 wf1[NF1], wf2[NF2];
+        {
+            const int chB = h * 64 + tileB * 32 + (lane & 31);
+            gu16 row1 = up1 + (long)chB * R1 + (lane >> 5) * 8;
+            gu16 row2 = up2 + (long)chB * (m2 ? R2 : R1) + (lane >> 5) * 8;
+#pragma unroll
+            for (int i = 0; i < NF1; i++) wf1[i] = *(const bf16x8 __attribute__((address_space(1))) *)(row1 + 16 * (i < m1 ? i : 0));
+#pragma unroll
+            for (int i = 0; i < NF2; i++) wf2[i] = *(const bf16x8 __attribute__((address_space(1))) *)(row2 + 16 * (i < m2 ? i : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // C, E: per-channel parameters (waves 0, 1 use them)
+        const int chC = h * 64 + lane;
+        const uint16_t q_kk = k_k[chC], q_ka = k_a[chC], q_rk = r_k[chC], q_gw = gnw[chC], q_gb = gnb[chC];
+        const uint16_t q_w0 = w0[chC], q_a0 = a0[chC], q_v0 = v0[chC];
+        const float q_vf = d.vfirst[(long)((wave & 1) ? b1 : b0) * D + chC];   // layer 0: stale values, not used
+        __builtin_amdgcn_sched_barrier(0);
+        // D: the state rows
         const bool liveD = b0 + bbD < d.B;
-        float *S = kv_all + ((long)min(b0 + bbD, d.B - 1) * H + h) * 64 * 64;
+        gf32 S = kv_all + ((long)(bbD ? b1 : b0) * H + h) * 64 * 64;
         float4 st[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) st[i] = *reinterpret_cast<const float4 *>(S + (vr + 8 * i) * 64 + k4);
-        // per-channel parameters of steps C and E (waves 0,1)
-        const int chC = h * 64 + (tid & 63);
-        const float p_kk = bf2f(k_k[chC]), p_ka = bf2f(k_a[chC]), p_rk = bf2f(r_k[chC]), p_gw = bf2f(gnw[chC]), p_gb = bf2f(gnb[chC]);
-        const float p_vf = first ? 0.f : d.vfirst[(long)min(b0 + ((tid >> 6) & 1), d.B - 1) * D + chC];
-        const float p_w0 = bf2f(w0[chC]), p_a0 = bf2f(a0[chC]), p_v0 = first ? 0.f : bf2f(v0[chC]);
+        for (int i = 0; i < 8; i++) {
+            const f32x4v t = *(const f32x4v __attribute__((address_space(1))) *)(S + (vr + 8 * i) * 64 + k4);
+            st[i] = make_float4(t.x, t.y, t.z, t.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 6; it++) accA[it] = t0[it] + (two ? t1[it] : 0.f);
+        for (int p = 2; p < d.ks_qkv; p += 2) {   // K splits beyond two (wide models): two per round of loads
+            const float *pq = pp + (long)p * ps;
+            float u0[6], u1[6];
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                u0[it] = pq[addr[it]];
+                u1[it] = pq[ps + addr[it]];
+            }
+#pragma unroll
+            for (int it = 0; it < 6; it++) accA[it] += u0[it] + u1[it];
+        }
+        __syncthreads();  // LDS of the previous item is free
+        DSTAMP(0);
         // ---- A: low-rank hidden vectors (activation applied to the summed partials) and this head's r, k, v
-        {
-            long addr[6];
-            float acc[6];
+        sm.rkv[tid >> 7][(tid >> 6) & 1][tid & 63] = accA[0];
+        if (tid < 128) sm.rkv[2][(tid >> 6) & 1][tid & 63] = accA[1];
 #pragma unroll
-            for (int it = 0; it < 6; it++) {
-                const int idx = tid + kDecThreads * it;
-                acc[it] = 0.f;
-                addr[it] = -1;
-                if (idx < 2 * Rtot) {
-                    const int bb = idx / Rtot, r = idx - bb * Rtot;
-                    addr[it] = (long)min(b0 + bb, d.B - 1) * N2 + 3 * D + r;
-                } else if (idx < total) {
-                    const int e = idx - 2 * Rtot, which = e >> 7, bb = (e >> 6) & 1, c = e & 63;
-                    addr[it] = (long)min(b0 + bb, d.B - 1) * N2 + which * D + h * 64 + c;
-                }
-            }
-            for (int p = 0; p < d.ks_qkv; p += 2) {   // two splits per round of loads
-                const float *pp = d.p_qkv + (long)p * kRows * N2;
-                const bool two = p + 1 < d.ks_qkv;
-                float t[6], u[6];
-#pragma unroll
-                for (int it = 0; it < 6; it++) {
-                    t[it] = addr[it] >= 0 ? pp[addr[it]] : 0.f;
-                    u[it] = addr[it] >= 0 && two ? pp[(long)kRows * N2 + addr[it]] : 0.f;
-                }
-#pragma unroll
-                for (int it = 0; it < 6; it++) acc[it] += t[it] + u[it];
-            }
-            __syncthreads();  // LDS of the previous item is free
-            DSTAMP(0);
-#pragma unroll
-            for (int it = 0; it < 6; it++) {
-                const int idx = tid + kDecThreads * it;
-                if (idx < 2 * Rtot) {
-                    const int bb = idx / Rtot, r = idx - bb * Rtot;
-                    float v = acc[it];
-                    if (r < oA) v = tanh_(v);
-                    else if (r >= oG) v = sigm(v);
-                    sm.hid[bb][r] = f2bf(v);
-                } else if (idx < total) {
-                    const int e = idx - 2 * Rtot;
-                    sm.rkv[e >> 7][(e >> 6) & 1][e & 63] = acc[it];
-                }
+        for (int j = 0; j < 4; j++) {
+            const int idx = tid + kDecThreads * j;
+            if (idx < nhid) {
+                const int bb = idx >= Rtot, r = idx - (bb ? Rtot : 0);
+                const float x = accA[2 + j];
+                // tanh (decay branch), identity (a, v branches), sigmoid (gate branch): one exp, one reciprocal
+                const float e = __expf(r < oA ? 2.f * x : -x), rc = 1.f / (e + 1.f);
+                const float v = r < oA ? fmaf(-2.f, rc, 1.f) : (r >= oG ? rc : x);
+                sm.hid[bb][r] = f2bf(v);
             }
         }
         __syncthreads();
@@ -466,39 +519,43 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
         // ---- B: up projections on MFMA: D[m = channel][n = sequence], only n = 0, 1 are real (the B operand repeats them)
         {
             const uint16_t *hp = &sm.hid[lane & 1][(lane >> 5) * 8];
+            bf16x8 hf1[NF1], hf2[NF2];
+#pragma unroll
+            for (int i = 0; i < NF1; i++) hf1[i] = *reinterpret_cast<const bf16x8 *>(hp + off1 + 16 * (i < m1 ? i : 0));
+#pragma unroll
+            for (int i = 0; i < NF2; i++) hf2[i] = *reinterpret_cast<const bf16x8 *>(hp + off2 + 16 * (i < m2 ? i : 0));
             f32x16 acc1 = zero16(), acc2 = zero16();
 #pragma unroll
-            for (int i = 0; i < kUpFrags; i++) {
-                if (i < n1) {
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], *reinterpret_cast<const bf16x8 *>(hp + off1 + 16 * i), acc1, 0, 0, 0);
-                } else if (i < n1 + n2) {
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], *reinterpret_cast<const bf16x8 *>(hp + off2 + 16 * (i - n1)), acc2, 0, 0, 0);
-                }
-            }
+            for (int i = 0; i < NF1; i++)   // scalar branches around register-only work
+                if (i < m1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[i], hf1[i], acc1, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NF2; i++)
+                if (i < m2) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[i], hf2[i], acc2, 0, 0, 0);
             if ((lane & 31) < 2) {
                 const int n = lane & 31;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int m = tileB * 32 + d_row(r, lane);
-                    sm.up[wave < 2 ? 0 : 1][n][m] = acc1[r];
-                    sm.up[wave < 2 ? 2 : 3][n][m] = acc2[r];
+                    sm.up[wv ? 0 : 1][n][m] = acc1[r];
+                    sm.up[wv ? 2 : 3][n][m] = acc2[r];
                 }
             }
         }
         __syncthreads();
         DSTAMP(2);
         // ---- C: decay, gates, value residual, kk normalisation (rwkv_s2s_single_ffn.py:493-500)
-        if (tid < 128) {
-            const int c = tid & 63, bb = tid >> 6;
-            const int b = min(b0 + bb, d.B - 1), ch = h * 64 + c;
+        if (wave < 2) {
+            const int c = lane, bb = wave;
+            const int b = bb ? b1 : b0, ch = h * 64 + c;
+            const float p_kk = bf2f(q_kk), p_ka = bf2f(q_ka), p_rk = bf2f(q_rk);
             const float r = sm.rkv[0][bb][c], k = sm.rkv[1][bb][c];
             float v = sm.rkv[2][bb][c];
-            const float w = -softplus_d(-(sm.up[0][bb][c] + p_w0)) - 0.5f;
-            const float a = sigm(sm.up[1][bb][c] + p_a0);
+            const float w = -softplus_d(-(sm.up[0][bb][c] + bf2f(q_w0))) - 0.5f;
+            const float a = sigm(sm.up[1][bb][c] + bf2f(q_a0));
             if (first) {
                 if (b0 + bb < d.B) d.vfirst[(long)b * D + ch] = v;
             } else {
-                v = fmaf(p_vf - v, sigm(sm.up[2][bb][c] + p_v0), v);
+                v = fmaf(q_vf - v, sigm(sm.up[2][bb][c] + bf2f(q_v0)), v);
             }
             const float kkr = k * p_kk;
             const float ss = wave_sum(kkr * kkr);
@@ -530,7 +587,11 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
                 st[i].y = fmaf(st[i].y, dc.y, fmaf(sa, bv.y, vv * kk.y));
                 st[i].z = fmaf(st[i].z, dc.z, fmaf(sa, bv.z, vv * kk.z));
                 st[i].w = fmaf(st[i].w, dc.w, fmaf(sa, bv.w, vv * kk.w));
-                if (liveD) *reinterpret_cast<float4 *>(S + (vr + 8 * i) * 64 + k4) = st[i];
+                if (liveD) {
+                    f32x4v t;
+                    t.x = st[i].x; t.y = st[i].y; t.z = st[i].z; t.w = st[i].w;
+                    *(f32x4v __attribute__((address_space(1))) *)(S + (vr + 8 * i) * 64 + k4) = t;
+                }
                 const float y = sum16(st[i].x * rr.x + st[i].y * rr.y + st[i].z * rr.z + st[i].w * rr.w);
                 if ((tt & 15) == 0) sm.y[bbD][vr + 8 * i] = y;
             }
@@ -538,14 +599,14 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
         __syncthreads();
         DSTAMP(4);
         // ---- E: GroupNorm over the head, bonus, gate (rwkv_s2s_single_ffn.py:504-505)
-        if (tid < 128) {
-            const int c = tid & 63, bb = tid >> 6;
+        if (wave < 2) {
+            const int c = lane, bb = wave;
             const int ch = h * 64 + c;
             const float y = sm.y[bb][c];
             const float mean = wave_sum(y) * (1.f / 64.f);
             const float dv = y - mean;
             const float rstd = rsqrtf(wave_sum(dv * dv) * (1.f / 64.f) + d.gn_eps);
-            const float o = (fmaf(dv * rstd, p_gw, p_gb) + sm.dot[bb] * sm.vec[3][bb][c]) * sm.up[3][bb][c];
+            const float o = (fmaf(dv * rstd, bf2f(q_gw), bf2f(q_gb)) + sm.dot[bb] * sm.vec[3][bb][c]) * sm.up[3][bb][c];
             if (b0 + bb < d.B) d.yg[(long)(b0 + bb) * D + ch] = f2bf(o);
         }
         DSTAMP(5);
@@ -559,31 +620,25 @@ struct TblRow {
     __device__ __forceinline__ const void *operator[](int i) const { return base[i]; }
 };
 
-template <class LP>
-__device__ __forceinline__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, int ph, const LP &lp) {
+// PH 0-6: the phases of layer l; PH 7, 8: the tail (last residual add + model norm; head projection)
+template <int PH, int NF1, int NF2, class LP>
+__device__ __forceinline__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, const LP &lp) {
     const int D = d.D;
-    if (l == d.L) {  // tail: last residual add + model norm, then the head
-        if (ph == 0) {
-            for (int b = blockIdx.x; b < d.B; b += gridDim.x)
-                row_phase<0>(d, b, sm.red, d.xa, d.p_val, d.ks_val, nullptr, nullptr, nullptr, nullptr, d.norm_w, d.norm_b, nullptr,
-                             nullptr, d.hfin);
-        } else {
-            const GemvSeg seg[1] = {{d.head_w, d.hfin, (d.V + 31) / 32, d.V}};
-            gemv_phase<0, 1>(d, sm, seg, D, 1, d.logits, d.V, d.head_b);
-        }
-        return;
-    }
-    switch (ph) {
-    case 0: {
+    if constexpr (PH == 7) {
+        for (int b = blockIdx.x; b < d.B; b += gridDim.x)
+            row_phase<0>(d, b, sm.red, d.xa, d.p_val, d.ks_val, nullptr, nullptr, nullptr, nullptr, d.norm_w, d.norm_b, nullptr, nullptr,
+                         d.hfin);
+    } else if constexpr (PH == 8) {
+        const GemvSeg seg[1] = {{d.head_w, d.hfin, (d.V + 31) / 32, d.V}};
+        gemv_phase<0, 1>(d, sm, seg, D, 1, d.logits, d.V, d.head_b);
+    } else if constexpr (PH == 0) {
         const uint16_t *mixp[6] = {(const uint16_t *)lp[DP_XR], (const uint16_t *)lp[DP_XW], (const uint16_t *)lp[DP_XK],
                                    (const uint16_t *)lp[DP_XV], (const uint16_t *)lp[DP_XA], (const uint16_t *)lp[DP_XG]};
         for (int b = blockIdx.x; b < d.B; b += gridDim.x)
             row_phase<6>(d, b, sm.red, d.xa, d.p_val, d.ks_val, l == 0 ? d.x_in : nullptr, (const uint16_t *)lp[DP_LN0_W],
                          (const uint16_t *)lp[DP_LN0_B], d.xb, (const uint16_t *)lp[DP_LN1_W], (const uint16_t *)lp[DP_LN1_B],
                          (uint16_t *)lp[DP_ATT_XPREV], mixp, d.mixed);
-        break;
-    }
-    case 1: {
+    } else if constexpr (PH == 1) {
         const long RS = (long)kRows * D;  // one mixed plane: order r, w, k, v, a, g
         // layer 0 has no value-residual branch: its columns stay unwritten and unread
         const GemvSeg segs[7] = {{(const uint16_t *)lp[DP_WR], d.mixed + 0 * RS, D / 32, D},
@@ -594,33 +649,22 @@ __device__ __forceinline__ void run_phase(const DecodeDesc &d, DecSmem &sm, int 
                                  {(const uint16_t *)(l == 0 ? lp[DP_A1] : lp[DP_V1]), d.mixed + 3 * RS, l == 0 ? 0 : d.Rv / 32, d.Rv},
                                  {(const uint16_t *)lp[DP_G1], d.mixed + 5 * RS, d.Rg / 32, d.Rg}};
         gemv_phase<0, 7>(d, sm, segs, D, d.ks_qkv, d.p_qkv, 3 * D + d.Rw + d.Ra + d.Rv + d.Rg, nullptr);
-        break;
-    }
-    case 2:
-        head_phase(d, sm, l, lp);
-        break;
-    case 3: {
+    } else if constexpr (PH == 2) {
+        head_phase<NF1, NF2>(d, sm, l, lp);
+    } else if constexpr (PH == 3) {
         const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WO], d.yg, D / 32, D}};
         gemv_phase<0, 1>(d, sm, seg, D, d.ks_o, d.p_att, D, nullptr);
-        break;
-    }
-    case 4: {
+    } else if constexpr (PH == 4) {
         const uint16_t *mixp[1] = {(const uint16_t *)lp[DP_FXK]};
         for (int b = blockIdx.x; b < d.B; b += gridDim.x)
             row_phase<1>(d, b, sm.red, d.xb, d.p_att, d.ks_o, nullptr, nullptr, nullptr, d.xa, (const uint16_t *)lp[DP_LN2_W],
                          (const uint16_t *)lp[DP_LN2_B], (uint16_t *)lp[DP_FFN_XPREV], mixp, d.kx);
-        break;
-    }
-    case 5: {
+    } else if constexpr (PH == 5) {
         const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WKEY], d.kx, d.F / 16, d.F}};
         gemv_phase<1, 1, 16>(d, sm, seg, D, 1, d.kact, d.F, nullptr);
-        break;
-    }
-    default: {
+    } else {
         const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WVAL], d.kact, D / 32, D}};
         gemv_phase<0, 1>(d, sm, seg, d.F, d.ks_val, d.p_val, D, nullptr);
-        break;
-    }
     }
 }
 
@@ -629,18 +673,38 @@ __global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDe
     __shared__ DecSmem sm;
     unsigned target = 0;
     const int nphase = 7 * d.L + 2;
-    for (int idx = 0; idx < nphase; idx++) {   // one call site: the phase bodies are inlined once
-        const int l = idx / 7, ph = idx - 7 * l;
-        if (mode == 1) run_phase(d, sm, l, ph, TblRow{d.tbl + (long)(l < d.L ? l : 0) * DP_COUNT});
+    for (int idx = 0; idx < nphase; idx++) {   // one call site per phase body
+        const int l = idx / 7, ph = idx - 7 * l + (l == d.L ? 7 : 0);
+        if (mode == 1) {
+            const TblRow lp{d.tbl + (long)(l < d.L ? l : 0) * DP_COUNT};
+            switch (ph) {
+            case 0: run_phase<0, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            case 1: run_phase<1, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            case 2: run_phase<2, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            case 3: run_phase<3, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            case 4: run_phase<4, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            case 5: run_phase<5, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            case 6: run_phase<6, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            case 7: run_phase<7, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            default: run_phase<8, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            }
+        }
         if (idx + 1 < nphase) grid_barrier(d.bar, target, gridDim.x, mode);
     }
 }
 
-// (Reading the descriptor from device memory through a 16-byte kernel argument instead was measured 3 % slower in the
-// replayed graph: one more dependent load at the head of every phase.)
-__global__ __launch_bounds__(kDecThreads) void decode_phase_kernel(DecodeDesc d, int l, int ph) {
+// One kernel per phase (round 3; until then one kernel with a switch over the phase: every phase paid for the registers and
+// the SGPR spills of the largest one).  (Reading the descriptor from device memory through a 16-byte kernel argument instead was
+// measured 3 % slower in the replayed graph: one more dependent load at the head of every phase.)
+template <int PH, int NF1, int NF2>
+__global__ __launch_bounds__(kDecThreads) void decode_phase_kernel(DecodeDesc d, int l) {
     __shared__ DecSmem sm;
-    run_phase(d, sm, l, ph, TblRow{d.tbl + (long)(l < d.L ? l : 0) * DP_COUNT});
+    run_phase<PH, NF1, NF2>(d, sm, l, TblRow{d.tbl + (long)(PH < 7 ? l : 0) * DP_COUNT});
+}
+
+template <int PH, int NF1 = 4, int NF2 = 8>
+inline void launch_phase(int items, hipStream_t st, const DecodeDesc &d, int l) {
+    decode_phase_kernel<PH, NF1, NF2><<<dim3(items), dim3(kDecThreads), 0, st>>>(d, l);
 }
 
 // K split of a GEMV phase: minimise the work of the busiest workgroup, where an item costs its K range plus a fixed
@@ -694,9 +758,9 @@ bool ws_layout(int D, int F, int Rw, int Ra, int Rv, int Rg, WsLayout &w) {
 }
 
 bool shape_ok(int B, int D, int H, int F, int V, int Rw, int Ra, int Rv, int Rg) {
-    auto r_ok = [](int r) { return r >= 32 && r % 32 == 0; };
+    auto r_ok = [](int r) { return r >= 32 && r % 32 == 0 && r <= 16 * kUpFrags; };
     return B >= 1 && B <= kRows && D == H * 64 && D % 64 == 0 && D <= kDecThreads * kMaxE && F % 64 == 0 && V >= 1 && r_ok(Rw) &&
-           r_ok(Ra) && r_ok(Rv) && r_ok(Rg) && Rw + Ra + Rv + Rg <= kMaxR && (Rw + Rv) / 16 <= kUpFrags && (Ra + Rg) / 16 <= kUpFrags;
+           r_ok(Ra) && r_ok(Rv) && r_ok(Rg) && Rw + Ra + Rv + Rg <= kMaxR;
 }
 
 }  // namespace
@@ -745,14 +809,21 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
     } else {
         // one launch per phase, each sized to its own item count
         const int N2 = 3 * D + Rw + Ra + Rv + Rg;
+        const int nf1 = max(Rw, Ra) / 16, nf2 = max(Rv, Rg) / 16;   // fragment slots of the head phase's two jobs
         const int g_phase[7] = {B, (N2 / 32) * w.ks_qkv, H * ((B + 1) / 2), (D / 32) * w.ks_o, B, F / 16, (D / 32) * w.ks_val};
-        for (int l = 0; l < L; l++)
-            for (int ph = 0; ph < 7; ph++) {
-                const int items = l == 0 && ph == 1 ? g_phase[1] - (Rv / 32) * w.ks_qkv : g_phase[ph];
-                hipLaunchKernelGGL(decode_phase_kernel, dim3(items), dim3(kDecThreads), 0, st, d, l, ph);
-            }
-        hipLaunchKernelGGL(decode_phase_kernel, dim3(B), dim3(kDecThreads), 0, st, d, L, 0);
-        hipLaunchKernelGGL(decode_phase_kernel, dim3((V + 31) / 32), dim3(kDecThreads), 0, st, d, L, 1);
+        for (int l = 0; l < L; l++) {
+            launch_phase<0>(g_phase[0], st, d, l);
+            launch_phase<1>(l == 0 ? g_phase[1] - (Rv / 32) * w.ks_qkv : g_phase[1], st, d, l);
+            if (nf1 <= 4 && nf2 <= 8) launch_phase<2, 4, 8>(g_phase[2], st, d, l);          // 0.4B: 64, 64, 32, 128
+            else if (nf1 <= 8 && nf2 <= 16) launch_phase<2, 8, 16>(g_phase[2], st, d, l);   // 1.5B: 96, 96, 64, 256
+            else launch_phase<2, kUpFrags, kUpFrags>(g_phase[2], st, d, l);
+            launch_phase<3>(g_phase[3], st, d, l);
+            launch_phase<4>(g_phase[4], st, d, l);
+            launch_phase<5>(g_phase[5], st, d, l);
+            launch_phase<6>(g_phase[6], st, d, l);
+        }
+        launch_phase<7>(B, st, d, L);
+        launch_phase<8>((V + 31) / 32, st, d, L);
     }
     return (int)hipGetLastError();
 }

@@ -103,7 +103,7 @@ class DecodeStep:
             return "parameters must be contiguous bf16 tensors on the HIP device"
         a0 = backbone.layers[0].attn
         ranks = [a0.w_lora.rank, a0.a_lora.rank, a0.g_lora.rank] + ([backbone.layers[1].attn.v_lora.rank] if len(backbone.layers) > 1 else [])
-        if any(r % 32 for r in ranks) or sum(ranks) > 512:
+        if any(r % 32 or r > 256 for r in ranks) or sum(ranks) > 512:
             return f"low-rank sizes {ranks}"
         if backbone.layers[0].ffn.key.weight.shape[0] % 64:
             return "channel-mix width"

@@ -52,7 +52,8 @@ def _clone_cache(c):
     (128, 2, 64, (64, 32, 32, 96), 32, False),
     (1024, 2, 8193, (64, 64, 32, 128), 32, False),  # 0.4B widths (BASELINE configs[4]), two layers
     (768, 2, 300, (64, 64, 32, 128), 7, False),     # 0.1B width: K splits that are not powers of two away from 1024
-    (2048, 2, 1025, (96, 96, 64, 256), 4, True),    # 1.5B widths
+    (2048, 2, 1025, (96, 96, 64, 256), 4, True),    # 1.5B widths (head phase: the 8 + 16 fragment-slot instantiation)
+    (256, 2, 200, (160, 32, 32, 64), 6, False),     # a rank above 128: the generic 16 + 16 slot instantiation in the per-phase mode too
 ])
 def test_step_kernel_vs_module_path_and_fp32(D, L, V, ranks, B, bias):
     cfg, m16, m32 = _model(D, L, V, ranks, seed=D + B, head_bias=bias)
