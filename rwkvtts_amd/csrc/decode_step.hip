@@ -103,6 +103,17 @@ union DecSmem {
     float red[32];
 };
 
+// Pointers read from the layer table are generic: loads through them are flat_load, which counts on BOTH memory counters and
+// may return out of order -- the compiler then waits with vmcnt(0) lgkmcnt(0) everywhere (LDS reads behind state loads).  The
+// table holds device-memory addresses only.
+typedef const uint16_t __attribute__((address_space(1))) *gu16;
+typedef float __attribute__((address_space(1))) *gf32;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+typedef uint16_t __attribute__((address_space(1))) *gu16m;   // written through (the token-shift rows)
+#define G_U16M(p) ((gu16m)(p))
+#define G_U16(p) ((gu16)(p))
+#define G_F32(p) ((gf32)(p))
 __device__ __forceinline__ float wave_sum(float x) {
     x = sum16(x);
     x += __shfl_xor(x, 16);
@@ -121,14 +132,6 @@ __device__ __forceinline__ float block_sum256(float v, float *red) {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
-// Pointers read from the layer table are generic: loads through them are flat_load, which counts on BOTH memory counters and
-// may return out of order -- the compiler then waits with vmcnt(0) lgkmcnt(0) everywhere (LDS reads behind state loads).  The
-// table holds device-memory addresses only.
-typedef const uint16_t __attribute__((address_space(1))) *gu16;
-typedef float __attribute__((address_space(1))) *gf32;
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-#define G_U16(p) ((gu16)(p))
-#define G_F32(p) ((gf32)(p))
 // an opaque copy of a scalar: conditions derived from it cannot be hoisted out of the item loop (24 + 24 + 24 loop-invariant
 // guards kept as SGPR pairs were 245 spilled SGPRs in the head phase)
 __device__ __forceinline__ int fresh_s(int x) {
@@ -168,101 +171,119 @@ __device__ __forceinline__ float4 bf4(uint2 r) {
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// Every thread owns float4 column groups g = tid + 256 i.  All loads of a group (residual, up to 8 partials at a time, norm
-// and lerp parameters, the shifted row) are issued before the first reduction: a phase is a chain of load latencies.
-template <int NMIX>
+// Every thread owns float4 column groups g = tid + 256 i, i < NG (NG = ceil(D / 1024): the host picks the instantiation).  All
+// loads of the row (residual, the partial sums eight at a time, norm and lerp parameters, the shifted row) are unconditional --
+// lanes beyond the row repeat its last group, partial sums beyond `nparts` repeat the last one and are dropped -- and are issued
+// before the first reduction: the phase pays one memory latency.  (Round 2's form guarded each load by `g < D / 4` and
+// `p < nparts`: every guarded load is waited for behind its issue, and the parameter rows came through generic pointers, i.e.
+// flat_load -- four serialised latencies per phase.)
+template <int NMIX, int NG>
 __device__ __forceinline__ void row_phase(const DecodeDesc &d, int b, float *red, const float *x_old, const float *parts, int nparts,
-                                          const uint16_t *x_in, const uint16_t *ln0w, const uint16_t *ln0b, float *x_out,
-                                          const uint16_t *lnw, const uint16_t *lnb, uint16_t *x_prev, const uint16_t *const *mixp,
-                                          uint16_t *out) {
-    constexpr int NG = kMaxE / 4;
+                                          const uint16_t *x_in, gu16 ln0w, gu16 ln0b, float *x_out, gu16 lnw, gu16 lnb, gu16m x_prev,
+                                          const gu16 *mixp, uint16_t *out) {
+// the NG instantiations (per-phase kernels: the model's; persistent kernel: the widest) must round alike: no reassociation of the
+// row sums under -ffast-math, no contraction left to the optimiser (it differs between the instantiations)
+#pragma clang fp reassociate(off) contract(off)
+    typedef const uint2v __attribute__((address_space(1))) *gq;
     const int D = d.D, tid = threadIdx.x, D4 = D >> 2;
     const float invD = 1.f / (float)D;
     const long rb = (long)b * D;
     float4 x[NG];
-    uint2 wln[NG], bln[NG], xp[NG], mx[NMIX > 0 ? NMIX : 1][NG];
-    float s = 0.f;
+    uint2v wln[NG], bln[NG], xp[NG], mx[NMIX > 0 ? NMIX : 1][NG];
+    bool live[NG];
+    int col[NG];
 #pragma unroll
     for (int i = 0; i < NG; i++) {
         const int g = tid + kDecThreads * i;
-        x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < D4) {
-            const int c = 4 * g;
-            wln[i] = *reinterpret_cast<const uint2 *>(lnw + c);
-            bln[i] = *reinterpret_cast<const uint2 *>(lnb + c);
-            if (NMIX > 0) {
-                xp[i] = *reinterpret_cast<const uint2 *>(x_prev + rb + c);
+        live[i] = g < D4;
+        col[i] = 4 * min(g, D4 - 1);
+        wln[i] = *(gq)(lnw + col[i]);
+        bln[i] = *(gq)(lnb + col[i]);
+        if (NMIX > 0) {
+            xp[i] = *(gq)(x_prev + rb + col[i]);
 #pragma unroll
-                for (int j = 0; j < NMIX; j++) mx[j][i] = *reinterpret_cast<const uint2 *>(mixp[j] + c);
-            }
-            if (x_in) {
-                x[i] = bf4(*reinterpret_cast<const uint2 *>(x_in + rb + c));
-            } else {
-                float4 acc = *reinterpret_cast<const float4 *>(x_old + rb + c);
-                for (int p0 = 0; p0 < nparts; p0 += 8) {
-                    float4 t[8];
-#pragma unroll
-                    for (int p = 0; p < 8; p++)
-                        t[p] = p0 + p < nparts ? *reinterpret_cast<const float4 *>(parts + ((long)(p0 + p) * kRows + b) * D + c)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int p = 0; p < 8; p++) acc = add4(acc, t[p]);
-                }
-                x[i] = acc;
-            }
-            s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+            for (int j = 0; j < NMIX; j++) mx[j][i] = *(gq)(mixp[j] + col[i]);
         }
     }
+    float s = 0.f;
+    if (x_in) {   // layer 0: the embeddings (scalar branch)
+#pragma unroll
+        for (int i = 0; i < NG; i++) x[i] = bf4(*reinterpret_cast<const uint2 *>(x_in + rb + col[i]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < NG; i++) x[i] = *reinterpret_cast<const float4 *>(x_old + rb + col[i]);
+        for (int p0 = 0; p0 < nparts; p0 += 8) {
+            float4 t[NG][8];
+#pragma unroll
+            for (int i = 0; i < NG; i++)
+#pragma unroll
+                for (int p = 0; p < 8; p++)
+                    t[i][p] = *reinterpret_cast<const float4 *>(parts + ((long)min(p0 + p, nparts - 1) * kRows + b) * D + col[i]);
+#pragma unroll
+            for (int i = 0; i < NG; i++)
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    const float m = p0 + p < nparts ? 1.f : 0.f;
+                    x[i].x = fmaf(t[i][p].x, m, x[i].x); x[i].y = fmaf(t[i][p].y, m, x[i].y);
+                    x[i].z = fmaf(t[i][p].z, m, x[i].z); x[i].w = fmaf(t[i][p].w, m, x[i].w);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NG; i++) s += live[i] ? (x[i].x + x[i].y) + (x[i].z + x[i].w) : 0.f;
     auto sqdev = [&](float mean) {
+#pragma clang fp reassociate(off) contract(off)
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NG; i++) {
-            if (tid + kDecThreads * i < D4) {
-                const float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, e = x[i].w - mean;
-                q += (a * a + bb * bb) + (c * c + e * e);
-            }
+            const float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, e = x[i].w - mean;
+            q += live[i] ? (a * a + bb * bb) + (c * c + e * e) : 0.f;
         }
         return q;
     };
     if (x_in) {  // pre_norm of the first block (rwkv_s2s_single_ffn.py:253-254); its output is a bf16 tensor
+        uint2v w0[NG], b0[NG];
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            w0[i] = *(gq)(ln0w + col[i]);
+            b0[i] = *(gq)(ln0b + col[i]);
+        }
         const float mean = block_sum256(s, red) * invD;
         const float rstd = rsqrtf(block_sum256(sqdev(mean), red) * invD + d.ln_eps);
         s = 0.f;
 #pragma unroll
         for (int i = 0; i < NG; i++) {
-            const int g = tid + kDecThreads * i;
-            if (g < D4) {
-                const float4 w = bf4(*reinterpret_cast<const uint2 *>(ln0w + 4 * g)), bi = bf4(*reinterpret_cast<const uint2 *>(ln0b + 4 * g));
-                const uint32_t lo = cvt_pk((x[i].x - mean) * rstd * w.x + bi.x, (x[i].y - mean) * rstd * w.y + bi.y);
-                const uint32_t hi = cvt_pk((x[i].z - mean) * rstd * w.z + bi.z, (x[i].w - mean) * rstd * w.w + bi.w);
-                x[i] = bf4(make_uint2(lo, hi));
-                s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-            }
+            const float4 w = bf4(make_uint2(w0[i].x, w0[i].y)), bi = bf4(make_uint2(b0[i].x, b0[i].y));
+            const uint32_t lo = cvt_pk((x[i].x - mean) * rstd * w.x + bi.x, (x[i].y - mean) * rstd * w.y + bi.y);
+            const uint32_t hi = cvt_pk((x[i].z - mean) * rstd * w.z + bi.z, (x[i].w - mean) * rstd * w.w + bi.w);
+            x[i] = bf4(make_uint2(lo, hi));
+            s += live[i] ? (x[i].x + x[i].y) + (x[i].z + x[i].w) : 0.f;
         }
     }
     const float mean = block_sum256(s, red) * invD;
     const float rstd = rsqrtf(block_sum256(sqdev(mean), red) * invD + d.ln_eps);
 #pragma unroll
     for (int i = 0; i < NG; i++) {
-        const int g = tid + kDecThreads * i;
-        if (g < D4) {
-            const int c = 4 * g;
+        if (live[i]) {
+            const int c = col[i];
             if (x_out) *reinterpret_cast<float4 *>(x_out + rb + c) = x[i];
-            const float4 w = bf4(wln[i]), bi = bf4(bln[i]);
+            const float4 w = bf4(make_uint2(wln[i].x, wln[i].y)), bi = bf4(make_uint2(bln[i].x, bln[i].y));
             const uint2 hb = make_uint2(cvt_pk((x[i].x - mean) * rstd * w.x + bi.x, (x[i].y - mean) * rstd * w.y + bi.y),
                                         cvt_pk((x[i].z - mean) * rstd * w.z + bi.z, (x[i].w - mean) * rstd * w.w + bi.w));
             if (NMIX == 0) {
                 *reinterpret_cast<uint2 *>(out + rb + c) = hb;
             } else {
-                const float4 h = bf4(hb), pv = bf4(xp[i]);
+                const float4 h = bf4(hb), pv = bf4(make_uint2(xp[i].x, xp[i].y));
                 const float4 xx = make_float4(pv.x - h.x, pv.y - h.y, pv.z - h.z, pv.w - h.w);
 #pragma unroll
                 for (int j = 0; j < NMIX; j++) {
-                    const float4 m = bf4(mx[j][i]);
+                    const float4 m = bf4(make_uint2(mx[j][i].x, mx[j][i].y));
                     *reinterpret_cast<uint2 *>(out + ((long)j * kRows + b) * D + c) =
                         make_uint2(cvt_pk(fmaf(xx.x, m.x, h.x), fmaf(xx.y, m.y, h.y)), cvt_pk(fmaf(xx.z, m.z, h.z), fmaf(xx.w, m.w, h.w)));
                 }
-                *reinterpret_cast<uint2 *>(x_prev + rb + c) = hb;
+                uint2v hv;
+                hv.x = hb.x; hv.y = hb.y;
+                *(uint2v __attribute__((address_space(1))) *)(x_prev + rb + c) = hv;
             }
         }
     }
@@ -273,20 +294,24 @@ __device__ __forceinline__ void row_phase(const DecodeDesc &d, int b, float *red
 // D[m][n]: m = output column inside the tile (A operand = W rows), n = sequence (B operand = X rows).
 // ---------------------------------------------------------------------------------------------------------------------
 struct GemvSeg {
-    const uint16_t *W;   // [ncols][K]
+    gu16 W;              // [ncols][K]; global address space: through a generic pointer the weight rows are flat_load, which the
+                         // compiler drains with vmcnt(0) every two k-steps (four serialised latencies per sweep, round 2)
     const uint16_t *X;   // bf16 [32][K]
     int ntiles;          // 32-column tiles (the last one may be partial: ncols)
     int ncols;
 };
 
 template <int KSTEPS>
-__device__ __forceinline__ void gemv_steps(f32x16 &acc, const uint16_t *wp, const uint16_t *xp) {
+__device__ __forceinline__ void gemv_steps(f32x16 &acc, gu16 wp, const uint16_t *xp) {
     bf16x8 a[KSTEPS], b[KSTEPS];
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) {
-        a[i] = *reinterpret_cast<const bf16x8 *>(wp + 16 * i);
+        a[i] = *(const bf16x8 __attribute__((address_space(1))) *)(wp + 16 * i);
         b[i] = *reinterpret_cast<const bf16x8 *>(xp + 16 * i);
     }
+    // all loads of the round are issued before the first MFMA: left alone, the scheduler sinks each pair of loads to its MFMA
+    // (shorter live ranges) and the sweep walks through its K range with 2.5 k-steps in flight
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
 }
@@ -297,7 +322,7 @@ __device__ __forceinline__ void gemv_steps(f32x16 &acc, const uint16_t *wp, cons
 template <int OUTMODE, int NSEG, int TW = 32>
 __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, const GemvSeg (&segs)[NSEG], int K, int KS, void *out_,
                                            int ldo, const uint16_t *bias) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int ntiles = 0;
 #pragma unroll
     for (int s = 0; s < NSEG; s++) ntiles += segs[s].ntiles;
@@ -324,10 +349,11 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
         const int c0 = t * TW;                                  // first column of the tile inside its segment
         const int mrow = min(c0 + (lane & (TW - 1)), sg.ncols - 1);
         const int kbeg = ks * (K / KS) + wave * kw + (lane >> 5) * 8;
-        const uint16_t *wp = sg.W + (long)mrow * K + kbeg;
+        gu16 wp = sg.W + (long)mrow * K + kbeg;
         const uint16_t *xp = sg.X + (long)nrow * K + kbeg;
         f32x16 acc = zero16();
         int k = 0;
+        for (; k + 256 <= kw; k += 256) gemv_steps<16>(acc, wp + k, xp + k);   // un-split sweeps (key, head): one round of loads
         for (; k + 128 <= kw; k += 128) gemv_steps<8>(acc, wp + k, xp + k);
         for (; k + 32 <= kw; k += 32) gemv_steps<2>(acc, wp + k, xp + k);
         for (; k + 16 <= kw; k += 16) gemv_steps<1>(acc, wp + k, xp + k);
@@ -620,56 +646,68 @@ struct TblRow {
     __device__ __forceinline__ const void *operator[](int i) const { return base[i]; }
 };
 
-// PH 0-6: the phases of layer l; PH 7, 8: the tail (last residual add + model norm; head projection)
-template <int PH, int NF1, int NF2, class LP>
+// PH 0-6: the phases of layer l; PH 7, 8: the tail (last residual add + model norm; head projection).  P1, P2: row phases:
+// P1 = NG (float4 groups per thread); head phase: fragment slots NF1, NF2.
+template <int PH, int P1, int P2, class LP>
 __device__ __forceinline__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, const LP &lp) {
     const int D = d.D;
     if constexpr (PH == 7) {
         for (int b = blockIdx.x; b < d.B; b += gridDim.x)
-            row_phase<0>(d, b, sm.red, d.xa, d.p_val, d.ks_val, nullptr, nullptr, nullptr, nullptr, d.norm_w, d.norm_b, nullptr, nullptr,
-                         d.hfin);
+            row_phase<0, P1>(d, b, sm.red, d.xa, d.p_val, d.ks_val, nullptr, nullptr, nullptr, nullptr, G_U16(d.norm_w), G_U16(d.norm_b),
+                             nullptr, nullptr, d.hfin);
     } else if constexpr (PH == 8) {
-        const GemvSeg seg[1] = {{d.head_w, d.hfin, (d.V + 31) / 32, d.V}};
+        const GemvSeg seg[1] = {{G_U16(d.head_w), d.hfin, (d.V + 31) / 32, d.V}};
         gemv_phase<0, 1>(d, sm, seg, D, 1, d.logits, d.V, d.head_b);
     } else if constexpr (PH == 0) {
-        const uint16_t *mixp[6] = {(const uint16_t *)lp[DP_XR], (const uint16_t *)lp[DP_XW], (const uint16_t *)lp[DP_XK],
-                                   (const uint16_t *)lp[DP_XV], (const uint16_t *)lp[DP_XA], (const uint16_t *)lp[DP_XG]};
+        const gu16 mixp[6] = {G_U16(lp[DP_XR]), G_U16(lp[DP_XW]), G_U16(lp[DP_XK]), G_U16(lp[DP_XV]), G_U16(lp[DP_XA]), G_U16(lp[DP_XG])};
+        const gu16 ln0w = G_U16(lp[DP_LN0_W]), ln0b = G_U16(lp[DP_LN0_B]), ln1w = G_U16(lp[DP_LN1_W]), ln1b = G_U16(lp[DP_LN1_B]);
+        const gu16m xprev = G_U16M(lp[DP_ATT_XPREV]);
         for (int b = blockIdx.x; b < d.B; b += gridDim.x)
-            row_phase<6>(d, b, sm.red, d.xa, d.p_val, d.ks_val, l == 0 ? d.x_in : nullptr, (const uint16_t *)lp[DP_LN0_W],
-                         (const uint16_t *)lp[DP_LN0_B], d.xb, (const uint16_t *)lp[DP_LN1_W], (const uint16_t *)lp[DP_LN1_B],
-                         (uint16_t *)lp[DP_ATT_XPREV], mixp, d.mixed);
+            row_phase<6, P1>(d, b, sm.red, d.xa, d.p_val, d.ks_val, l == 0 ? d.x_in : nullptr, ln0w, ln0b, d.xb, ln1w, ln1b, xprev, mixp,
+                             d.mixed);
     } else if constexpr (PH == 1) {
         const long RS = (long)kRows * D;  // one mixed plane: order r, w, k, v, a, g
         // layer 0 has no value-residual branch: its columns stay unwritten and unread
-        const GemvSeg segs[7] = {{(const uint16_t *)lp[DP_WR], d.mixed + 0 * RS, D / 32, D},
-                                 {(const uint16_t *)lp[DP_WK], d.mixed + 2 * RS, D / 32, D},
-                                 {(const uint16_t *)lp[DP_WV], d.mixed + 3 * RS, D / 32, D},
-                                 {(const uint16_t *)lp[DP_W1], d.mixed + 1 * RS, d.Rw / 32, d.Rw},
-                                 {(const uint16_t *)lp[DP_A1], d.mixed + 4 * RS, d.Ra / 32, d.Ra},
-                                 {(const uint16_t *)(l == 0 ? lp[DP_A1] : lp[DP_V1]), d.mixed + 3 * RS, l == 0 ? 0 : d.Rv / 32, d.Rv},
-                                 {(const uint16_t *)lp[DP_G1], d.mixed + 5 * RS, d.Rg / 32, d.Rg}};
+        const GemvSeg segs[7] = {{G_U16(lp[DP_WR]), d.mixed + 0 * RS, D / 32, D},
+                                 {G_U16(lp[DP_WK]), d.mixed + 2 * RS, D / 32, D},
+                                 {G_U16(lp[DP_WV]), d.mixed + 3 * RS, D / 32, D},
+                                 {G_U16(lp[DP_W1]), d.mixed + 1 * RS, d.Rw / 32, d.Rw},
+                                 {G_U16(lp[DP_A1]), d.mixed + 4 * RS, d.Ra / 32, d.Ra},
+                                 {G_U16(l == 0 ? lp[DP_A1] : lp[DP_V1]), d.mixed + 3 * RS, l == 0 ? 0 : d.Rv / 32, d.Rv},
+                                 {G_U16(lp[DP_G1]), d.mixed + 5 * RS, d.Rg / 32, d.Rg}};
         gemv_phase<0, 7>(d, sm, segs, D, d.ks_qkv, d.p_qkv, 3 * D + d.Rw + d.Ra + d.Rv + d.Rg, nullptr);
     } else if constexpr (PH == 2) {
-        head_phase<NF1, NF2>(d, sm, l, lp);
+        head_phase<P1, P2>(d, sm, l, lp);
     } else if constexpr (PH == 3) {
-        const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WO], d.yg, D / 32, D}};
+        const GemvSeg seg[1] = {{G_U16(lp[DP_WO]), d.yg, D / 32, D}};
         gemv_phase<0, 1>(d, sm, seg, D, d.ks_o, d.p_att, D, nullptr);
     } else if constexpr (PH == 4) {
-        const uint16_t *mixp[1] = {(const uint16_t *)lp[DP_FXK]};
+        const gu16 mixp[1] = {G_U16(lp[DP_FXK])};
+        const gu16 ln2w = G_U16(lp[DP_LN2_W]), ln2b = G_U16(lp[DP_LN2_B]);
+        const gu16m xprev = G_U16M(lp[DP_FFN_XPREV]);
         for (int b = blockIdx.x; b < d.B; b += gridDim.x)
-            row_phase<1>(d, b, sm.red, d.xb, d.p_att, d.ks_o, nullptr, nullptr, nullptr, d.xa, (const uint16_t *)lp[DP_LN2_W],
-                         (const uint16_t *)lp[DP_LN2_B], (uint16_t *)lp[DP_FFN_XPREV], mixp, d.kx);
+            row_phase<1, P1>(d, b, sm.red, d.xb, d.p_att, d.ks_o, nullptr, nullptr, nullptr, d.xa, ln2w, ln2b, xprev, mixp, d.kx);
     } else if constexpr (PH == 5) {
-        const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WKEY], d.kx, d.F / 16, d.F}};
+        const GemvSeg seg[1] = {{G_U16(lp[DP_WKEY]), d.kx, d.F / 16, d.F}};
         gemv_phase<1, 1, 16>(d, sm, seg, D, 1, d.kact, d.F, nullptr);
     } else {
-        const GemvSeg seg[1] = {{(const uint16_t *)lp[DP_WVAL], d.kact, D / 32, D}};
+        const GemvSeg seg[1] = {{G_U16(lp[DP_WVAL]), d.kact, D / 32, D}};
         gemv_phase<0, 1>(d, sm, seg, d.F, d.ks_val, d.p_val, D, nullptr);
     }
 }
 
+// Three instantiations of the width-dependent phases, shared by both launch modes so that they round alike (-ffast-math contracts
+// and reassociates differently in different instantiations): NG float4 groups per thread in the row phases, NF1 / NF2 fragment
+// slots in the head phase.  0: D <= 1024, ranks <= 64 / 128 (0.4B); 1: D <= 2048, ranks <= 128 / 256 (1.5B); 2: D <= 4096, ranks <= 256.
+template <int V> struct Variant;
+template <> struct Variant<0> { static constexpr int NG = 1, NF1 = 4, NF2 = 8; };
+template <> struct Variant<1> { static constexpr int NG = 2, NF1 = 8, NF2 = 16; };
+template <> struct Variant<2> { static constexpr int NG = kMaxE / 4, NF1 = kUpFrags, NF2 = kUpFrags; };
+
 // mode 1: the step; mode 2 (debug): the barriers alone
+template <int V>
 __global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDesc d, int mode) {
+    using W = Variant<V>;
     __shared__ DecSmem sm;
     unsigned target = 0;
     const int nphase = 7 * d.L + 2;
@@ -678,15 +716,15 @@ __global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDe
         if (mode == 1) {
             const TblRow lp{d.tbl + (long)(l < d.L ? l : 0) * DP_COUNT};
             switch (ph) {
-            case 0: run_phase<0, kUpFrags, kUpFrags>(d, sm, l, lp); break;
-            case 1: run_phase<1, kUpFrags, kUpFrags>(d, sm, l, lp); break;
-            case 2: run_phase<2, kUpFrags, kUpFrags>(d, sm, l, lp); break;
-            case 3: run_phase<3, kUpFrags, kUpFrags>(d, sm, l, lp); break;
-            case 4: run_phase<4, kUpFrags, kUpFrags>(d, sm, l, lp); break;
-            case 5: run_phase<5, kUpFrags, kUpFrags>(d, sm, l, lp); break;
-            case 6: run_phase<6, kUpFrags, kUpFrags>(d, sm, l, lp); break;
-            case 7: run_phase<7, kUpFrags, kUpFrags>(d, sm, l, lp); break;
-            default: run_phase<8, kUpFrags, kUpFrags>(d, sm, l, lp); break;
+            case 0: run_phase<0, W::NG, 0>(d, sm, l, lp); break;
+            case 1: run_phase<1, 0, 0>(d, sm, l, lp); break;
+            case 2: run_phase<2, W::NF1, W::NF2>(d, sm, l, lp); break;
+            case 3: run_phase<3, 0, 0>(d, sm, l, lp); break;
+            case 4: run_phase<4, W::NG, 0>(d, sm, l, lp); break;
+            case 5: run_phase<5, 0, 0>(d, sm, l, lp); break;
+            case 6: run_phase<6, 0, 0>(d, sm, l, lp); break;
+            case 7: run_phase<7, W::NG, 0>(d, sm, l, lp); break;
+            default: run_phase<8, 0, 0>(d, sm, l, lp); break;
             }
         }
         if (idx + 1 < nphase) grid_barrier(d.bar, target, gridDim.x, mode);
@@ -696,15 +734,41 @@ __global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDe
 // One kernel per phase (round 3; until then one kernel with a switch over the phase: every phase paid for the registers and
 // the SGPR spills of the largest one).  (Reading the descriptor from device memory through a 16-byte kernel argument instead was
 // measured 3 % slower in the replayed graph: one more dependent load at the head of every phase.)
-template <int PH, int NF1, int NF2>
+template <int PH, int P1, int P2>
 __global__ __launch_bounds__(kDecThreads) void decode_phase_kernel(DecodeDesc d, int l) {
     __shared__ DecSmem sm;
-    run_phase<PH, NF1, NF2>(d, sm, l, TblRow{d.tbl + (long)(PH < 7 ? l : 0) * DP_COUNT});
+    run_phase<PH, P1, P2>(d, sm, l, TblRow{d.tbl + (long)(PH < 7 ? l : 0) * DP_COUNT});
 }
 
-template <int PH, int NF1 = 4, int NF2 = 8>
+template <int PH, int P1 = 0, int P2 = 0>
 inline void launch_phase(int items, hipStream_t st, const DecodeDesc &d, int l) {
-    decode_phase_kernel<PH, NF1, NF2><<<dim3(items), dim3(kDecThreads), 0, st>>>(d, l);
+    decode_phase_kernel<PH, P1, P2><<<dim3(items), dim3(kDecThreads), 0, st>>>(d, l);
+}
+
+template <int V>
+void launch_phases(const int (&g_phase)[7], int items_l0_p1, int B, int L, int V_, hipStream_t st, const DecodeDesc &d) {
+    using W = Variant<V>;
+    for (int l = 0; l < L; l++) {
+        launch_phase<0, W::NG>(g_phase[0], st, d, l);
+        launch_phase<1>(l == 0 ? items_l0_p1 : g_phase[1], st, d, l);
+        launch_phase<2, W::NF1, W::NF2>(g_phase[2], st, d, l);
+        launch_phase<3>(g_phase[3], st, d, l);
+        launch_phase<4, W::NG>(g_phase[4], st, d, l);
+        launch_phase<5>(g_phase[5], st, d, l);
+        launch_phase<6>(g_phase[6], st, d, l);
+    }
+    launch_phase<7, W::NG>(B, st, d, L);
+    launch_phase<8>((V_ + 31) / 32, st, d, L);
+}
+
+inline int pick_variant(int D, int Rw, int Ra, int Rv, int Rg) {
+    const int ng = (D / 4 + kDecThreads - 1) / kDecThreads, nf1 = max(Rw, Ra) / 16, nf2 = max(Rv, Rg) / 16;
+    for (int v = 0; v < 2; v++) {
+        const int NG = v == 0 ? Variant<0>::NG : Variant<1>::NG, NF1 = v == 0 ? Variant<0>::NF1 : Variant<1>::NF1,
+                  NF2 = v == 0 ? Variant<0>::NF2 : Variant<1>::NF2;
+        if (ng <= NG && nf1 <= NF1 && nf2 <= NF2) return v;
+    }
+    return 2;
 }
 
 // K split of a GEMV phase: minimise the work of the busiest workgroup, where an item costs its K range plus a fixed
@@ -796,34 +860,27 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
     d.hfin = (uint16_t *)(ws + w.hfin);
     d.bar = (unsigned *)(ws + w.bar);
     (void)hipGetLastError();
+    const int variant = pick_variant(D, Rw, Ra, Rv, Rg);
     if (persistent) {
         int dev = 0, cus = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return (int)e;
-        // every workgroup must be resident at once: one per CU (14 KB of LDS and < 128 VGPRs leave room for it anywhere)
+        // every workgroup must be resident at once: one per CU (14 KB of LDS; 4 waves of <= 512 VGPRs fit any CU)
         const int grid = cus < kGrid ? cus : kGrid;
         e = hipMemsetAsync(d.bar, 0, 8, st);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(decode_persistent_kernel, dim3(grid), dim3(kDecThreads), 0, st, d, persistent);
+        if (variant == 0) decode_persistent_kernel<0><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
+        else if (variant == 1) decode_persistent_kernel<1><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
+        else decode_persistent_kernel<2><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
     } else {
         // one launch per phase, each sized to its own item count
         const int N2 = 3 * D + Rw + Ra + Rv + Rg;
-        const int nf1 = max(Rw, Ra) / 16, nf2 = max(Rv, Rg) / 16;   // fragment slots of the head phase's two jobs
         const int g_phase[7] = {B, (N2 / 32) * w.ks_qkv, H * ((B + 1) / 2), (D / 32) * w.ks_o, B, F / 16, (D / 32) * w.ks_val};
-        for (int l = 0; l < L; l++) {
-            launch_phase<0>(g_phase[0], st, d, l);
-            launch_phase<1>(l == 0 ? g_phase[1] - (Rv / 32) * w.ks_qkv : g_phase[1], st, d, l);
-            if (nf1 <= 4 && nf2 <= 8) launch_phase<2, 4, 8>(g_phase[2], st, d, l);          // 0.4B: 64, 64, 32, 128
-            else if (nf1 <= 8 && nf2 <= 16) launch_phase<2, 8, 16>(g_phase[2], st, d, l);   // 1.5B: 96, 96, 64, 256
-            else launch_phase<2, kUpFrags, kUpFrags>(g_phase[2], st, d, l);
-            launch_phase<3>(g_phase[3], st, d, l);
-            launch_phase<4>(g_phase[4], st, d, l);
-            launch_phase<5>(g_phase[5], st, d, l);
-            launch_phase<6>(g_phase[6], st, d, l);
-        }
-        launch_phase<7>(B, st, d, L);
-        launch_phase<8>((V + 31) / 32, st, d, L);
+        const int p1_l0 = g_phase[1] - (Rv / 32) * w.ks_qkv;   // layer 0 has no value-residual columns
+        if (variant == 0) launch_phases<0>(g_phase, p1_l0, B, L, V, st, d);
+        else if (variant == 1) launch_phases<1>(g_phase, p1_l0, B, L, V, st, d);
+        else launch_phases<2>(g_phase, p1_l0, B, L, V, st, d);
     }
     return (int)hipGetLastError();
 }
