@@ -416,6 +416,13 @@ size_t rwkv7_decode_workspace_bytes(const rwkv7_decode_dims *dims);   /* 0: unsu
 int rwkv7_decode_step_bf16(const rwkv7_decode_dims *dims, const void *const *layer_tbl, const void *x_in, const void *norm_w,
                            const void *norm_b, const void *head_w, const void *head_b, float *logits, void *workspace,
                            int persistent, rwkv7_stream_t stream);
+/* the same step for a caller that also holds the table in HOST memory (layer_tbl_host: the same [L][RWKV7_DEC_COUNT] addresses,
+ * read during the call only): with persistent = 0 every phase kernel then receives its 1-13 pointers as kernel arguments instead of
+ * fetching its table row first -- one dependent load less at the head of each of the 7 L + 2 launches (0.3-0.4 us each, measured).
+ * Results are bit-identical to rwkv7_decode_step_bf16. */
+int rwkv7_decode_step_tbl_bf16(const rwkv7_decode_dims *dims, const void *const *layer_tbl, const void *const *layer_tbl_host,
+                               const void *x_in, const void *norm_w, const void *norm_b, const void *head_w, const void *head_b,
+                               float *logits, void *workspace, int persistent, rwkv7_stream_t stream);
 
 /* the low-rank pair of the decode step in one launch: y[M,N] = act(x[M,K] @ w1[R,K]^T) @ w2[N,R]^T (+ bias); M <= 32,
  * K % 64 == 0, R in {32,64,128}, act 0 none / 1 tanh / 2 sigmoid (rwkv_s2s_single_ffn.py:497-500: w, a, v, g branches) */

@@ -53,8 +53,8 @@ int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
 int decode_layer_ptrs();
 size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
-int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *, const void *,
-                     const void *, const void *, const void *, float *, void *, int, hipStream_t);
+int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *const *, const void *,
+                     const void *, const void *, const void *, const void *, float *, void *, int, hipStream_t);
 struct bf16_t;
 template <typename T> int mix_fwd(int, int, int, int, const void *, const void *, const void *, const void *, void *, int, hipStream_t);
 template <typename T> int mix_bwd(int, int, int, int, const void *const *, const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t);
@@ -515,7 +515,18 @@ int rwkv7_decode_step_bf16(const rwkv7_decode_dims *dm, const void *const *layer
         return RWKV7_EINVAL;
     if (dm->H * RWKV7_HEAD_SIZE != dm->D) return RWKV7_EHEAD;
     return rwkv7::decode_step_bf16(dm->B, dm->D, dm->H, dm->L, dm->F, dm->V, dm->Rw, dm->Ra, dm->Rv, dm->Rg, dm->ln_eps, dm->gn_eps,
-                                   layer_tbl, x_in, norm_w, norm_b, head_w, head_b, logits, workspace, persistent,
+                                   layer_tbl, nullptr, x_in, norm_w, norm_b, head_w, head_b, logits, workspace, persistent,
+                                   (hipStream_t)stream);
+}
+int rwkv7_decode_step_tbl_bf16(const rwkv7_decode_dims *dm, const void *const *layer_tbl, const void *const *layer_tbl_host,
+                               const void *x_in, const void *norm_w, const void *norm_b, const void *head_w, const void *head_b,
+                               float *logits, void *workspace, int persistent, rwkv7_stream_t stream) {
+    if (!dm || any_null({(const void *)layer_tbl, (const void *)layer_tbl_host, x_in, norm_w, norm_b, head_w, (const void *)logits,
+                         (const void *)workspace}))
+        return RWKV7_EINVAL;
+    if (dm->H * RWKV7_HEAD_SIZE != dm->D) return RWKV7_EHEAD;
+    return rwkv7::decode_step_bf16(dm->B, dm->D, dm->H, dm->L, dm->F, dm->V, dm->Rw, dm->Ra, dm->Rv, dm->Rg, dm->ln_eps, dm->gn_eps,
+                                   layer_tbl, layer_tbl_host, x_in, norm_w, norm_b, head_w, head_b, logits, workspace, persistent,
                                    (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {

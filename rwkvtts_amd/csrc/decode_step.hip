@@ -639,11 +639,52 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
     }
 }
 
-// the layer's pointers: a row of the device table.  (Passing the 38 pointers as kernel arguments instead -- no dependent
-// table load at the head of a phase -- measured SLOWER: 0.5-1.5 us per phase for the 300 bytes of extra kernarg.)
+// the layer's pointers: a row of the device table (persistent kernel) ...
 struct TblRow {
     const void *const *base;
     __device__ __forceinline__ const void *operator[](int i) const { return base[i]; }
+};
+// ... or, in the one-kernel-per-phase mode, the phase's own pointers as kernel arguments: no dependent table load between the
+// kernel arguments and the first data.  (Round 2 measured all 38 pointers as arguments of the all-phases kernel SLOWER by 0.5-1.5 us
+// per phase -- 300 bytes of kernarg and 76 more live SGPRs in a kernel that already spilled them; a phase needs 1 to 13.)
+__host__ __device__ constexpr int dp_slot(int ph, int dp) {
+    switch (ph) {
+    case 0:
+        switch (dp) {
+        case DP_LN0_W: return 0; case DP_LN0_B: return 1; case DP_LN1_W: return 2; case DP_LN1_B: return 3; case DP_XR: return 4;
+        case DP_XW: return 5; case DP_XK: return 6; case DP_XV: return 7; case DP_XA: return 8; case DP_XG: return 9;
+        case DP_ATT_XPREV: return 10; default: return -1;
+        }
+    case 1:
+        switch (dp) {
+        case DP_WR: return 0; case DP_WK: return 1; case DP_WV: return 2; case DP_W1: return 3; case DP_A1: return 4; case DP_V1: return 5;
+        case DP_G1: return 6; default: return -1;
+        }
+    case 2:
+        switch (dp) {
+        case DP_W2: return 0; case DP_A2: return 1; case DP_V2: return 2; case DP_G2: return 3; case DP_KK: return 4; case DP_KA: return 5;
+        case DP_RK: return 6; case DP_GNW: return 7; case DP_GNB: return 8; case DP_W0: return 9; case DP_A0: return 10;
+        case DP_V0: return 11; case DP_ATT_KV: return 12; default: return -1;
+        }
+    case 3: return dp == DP_WO ? 0 : -1;
+    case 4:
+        switch (dp) {
+        case DP_LN2_W: return 0; case DP_LN2_B: return 1; case DP_FXK: return 2; case DP_FFN_XPREV: return 3; default: return -1;
+        }
+    case 5: return dp == DP_WKEY ? 0 : -1;
+    case 6: return dp == DP_WVAL ? 0 : -1;
+    default: return -1;
+    }
+}
+__host__ __device__ constexpr int dp_count(int ph) {
+    int n = 0;
+    for (int dp = 0; dp < DP_COUNT; dp++) n += dp_slot(ph, dp) >= 0;
+    return n;
+}
+template <int PH>
+struct ArgRow {
+    const void *p[dp_count(PH) ? dp_count(PH) : 1];
+    __device__ __forceinline__ const void *operator[](int dp) const { return p[dp_slot(PH, dp) >= 0 ? dp_slot(PH, dp) : 0]; }
 };
 
 // PH 0-6: the phases of layer l; PH 7, 8: the tail (last residual add + model norm; head projection).  P1, P2: row phases:
@@ -735,30 +776,47 @@ __global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDe
 // the SGPR spills of the largest one).  (Reading the descriptor from device memory through a 16-byte kernel argument instead was
 // measured 3 % slower in the replayed graph: one more dependent load at the head of every phase.)
 template <int PH, int P1, int P2>
-__global__ __launch_bounds__(kDecThreads) void decode_phase_kernel(DecodeDesc d, int l) {
+__global__ __launch_bounds__(kDecThreads) void decode_phase_kernel(DecodeDesc d, int l, ArgRow<PH> row) {
+    __shared__ DecSmem sm;
+    run_phase<PH, P1, P2>(d, sm, l, row);
+}
+// the same phase reading its pointers from the device table (callers that have no host copy of it)
+template <int PH, int P1, int P2>
+__global__ __launch_bounds__(kDecThreads) void decode_phase_tbl_kernel(DecodeDesc d, int l) {
     __shared__ DecSmem sm;
     run_phase<PH, P1, P2>(d, sm, l, TblRow{d.tbl + (long)(PH < 7 ? l : 0) * DP_COUNT});
 }
 
+// host_tbl: the layer table in host memory, or nullptr
 template <int PH, int P1 = 0, int P2 = 0>
-inline void launch_phase(int items, hipStream_t st, const DecodeDesc &d, int l) {
-    decode_phase_kernel<PH, P1, P2><<<dim3(items), dim3(kDecThreads), 0, st>>>(d, l);
+inline void launch_phase(int items, hipStream_t st, const DecodeDesc &d, int l, const void *const *host_tbl) {
+    if (!host_tbl) {
+        decode_phase_tbl_kernel<PH, P1, P2><<<dim3(items), dim3(kDecThreads), 0, st>>>(d, l);
+        return;
+    }
+    ArgRow<PH> row;
+    row.p[0] = nullptr;
+    if (PH < 7)
+        for (int dp = 0; dp < DP_COUNT; dp++)
+            if (dp_slot(PH, dp) >= 0) row.p[dp_slot(PH, dp)] = host_tbl[(long)l * DP_COUNT + dp];
+    decode_phase_kernel<PH, P1, P2><<<dim3(items), dim3(kDecThreads), 0, st>>>(d, l, row);
 }
 
 template <int V>
-void launch_phases(const int (&g_phase)[7], int items_l0_p1, int B, int L, int V_, hipStream_t st, const DecodeDesc &d) {
+void launch_phases(const int (&g_phase)[7], int items_l0_p1, int B, int L, int V_, hipStream_t st, const DecodeDesc &d,
+                   const void *const *ht) {
     using W = Variant<V>;
     for (int l = 0; l < L; l++) {
-        launch_phase<0, W::NG>(g_phase[0], st, d, l);
-        launch_phase<1>(l == 0 ? items_l0_p1 : g_phase[1], st, d, l);
-        launch_phase<2, W::NF1, W::NF2>(g_phase[2], st, d, l);
-        launch_phase<3>(g_phase[3], st, d, l);
-        launch_phase<4, W::NG>(g_phase[4], st, d, l);
-        launch_phase<5>(g_phase[5], st, d, l);
-        launch_phase<6>(g_phase[6], st, d, l);
+        launch_phase<0, W::NG>(g_phase[0], st, d, l, ht);
+        launch_phase<1>(l == 0 ? items_l0_p1 : g_phase[1], st, d, l, ht);
+        launch_phase<2, W::NF1, W::NF2>(g_phase[2], st, d, l, ht);
+        launch_phase<3>(g_phase[3], st, d, l, ht);
+        launch_phase<4, W::NG>(g_phase[4], st, d, l, ht);
+        launch_phase<5>(g_phase[5], st, d, l, ht);
+        launch_phase<6>(g_phase[6], st, d, l, ht);
     }
-    launch_phase<7, W::NG>(B, st, d, L);
-    launch_phase<8>((V_ + 31) / 32, st, d, L);
+    launch_phase<7, W::NG>(B, st, d, L, ht);
+    launch_phase<8>((V_ + 31) / 32, st, d, L, ht);
 }
 
 inline int pick_variant(int D, int Rw, int Ra, int Rv, int Rg) {
@@ -838,8 +896,9 @@ size_t decode_workspace_bytes(int B, int D, int H, int F, int V, int Rw, int Ra,
 }
 
 int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, int Rv, int Rg, float ln_eps, float gn_eps,
-                     const void *const *layer_tbl, const void *x_in, const void *norm_w, const void *norm_b, const void *head_w,
-                     const void *head_b, float *logits, void *workspace, int persistent, hipStream_t st) {
+                     const void *const *layer_tbl, const void *const *layer_tbl_host, const void *x_in, const void *norm_w,
+                     const void *norm_b, const void *head_w, const void *head_b, float *logits, void *workspace, int persistent,
+                     hipStream_t st) {
     WsLayout w;
     if (!shape_ok(B, D, H, F, V, Rw, Ra, Rv, Rg) || L < 1 || !ws_layout(D, F, Rw, Ra, Rv, Rg, w)) return -4;  // RWKV7_ESHAPE
     char *ws = (char *)workspace;
@@ -878,9 +937,9 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
         const int N2 = 3 * D + Rw + Ra + Rv + Rg;
         const int g_phase[7] = {B, (N2 / 32) * w.ks_qkv, H * ((B + 1) / 2), (D / 32) * w.ks_o, B, F / 16, (D / 32) * w.ks_val};
         const int p1_l0 = g_phase[1] - (Rv / 32) * w.ks_qkv;   // layer 0 has no value-residual columns
-        if (variant == 0) launch_phases<0>(g_phase, p1_l0, B, L, V, st, d);
-        else if (variant == 1) launch_phases<1>(g_phase, p1_l0, B, L, V, st, d);
-        else launch_phases<2>(g_phase, p1_l0, B, L, V, st, d);
+        if (variant == 0) launch_phases<0>(g_phase, p1_l0, B, L, V, st, d, layer_tbl_host);
+        else if (variant == 1) launch_phases<1>(g_phase, p1_l0, B, L, V, st, d, layer_tbl_host);
+        else launch_phases<2>(g_phase, p1_l0, B, L, V, st, d, layer_tbl_host);
     }
     return (int)hipGetLastError();
 }

@@ -37,10 +37,12 @@ class DecodeStep:
     """logits[B,V] (fp32) = step(x_in[B,D] bf16) on the live `cache` of a bf16 RWKV7Model + head; the cache's state tensors
     are updated in place.  Raises ValueError for shapes/dtypes the kernel does not cover (see `supported`)."""
 
-    def __init__(self, backbone, lm_head, cache: Cache, persistent: int = 0):
+    def __init__(self, backbone, lm_head, cache: Cache, persistent: int = 0, host_table: bool = True):
         why = self.supported(backbone, lm_head, cache)
         if why:
             raise ValueError("rwkv7_decode_step_bf16: " + why)
+        # host_table = False: rwkv7_decode_step_bf16 (device table only: every phase kernel fetches its pointer row first)
+        self.host_table = bool(host_table)
         cfg = backbone.config
         lib = _lib.lib()
         if lib.rwkv7_decode_layer_ptrs() != len(_DEC_ORDER):
@@ -80,7 +82,8 @@ class DecodeStep:
                     self._keep.append(ten)
                 row.append(0 if ten is None else ten.data_ptr())
             rows.append(row)
-        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.table_host = torch.tensor(rows, dtype=torch.int64)   # the phase kernels take their pointers as arguments
+        self.table = self.table_host.to(dev)
         self.norm, self.head = backbone.norm, lm_head
         self.logits = torch.empty(self.B, self.dims.V, dtype=torch.float32, device=dev)
         self.persistent = int(persistent)   # 2 (debug): the barriers of the persistent kernel without the phases
@@ -116,13 +119,17 @@ class DecodeStep:
         assert x_in.shape == (self.B, self.dims.D) and x_in.dtype == torch.bfloat16 and x_in.is_contiguous()
         hb = self.head.bias
         with torch.cuda.device_of(x_in):
-            rc = _lib.lib().rwkv7_decode_step_bf16(
-                ctypes.byref(self.dims), ctypes.c_void_p(self.table.data_ptr()), ctypes.c_void_p(x_in.data_ptr()),
-                ctypes.c_void_p(self.norm.weight.data_ptr()), ctypes.c_void_p(self.norm.bias.data_ptr()),
-                ctypes.c_void_p(self.head.weight.data_ptr()), ctypes.c_void_p(hb.data_ptr() if hb is not None else None),
-                ctypes.c_void_p(self.logits.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()), int(self.persistent),
-                ctypes.c_void_p(torch.cuda.current_stream(x_in.device).cuda_stream))
-        _lib.check(rc, "rwkv7_decode_step_bf16")
+            tail = (ctypes.c_void_p(x_in.data_ptr()),
+                    ctypes.c_void_p(self.norm.weight.data_ptr()), ctypes.c_void_p(self.norm.bias.data_ptr()),
+                    ctypes.c_void_p(self.head.weight.data_ptr()), ctypes.c_void_p(hb.data_ptr() if hb is not None else None),
+                    ctypes.c_void_p(self.logits.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()), int(self.persistent),
+                    ctypes.c_void_p(torch.cuda.current_stream(x_in.device).cuda_stream))
+            if self.host_table:
+                rc = _lib.lib().rwkv7_decode_step_tbl_bf16(ctypes.byref(self.dims), ctypes.c_void_p(self.table.data_ptr()),
+                                                           ctypes.c_void_p(self.table_host.data_ptr()), *tail)
+            else:
+                rc = _lib.lib().rwkv7_decode_step_bf16(ctypes.byref(self.dims), ctypes.c_void_p(self.table.data_ptr()), *tail)
+        _lib.check(rc, "rwkv7_decode_step_tbl_bf16" if self.host_table else "rwkv7_decode_step_bf16")
         return self.logits
 
     def barrier_timed_out(self) -> bool:
@@ -266,7 +273,7 @@ class MultiGroupDecoder:
     """More sequences than one step kernel launch covers (B <= 32), and more of the GPU than one group uses: a decode step is a
     chain of ~170 latency-bound launches that leaves most of the chip idle, so k independent groups of up to 32 sequences -- each
     a GraphDecoder with its own recurrent state, static buffers and captured step -- are replayed round-robin on k streams and
-    overlap (measured on MI355X, 0.4B, greedy: 1 x 32 sequences 27.8 k tokens/s, 2 x 32 41 k, 8 x 32 44.5 k).  The serving shape
+    overlap (measured on MI355X, 0.4B, greedy: round 2 kernels: 1 x 32 sequences 27.8 k tokens/s, 2 x 32 41 k, 8 x 32 44.5 k; round 3: 1 x 32 = 32.7 k).  The serving shape
     of SURVEY 8f N3 ("persistent multi-request decode"): the reference runs one engine thread per request on a side stream
     (service/tts_service.py:42-60, cosyvoice/cli/model.py:64,147-169).
 

@@ -63,8 +63,10 @@ def test_step_kernel_vs_module_path_and_fp32(D, L, V, ranks, B, bias):
     c32, lg32 = _prefill(m32, prompt, B, torch.float32)
     ck = _clone_cache(c16)   # step kernel, persistent
     cp = _clone_cache(c16)   # step kernel, one launch per phase
+    ct = _clone_cache(c16)   # one launch per phase through the device-table entry (rwkv7_decode_step_bf16)
     step_k = DecodeStep(m16.model, m16.lm_head, ck, persistent=True)
     step_p = DecodeStep(m16.model, m16.lm_head, cp, persistent=False)
+    step_t = DecodeStep(m16.model, m16.lm_head, ct, persistent=False, host_table=False)
     emb = m16.model.embeddings.weight
     worst_mod = worst_ker = 0.0
     for it in range(5):
@@ -75,6 +77,7 @@ def test_step_kernel_vs_module_path_and_fp32(D, L, V, ranks, B, bias):
             x = torch.nn.functional.embedding(ids, emb)
             lk = step_k(x).clone()
             lp = step_p(x).clone()
+            assert torch.equal(step_t(x), lp)   # pointers as kernel arguments or fetched from the table: the same kernels otherwise
         assert not step_k.barrier_timed_out()
         assert torch.isfinite(lk).all()
         # same arithmetic in both launch modes
@@ -84,6 +87,8 @@ def test_step_kernel_vs_module_path_and_fp32(D, L, V, ranks, B, bias):
         worst_ker = max(worst_ker, (lk - lg32).abs().max().item() / scale)
     assert worst_ker < 3e-2, (worst_ker, worst_mod)
     assert worst_ker < 1.5 * worst_mod + 2e-3, (worst_ker, worst_mod)
+    for st_, sp in zip(ct.states, cp.states):
+        assert torch.equal(st_.att_kv, sp.att_kv) and torch.equal(st_.att_x_prev, sp.att_x_prev) and torch.equal(st_.ffn_x_prev, sp.ffn_x_prev)
     for sk, sp, s32 in zip(ck.states, cp.states, c32.states):
         assert torch.equal(sk.att_kv, sp.att_kv) and torch.equal(sk.att_x_prev, sp.att_x_prev) and torch.equal(sk.ffn_x_prev, sp.ffn_x_prev)
         ref = s32.att_kv
