@@ -185,7 +185,7 @@ def decode_rate(model, dev, B=32, P=128, n1=256, n2=2048):
             "value": round(B / step, 1), "unit": "tokens/s", "ms_per_step": round(step * 1e3, 4), "batch": B, "prompt": P,
             "new_tokens": n2, "total_s_incl_prefill_capture": round(t2, 3),
             "bytes_per_step": wbytes + sbytes, "hbm_floor_ms": round(floor * 1e3, 4), "frac_of_hbm_bound": round(floor / step, 4),
-            "path": "rwkv7_decode_step_bf16, one launch per phase, hipGraph replay" if kernel else "module by module, hipGraph replay",
+            "path": "rwkv7_decode_step_tbl_bf16, one kernel launch per phase, hipGraph replay" if kernel else "module by module, hipGraph replay",
             "multi_group": multi}
 
 
