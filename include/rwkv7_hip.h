@@ -424,6 +424,29 @@ int rwkv7_decode_step_tbl_bf16(const rwkv7_decode_dims *dims, const void *const 
                                const void *x_in, const void *norm_w, const void *norm_b, const void *head_w, const void *head_b,
                                float *logits, void *workspace, int persistent, rwkv7_stream_t stream);
 
+/* ---- token draws of the generation loops, one launch each (csrc/sampling.hip).
+ *
+ * rwkv7_sample_rows_f32: for every row r < rows and segment s < nseg one id from logits[r * ld + seg_off[s] .. + seg_len[s])
+ *      (fp32), restricted to the ids [allow_lo[s], allow_hi[s]) of the segment (NULL: the whole segment) and never one of
+ *      `suppress` (segment-relative ids, nsuppress <= 256).  do_sample = 0: argmax (first maximum).  do_sample = 1: the warper
+ *      chain the reference's generate() runs (HF temperature -> top-k -> top-p -> softmax -> multinomial; utils/utilities.py:101-117,
+ *      model/llm/xy_llm.py:88-101 for the eight channels of a frame): top_k in [1, 64] with any top_p in (0, 1], or top_k = 0 with
+ *      top_p = 1 (plain multinomial); temperature > 0.  seg_off / seg_len / allow_* / suppress are DEVICE int arrays; max_domain =
+ *      the largest allow_hi - allow_lo (or seg_len), <= 15360.  out: [rows][nseg] int64 ids (segment-relative).
+ *      Randomness: Philox4x32-10 keyed by `seed`, counter (*step, workgroup): `step` is a DEVICE int64 the caller advances between
+ *      calls (the position counter of the decode loop), so a captured launch draws fresh ids on every replay and (seed, *step)
+ *      fixes them.  RWKV7_ESHAPE for parameter combinations outside the above (the Python host then runs the torch chain).
+ * rwkv7_ras_step_f32: one token of CosyVoice's streaming loop (B = 1): ras_sampling (third_party/cosyvoice/utils/common.py:109-137:
+ *      nucleus top_p / top_k, and random_sampling when the candidate already occurs >= win_size * tau_r times in `recent`) with the
+ *      EOS rejection of sampling_ids (model/llm/llm.py:160-176) while *step_i < n_ignore, followed by the loop's bookkeeping:
+ *      *tok = id; if id != eos: recent[*ptr] = id, *ptr = (*ptr + 1) % win_size; *step_i += 1.  logits fp32 [V] (any shift of the
+ *      log-probabilities), V <= 15360, top_k <= 128, win_size <= 128; tok / recent [win_size] / ptr / step_i DEVICE int64. */
+int rwkv7_sample_rows_f32(int rows, int nseg, const float *logits, long ld, const int *seg_off, const int *seg_len, const int *allow_lo,
+                          const int *allow_hi, const int *suppress, int nsuppress, int max_domain, int do_sample, int top_k, float top_p,
+                          float temperature, unsigned long long seed, const long *step, long *out, rwkv7_stream_t stream);
+int rwkv7_ras_step_f32(int V, const float *logits, long *tok, long *recent, long *ptr, long *step_i, long n_ignore, int eos, float top_p,
+                       int top_k, int win_size, float tau_r, unsigned long long seed, rwkv7_stream_t stream);
+
 /* the low-rank pair of the decode step in one launch: y[M,N] = act(x[M,K] @ w1[R,K]^T) @ w2[N,R]^T (+ bias); M <= 32,
  * K % 64 == 0, R in {32,64,128}, act 0 none / 1 tanh / 2 sigmoid (rwkv_s2s_single_ffn.py:497-500: w, a, v, g branches) */
 int rwkv7_lora32_bf16(int M, int N, int K, int R, int act, const void *x, const void *w1, const void *w2, const void *bias,

@@ -271,8 +271,16 @@ class RWKV7CosyLM(HFModelMixin, nn.Module):
                 g_i = torch.tensor(i + 1, device=device)
                 n_ignore = min_len - original_text_len   # ignore_eos while step index < n_ignore
 
+                from .sampling import MAX_DOMAIN, ras_step
+                fused = getattr(self, "fused_sampling", True) and eos + 1 <= MAX_DOMAIN and 1 <= sampling <= 128
+                seed_ = torch.cuda.initial_seed()
+
                 def captured():
                     x = self.speech_embedding.weight[g_tok]                      # [1, D]
+                    if fused:   # draw + ring / counter update as ONE launch (csrc/sampling.hip); keyed by (seed, g_i)
+                        ras_step(step_kernel(x.contiguous())[0], g_tok, g_recent, g_ptr, g_i, n_ignore, eos, top_k=sampling, win_size=win,
+                                 seed=seed_)
+                        return
                     logp_ = step_kernel(x.contiguous())[0].float().log_softmax(dim=-1)
                     new = ras_sampling_device(logp_, g_recent, g_i < n_ignore, eos, top_k=sampling)
                     g_tok.copy_(new)

@@ -51,6 +51,9 @@ int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *,
                         hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
+int sample_rows_f32(int, int, const float *, long, const int *, const int *, const int *, const int *, const int *, int, int, int, int, float,
+                    float, unsigned long long, const long *, long *, hipStream_t);
+int ras_step_f32(int, const float *, long *, long *, long *, long *, long, int, float, int, int, float, unsigned long long, hipStream_t);
 int decode_layer_ptrs();
 size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
 int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *const *, const void *,
@@ -528,6 +531,22 @@ int rwkv7_decode_step_tbl_bf16(const rwkv7_decode_dims *dm, const void *const *l
     return rwkv7::decode_step_bf16(dm->B, dm->D, dm->H, dm->L, dm->F, dm->V, dm->Rw, dm->Ra, dm->Rv, dm->Rg, dm->ln_eps, dm->gn_eps,
                                    layer_tbl, layer_tbl_host, x_in, norm_w, norm_b, head_w, head_b, logits, workspace, persistent,
                                    (hipStream_t)stream);
+}
+int rwkv7_sample_rows_f32(int rows, int nseg, const float *logits, long ld, const int *seg_off, const int *seg_len, const int *allow_lo,
+                          const int *allow_hi, const int *suppress, int nsuppress, int max_domain, int do_sample, int top_k, float top_p,
+                          float temperature, unsigned long long seed, const long *step, long *out, rwkv7_stream_t stream) {
+    if (rows <= 0 || nseg <= 0 || max_domain <= 0 || nsuppress < 0 ||
+        any_null({(const void *)logits, (const void *)seg_off, (const void *)seg_len, (const void *)step, (const void *)out}) ||
+        (nsuppress > 0 && !suppress))
+        return RWKV7_EINVAL;
+    return rwkv7::sample_rows_f32(rows, nseg, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, max_domain, do_sample,
+                                  top_k, top_p, temperature, seed, step, out, (hipStream_t)stream);
+}
+int rwkv7_ras_step_f32(int V, const float *logits, long *tok, long *recent, long *ptr, long *step_i, long n_ignore, int eos, float top_p,
+                       int top_k, int win_size, float tau_r, unsigned long long seed, rwkv7_stream_t stream) {
+    if (V <= 0 || any_null({(const void *)logits, (const void *)tok, (const void *)recent, (const void *)ptr, (const void *)step_i}))
+        return RWKV7_EINVAL;
+    return rwkv7::ras_step_f32(V, logits, tok, recent, ptr, step_i, n_ignore, eos, top_p, top_k, win_size, tau_r, seed, (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {
     if (!in || !addr || !out) return RWKV7_EINVAL;

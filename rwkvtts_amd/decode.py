@@ -146,18 +146,18 @@ class GraphDecoder:
         self.graph = None
         self.step_kernel = step_kernel
         self.step = None
+        self.fused_sampling = True   # False: the torch chain (spark_llm.sample_next) on torch's device generator
+        self.seed_offset = 0         # added to the device seed for the fused sampler (MultiGroupDecoder: one stream of draws per group)
 
     @torch.no_grad()
     def _step(self):
         if self.step is not None:
             x = F.embedding(self.ids, self.model.get_input_embeddings().weight)
-            logits = self.step(x).clone()
+            logits = self.step(x)           # the step kernel's own buffer: _pick copies it before it edits it
             self.cache.seen_tokens += 1
         else:
             out = self.model(input_ids=self.ids.unsqueeze(1), past_key_values=self.cache, use_cache=True)
             logits = out.logits[:, -1].float()
-        if self.suppress is not None:
-            logits.index_fill_(1, self.suppress, float("-inf"))
         nxt = self._pick(logits)
         if self.eos is not None:
             nxt = torch.where(self.unfinished, nxt, self.pad_t)
@@ -170,7 +170,21 @@ class GraphDecoder:
         """argmax, or temperature / top-k / top-p multinomial sampling (spark_llm.sample_next: the HF warper order the reference's
         generate runs, utils/utilities.py:101-117) -- inside the captured step too: torch's device generator is graph-safe
         (philox seed/offset live in device memory and advance per replay), so sampled decode replays like greedy decode."""
+        from .sampling import RowSampler
         from .spark_llm import sample_next
+        if self.sampler is None and self._try_fused:
+            # suppression, the warper chain and the draw as ONE launch (csrc/sampling.hip) when the request is covered: the torch chain
+            # is ~15 launches (0.45 ms of a 1.4 ms step at B = 32); keyed by (seed, self.pos) instead of torch's generator
+            self._try_fused = False
+            sup = None if self.suppress is None else self.suppress.tolist()
+            if RowSampler.supported(logits.device, [logits.shape[-1]], None, sup, self.do_sample, self.top_k, self.top_p,
+                                    self.temperature) is None:
+                self.sampler = RowSampler(logits.device, [logits.shape[-1]], None, sup, self.do_sample, self.top_k, self.top_p,
+                                          self.temperature, seed=torch.cuda.initial_seed() + self.seed_offset)
+        if self.sampler is not None:
+            return self.sampler(logits, self.pos)[:, 0]
+        if self.suppress is not None:
+            logits = logits.clone().index_fill_(1, self.suppress, float("-inf"))
         return sample_next(logits, self.do_sample, self.top_k, self.top_p, self.temperature)
 
     @torch.no_grad()
@@ -205,6 +219,7 @@ class GraphDecoder:
         self.max_new_tokens, self.steps_left, self.graph = max_new_tokens, 0, None
         if seed is not None:
             torch.cuda.manual_seed(seed)
+        self.sampler, self._try_fused = None, self.fused_sampling
         m = self.model
         dev = m.device
         B = self.B
@@ -220,8 +235,6 @@ class GraphDecoder:
         o = m(input_ids=input_ids if inputs_embeds is None else None, inputs_embeds=inputs_embeds,
               attention_mask=attention_mask, past_key_values=self.cache, use_cache=True, logits_to_keep=1)
         logits = o.logits[:, -1].float()
-        if self.suppress is not None:
-            logits.index_fill_(1, self.suppress, float("-inf"))
         first = self._pick(logits)
         self.ids = first.clone()
         self.out[:, 0] = first
@@ -295,6 +308,8 @@ class MultiGroupDecoder:
         sl = lambda t, a: None if t is None else t[a:a + self.group_size]
         main = torch.cuda.current_stream()
         self.decoders = [GraphDecoder(self.model, min(self.group_size, B - a), self.step_kernel) for a in cuts]
+        for gi, d in enumerate(self.decoders):
+            d.seed_offset = gi
         while len(self.streams) < len(cuts):
             self.streams.append(torch.cuda.Stream())
         seed = kw.pop("seed", None)

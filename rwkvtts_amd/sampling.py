@@ -1,0 +1,96 @@
+"""Host side of csrc/sampling.hip: the token draws of the generation loops as one launch each.
+
+RowSampler   argmax or HF's temperature -> top-k -> top-p -> multinomial chain (spark_llm.sample_next, the reference's generate():
+             utils/utilities.py:101-117; the eight channels of an XY frame: model/llm/xy_llm.py:88-101) for every (row, segment)
+             of a logits matrix, ids straight from the decode step's fp32 logits.
+ras_step     CosyVoice's repetition-aware sampler + the streaming loop's bookkeeping (cosy_llm.ras_sampling_device).
+Both draw with a counter-based generator keyed by (seed, step tensor): no torch generator state, graph-capturable, reproducible.
+"""
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+MAX_DOMAIN = 15360
+MAX_TOP_K = 64
+
+
+class RowSampler:
+    @staticmethod
+    def supported(logits_device, seg_len: Sequence[int], allow=None, suppress=None, do_sample=False, top_k=0, top_p=1.0,
+                  temperature=1.0) -> Optional[str]:
+        """None if rwkv7_sample_rows_f32 covers the request, else the reason (the caller then runs the torch chain)."""
+        if logits_device.type != "cuda":
+            return "logits not on the HIP device"
+        dom = [(hi - lo) for lo, hi in allow] if allow is not None else list(seg_len)
+        if max(dom) > MAX_DOMAIN or min(dom) < 1:
+            return f"segment of {max(dom)} ids"
+        if suppress is not None and len(suppress) > 256:
+            return "more than 256 suppressed ids"
+        if do_sample:
+            top_k, top_p = int(top_k or 0), 1.0 if top_p is None else float(top_p)
+            if not (temperature and temperature > 0):
+                return "temperature"
+            if top_k < 0 or top_k > MAX_TOP_K:
+                return f"top_k = {top_k}"
+            if top_k == 0 and top_p < 1.0:
+                return "top_p without top_k"
+        return None
+
+    def __init__(self, device, seg_len: Sequence[int], allow=None, suppress=None, do_sample=False, top_k=0, top_p=1.0, temperature=1.0,
+                 seed: Optional[int] = None):
+        why = self.supported(device, seg_len, allow, suppress, do_sample, top_k, top_p, temperature)
+        if why:
+            raise ValueError("rwkv7_sample_rows_f32: " + why)
+        self.nseg = len(seg_len)
+        off = [0]
+        for n in seg_len[:-1]:
+            off.append(off[-1] + int(n))
+        self.width = off[-1] + int(seg_len[-1])
+        i32 = dict(dtype=torch.int32, device=device)
+        self.seg_off, self.seg_len = torch.tensor(off, **i32), torch.tensor([int(n) for n in seg_len], **i32)
+        self.allow_lo = self.allow_hi = None
+        if allow is not None:
+            self.allow_lo, self.allow_hi = torch.tensor([a[0] for a in allow], **i32), torch.tensor([a[1] for a in allow], **i32)
+        self.max_domain = max((hi - lo) for lo, hi in allow) if allow is not None else max(int(n) for n in seg_len)
+        self.suppress = torch.tensor([int(t) for t in suppress], **i32) if suppress is not None and len(suppress) else None
+        self.do_sample, self.top_k = int(bool(do_sample)), int(top_k or 0)
+        self.top_p, self.temperature = 1.0 if top_p is None else float(top_p), float(temperature or 1.0)
+        self.seed = int(torch.cuda.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
+
+    def __call__(self, logits: torch.Tensor, step: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """logits fp32 [rows, >= width] (row stride arbitrary, unit column stride); step: int64 device tensor (first element is
+        read); returns int64 [rows, nseg]."""
+        assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[1] >= self.width
+        assert step.dtype == torch.int64 and step.is_cuda
+        rows = logits.shape[0]
+        if out is None:
+            out = torch.empty(rows, self.nseg, dtype=torch.int64, device=logits.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else None)
+        with torch.cuda.device_of(logits):
+            rc = _lib.lib().rwkv7_sample_rows_f32(
+                rows, self.nseg, p(logits), ctypes.c_long(logits.stride(0)), p(self.seg_off), p(self.seg_len), p(self.allow_lo),
+                p(self.allow_hi), p(self.suppress), 0 if self.suppress is None else self.suppress.numel(), self.max_domain,
+                self.do_sample, self.top_k, ctypes.c_float(self.top_p), ctypes.c_float(self.temperature),
+                ctypes.c_ulonglong(self.seed), p(step), p(out), ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream))
+        _lib.check(rc, "rwkv7_sample_rows_f32")
+        return out
+
+
+def ras_step(logits: torch.Tensor, tok: torch.Tensor, recent: torch.Tensor, ptr: torch.Tensor, step_i: torch.Tensor, n_ignore: int,
+             eos: int, top_p=0.8, top_k=25, win_size=10, tau_r=0.1, seed: Optional[int] = None):
+    """One token of CosyVoice's streaming loop on device tensors (see rwkv7_ras_step_f32): logits fp32 [V]; tok [1], recent
+    [win_size], ptr [1], step_i [] int64, all updated in place."""
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 1
+    for t in (tok, recent, ptr, step_i):
+        assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
+    assert recent.numel() == win_size
+    seed = int(torch.cuda.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device_of(logits):
+        rc = _lib.lib().rwkv7_ras_step_f32(logits.numel(), p(logits), p(tok), p(recent), p(ptr), p(step_i), ctypes.c_long(int(n_ignore)),
+                                           int(eos), ctypes.c_float(top_p), int(top_k), int(win_size), ctypes.c_float(tau_r),
+                                           ctypes.c_ulonglong(seed), ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream))
+    _lib.check(rc, "rwkv7_ras_step_f32")

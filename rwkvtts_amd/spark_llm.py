@@ -217,3 +217,6 @@ def sample_next(logits, do_sample=False, top_k=0, top_p=1.0, temperature=1.0, ge
         logits = logits.masked_fill(remove.scatter(1, sorted_idx, remove), float("-inf"))
     probs = torch.softmax(logits, dim=-1)
     return torch.multinomial(probs, 1, generator=generator).squeeze(1)
+
+
+_STOCK_SAMPLE_NEXT = sample_next   # (tests script the draws by replacing spark_llm.sample_next: the fused sampler then stands down)

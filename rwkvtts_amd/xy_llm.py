@@ -163,13 +163,14 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
             if DecodeStep.supported(self.model, head, cache) is None:
                 step_kernel = DecodeStep(self.model, head, cache)
         st = _XYFrameState(self, input_ids, total, eos, do_sample, top_k, top_p, temperature, generator, reference_termination)
-        st.logits = [l[:, -1, :].float().contiguous() for l in out.logits]
+        # the frame's logits as ONE [B, V0 + 7 V1] buffer (the step kernel's layout); st.logits are views of its eight segments
+        st.logits_cat = torch.cat([l[:, -1, :].float() for l in out.logits], 1).contiguous()
+        st.logits = list(torch.split(st.logits_cat, sizes, dim=1))
+        st.make_sampler(sizes, getattr(self, "fused_sampling", True))
 
         def advance():   # the model step that follows a frame: logits of the next one
             if step_kernel is not None:
-                lg = step_kernel(self.embed(st.row.unsqueeze(1))[:, 0].contiguous())
-                for dst, src in zip(st.logits, torch.split(lg, sizes, dim=1)):
-                    dst.copy_(src)
+                st.logits_cat.copy_(step_kernel(self.embed(st.row.unsqueeze(1))[:, 0].contiguous()))
             else:
                 o = self(input_ids=st.row.unsqueeze(1), past_key_values=cache, use_cache=True)
                 for dst, l in zip(st.logits, o.logits):
@@ -268,6 +269,22 @@ class _XYFrameState:
         self.ch0_block = torch.ones(cfg.vocab_size, dtype=torch.bool, device=dev)
         self.ch0_block[cfg.text_shift_size: cfg.text_shift_size + cfg.speech_vocab_size] = False
         self.logits: List[torch.Tensor] = []
+        self.logits_cat: Optional[torch.Tensor] = None
+        self.sampler = None
+
+    def make_sampler(self, sizes, enabled=True):
+        """The eight draws of a frame as ONE launch (csrc/sampling.hip: channel 0 restricted to the audio ids, xy_llm.py:82-86) when
+        the request is covered -- default generator, the stock sample_next, top-k <= 64 ...; as torch operations the eight warper
+        chains are ~120 launches, 1.8 ms of a 3.1 ms frame."""
+        from . import spark_llm
+        from .sampling import RowSampler
+        cfg, sm = self.cfg, self.sample
+        if not enabled or sm["generator"] is not None or spark_llm.sample_next is not spark_llm._STOCK_SAMPLE_NEXT:
+            return
+        allow = [(cfg.text_shift_size, cfg.text_shift_size + cfg.speech_vocab_size)] + [(0, n) for n in sizes[1:]]
+        kw = dict(do_sample=sm["do_sample"], top_k=sm["top_k"], top_p=sm["top_p"], temperature=sm["temperature"])
+        if RowSampler.supported(self.logits_cat.device, sizes, allow, None, **kw) is None:
+            self.sampler = RowSampler(self.logits_cat.device, sizes, allow, None, **kw)
 
     def need_rows(self, frames_after):
         return self.cur_len + frames_after > self.out.shape[1]
@@ -277,10 +294,10 @@ class _XYFrameState:
 
     def snapshot(self):
         return [t.clone() for t in (self.out, self.row, self.pos, self.unfinished, self.needs, self.all_done, self.n_rows)] + \
-               [l.clone() for l in self.logits]
+               [self.logits_cat.clone()]
 
     def restore(self, keep):
-        for t, k in zip([self.out, self.row, self.pos, self.unfinished, self.needs, self.all_done, self.n_rows] + self.logits, keep):
+        for t, k in zip([self.out, self.row, self.pos, self.unfinished, self.needs, self.all_done, self.n_rows, self.logits_cat], keep):
             t.copy_(k)
 
     def step(self):
@@ -288,9 +305,12 @@ class _XYFrameState:
         cfg, C = self.cfg, self.C
         pad = cfg.speech_pad_token
         running = (~self.all_done).long()            # 0 once the reference's loop would have left: later frames change nothing
-        lg0 = self.logits[0].masked_fill(self.ch0_block, float("-inf"))   # channel 0 may only emit audio ids (:82-86)
-        toks = [sample_next(lg0, **self.sample)] + [sample_next(l, **self.sample) for l in self.logits[1:]]
-        nt = torch.stack(toks, -1)
+        if self.sampler is not None:
+            nt = self.sampler(self.logits_cat, self.pos).to(self.row.dtype)
+        else:
+            lg0 = self.logits[0].masked_fill(self.ch0_block, float("-inf"))   # channel 0 may only emit audio ids (:82-86)
+            toks = [sample_next(lg0, **self.sample)] + [sample_next(l, **self.sample) for l in self.logits[1:]]
+            nt = torch.stack(toks, -1)
         is_audio = self.model.is_audio_token(nt[:, 0])
         to_flush = (~is_audio) & (self.needs < 0)
         needs = torch.where(to_flush, torch.full_like(self.needs, C - 1), self.needs)
