@@ -447,6 +447,19 @@ int rwkv7_sample_rows_f32(int rows, int nseg, const float *logits, long ld, cons
 int rwkv7_ras_step_f32(int V, const float *logits, long *tok, long *recent, long *ptr, long *step_i, long n_ignore, int eos, float top_p,
                        int top_k, int win_size, float tau_r, unsigned long long seed, rwkv7_stream_t stream);
 
+/* ---- one frame of the XY generation loop (model/llm/xy_llm.py:39-146, CustomGenerationMixin._sample) after the eight draws:
+ * rwkv7_xy_frame_step: flush countdown, EOS / pad substitution, append of the row, stopping criteria and the `all finished` flag for
+ *      B <= 64 sequences of C channels, on DEVICE int64 state (out [B][rows][C], row [B][C] = the row just written, pos / n_rows
+ *      scalars, unfinished / needs [B], all_done one byte), from the drawn ids nt [B][C] (channel 0 in vocabulary ids).  eos0 < 0:
+ *      no EOS id; total < 0: no length bound; eos_list: n_eos DEVICE ids for the stopping criterion; reference_termination = 1
+ *      reproduces lines :139-140 literally.  The torch form of the same rules is rwkvtts_amd/xy_llm.py _XYFrameState.step.
+ * rwkv7_xy_embed_bf16: x[b] = sum_c table_c[row[b][c]] (bf16 rows of D, added in channel order with bf16 rounding after every
+ *      addition, like the module's chain of tensor additions; xy_llm.py:189-200); tables_host: HOST array of C <= 16 DEVICE pointers. */
+int rwkv7_xy_frame_step(int B, int C, int rows, long text_shift, long speech_vocab, long pad, long eos0, long total, const long *eos_list,
+                        int n_eos, int reference_termination, const long *nt, long *out, long *row, long *pos, long *unfinished, long *needs,
+                        unsigned char *all_done, long *n_rows, rwkv7_stream_t stream);
+int rwkv7_xy_embed_bf16(int B, int C, int D, const void *const *tables_host, const long *row, void *x, rwkv7_stream_t stream);
+
 /* the low-rank pair of the decode step in one launch: y[M,N] = act(x[M,K] @ w1[R,K]^T) @ w2[N,R]^T (+ bias); M <= 32,
  * K % 64 == 0, R in {32,64,128}, act 0 none / 1 tanh / 2 sigmoid (rwkv_s2s_single_ffn.py:497-500: w, a, v, g branches) */
 int rwkv7_lora32_bf16(int M, int N, int K, int R, int act, const void *x, const void *w1, const void *w2, const void *bias,

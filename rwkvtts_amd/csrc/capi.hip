@@ -54,6 +54,9 @@ int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, 
 int sample_rows_f32(int, int, const float *, long, const int *, const int *, const int *, const int *, const int *, int, int, int, int, float,
                     float, unsigned long long, const long *, long *, hipStream_t);
 int ras_step_f32(int, const float *, long *, long *, long *, long *, long, int, float, int, int, float, unsigned long long, hipStream_t);
+int xy_frame_step(int, int, int, long, long, long, long, long, const long *, int, int, const long *, long *, long *, long *, long *, long *,
+                  unsigned char *, long *, hipStream_t);
+int xy_embed_bf16(int, int, int, const void *const *, const long *, void *, hipStream_t);
 int decode_layer_ptrs();
 size_t decode_workspace_bytes(int, int, int, int, int, int, int, int, int);
 int decode_step_bf16(int, int, int, int, int, int, int, int, int, int, float, float, const void *const *, const void *const *, const void *,
@@ -547,6 +550,22 @@ int rwkv7_ras_step_f32(int V, const float *logits, long *tok, long *recent, long
     if (V <= 0 || any_null({(const void *)logits, (const void *)tok, (const void *)recent, (const void *)ptr, (const void *)step_i}))
         return RWKV7_EINVAL;
     return rwkv7::ras_step_f32(V, logits, tok, recent, ptr, step_i, n_ignore, eos, top_p, top_k, win_size, tau_r, seed, (hipStream_t)stream);
+}
+int rwkv7_xy_frame_step(int B, int C, int rows, long text_shift, long speech_vocab, long pad, long eos0, long total, const long *eos_list,
+                        int n_eos, int reference_termination, const long *nt, long *out, long *row, long *pos, long *unfinished, long *needs,
+                        unsigned char *all_done, long *n_rows, rwkv7_stream_t stream) {
+    if (B <= 0 || n_eos < 0 || (n_eos > 0 && !eos_list) ||
+        any_null({(const void *)nt, (const void *)out, (const void *)row, (const void *)pos, (const void *)unfinished, (const void *)needs,
+                  (const void *)all_done, (const void *)n_rows}))
+        return RWKV7_EINVAL;
+    return rwkv7::xy_frame_step(B, C, rows, text_shift, speech_vocab, pad, eos0, total, eos_list, n_eos, reference_termination, nt, out, row,
+                                pos, unfinished, needs, all_done, n_rows, (hipStream_t)stream);
+}
+int rwkv7_xy_embed_bf16(int B, int C, int D, const void *const *tables_host, const long *row, void *x, rwkv7_stream_t stream) {
+    if (B <= 0 || D <= 0 || any_null({(const void *)tables_host, (const void *)row, (const void *)x})) return RWKV7_EINVAL;
+    for (int c = 0; c < C && c < 16; c++)
+        if (!tables_host[c]) return RWKV7_EINVAL;
+    return rwkv7::xy_embed_bf16(B, C, D, tables_host, row, x, (hipStream_t)stream);
 }
 int rwkv7_debug_tr16(const void *in, const int *addr, void *out, rwkv7_stream_t stream) {
     if (!in || !addr || !out) return RWKV7_EINVAL;

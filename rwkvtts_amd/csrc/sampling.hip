@@ -522,6 +522,110 @@ __global__ __launch_bounds__(kSmpThreads) void ras_step_kernel(int V, const floa
     }
 }
 
+// ---- XY frame: the bookkeeping of CustomGenerationMixin._sample (model/llm/xy_llm.py:104-146) for one frame --------------------------
+// One wave, lane = sequence (B <= 64).  The torch form of this (xy_llm._XYFrameState.step) is ~45 launches per frame.  Semantics
+// (identical to that function, which stays as the reference path and is compared id for id in tests/test_heads_gpu.py):
+//   a non-audio id on channel 0 starts a countdown of C - 1 further rows (needs = C - 1 .. -1); while it runs channel 0 carries EOS
+//   (if configured) and channel i keeps its drawn ids for i more rows, then the pad id; finished sequences emit EOS / pad; the row
+//   is appended at `pos` while the reference's loop would still be running (`all_done` not yet set); stop = length bound | EOS hit
+//   (flushing sequences excepted unless reference_termination); unfinished &= ~stop & ~(needs == -1 [& flushing]).
+struct XYFrameArgs {
+    int B, C, rows;                 // out is [B][rows][C]
+    long text_shift, speech_vocab, pad, eos0, total;   // eos0 < 0: no EOS id; total < 0: no length bound
+    int n_eos, reference_termination;
+};
+__global__ __launch_bounds__(64) void xy_frame_kernel(XYFrameArgs a, const long *__restrict__ nt, const long *__restrict__ eos_list,
+                                                      long *__restrict__ out, long *__restrict__ row, long *__restrict__ pos,
+                                                      long *__restrict__ unfinished, long *__restrict__ needs_, unsigned char *__restrict__ all_done,
+                                                      long *__restrict__ n_rows) {
+    const int b = threadIdx.x, C = a.C;
+    const bool live = b < a.B;
+    const bool running = *all_done == 0;
+    const long p0 = *pos;
+    const long pw = min(p0, (long)a.rows - 1);                 // where the row goes (clamped like the torch form)
+    const long p1 = p0 + (running ? 1 : 0);
+    long u = 1, needs = -1;
+    if (live) {
+        u = unfinished[b];
+        needs = needs_[b];
+        const long *t = nt + (long)b * C;
+        const long t0 = t[0];
+        const bool is_audio = t0 >= a.text_shift && t0 < a.text_shift + a.speech_vocab;
+        if (!is_audio && needs < 0) needs = C - 1;
+        const bool flushing = needs >= 0;
+        const long pddp_text = a.eos0 >= 0 ? a.eos0 : 0;
+        long c0 = (a.eos0 >= 0 && flushing) ? a.eos0 : t0;
+        c0 = u ? c0 : pddp_text;
+        long *ob = out + ((long)b * a.rows + pw) * C, *rb = row + (long)b * C;
+        if (running) ob[0] = c0;
+        rb[0] = c0;
+        for (int i = 1; i < C; i++) {
+            long ci = (flushing && needs < C - i) ? a.pad : t[i];
+            ci = u ? ci : a.pad;
+            if (running) ob[i] = ci;
+            rb[i] = ci;
+        }
+        if (flushing) needs -= 1;
+        bool stop = a.total >= 0 && p1 >= a.total;
+        bool hit = false;
+        for (int e = 0; e < a.n_eos; e++) hit |= c0 == eos_list[e];
+        stop |= a.reference_termination ? hit : (hit && !flushing);
+        const bool gone = a.reference_termination ? needs == -1 : (needs == -1 && flushing);
+        const long un = (u && !stop && !gone) ? 1 : 0;
+        if (running) {
+            unfinished[b] = un;
+            needs_[b] = needs;
+            u = un;
+        }
+    }
+    const bool any = __ballot(live && u != 0) != 0;            // u: the value `unfinished` holds after this frame
+    if (b == 0) {
+        *pos = p1;
+        *n_rows += running ? 1 : 0;
+        if (!any) *all_done = 1;
+    }
+}
+
+// the next frame's input: x[b] = emb_0[row[b][0]] + emb_1[row[b][1]] + ... in bf16, added in channel order like the module
+// (model/llm/xy_llm.py:189-200: a chain of bf16 tensor additions)
+constexpr int kXYMaxC = 16;
+struct XYTables {
+    const uint16_t *t[kXYMaxC];
+};
+__global__ __launch_bounds__(256) void xy_embed_kernel(int C, int D, XYTables tb, const long *__restrict__ row, uint16_t *__restrict__ x) {
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x * 8; d < D; d += 256 * 8) {
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < kXYMaxC; c++) {
+            if (c < C) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(tb.t[c] + row[(long)b * C + c] * D + d);
+                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+                    if (c == 0) {
+                        acc[2 * j] = lo;
+                        acc[2 * j + 1] = hi;
+                    } else {   // bf16 + bf16 -> bf16 (round to nearest even), as torch adds two bf16 tensors
+                        float s0 = acc[2 * j] + lo, s1 = acc[2 * j + 1] + hi;
+                        uint32_t u0 = __float_as_uint(s0), u1 = __float_as_uint(s1);
+                        u0 += 0x7fffu + ((u0 >> 16) & 1u);
+                        u1 += 0x7fffu + ((u1 >> 16) & 1u);
+                        acc[2 * j] = __uint_as_float(u0 & 0xffff0000u);
+                        acc[2 * j + 1] = __uint_as_float(u1 & 0xffff0000u);
+                    }
+                }
+            }
+        }
+        uint4 o;
+        uint32_t *ow = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+        for (int j = 0; j < 4; j++) ow[j] = (__float_as_uint(acc[2 * j]) >> 16) | (__float_as_uint(acc[2 * j + 1]) & 0xffff0000u);
+        *reinterpret_cast<uint4 *>(x + (long)b * D + d) = o;
+    }
+}
+
 // elements per thread: the XY channels (1025 ids), the Spark / Cosy vocabularies (8193, 6562), the LDS-free maximum
 constexpr int kEptS = 5, kEptM = 33, kEptL = kSmpMaxN / kSmpThreads;
 
@@ -559,6 +663,28 @@ int ras_step_f32(int V, const float *logits, long *tok, long *recent, long *ptr,
         ras_step_kernel<kEptM><<<dim3(1), dim3(kSmpThreads), 0, st>>>(V, logits, tok, recent, ptr, step_i, n_ignore, eos, top_p, top_k, win_size, tau_r, key);
     else
         ras_step_kernel<kEptL><<<dim3(1), dim3(kSmpThreads), 0, st>>>(V, logits, tok, recent, ptr, step_i, n_ignore, eos, top_p, top_k, win_size, tau_r, key);
+    return (int)hipGetLastError();
+}
+
+int xy_frame_step(int B, int C, int rows, long text_shift, long speech_vocab, long pad, long eos0, long total, const long *eos_list, int n_eos,
+                  int reference_termination, const long *nt, long *out, long *row, long *pos, long *unfinished, long *needs,
+                  unsigned char *all_done, long *n_rows, hipStream_t st) {
+    if (B > 64 || C < 1 || rows < 1) return -4;
+    XYFrameArgs a;
+    a.B = B; a.C = C; a.rows = rows;
+    a.text_shift = text_shift; a.speech_vocab = speech_vocab; a.pad = pad; a.eos0 = eos0; a.total = total;
+    a.n_eos = n_eos; a.reference_termination = reference_termination;
+    (void)hipGetLastError();
+    xy_frame_kernel<<<dim3(1), dim3(64), 0, st>>>(a, nt, eos_list, out, row, pos, unfinished, needs, all_done, n_rows);
+    return (int)hipGetLastError();
+}
+
+int xy_embed_bf16(int B, int C, int D, const void *const *tables_host, const long *row, void *x, hipStream_t st) {
+    if (C < 1 || C > kXYMaxC || D % 8 != 0) return -4;
+    XYTables tb;
+    for (int c = 0; c < kXYMaxC; c++) tb.t[c] = (const uint16_t *)tables_host[c < C ? c : 0];
+    (void)hipGetLastError();
+    xy_embed_kernel<<<dim3(B), dim3(256), 0, st>>>(C, D, tb, row, (uint16_t *)x);
     return (int)hipGetLastError();
 }
 

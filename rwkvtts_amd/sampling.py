@@ -94,3 +94,46 @@ def ras_step(logits: torch.Tensor, tok: torch.Tensor, recent: torch.Tensor, ptr:
                                            int(eos), ctypes.c_float(top_p), int(top_k), int(win_size), ctypes.c_float(tau_r),
                                            ctypes.c_ulonglong(seed), ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream))
     _lib.check(rc, "rwkv7_ras_step_f32")
+
+
+def xy_frame_step(nt, out, row, pos, unfinished, needs, all_done, n_rows, text_shift, speech_vocab, pad, eos0, total, eos_list,
+                  reference_termination):
+    """One frame of the XY loop's bookkeeping on device tensors (rwkv7_xy_frame_step; the torch form: xy_llm._XYFrameState.step).
+    nt [B, C] int64 drawn ids; out [B, rows, C], row [B, C], pos [1], unfinished / needs [B], n_rows [] int64; all_done [] bool."""
+    B, C = nt.shape
+    for t in (nt, out, row, pos, unfinished, needs, n_rows):
+        assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
+    assert all_done.dtype == torch.bool and out.shape[0] == B and out.shape[2] == C
+    p = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else None)
+    L = ctypes.c_long
+    with torch.cuda.device_of(nt):
+        rc = _lib.lib().rwkv7_xy_frame_step(B, C, out.shape[1], L(text_shift), L(speech_vocab), L(pad), L(-1 if eos0 is None else eos0),
+                                            L(-1 if total is None else total), p(eos_list), 0 if eos_list is None else eos_list.numel(),
+                                            int(bool(reference_termination)), p(nt), p(out), p(row), p(pos), p(unfinished), p(needs),
+                                            p(all_done), p(n_rows), ctypes.c_void_p(torch.cuda.current_stream(nt.device).cuda_stream))
+    _lib.check(rc, "rwkv7_xy_frame_step")
+
+
+class XYEmbed:
+    """x[b] = sum over channels of table_c[row[b, c]] as one launch (rwkv7_xy_embed_bf16), into a fixed buffer."""
+
+    @staticmethod
+    def supported(tables) -> bool:
+        D = tables[0].shape[1]
+        return len(tables) <= 16 and D % 8 == 0 and all(t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous() and t.shape[1] == D
+                                                        for t in tables)
+
+    def __init__(self, tables, B):
+        self.tables = [t.detach() for t in tables]
+        self.C, self.D = len(tables), tables[0].shape[1]
+        self.ptrs = (ctypes.c_void_p * self.C)(*[t.data_ptr() for t in self.tables])
+        self.x = torch.empty(B, self.D, dtype=torch.bfloat16, device=tables[0].device)
+
+    def __call__(self, row: torch.Tensor) -> torch.Tensor:
+        assert row.dtype == torch.int64 and row.is_contiguous() and row.shape == (self.x.shape[0], self.C)
+        with torch.cuda.device_of(row):
+            rc = _lib.lib().rwkv7_xy_embed_bf16(row.shape[0], self.C, self.D, self.ptrs, ctypes.c_void_p(row.data_ptr()),
+                                                ctypes.c_void_p(self.x.data_ptr()),
+                                                ctypes.c_void_p(torch.cuda.current_stream(row.device).cuda_stream))
+        _lib.check(rc, "rwkv7_xy_embed_bf16")
+        return self.x

@@ -168,9 +168,21 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
         st.logits = list(torch.split(st.logits_cat, sizes, dim=1))
         st.make_sampler(sizes, getattr(self, "fused_sampling", True))
 
+        embed_k = None   # the embedding sum of the previous row as one launch (bf16 tables)
+        if step_kernel is not None and getattr(self, "fused_frame", True) and input_ids.dtype == torch.int64:
+            from .sampling import XYEmbed
+            tables = [e.weight for e in self.embs]
+            if XYEmbed.supported(tables):
+                embed_k = XYEmbed(tables, B)
+
         def advance():   # the model step that follows a frame: logits of the next one
             if step_kernel is not None:
-                st.logits_cat.copy_(step_kernel(self.embed(st.row.unsqueeze(1))[:, 0].contiguous()))
+                x = embed_k(st.row) if embed_k is not None else self.embed(st.row.unsqueeze(1))[:, 0].contiguous()
+                lg = step_kernel(x)
+                if st.sampler is not None:
+                    st.logits_cat = lg          # the fused draw reads the step kernel's own buffer
+                else:
+                    st.logits_cat.copy_(lg)     # st.logits are views of this buffer
             else:
                 o = self(input_ids=st.row.unsqueeze(1), past_key_values=cache, use_cache=True)
                 for dst, l in zip(st.logits, o.logits):
@@ -271,6 +283,8 @@ class _XYFrameState:
         self.logits: List[torch.Tensor] = []
         self.logits_cat: Optional[torch.Tensor] = None
         self.sampler = None
+        # the frame's bookkeeping as one launch (csrc/sampling.hip xy_frame_kernel) instead of the ~45 tensor operations below
+        self.fused_frame = getattr(model, "fused_frame", True) and input_ids.dtype == torch.int64 and input_ids.is_cuda and B <= 64
 
     def make_sampler(self, sizes, enabled=True):
         """The eight draws of a frame as ONE launch (csrc/sampling.hip: channel 0 restricted to the audio ids, xy_llm.py:82-86) when
@@ -311,6 +325,11 @@ class _XYFrameState:
             lg0 = self.logits[0].masked_fill(self.ch0_block, float("-inf"))   # channel 0 may only emit audio ids (:82-86)
             toks = [sample_next(lg0, **self.sample)] + [sample_next(l, **self.sample) for l in self.logits[1:]]
             nt = torch.stack(toks, -1)
+        if self.fused_frame:
+            from .sampling import xy_frame_step
+            xy_frame_step(nt.contiguous(), self.out, self.row, self.pos, self.unfinished, self.needs, self.all_done, self.n_rows,
+                          cfg.text_shift_size, cfg.speech_vocab_size, pad, self.eos0, self.total, self.eos, self.reference_termination)
+            return
         is_audio = self.model.is_audio_token(nt[:, 0])
         to_flush = (~is_audio) & (self.needs < 0)
         needs = torch.where(to_flush, torch.full_like(self.needs, C - 1), self.needs)

@@ -218,7 +218,8 @@ def test_cosy_inference_step_kernel_vs_fp32_twin():
     assert checked >= len(a) // 2, (checked, len(a))
 
 
-def test_xy_generate_flush_stagger_eos_and_stop_at_full_channel_count(monkeypatch):
+@pytest.mark.parametrize("fused_frame", [True, False])   # the frame's bookkeeping as one HIP launch / as tensor operations
+def test_xy_generate_flush_stagger_eos_and_stop_at_full_channel_count(monkeypatch, fused_frame):
     """CustomGenerationMixin._sample (xy_llm.py:88-146) at the real channel count and vocabularies (8 channels, V0 = 66 661,
     1 025 per speech channel): once channel 0 leaves the audio range a C-1 = 7 step countdown starts; during its 8 rows channel 0
     carries EOS, and channel i keeps its sampled value for i more rows (the delay pattern: RVQ-i lags i steps) before it is
@@ -234,6 +235,7 @@ def test_xy_generate_flush_stagger_eos_and_stop_at_full_channel_count(monkeypatc
     model = RWKV7XYLM(cfg).init_weights(seed=2)
     model.zero_embs()
     model = model.to(DEV).eval()
+    model.fused_frame = fused_frame
     PAD, EOS = cfg.speech_pad_token, 65535          # EOS: a text id, outside the audio range
     assert PAD == SV - 1
     B, T0 = 3, 4
@@ -343,6 +345,18 @@ def test_xy_generate_captured_frame_step_equals_eager_loop():
     # sampled decode replays from the graph as well (device generator): shape and channel-0 constraint
     s = model.generate(ids, max_new_tokens=9, do_sample=True, top_k=5, use_graph=True)
     assert s.shape == (B, 15, 4) and ((s[:, 6:, 0] >= 100) & (s[:, 6:, 0] < 116)).all()
+    # the fused frame (embedding sum, draws and bookkeeping as three launches) against the tensor-operation forms of the same
+    # steps on the same draws -- the fused sampler is keyed by (seed, frame), so both runs see identical ids: greedy, sampled,
+    # with an EOS that is reached, eager and captured
+    for kw in (dict(do_sample=False), dict(do_sample=True, top_k=5, top_p=0.9), dict(do_sample=True, top_k=5, eos_token_id=eos)):
+        for graph in (False, True):
+            outs = []
+            for fused in (True, False):
+                model.fused_frame = fused
+                torch.manual_seed(11)
+                outs.append(model.generate(ids, max_new_tokens=21, use_graph=graph, **kw))
+            assert outs[0].shape == outs[1].shape and torch.equal(outs[0], outs[1]), (kw, graph)
+    model.fused_frame = True
 
 
 def test_cosy_streaming_inference_replays_the_step_from_a_graph_with_the_stock_sampler():
