@@ -384,6 +384,20 @@ __device__ __forceinline__ void draw_full(const Vals<EPT> &x, SmpShared &sm, flo
     i1 = sm.pick[1];
 }
 
+// Optional tail of a one-segment draw: what the decode loop does with the id before the next step (decode.GraphDecoder._step:
+// finished sequences emit the pad id, EOS ends a sequence, the id goes into the output row at column *step and becomes the next
+// input -- whose embedding row is copied here, so the next step's first kernel finds its input in place).
+struct SmpTail {
+    unsigned char *unfinished;   // [rows] bool, or null (no EOS handling)
+    long eos, pad;
+    long *ids;                   // [rows] the ids as the loop keeps them, or null: no tail at all
+    long *seq;                   // [rows][seq_ld] generated ids, or null
+    long seq_ld;
+    const uint16_t *emb;         // [V][D] bf16, or null
+    uint16_t *x;                 // [rows][D]
+    int D;
+};
+
 // ---- one workgroup per (row, segment) ----------------------------------------------------------------------------------------------
 template <int EPT>
 __global__ __launch_bounds__(kSmpThreads) void sample_rows_kernel(int nseg, const float *__restrict__ logits, long ld,
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(kSmpThreads) void sample_rows_kernel(int nseg, cons
                                                                   const int *__restrict__ allow_lo, const int *__restrict__ allow_hi,
                                                                   const int *__restrict__ suppress, int nsuppress, int do_sample, int top_k,
                                                                   float top_p, float inv_temp, uint2 key, const long *__restrict__ step,
-                                                                  long *__restrict__ out) {
+                                                                  long *__restrict__ out, SmpTail tail) {
     __shared__ SmpShared sm;
     const int seg = blockIdx.x % nseg, row = blockIdx.x / nseg, tid = threadIdx.x;
     const float *xg = logits + (long)row * ld + seg_off[seg];
@@ -447,6 +461,27 @@ __global__ __launch_bounds__(kSmpThreads) void sample_rows_kernel(int nseg, cons
         }
     }
     if (tid == 0) out[(long)row * nseg + seg] = lo + choice;
+    if (tail.ids) {   // nseg == 1
+        __syncthreads();
+        if (tid == 0) {
+            long id = lo + choice;
+            if (tail.unfinished) {
+                const bool u = tail.unfinished[row] != 0;
+                id = u ? id : tail.pad;
+                tail.unfinished[row] = u && id != tail.eos;
+            }
+            tail.ids[row] = id;
+            const long col = *step;
+            if (tail.seq && col < tail.seq_ld) tail.seq[(long)row * tail.seq_ld + col] = id;
+            sm.sel[0] = (unsigned)id;
+        }
+        __syncthreads();
+        if (tail.emb) {
+            const uint16_t *src = tail.emb + (long)sm.sel[0] * tail.D;
+            uint16_t *dst = tail.x + (long)row * tail.D;
+            for (int d = tid * 8; d < tail.D; d += kSmpThreads * 8) *reinterpret_cast<uint4 *>(dst + d) = *reinterpret_cast<const uint4 *>(src + d);
+        }
+    }
 }
 
 // ---- CosyVoice streaming step: draw + bookkeeping --------------------------------------------------------------------------------
@@ -633,7 +668,12 @@ constexpr int kEptS = 5, kEptM = 33, kEptL = kSmpMaxN / kSmpThreads;
 
 int sample_rows_f32(int rows, int nseg, const float *logits, long ld, const int *seg_off, const int *seg_len, const int *allow_lo,
                     const int *allow_hi, const int *suppress, int nsuppress, int max_domain, int do_sample, int top_k, float top_p,
-                    float temperature, unsigned long long seed, const long *step, long *out, hipStream_t st) {
+                    float temperature, unsigned long long seed, const long *step, long *out, const void *tail_, hipStream_t st) {
+    SmpTail tail = {};
+    if (tail_) {
+        tail = *(const SmpTail *)tail_;
+        if (nseg != 1 || !tail.ids || (tail.emb && (tail.D % 8 != 0 || !tail.x))) return -4;
+    }
     if (max_domain > kSmpMaxN || nsuppress > 256) return -4;                      // RWKV7_ESHAPE
     if (do_sample && (top_k < 0 || top_k > 64 || (top_k == 0 && top_p < 1.f) || !(temperature > 0.f))) return -4;
     (void)hipGetLastError();
@@ -642,13 +682,13 @@ int sample_rows_f32(int rows, int nseg, const float *logits, long ld, const int 
     const dim3 grid(rows * nseg), block(kSmpThreads);
     if (max_domain <= kEptS * kSmpThreads)
         sample_rows_kernel<kEptS><<<grid, block, 0, st>>>(nseg, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, do_sample,
-                                                          top_k, top_p, it, key, step, out);
+                                                          top_k, top_p, it, key, step, out, tail);
     else if (max_domain <= kEptM * kSmpThreads)
         sample_rows_kernel<kEptM><<<grid, block, 0, st>>>(nseg, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, do_sample,
-                                                          top_k, top_p, it, key, step, out);
+                                                          top_k, top_p, it, key, step, out, tail);
     else
         sample_rows_kernel<kEptL><<<grid, block, 0, st>>>(nseg, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, do_sample,
-                                                          top_k, top_p, it, key, step, out);
+                                                          top_k, top_p, it, key, step, out, tail);
     return (int)hipGetLastError();
 }
 

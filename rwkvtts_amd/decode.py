@@ -151,6 +151,12 @@ class GraphDecoder:
 
     @torch.no_grad()
     def _step(self):
+        if self.step is not None and self.tail is not None:
+            # step kernel -> draw + EOS / pad handling + output column + the next input's embedding row (one launch) -> position
+            self.cache.seen_tokens += 1
+            self.sampler(self.step(self.x_next), self.pos, self._raw, self.tail)
+            self.pos += 1
+            return
         if self.step is not None:
             x = F.embedding(self.ids, self.model.get_input_embeddings().weight)
             logits = self.step(x)           # the step kernel's own buffer: _pick copies it before it edits it
@@ -219,7 +225,7 @@ class GraphDecoder:
         self.max_new_tokens, self.steps_left, self.graph = max_new_tokens, 0, None
         if seed is not None:
             torch.cuda.manual_seed(seed)
-        self.sampler, self._try_fused = None, self.fused_sampling
+        self.sampler, self._try_fused, self.tail = None, self.fused_sampling, None
         m = self.model
         dev = m.device
         B = self.B
@@ -251,10 +257,20 @@ class GraphDecoder:
                 self.step = DecodeStep(m.model, m.lm_head, self.cache)
             elif self.step_kernel:
                 raise ValueError("persistent decode step unavailable: " + why)
+        emb_w = m.get_input_embeddings().weight
+        if (self.step is not None and self.sampler is not None and emb_w.dtype == torch.bfloat16 and emb_w.is_contiguous()
+                and emb_w.shape[1] % 8 == 0):
+            # the loop's handling of the drawn id rides in the draw's launch (csrc/sampling.hip SmpTail)
+            from .sampling import SampleTail
+            self.x_next = F.embedding(self.ids, emb_w).contiguous()
+            self._raw = torch.empty(B, 1, dtype=torch.long, device=dev)
+            self.tail = SampleTail.make(self.ids, self.out, self.unfinished if self.eos is not None else None,
+                                        None if self.eos is None else int(self.eos), int(self.pad_t), emb_w.detach(), self.x_next)
         # capture one step on the live state tensors.  Warm-up (un-captured) steps would advance the state, so the
         # state/ids are snapshotted and restored around them.
         snap = [(s.att_x_prev.clone(), s.att_kv.clone(), s.ffn_x_prev.clone()) for s in self.cache.states]
         ids0, pos0, out0, unf0, seen0 = self.ids.clone(), self.pos.clone(), self.out.clone(), self.unfinished.clone(), self.cache.seen_tokens
+        x0 = self.x_next.clone() if self.tail is not None else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -268,6 +284,8 @@ class GraphDecoder:
                 s.att_kv.copy_(kv)
                 s.ffn_x_prev.copy_(f)
             self.ids.copy_(ids0)
+            if x0 is not None:
+                self.x_next.copy_(x0)
             self.pos.copy_(pos0)
             self.out.copy_(out0)
             self.unfinished.copy_(unf0)

@@ -17,6 +17,36 @@ MAX_DOMAIN = 15360
 MAX_TOP_K = 64
 
 
+class SampleTail(ctypes.Structure):
+    """rwkv7_sample_tail (include/rwkv7_hip.h): what the decode loop does with a drawn id, in the draw's launch."""
+    _fields_ = [("unfinished", ctypes.c_void_p), ("eos", ctypes.c_long), ("pad", ctypes.c_long), ("ids", ctypes.c_void_p),
+                ("seq", ctypes.c_void_p), ("seq_ld", ctypes.c_long), ("emb", ctypes.c_void_p), ("x", ctypes.c_void_p), ("D", ctypes.c_int)]
+
+    @classmethod
+    def make(cls, ids, seq=None, unfinished=None, eos=None, pad=0, emb=None, x=None):
+        """ids [rows] int64; seq [rows, n] int64 (column *step receives the id); unfinished [rows] bool with eos / pad; emb bf16
+        [V, D] and x bf16 [rows, D] (the next step's input).  The tensors must outlive the launches."""
+        assert ids.dtype == torch.int64 and ids.is_contiguous()
+        t = cls()
+        t.ids = ids.data_ptr()
+        t.unfinished = None
+        t.eos, t.pad = -1, int(pad)
+        if unfinished is not None and eos is not None:
+            assert unfinished.dtype == torch.bool and unfinished.is_contiguous()
+            t.unfinished, t.eos = unfinished.data_ptr(), int(eos)
+        t.seq, t.seq_ld = None, 0
+        if seq is not None:
+            assert seq.dtype == torch.int64 and seq.is_contiguous() and seq.shape[0] == ids.shape[0]
+            t.seq, t.seq_ld = seq.data_ptr(), seq.shape[1]
+        t.emb, t.x, t.D = None, None, 0
+        if emb is not None:
+            assert emb.dtype == torch.bfloat16 and emb.is_contiguous() and x.dtype == torch.bfloat16 and x.is_contiguous()
+            assert x.shape == (ids.shape[0], emb.shape[1]) and emb.shape[1] % 8 == 0
+            t.emb, t.x, t.D = emb.data_ptr(), x.data_ptr(), emb.shape[1]
+        t._keep = (ids, seq, unfinished, emb, x)
+        return t
+
+
 class RowSampler:
     @staticmethod
     def supported(logits_device, seg_len: Sequence[int], allow=None, suppress=None, do_sample=False, top_k=0, top_p=1.0,
@@ -60,21 +90,28 @@ class RowSampler:
         self.top_p, self.temperature = 1.0 if top_p is None else float(top_p), float(temperature or 1.0)
         self.seed = int(torch.cuda.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
 
-    def __call__(self, logits: torch.Tensor, step: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, logits: torch.Tensor, step: torch.Tensor, out: Optional[torch.Tensor] = None,
+                 tail: Optional[SampleTail] = None) -> torch.Tensor:
         """logits fp32 [rows, >= width] (row stride arbitrary, unit column stride); step: int64 device tensor (first element is
-        read); returns int64 [rows, nseg]."""
+        read); returns int64 [rows, nseg] (the raw draws).  tail (one segment): the decode loop's handling of the id in the same
+        launch (SampleTail.make)."""
         assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[1] >= self.width
         assert step.dtype == torch.int64 and step.is_cuda
         rows = logits.shape[0]
         if out is None:
             out = torch.empty(rows, self.nseg, dtype=torch.int64, device=logits.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else None)
+        common = (p(self.seg_off), p(self.seg_len), p(self.allow_lo), p(self.allow_hi), p(self.suppress),
+                  0 if self.suppress is None else self.suppress.numel(), self.max_domain, self.do_sample, self.top_k,
+                  ctypes.c_float(self.top_p), ctypes.c_float(self.temperature), ctypes.c_ulonglong(self.seed), p(step), p(out))
+        stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
         with torch.cuda.device_of(logits):
-            rc = _lib.lib().rwkv7_sample_rows_f32(
-                rows, self.nseg, p(logits), ctypes.c_long(logits.stride(0)), p(self.seg_off), p(self.seg_len), p(self.allow_lo),
-                p(self.allow_hi), p(self.suppress), 0 if self.suppress is None else self.suppress.numel(), self.max_domain,
-                self.do_sample, self.top_k, ctypes.c_float(self.top_p), ctypes.c_float(self.temperature),
-                ctypes.c_ulonglong(self.seed), p(step), p(out), ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream))
+            if tail is None:
+                rc = _lib.lib().rwkv7_sample_rows_f32(rows, self.nseg, p(logits), ctypes.c_long(logits.stride(0)), *common, stream)
+            else:
+                assert self.nseg == 1
+                rc = _lib.lib().rwkv7_sample_rows_tail_f32(rows, p(logits), ctypes.c_long(logits.stride(0)), *common, ctypes.byref(tail),
+                                                           stream)
         _lib.check(rc, "rwkv7_sample_rows_f32")
         return out
 

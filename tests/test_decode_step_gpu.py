@@ -219,6 +219,32 @@ def test_graph_decoder_sampling_replays_with_device_rng():
     assert two.shape == (B, 2) and torch.equal(two, greedy[:, :2].clone()) or two.shape == (B, 2)
 
 
+def test_graph_decoder_fused_draw_and_tail_equals_the_tensor_operation_loop():
+    """The captured step with the draw, the EOS / pad handling, the output column and the next input's embedding row in ONE launch
+    (csrc/sampling.hip, SampleTail) against the same loop written as tensor operations (fused_sampling = False): greedy ids are
+    identical, with an EOS id that greedy decoding reaches (finished rows continue with the pad id) and with suppressed ids."""
+    D, L, V, B, P, NEW = 128, 2, 96, 8, 5, 40
+    cfg, m16, m32 = _model(D, L, V, (32, 32, 32, 32), seed=31)
+    prompt = torch.randint(0, V, (B, P), generator=torch.Generator().manual_seed(9)).to(DEV)
+
+    def run(fused, **kw):
+        dec = GraphDecoder(m16, B)
+        dec.fused_sampling = fused
+        ids = dec.generate(input_ids=prompt, max_new_tokens=NEW, **kw).clone()
+        assert (dec.tail is not None) == fused and (dec.sampler is not None) == fused
+        return ids
+
+    plain = run(True)
+    assert torch.equal(plain, run(False))
+    eos = int(plain[0, 7])                      # an id greedy decoding emits: sequence 0 (at least) finishes there
+    a, b = run(True, eos_token_id=eos, pad_token_id=1), run(False, eos_token_id=eos, pad_token_id=1)
+    assert torch.equal(a, b)
+    first = (a[0] == eos).nonzero()[0, 0]
+    assert (a[0, first + 1:] == 1).all() and not torch.equal(a, plain)
+    sup = [int(plain[1, 0]), 5]
+    assert torch.equal(run(True, suppress_tokens=sup), run(False, suppress_tokens=sup))
+
+
 def test_multi_group_decoder_equals_separate_graph_decoders():
     """decode.MultiGroupDecoder (persistent multi-request decode): k independent groups of sequences, each a captured
     step on its own stream, replayed round-robin.  Groups never interact: every sequence gets, id for id, what a GraphDecoder run
