@@ -127,10 +127,16 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
     def generate(self, input_ids=None, inputs_embeds=None, attention_mask=None, max_new_tokens=None, max_length=None,
                  do_sample=False, top_k=0, top_p=1.0, temperature=1.0, eos_token_id=None, pad_token_id=None,
                  suppress_tokens=None, min_new_tokens=0, return_dict_in_generate=False, use_cache=True,
-                 generator: Optional[torch.Generator] = None, **unused):
+                 generator: Optional[torch.Generator] = None, use_graph: Optional[bool] = None, **unused):
         """Prefill on the state-carrying kernel, then one persistent-state step per token.
         With inputs_embeds only, the returned sequences hold the NEW tokens only (HF semantics the reference
-        relies on, inference/rwkv7speech_inference.py:108-118)."""
+        relies on, inference/rwkv7speech_inference.py:108-118).
+
+        use_graph: the per-token loop replayed from a hipGraph with the draw on the device (decode.GraphDecoder /
+        MultiGroupDecoder: ~33 k tokens/s at B = 32 on MI355X against ~3 k for the host loop below, which reads `unfinished.any()`
+        back every token).  None = when the request is covered: bf16 model on the step kernel, default generator, at most one EOS
+        id, no min_new_tokens, >= 32 new tokens.  Same ids as the host loop for greedy decoding (tests/test_model_gpu.py); sampled
+        draws follow the same distribution through the fused sampler's own random stream."""
         was_training = self.training
         self.eval()
         if inputs_embeds is None:
@@ -143,6 +149,35 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
         eos = [] if eos_token_id is None else ([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id))
         pad = pad_token_id if pad_token_id is not None else (eos[0] if eos else 0)
         dev = self.device
+        graph_ok = (generator is None and len(eos) <= 1 and not min_new_tokens and max_new_tokens >= 2 and self.dtype == torch.bfloat16
+                    and dev.type == "cuda")
+        if use_graph and not graph_ok:
+            raise ValueError("use_graph=True needs a bf16 model on the HIP device, the default generator, at most one EOS id and no "
+                             "min_new_tokens")
+        if use_graph is None:
+            use_graph = graph_ok and max_new_tokens >= 32
+        if use_graph:
+            from .decode import DecodeStep, GraphDecoder, MultiGroupDecoder
+            probe = Cache.zeros(self.config, min(B, 32), dev, self.dtype)
+            if DecodeStep.supported(self.model, self.lm_head, probe) is None:
+                dec = GraphDecoder(self, B, step_kernel=True) if B <= 32 else MultiGroupDecoder(self, 32, step_kernel=True)
+                seq = dec.generate(inputs_embeds=inputs_embeds, input_ids=input_ids if inputs_embeds is None else None,
+                                   attention_mask=attention_mask, max_new_tokens=max_new_tokens, eos_token_id=eos[0] if eos else None,
+                                   pad_token_id=pad, suppress_tokens=suppress_tokens, do_sample=do_sample, temperature=temperature,
+                                   top_k=top_k, top_p=top_p)
+                if eos:   # the host loop leaves with the step in which the last sequence finishes
+                    done = (seq == eos[0]).long().cumsum(1) > 0
+                    if bool(done[:, -1].all()):
+                        seq = seq[:, :int((~done).sum(1).max()) + 1]
+                seq = seq.clone()
+                if input_ids is not None and inputs_embeds is None:
+                    seq = torch.cat([input_ids, seq], 1)
+                if was_training:
+                    self.train()
+                if return_dict_in_generate:
+                    cache = dec.cache if B <= 32 else None
+                    return _GenerateOutput(sequences=seq, past_key_values=cache)
+                return seq
         cache = Cache.zeros(self.config, B, dev, self.dtype)
         out = self(input_ids=input_ids if inputs_embeds is None else None, inputs_embeds=inputs_embeds,
                    attention_mask=attention_mask, past_key_values=cache, use_cache=True, logits_to_keep=1)

@@ -532,6 +532,46 @@ def test_auto_model_from_pretrained_round_trips_logits_and_generate(tmp_path, mo
     assert ids2.shape == (2, 12) and torch.equal(ids1, ids2)
 
 
+def test_generate_replays_the_loop_from_a_graph_when_covered_and_equals_the_host_loop():
+    """RWKV7ForSpeech.generate -- the reference's entry point (inference/rwkv7speech_inference.py:108-118) -- hands the per-token
+    loop to decode.GraphDecoder / MultiGroupDecoder when the request is covered (bf16 model, default generator, <= 1 EOS id, no
+    min_new_tokens, >= 32 new tokens): greedy ids identical to the host loop (use_graph=False), including the early exit once every
+    sequence has emitted EOS, input_ids prepended, more than 32 sequences, and the cache handed back on request."""
+    model, p, rcfg = _spark_pair(seed=7)
+    model = model.to(torch.bfloat16)
+    g = torch.Generator().manual_seed(2)
+    B, P, NEW = 5, 24, 48
+    x = (torch.randn(B, P, 128, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    host = model.generate(inputs_embeds=x, max_new_tokens=NEW, suppress_tokens=[256], use_graph=False)
+    auto = model.generate(inputs_embeds=x, max_new_tokens=NEW, suppress_tokens=[256])
+    assert host.shape == (B, NEW) and torch.equal(host, auto)
+    # an EOS every sequence reaches: take, per construction, the id most sequences emit first ... simpler: every id of column 3 is
+    # forced to be the EOS by suppressing nothing and choosing eos = the id sequence 0 emits at step 3; sequences that never emit it
+    # keep the run at full length, so use a prompt batch of identical rows (all finish together) for the early exit
+    same = x[:1].expand(B, -1, -1).contiguous()
+    ref = model.generate(inputs_embeds=same, max_new_tokens=NEW, use_graph=False)
+    eos = int(ref[0, 5])
+    h2 = model.generate(inputs_embeds=same, max_new_tokens=NEW, eos_token_id=eos, pad_token_id=0, use_graph=False)
+    a2 = model.generate(inputs_embeds=same, max_new_tokens=NEW, eos_token_id=eos, pad_token_id=0)
+    first = int((ref[0] == eos).nonzero()[0, 0])
+    assert h2.shape == (B, first + 1) and torch.equal(h2, a2)
+    # mixed: one sequence with another prompt may or may not reach the EOS -> padded rows, same shape either way
+    mixed = torch.cat([same[:2], x[2:4]], 0)
+    h3 = model.generate(inputs_embeds=mixed, max_new_tokens=NEW, eos_token_id=eos, pad_token_id=0, use_graph=False)
+    a3 = model.generate(inputs_embeds=mixed, max_new_tokens=NEW, eos_token_id=eos, pad_token_id=0)
+    assert h3.shape == a3.shape and torch.equal(h3, a3)
+    # token prompts: the prompt is prepended; the cache comes back
+    ids = torch.randint(0, 256, (3, 10), generator=g).to(DEV)
+    h4 = model.generate(input_ids=ids, max_new_tokens=40, use_graph=False)
+    a4 = model.generate(input_ids=ids, max_new_tokens=40, return_dict_in_generate=True)
+    assert torch.equal(h4, a4.sequences) and a4.past_key_values is not None and h4.shape == (3, 50)
+    # more than 32 sequences: groups of 32 on their own streams
+    many = (torch.randn(40, 16, 128, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    assert torch.equal(model.generate(inputs_embeds=many, max_new_tokens=33, use_graph=False), model.generate(inputs_embeds=many, max_new_tokens=33))
+    with pytest.raises(ValueError):
+        model.generate(inputs_embeds=x, max_new_tokens=NEW, min_new_tokens=3, use_graph=True)
+
+
 def test_bf16_training_batch_with_T_16_mod_32_stays_on_the_chunked_kernels():
     """backbone.RWKV7Model.forward pads a bf16 batch to a multiple of 32 (the reference pads to its kernel's 16,
     rwkv_asr_cuda_whisper.py:482-486): a T = 48 batch -- half of all padded batches have T % 32 == 16 -- must run the chunked MFMA
