@@ -435,7 +435,8 @@ int rwkv7_decode_step_tbl_bf16(const rwkv7_decode_dims *dims, const void *const 
  *      the largest allow_hi - allow_lo (or seg_len), <= 15360.  out: [rows][nseg] int64 ids (segment-relative).
  *      Randomness: Philox4x32-10 keyed by `seed`, counter (*step, workgroup): `step` is a DEVICE int64 the caller advances between
  *      calls (the position counter of the decode loop), so a captured launch draws fresh ids on every replay and (seed, *step)
- *      fixes them.  RWKV7_ESHAPE for parameter combinations outside the above (the Python host then runs the torch chain).
+ *      fixes them.  RWKV7_ESHAPE for parameter combinations outside the above (the Python host then runs the torch chain).  At most
+ *      128 candidates survive top-k: a row with more than 128 ids tied at the k-th value keeps the 128 smallest of them.
  * rwkv7_ras_step_f32: one token of CosyVoice's streaming loop (B = 1): ras_sampling (third_party/cosyvoice/utils/common.py:109-137:
  *      nucleus top_p / top_k, and random_sampling when the candidate already occurs >= win_size * tau_r times in `recent`) with the
  *      EOS rejection of sampling_ids (model/llm/llm.py:160-176) while *step_i < n_ignore, followed by the loop's bookkeeping:

@@ -180,7 +180,7 @@ __device__ __forceinline__ int select_radix(Vals<EPT> &x, SmpShared &sm, int wan
         const uint32_t b = __float_as_uint(x.v[e]);
         o[e] = x.v[e] == -INFINITY ? 0u : ((b & 0x80000000u) ? ~b : (b | 0x80000000u));   // 0: never a candidate
     }
-    uint32_t prefix = 0, need = (uint32_t)want, above = 0;
+    uint32_t prefix = 0, need = (uint32_t)want;
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
@@ -225,16 +225,14 @@ __device__ __forceinline__ int select_radix(Vals<EPT> &x, SmpShared &sm, int wan
         __syncthreads();
         if (sm.sel[0] == 0xffffffffu) {
             prefix = 0;
-            above = sm.sel[3];
             need = 0;
             break;
         }
         prefix = (prefix << 8) | sm.sel[0];
-        above += sm.sel[3];
         need = sm.sel[1];
         __syncthreads();
     }
-    // prefix = the key of the want-th largest value (0: take every valid element); elements above it: `above`
+    // prefix = the key of the want-th largest value (need == 0: take every valid element)
     const uint32_t thr = need == 0 ? 1u : prefix;
     unsigned mine = 0;
 #pragma unroll

@@ -96,6 +96,25 @@ def test_ties_at_the_kth_value_stay_in_the_candidate_set():
     assert set(ids.unique().tolist()) == {0, 2, 3, 4}
 
 
+def test_clustered_and_constant_rows_take_the_exact_fallback_paths():
+    """select_bins bins the values linearly between the row's minimum and maximum; a row whose values sit in one bin (one far
+    outlier below, everything else within 1e-2) has more than 256 elements at or above the k-th value's bin and goes through the
+    radix select on the order-preserving bit image instead -- same exact candidate set.  A constant row (every id tied at the k-th
+    value) goes one level further, to the round-per-candidate form, which caps the candidate list at 128 ids (smallest first)."""
+    g = torch.Generator().manual_seed(5)
+    V, N = 8193, 16384
+    row = torch.randn(V, generator=g) * 1e-2 + 10.0
+    row[100] = -1000.0
+    lg = row.to(DEV).unsqueeze(0).expand(N, V).contiguous()
+    step = torch.zeros(1, dtype=torch.long, device=DEV)
+    ids = RowSampler(lg.device, [V], do_sample=True, top_k=20, top_p=0.9, temperature=0.01, seed=8)(lg, step)[:, 0]
+    _check_freq(ids, _exact_probs(row.double(), 20, 0.9, 0.01), "clustered")
+    flat = torch.full((64, 1000), 3.0, device=DEV)
+    ids = RowSampler(flat.device, [1000], do_sample=True, top_k=5, seed=1)(flat, step)[:, 0]
+    assert ((ids >= 0) & (ids < 128)).all() and ids.unique().numel() > 8
+    assert (RowSampler(flat.device, [1000])(flat, step) == 0).all()          # argmax: the first of the equal maxima
+
+
 def test_plain_multinomial_over_a_wide_row_and_eight_channel_frame():
     g = torch.Generator().manual_seed(4)
     V = 5000
