@@ -448,7 +448,9 @@ int rwkv7_sample_rows_f32(int rows, int nseg, const float *logits, long ld, cons
 /* the one-segment draw followed by what the decode loop does with the id (decode.GraphDecoder._step; the reference's generate():
  * finished sequences emit `pad`, `eos` ends a sequence, the id is stored in the output row at column *step and is the next input):
  * unfinished [rows] bytes or NULL (no EOS handling), ids [rows] (required), seq [rows][seq_ld] or NULL, emb bf16 [V][D] + x bf16
- * [rows][D] or NULL: the embedding row of the id is copied to x, where the next decode step reads its input. */
+ * [rows][D] or NULL: the embedding row of the id is copied to x, where the next decode step reads its input.  tail may be NULL
+ * (the draw alone).  min_eos_id >= 0: that id cannot be drawn while *step < min_eos_until (min_new_tokens of the reference's
+ * generate(): utils/utilities.py:106). */
 typedef struct rwkv7_sample_tail {
     unsigned char *unfinished;
     long eos, pad;
@@ -462,7 +464,7 @@ typedef struct rwkv7_sample_tail {
 int rwkv7_sample_rows_tail_f32(int rows, const float *logits, long ld, const int *seg_off, const int *seg_len, const int *allow_lo,
                                const int *allow_hi, const int *suppress, int nsuppress, int max_domain, int do_sample, int top_k, float top_p,
                                float temperature, unsigned long long seed, const long *step, long *out, const rwkv7_sample_tail *tail,
-                               rwkv7_stream_t stream);
+                               int min_eos_id, long min_eos_until, rwkv7_stream_t stream);
 int rwkv7_ras_step_f32(int V, const float *logits, long *tok, long *recent, long *ptr, long *step_i, long n_ignore, int eos, float top_p,
                        int top_k, int win_size, float tau_r, unsigned long long seed, rwkv7_stream_t stream);
 

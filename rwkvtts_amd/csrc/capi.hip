@@ -52,7 +52,7 @@ int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *,
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
 int sample_rows_f32(int, int, const float *, long, const int *, const int *, const int *, const int *, const int *, int, int, int, int, float,
-                    float, unsigned long long, const long *, long *, const void *, hipStream_t);
+                    float, unsigned long long, const long *, long *, const void *, int, long, hipStream_t);
 int ras_step_f32(int, const float *, long *, long *, long *, long *, long, int, float, int, int, float, unsigned long long, hipStream_t);
 int xy_frame_step(int, int, int, long, long, long, long, long, const long *, int, int, const long *, long *, long *, long *, long *, long *,
                   unsigned char *, long *, hipStream_t);
@@ -543,18 +543,18 @@ int rwkv7_sample_rows_f32(int rows, int nseg, const float *logits, long ld, cons
         (nsuppress > 0 && !suppress))
         return RWKV7_EINVAL;
     return rwkv7::sample_rows_f32(rows, nseg, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, max_domain, do_sample,
-                                  top_k, top_p, temperature, seed, step, out, nullptr, (hipStream_t)stream);
+                                  top_k, top_p, temperature, seed, step, out, nullptr, -1, 0, (hipStream_t)stream);
 }
 int rwkv7_sample_rows_tail_f32(int rows, const float *logits, long ld, const int *seg_off, const int *seg_len, const int *allow_lo,
                                const int *allow_hi, const int *suppress, int nsuppress, int max_domain, int do_sample, int top_k, float top_p,
                                float temperature, unsigned long long seed, const long *step, long *out, const rwkv7_sample_tail *tail,
-                               rwkv7_stream_t stream) {
-    if (rows <= 0 || max_domain <= 0 || nsuppress < 0 || !tail ||
+                               int min_eos_id, long min_eos_until, rwkv7_stream_t stream) {
+    if (rows <= 0 || max_domain <= 0 || nsuppress < 0 ||
         any_null({(const void *)logits, (const void *)seg_off, (const void *)seg_len, (const void *)step, (const void *)out}) ||
         (nsuppress > 0 && !suppress))
         return RWKV7_EINVAL;
     return rwkv7::sample_rows_f32(rows, 1, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, max_domain, do_sample, top_k,
-                                  top_p, temperature, seed, step, out, tail, (hipStream_t)stream);
+                                  top_p, temperature, seed, step, out, tail, min_eos_id, min_eos_until, (hipStream_t)stream);
 }
 int rwkv7_ras_step_f32(int V, const float *logits, long *tok, long *recent, long *ptr, long *step_i, long n_ignore, int eos, float top_p,
                        int top_k, int win_size, float tau_r, unsigned long long seed, rwkv7_stream_t stream) {

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kSmpThreads) void sample_rows_kernel(int nseg, cons
                                                                   const int *__restrict__ allow_lo, const int *__restrict__ allow_hi,
                                                                   const int *__restrict__ suppress, int nsuppress, int do_sample, int top_k,
                                                                   float top_p, float inv_temp, uint2 key, const long *__restrict__ step,
-                                                                  long *__restrict__ out, SmpTail tail) {
+                                                                  long *__restrict__ out, SmpTail tail, int min_id, long min_until) {
     __shared__ SmpShared sm;
     const int seg = blockIdx.x % nseg, row = blockIdx.x / nseg, tid = threadIdx.x;
     const float *xg = logits + (long)row * ld + seg_off[seg];
@@ -419,6 +419,10 @@ __global__ __launch_bounds__(kSmpThreads) void sample_rows_kernel(int nseg, cons
     }
     for (int t = 0; t < nsuppress; t++) {   // a handful of ids
         const int sidx = suppress[t] - lo;
+        if (sidx >= 0 && sidx < m && (sidx & (kSmpThreads - 1)) == tid) x.drop(sidx);
+    }
+    if (min_id >= 0 && *step < min_until) {   // min_new_tokens: no EOS before that many draws (HF MinNewTokensLengthLogitsProcessor)
+        const int sidx = min_id - lo;
         if (sidx >= 0 && sidx < m && (sidx & (kSmpThreads - 1)) == tid) x.drop(sidx);
     }
     int choice;
@@ -666,7 +670,8 @@ constexpr int kEptS = 5, kEptM = 33, kEptL = kSmpMaxN / kSmpThreads;
 
 int sample_rows_f32(int rows, int nseg, const float *logits, long ld, const int *seg_off, const int *seg_len, const int *allow_lo,
                     const int *allow_hi, const int *suppress, int nsuppress, int max_domain, int do_sample, int top_k, float top_p,
-                    float temperature, unsigned long long seed, const long *step, long *out, const void *tail_, hipStream_t st) {
+                    float temperature, unsigned long long seed, const long *step, long *out, const void *tail_, int min_id, long min_until,
+                    hipStream_t st) {
     SmpTail tail = {};
     if (tail_) {
         tail = *(const SmpTail *)tail_;
@@ -680,13 +685,13 @@ int sample_rows_f32(int rows, int nseg, const float *logits, long ld, const int 
     const dim3 grid(rows * nseg), block(kSmpThreads);
     if (max_domain <= kEptS * kSmpThreads)
         sample_rows_kernel<kEptS><<<grid, block, 0, st>>>(nseg, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, do_sample,
-                                                          top_k, top_p, it, key, step, out, tail);
+                                                          top_k, top_p, it, key, step, out, tail, min_id, min_until);
     else if (max_domain <= kEptM * kSmpThreads)
         sample_rows_kernel<kEptM><<<grid, block, 0, st>>>(nseg, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, do_sample,
-                                                          top_k, top_p, it, key, step, out, tail);
+                                                          top_k, top_p, it, key, step, out, tail, min_id, min_until);
     else
         sample_rows_kernel<kEptL><<<grid, block, 0, st>>>(nseg, logits, ld, seg_off, seg_len, allow_lo, allow_hi, suppress, nsuppress, do_sample,
-                                                          top_k, top_p, it, key, step, out, tail);
+                                                          top_k, top_p, it, key, step, out, tail, min_id, min_until);
     return (int)hipGetLastError();
 }
 

@@ -182,13 +182,17 @@ class GraphDecoder:
             # suppression, the warper chain and the draw as ONE launch (csrc/sampling.hip) when the request is covered: the torch chain
             # is ~15 launches (0.45 ms of a 1.4 ms step at B = 32); keyed by (seed, self.pos) instead of torch's generator
             self._try_fused = False
-            sup = None if self.suppress is None else self.suppress.tolist()
-            if RowSampler.supported(logits.device, [logits.shape[-1]], None, sup, self.do_sample, self.top_k, self.top_p,
-                                    self.temperature) is None:
-                self.sampler = RowSampler(logits.device, [logits.shape[-1]], None, sup, self.do_sample, self.top_k, self.top_p,
-                                          self.temperature, seed=torch.cuda.initial_seed() + self.seed_offset)
+            V = logits.shape[-1]
+            allow, sup = RowSampler.fold_suppress(V, None if self.suppress is None else self.suppress.tolist())
+            allow = None if allow is None else [allow]
+            if RowSampler.supported(logits.device, [V], allow, sup, self.do_sample, self.top_k, self.top_p, self.temperature) is None:
+                min_eos = (int(self.eos), self.min_new_tokens) if self.eos is not None and self.min_new_tokens else None
+                self.sampler = RowSampler(logits.device, [V], allow, sup, self.do_sample, self.top_k, self.top_p, self.temperature,
+                                          seed=torch.cuda.initial_seed() + self.seed_offset, min_eos=min_eos)
         if self.sampler is not None:
             return self.sampler(logits, self.pos)[:, 0]
+        if self.min_new_tokens:
+            raise ValueError("min_new_tokens needs the fused sampler (csrc/sampling.hip): request outside its range")
         if self.suppress is not None:
             logits = logits.clone().index_fill_(1, self.suppress, float("-inf"))
         return sample_next(logits, self.do_sample, self.top_k, self.top_p, self.temperature)
@@ -197,10 +201,10 @@ class GraphDecoder:
     def generate(self, inputs_embeds=None, input_ids=None, attention_mask=None, max_new_tokens=256,
                  eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
                  suppress_tokens: Optional[Sequence[int]] = None, do_sample: bool = False, temperature: float = 1.0,
-                 top_k: int = 0, top_p: float = 1.0, seed: Optional[int] = None):
+                 top_k: int = 0, top_p: float = 1.0, seed: Optional[int] = None, min_new_tokens: int = 0):
         self.prepare(inputs_embeds=inputs_embeds, input_ids=input_ids, attention_mask=attention_mask, max_new_tokens=max_new_tokens,
                      eos_token_id=eos_token_id, pad_token_id=pad_token_id, suppress_tokens=suppress_tokens, do_sample=do_sample,
-                     temperature=temperature, top_k=top_k, top_p=top_p, seed=seed)
+                     temperature=temperature, top_k=top_k, top_p=top_p, seed=seed, min_new_tokens=min_new_tokens)
         for _ in range(self.steps_left):
             self.graph.replay()
         return self.finish()
@@ -217,12 +221,13 @@ class GraphDecoder:
     def prepare(self, inputs_embeds=None, input_ids=None, attention_mask=None, max_new_tokens=256,
                 eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
                 suppress_tokens: Optional[Sequence[int]] = None, do_sample: bool = False, temperature: float = 1.0,
-                top_k: int = 0, top_p: float = 1.0, seed: Optional[int] = None):
+                top_k: int = 0, top_p: float = 1.0, seed: Optional[int] = None, min_new_tokens: int = 0):
         """Prefill, first token, and the capture of one decode step on this decoder's static buffers (on the current stream).
         Afterwards `self.graph.replay()` advances every sequence by one token, `self.steps_left` times for max_new_tokens, and
         `finish()` returns the ids."""
         self.do_sample, self.temperature, self.top_k, self.top_p = bool(do_sample), float(temperature), int(top_k or 0), float(top_p)
         self.max_new_tokens, self.steps_left, self.graph = max_new_tokens, 0, None
+        self.min_new_tokens = int(min_new_tokens or 0)   # the EOS id cannot be drawn before that many tokens (fused sampler only)
         if seed is not None:
             torch.cuda.manual_seed(seed)
         self.sampler, self._try_fused, self.tail = None, self.fused_sampling, None

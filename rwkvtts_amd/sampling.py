@@ -69,8 +69,24 @@ class RowSampler:
                 return "top_p without top_k"
         return None
 
+    @staticmethod
+    def fold_suppress(n: int, suppress):
+        """A long suppress list that leaves one contiguous range of ids (the reference's global-token stage suppresses
+        range(num_global_tokens, vocab_size): utils/utilities.py:100) -> (allowed range, the suppressed ids inside it)."""
+        if suppress is None or len(suppress) <= 256:
+            return None, suppress
+        sup = sorted({int(t) for t in suppress if 0 <= int(t) < n})
+        blocked = set(sup)
+        lo = next((i for i in range(n) if i not in blocked), None)
+        if lo is None:
+            return None, suppress
+        hi = next(i for i in range(n - 1, -1, -1) if i not in blocked) + 1
+        return (lo, hi), [t for t in sup if lo <= t < hi]
+
     def __init__(self, device, seg_len: Sequence[int], allow=None, suppress=None, do_sample=False, top_k=0, top_p=1.0, temperature=1.0,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, min_eos: Optional[tuple] = None):
+        """min_eos = (id, n): `id` cannot be drawn while the step counter is below n (min_new_tokens)."""
+        self.min_id, self.min_until = (-1, 0) if min_eos is None else (int(min_eos[0]), int(min_eos[1]))
         why = self.supported(device, seg_len, allow, suppress, do_sample, top_k, top_p, temperature)
         if why:
             raise ValueError("rwkv7_sample_rows_f32: " + why)
@@ -106,12 +122,13 @@ class RowSampler:
                   ctypes.c_float(self.top_p), ctypes.c_float(self.temperature), ctypes.c_ulonglong(self.seed), p(step), p(out))
         stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
         with torch.cuda.device_of(logits):
-            if tail is None:
+            if tail is None and self.min_id < 0:
                 rc = _lib.lib().rwkv7_sample_rows_f32(rows, self.nseg, p(logits), ctypes.c_long(logits.stride(0)), *common, stream)
             else:
                 assert self.nseg == 1
-                rc = _lib.lib().rwkv7_sample_rows_tail_f32(rows, p(logits), ctypes.c_long(logits.stride(0)), *common, ctypes.byref(tail),
-                                                           stream)
+                rc = _lib.lib().rwkv7_sample_rows_tail_f32(rows, p(logits), ctypes.c_long(logits.stride(0)), *common,
+                                                           ctypes.byref(tail) if tail is not None else None, self.min_id,
+                                                           ctypes.c_long(self.min_until), stream)
         _lib.check(rc, "rwkv7_sample_rows_f32")
         return out
 

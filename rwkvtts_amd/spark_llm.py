@@ -135,7 +135,7 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
         use_graph: the per-token loop replayed from a hipGraph with the draw on the device (decode.GraphDecoder /
         MultiGroupDecoder: ~33 k tokens/s at B = 32 on MI355X against ~3 k for the host loop below, which reads `unfinished.any()`
         back every token).  None = when the request is covered: bf16 model on the step kernel, default generator, at most one EOS
-        id, no min_new_tokens, >= 32 new tokens.  Same ids as the host loop for greedy decoding (tests/test_model_gpu.py); sampled
+        id, >= 32 new tokens.  Same ids as the host loop for greedy decoding (tests/test_model_gpu.py); sampled
         draws follow the same distribution through the fused sampler's own random stream."""
         was_training = self.training
         self.eval()
@@ -149,11 +149,14 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
         eos = [] if eos_token_id is None else ([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id))
         pad = pad_token_id if pad_token_id is not None else (eos[0] if eos else 0)
         dev = self.device
-        graph_ok = (generator is None and len(eos) <= 1 and not min_new_tokens and max_new_tokens >= 2 and self.dtype == torch.bfloat16
-                    and dev.type == "cuda")
+        graph_ok = generator is None and len(eos) <= 1 and max_new_tokens >= 2 and self.dtype == torch.bfloat16 and dev.type == "cuda"
+        if graph_ok and min_new_tokens and eos:   # min_new_tokens lives in the fused sampler only
+            from .sampling import RowSampler
+            V = self.lm_head.weight.shape[0]
+            allow, sup = RowSampler.fold_suppress(V, suppress_tokens)
+            graph_ok = RowSampler.supported(dev, [V], None if allow is None else [allow], sup, do_sample, top_k, top_p, temperature) is None
         if use_graph and not graph_ok:
-            raise ValueError("use_graph=True needs a bf16 model on the HIP device, the default generator, at most one EOS id and no "
-                             "min_new_tokens")
+            raise ValueError("use_graph=True needs a bf16 model on the HIP device, the default generator and at most one EOS id")
         if use_graph is None:
             use_graph = graph_ok and max_new_tokens >= 32
         if use_graph:
@@ -164,7 +167,7 @@ class RWKV7ForSpeech(HFModelMixin, nn.Module):
                 seq = dec.generate(inputs_embeds=inputs_embeds, input_ids=input_ids if inputs_embeds is None else None,
                                    attention_mask=attention_mask, max_new_tokens=max_new_tokens, eos_token_id=eos[0] if eos else None,
                                    pad_token_id=pad, suppress_tokens=suppress_tokens, do_sample=do_sample, temperature=temperature,
-                                   top_k=top_k, top_p=top_p)
+                                   top_k=top_k, top_p=top_p, min_new_tokens=min_new_tokens)
                 if eos:   # the host loop leaves with the step in which the last sequence finishes
                     done = (seq == eos[0]).long().cumsum(1) > 0
                     if bool(done[:, -1].all()):

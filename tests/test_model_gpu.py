@@ -568,8 +568,20 @@ def test_generate_replays_the_loop_from_a_graph_when_covered_and_equals_the_host
     # more than 32 sequences: groups of 32 on their own streams
     many = (torch.randn(40, 16, 128, generator=g) * 0.5).to(DEV, torch.bfloat16)
     assert torch.equal(model.generate(inputs_embeds=many, max_new_tokens=33, use_graph=False), model.generate(inputs_embeds=many, max_new_tokens=33))
-    with pytest.raises(ValueError):
-        model.generate(inputs_embeds=x, max_new_tokens=NEW, min_new_tokens=3, use_graph=True)
+    # min_new_tokens (no EOS before that many tokens) and the reference's global-token stage (utils/utilities.py:99-112: every id from
+    # num_global_tokens up suppressed -- a long list that folds into an allowed range -- and min = max new tokens)
+    h5 = model.generate(inputs_embeds=same, max_new_tokens=NEW, eos_token_id=eos, pad_token_id=0, min_new_tokens=first + 3, use_graph=False)
+    a5 = model.generate(inputs_embeds=same, max_new_tokens=NEW, eos_token_id=eos, pad_token_id=0, min_new_tokens=first + 3)
+    assert torch.equal(h5, a5) and (h5[:, :first + 3] != eos).all() and h5.shape[1] > first + 1
+    sup = list(range(64, 257))
+    h6 = model.generate(inputs_embeds=x, max_new_tokens=32, min_new_tokens=32, eos_token_id=256, pad_token_id=0, suppress_tokens=sup, use_graph=False)
+    a6 = model.generate(inputs_embeds=x, max_new_tokens=32, min_new_tokens=32, eos_token_id=256, pad_token_id=0, suppress_tokens=sup)
+    assert torch.equal(h6, a6) and (a6 < 64).all() and a6.shape == (B, 32)
+    s6 = model.generate(inputs_embeds=x, max_new_tokens=32, min_new_tokens=32, eos_token_id=256, pad_token_id=0, suppress_tokens=sup,
+                        do_sample=True, top_k=50, top_p=0.95)
+    assert (s6 < 64).all() and s6.shape == (B, 32) and not torch.equal(s6, a6)
+    with pytest.raises(ValueError):   # two EOS ids: the host loop only
+        model.generate(inputs_embeds=x, max_new_tokens=NEW, eos_token_id=[1, 2], use_graph=True)
 
 
 def test_bf16_training_batch_with_T_16_mod_32_stays_on_the_chunked_kernels():
