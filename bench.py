@@ -139,11 +139,11 @@ def decode_rate(model, dev, B=32, P=128, n1=256, n2=2048):
     mask = torch.ones(B, P, dtype=torch.long, device=dev)
     eos = model.config.vocab_size - 1   # suppressed, as in the synthetic workload
 
-    def run(n):
+    def run(n, **kw):
         dec = GraphDecoder(model, B)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dec.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=n, suppress_tokens=[eos])
+        dec.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=n, suppress_tokens=[eos], **kw)
         torch.cuda.synchronize()
         return time.perf_counter() - t0, dec.step is not None
 
@@ -151,6 +151,19 @@ def decode_rate(model, dev, B=32, P=128, n1=256, n2=2048):
     t1, _ = run(n1)
     t2, kernel = run(n2)
     step = (t2 - t1) / (n2 - n1)
+    # the same loop with the sampling parameters the reference's inference scripts use (inference/rwkv7speech_inference.py:99-107:
+    # do_sample, top_k 50, top_p 0.95): the draw is one launch of csrc/sampling.hip inside the captured step
+    sampled = None
+    try:
+        skw = dict(do_sample=True, top_k=50, top_p=0.95, temperature=1.0, seed=1)
+        run(8, **skw)
+        s1, _ = run(128, **skw)
+        s2, _ = run(640, **skw)
+        sstep = (s2 - s1) / (640 - 128)
+        sampled = {"do_sample": True, "top_k": 50, "top_p": 0.95, "ms_per_step": round(sstep * 1e3, 4), "value": round(B / sstep, 1),
+                   "unit": "tokens/s"}
+    except Exception as e:
+        sampled = {"error": repr(e)}
     # more requests than one 32-sequence group: k groups, each its own captured step, replayed round-robin on k streams
     # (decode.MultiGroupDecoder) -- the launch-latency-bound step of one group leaves most of the chip idle
     multi = None
@@ -186,7 +199,7 @@ def decode_rate(model, dev, B=32, P=128, n1=256, n2=2048):
             "new_tokens": n2, "total_s_incl_prefill_capture": round(t2, 3),
             "bytes_per_step": wbytes + sbytes, "hbm_floor_ms": round(floor * 1e3, 4), "frac_of_hbm_bound": round(floor / step, 4),
             "path": "rwkv7_decode_step_tbl_bf16, one kernel launch per phase, hipGraph replay" if kernel else "module by module, hipGraph replay",
-            "multi_group": multi}
+            "sampled": sampled, "multi_group": multi}
 
 
 def main():
