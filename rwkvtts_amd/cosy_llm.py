@@ -273,7 +273,8 @@ class RWKV7CosyLM(HFModelMixin, nn.Module):
 
                 from .sampling import MAX_DOMAIN, ras_step
                 fused = getattr(self, "fused_sampling", True) and eos + 1 <= MAX_DOMAIN and 1 <= sampling <= 128
-                seed_ = torch.cuda.initial_seed()
+                from .sampling import fresh_seed
+                seed_ = fresh_seed()   # one key per utterance, from torch's default generator (torch.manual_seed reproduces it)
 
                 def captured():
                     x = self.speech_embedding.weight[g_tok]                      # [1, D]

@@ -176,7 +176,7 @@ class GraphDecoder:
         """argmax, or temperature / top-k / top-p multinomial sampling (spark_llm.sample_next: the HF warper order the reference's
         generate runs, utils/utilities.py:101-117) -- inside the captured step too: torch's device generator is graph-safe
         (philox seed/offset live in device memory and advance per replay), so sampled decode replays like greedy decode."""
-        from .sampling import RowSampler
+        from .sampling import RowSampler, fresh_seed
         from .spark_llm import sample_next
         if self.sampler is None and self._try_fused:
             # suppression, the warper chain and the draw as ONE launch (csrc/sampling.hip) when the request is covered: the torch chain
@@ -188,7 +188,7 @@ class GraphDecoder:
             if RowSampler.supported(logits.device, [V], allow, sup, self.do_sample, self.top_k, self.top_p, self.temperature) is None:
                 min_eos = (int(self.eos), self.min_new_tokens) if self.eos is not None and self.min_new_tokens else None
                 self.sampler = RowSampler(logits.device, [V], allow, sup, self.do_sample, self.top_k, self.top_p, self.temperature,
-                                          seed=torch.cuda.initial_seed() + self.seed_offset, min_eos=min_eos)
+                                          seed=(fresh_seed() if self._seed is None else self._seed) + self.seed_offset, min_eos=min_eos)
         if self.sampler is not None:
             return self.sampler(logits, self.pos)[:, 0]
         if self.min_new_tokens:
@@ -230,6 +230,7 @@ class GraphDecoder:
         self.min_new_tokens = int(min_new_tokens or 0)   # the EOS id cannot be drawn before that many tokens (fused sampler only)
         if seed is not None:
             torch.cuda.manual_seed(seed)
+        self._seed = seed   # None: one fresh key per generation from torch's default generator
         self.sampler, self._try_fused, self.tail = None, self.fused_sampling, None
         m = self.model
         dev = m.device
@@ -335,7 +336,7 @@ class MultiGroupDecoder:
             d.seed_offset = gi
         while len(self.streams) < len(cuts):
             self.streams.append(torch.cuda.Stream())
-        seed = kw.pop("seed", None)
+        seed = kw.get("seed", None)   # handed to every group: their draws differ by seed_offset
         if seed is not None:
             torch.cuda.manual_seed(seed)
         for d, st, a in zip(self.decoders, self.streams, cuts):

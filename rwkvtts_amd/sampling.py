@@ -17,6 +17,12 @@ MAX_DOMAIN = 15360
 MAX_TOP_K = 64
 
 
+def fresh_seed() -> int:
+    """A key for one generation call: drawn from torch's default (CPU) generator, so that repeated calls draw different ids and
+    torch.manual_seed(...) makes a run reproducible -- like the torch chains, which consume the global generator."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
 class SampleTail(ctypes.Structure):
     """rwkv7_sample_tail (include/rwkv7_hip.h): what the decode loop does with a drawn id, in the draw's launch."""
     _fields_ = [("unfinished", ctypes.c_void_p), ("eos", ctypes.c_long), ("pad", ctypes.c_long), ("ids", ctypes.c_void_p),
@@ -104,7 +110,7 @@ class RowSampler:
         self.suppress = torch.tensor([int(t) for t in suppress], **i32) if suppress is not None and len(suppress) else None
         self.do_sample, self.top_k = int(bool(do_sample)), int(top_k or 0)
         self.top_p, self.temperature = 1.0 if top_p is None else float(top_p), float(temperature or 1.0)
-        self.seed = int(torch.cuda.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
+        self.seed = int(fresh_seed() if seed is None else seed) & ((1 << 64) - 1)
 
     def __call__(self, logits: torch.Tensor, step: torch.Tensor, out: Optional[torch.Tensor] = None,
                  tail: Optional[SampleTail] = None) -> torch.Tensor:
@@ -141,7 +147,7 @@ def ras_step(logits: torch.Tensor, tok: torch.Tensor, recent: torch.Tensor, ptr:
     for t in (tok, recent, ptr, step_i):
         assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
     assert recent.numel() == win_size
-    seed = int(torch.cuda.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
+    seed = int(fresh_seed() if seed is None else seed) & ((1 << 64) - 1)   # (callers in a loop pass one seed per generation)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     with torch.cuda.device_of(logits):
         rc = _lib.lib().rwkv7_ras_step_f32(logits.numel(), p(logits), p(tok), p(recent), p(ptr), p(step_i), ctypes.c_long(int(n_ignore)),

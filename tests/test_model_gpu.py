@@ -580,6 +580,15 @@ def test_generate_replays_the_loop_from_a_graph_when_covered_and_equals_the_host
     s6 = model.generate(inputs_embeds=x, max_new_tokens=32, min_new_tokens=32, eos_token_id=256, pad_token_id=0, suppress_tokens=sup,
                         do_sample=True, top_k=50, top_p=0.95)
     assert (s6 < 64).all() and s6.shape == (B, 32) and not torch.equal(s6, a6)
+    # sampled calls draw a fresh key per generation (like the torch chain consuming the global generator): two calls differ, a
+    # torch.manual_seed before each makes them equal
+    kw = dict(inputs_embeds=x, max_new_tokens=40, do_sample=True, top_k=50, top_p=0.95)
+    r1, r2 = model.generate(**kw), model.generate(**kw)
+    assert not torch.equal(r1, r2)
+    torch.manual_seed(5)
+    r3 = model.generate(**kw)
+    torch.manual_seed(5)
+    assert torch.equal(r3, model.generate(**kw))
     with pytest.raises(ValueError):   # two EOS ids: the host loop only
         model.generate(inputs_embeds=x, max_new_tokens=NEW, eos_token_id=[1, 2], use_graph=True)
 
