@@ -728,14 +728,17 @@ __device__ __forceinline__ void run_phase(const DecodeDesc &d, DecSmem &sm, int 
         const gu16m xprev = G_U16M(lp[DP_FFN_XPREV]);
         for (int b = blockIdx.x; b < d.B; b += gridDim.x)
             row_phase<1, P1>(d, b, sm.red, d.xb, d.p_att, d.ks_o, nullptr, nullptr, nullptr, d.xa, ln2w, ln2b, xprev, mixp, d.kx);
-    } else if constexpr (PH == 5) {
-        const GemvSeg seg[1] = {{G_U16(lp[DP_WKEY]), d.kx, d.F / 16, d.F}};
-        gemv_phase<1, 1, 16>(d, sm, seg, D, 1, d.kact, d.F, nullptr);
+    } else if constexpr (PH == 5) {   // P1 = columns per tile: 16 while F / 32 tiles would leave CUs idle (0.4B: 128), else 32
+        const GemvSeg seg[1] = {{G_U16(lp[DP_WKEY]), d.kx, d.F / P1, d.F}};
+        gemv_phase<1, 1, P1>(d, sm, seg, D, 1, d.kact, d.F, nullptr);
     } else {
         const GemvSeg seg[1] = {{G_U16(lp[DP_WVAL]), d.kact, D / 32, D}};
         gemv_phase<0, 1>(d, sm, seg, d.F, d.ks_val, d.p_val, D, nullptr);
     }
 }
+
+constexpr int kGrid = 256;
+constexpr int kSplitCap = 256;   // workgroups a GEMV phase counts on (512 -- two per CU, finer K splits -- measured 15 % slower)
 
 // Three instantiations of the width-dependent phases, shared by both launch modes so that they round alike (-ffast-math contracts
 // and reassociates differently in different instantiations): NG float4 groups per thread in the row phases, NF1 / NF2 fragment
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDe
             case 2: run_phase<2, W::NF1, W::NF2>(d, sm, l, lp); break;
             case 3: run_phase<3, 0, 0>(d, sm, l, lp); break;
             case 4: run_phase<4, W::NG, 0>(d, sm, l, lp); break;
-            case 5: run_phase<5, 0, 0>(d, sm, l, lp); break;
+            case 5: run_phase<5, 16, 0>(d, sm, l, lp); break;
             case 6: run_phase<6, 0, 0>(d, sm, l, lp); break;
             case 7: run_phase<7, W::NG, 0>(d, sm, l, lp); break;
             default: run_phase<8, 0, 0>(d, sm, l, lp); break;
@@ -812,7 +815,8 @@ void launch_phases(const int (&g_phase)[7], int items_l0_p1, int B, int L, int V
         launch_phase<2, W::NF1, W::NF2>(g_phase[2], st, d, l, ht);
         launch_phase<3>(g_phase[3], st, d, l, ht);
         launch_phase<4, W::NG>(g_phase[4], st, d, l, ht);
-        launch_phase<5>(g_phase[5], st, d, l, ht);
+        if (d.F / 32 >= kSplitCap) launch_phase<5, 32>(d.F / 32, st, d, l, ht);
+        else launch_phase<5, 16>(g_phase[5], st, d, l, ht);
         launch_phase<6>(g_phase[6], st, d, l, ht);
     }
     launch_phase<7, W::NG>(B, st, d, L, ht);
@@ -846,8 +850,6 @@ int pick_ks(int ntiles, int K, int grid) {
     return best;
 }
 
-constexpr int kGrid = 256;
-constexpr int kSplitCap = 256;   // workgroups a GEMV phase counts on (512 -- two per CU, finer K splits -- measured 15 % slower)
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {

@@ -12,7 +12,9 @@ from rwkvtts_amd.decode import GraphDecoder
 
 DEV = torch.device("cuda:0")
 TRACE = len(sys.argv) > 1 and sys.argv[1] == "trace"
-base = {k: v for k, v in backbone.config_0p4b().to_dict().items() if k in backbone.RWKV7Config.__dataclass_fields__ and k != "extra"}
+SIZE = os.environ.get("GEN_MODEL", "0.4b")   # 0.4b | 1.5b
+base = {k: v for k, v in (backbone.config_1p5b() if SIZE == "1.5b" else backbone.config_0p4b()).to_dict().items()
+        if k in backbone.RWKV7Config.__dataclass_fields__ and k != "extra"}
 
 
 def timed(fn, n1, n2):

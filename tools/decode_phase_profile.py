@@ -15,7 +15,7 @@ def run():
     from rwkvtts_amd import backbone
     from rwkvtts_amd.backbone import Cache, RWKV7ForCausalLM
     from rwkvtts_amd.decode import DecodeStep
-    cfg = backbone.config_0p4b(vocab_size=8193)
+    cfg = (backbone.config_1p5b if os.environ.get("GEN_MODEL") == "1.5b" else backbone.config_0p4b)(vocab_size=8193)
     m = RWKV7ForCausalLM(cfg)
     backbone.init_weights(m, cfg, seed=0)
     m = m.to("cuda:0", torch.bfloat16).eval()
