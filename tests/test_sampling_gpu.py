@@ -147,6 +147,30 @@ def test_plain_multinomial_over_a_wide_row_and_eight_channel_frame():
     assert len({tuple(r) for r in fr2.tolist()}) > B // 2
 
 
+def test_small_segments_k_larger_than_the_segment_and_single_rows():
+    step = torch.zeros(1, dtype=torch.long, device=DEV)
+    row = torch.tensor([0.3, -1.0, 2.0, 0.1, 1.5])
+    N = 8192
+    lg = row.to(DEV).unsqueeze(0).expand(N, -1).contiguous()
+    ids = RowSampler(lg.device, [5], do_sample=True, top_k=50, top_p=0.9, seed=4)(lg, step)[:, 0]      # k > number of ids
+    _check_freq(ids, _exact_probs(row.double(), 50, 0.9, 1.0), "k > n")
+    one = torch.tensor([[7.0]], device=DEV)
+    assert int(RowSampler(one.device, [1], do_sample=True, top_k=3, seed=1)(one, step)) == 0
+    assert int(RowSampler(one.device, [1], do_sample=True, seed=1)(one, step)) == 0
+    # one row, three segments of different widths, one of them with -inf entries (masked ids must never be drawn)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 300 + 7 + 40, generator=g).to(DEV)
+    x[0, 300:305] = float("-inf")
+    smp = RowSampler(x.device, [300, 7, 40], do_sample=True, top_k=4, seed=2)
+    seen = set()
+    for t in range(200):
+        step.fill_(t)
+        r = smp(x, step)[0].tolist()
+        assert 0 <= r[0] < 300 and r[1] in (5, 6) and 0 <= r[2] < 40
+        seen.add(tuple(r))
+    assert len(seen) > 20
+
+
 def test_unsupported_requests_are_refused():
     assert RowSampler.supported(torch.device(DEV), [20000]) is not None                                   # segment too wide for LDS
     assert RowSampler.supported(torch.device(DEV), [100], do_sample=True, top_k=0, top_p=0.9) is not None   # top-p needs the full sort
