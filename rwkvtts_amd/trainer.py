@@ -121,6 +121,8 @@ class FlatBuffers:
 
     def finish_backward(self):
         """After backward: zero the slices that received nothing, re-attach every .grad."""
+        from . import fused
+        fused.wgrad_side_sync()   # weight gradients queued on the side stream land before anything reads the buffer
         self.flush()
         for i, p in enumerate(self.params):
             if not self.fired[i]:
@@ -176,6 +178,8 @@ class BucketedAllReduce:
             self._launch(b)
 
     def _launch(self, b):
+        from . import fused
+        fused.wgrad_side_sync()   # ... including the weight gradients still running on fused's side stream
         self.flat.flush()   # the bucket's slices must hold the final gradients
         s, e, _ = self.buckets[b]
         if self.shard:

@@ -25,7 +25,8 @@ def steps(n):
     return ts
 
 
-switches = [("channel-mix key GEMM with relu^2 epilogue (own kernel)", fused, "FUSED_KEY_RELUSQ", False, True),   # measured: -0.13 ms, off
+switches = [("weight gradients on a side stream", fused, "WGRAD_SIDE_STREAM", False, True),
+            ("channel-mix key GEMM with relu^2 epilogue (own kernel)", fused, "FUSED_KEY_RELUSQ", False, True),   # measured: -0.13 ms, off
             ("add+LN+mix one pass (channel-mix side)", backbone, "FUSED_ADD_LN_MIX1", False, True),
             ("low-rank weight gradients: skinny kernel", fused, "SKINNY_WGRAD", False, True),
             ("value projection + value-residual branch as one node", backbone, "DUAL_LINEAR_XV", False, True),
