@@ -380,6 +380,12 @@ def main():
             roof["fwd"] = {"kernel": fwd_name, "launch_ms": round(fwd_ms, 4), "achieved": round(gbs(f_bytes, fwd_ms), 1),
                            "frac": round(gbs(f_bytes, fwd_ms) * 1e9 / HBM_PEAK, 4), "traffic": traffic(pf),
                            "mfma_util": pf.get("mfma_util"), "valu_frac": pf.get("valu_frac"), "algorithmic_bytes_per_launch": f_bytes}
+        from rwkvtts_amd import fused as _fused
+        if getattr(_fused, "WGRAD_SIDE_STREAM", False):
+            # the durations above are measured in the step, where the weight-gradient GEMMs of fused._wgrad run on a second stream
+            # beside these kernels (same-box A/B: the step is 2 ms shorter, these kernels ~5 % longer than when they run alone)
+            roof["concurrent"] = ("weight-gradient GEMMs on a side stream share the GPU with these kernels (RWKV7_WGRAD_SIDE_STREAM=0: "
+                                  "WKV7 group 1.05 ms / frac 0.16, step +2 ms)")
         roof["pmc_stale"] = bool(stale)
         if stale:
             roof["pmc_stale_why"] = stale

@@ -330,6 +330,8 @@ class _TmixCore(torch.autograd.Function):
               _p(r_k), ctypes.c_float(ctx.eps), _p(d_y), _p(d_r_post), _p(d_k2_post), _p(d_v2_post), _p(d_g),
               _p(part_post), nb)
         # 2. scan: chunked MFMA backward (bf16, T % 32 == 0) or the scalar kernel with two workgroups per head
+        if WGRAD_SYNC_BEFORE_SCAN:
+            wgrad_side_sync(k.device)
         v4 = lambda t: t.view(B, T, H, 64)
         if ctx.chunked_fwd:   # the chunked backward consumes what the chunked forward saved (hs bf16, sa, tinv)
             dw, dq, dk, dv, da, db = ops.wkv7_chunk_backward(v4(w), v4(r), v4(k2), v4(v2), v4(a_in), v4(b_in), v4(d_y), s, sa,
@@ -459,6 +461,8 @@ def wgrad_splitk(dy2, x2, out=None):
 # bucket launch of BucketedAllReduce, and a second use of a parameter in the same pass.  Only gradients written straight into the
 # trainer's flat buffer go this way (a gradient handed back to autograd as a fresh tensor may be consumed at once).
 WGRAD_SIDE_STREAM = os.environ.get("RWKV7_WGRAD_SIDE_STREAM", "1") != "0"
+WGRAD_SYNC_BEFORE_SCAN = False   # drain the side stream before the WKV7 backward kernels: +1.4 ms per step (A/B) -- most of the
+                                 # overlap IS with those kernels (latency-bound, matrix cores and HBM mostly idle)
 _SIDE = {}   # device index -> [stream, work pending]
 
 
