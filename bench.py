@@ -221,6 +221,8 @@ def main():
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="N > 1: gradient pieces reduced to slab owners, AdamW on 1/N of the flat buffers per rank, parameter slabs "
                          "broadcast (trainer.DataParallelTrainer(shard_optimizer=True), SURVEY H6) instead of all-reduce + replicated AdamW")
+    ap.add_argument("--wgrad-side-stream", action="store_true",
+                    help="A/B: weight gradients on a second stream (fused.WGRAD_SIDE_STREAM): -2 ms per step, kernels that share the GPU measure longer")
     ap.add_argument("--via-reference-op", action="store_true",
                     help="A/B: the scan through torch.ops.wind_backstepping.forward/backward (the reference's plug-in point, wkv7_op.cpp:21-29; "
                          "for bf16 and T % 32 == 0 it launches the same chunked MFMA kernels, with `s` as their arena) instead of the direct calls")
@@ -237,6 +239,9 @@ def main():
     if a.via_reference_op:
         from rwkvtts_amd import fused as _fused
         _fused.VIA_REFERENCE_OP = True
+    if a.wgrad_side_stream:
+        from rwkvtts_amd import fused as _fused
+        _fused.WGRAD_SIDE_STREAM = True
 
     from rwkvtts_amd import build
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -384,8 +389,8 @@ def main():
         if getattr(_fused, "WGRAD_SIDE_STREAM", False):
             # the durations above are measured in the step, where the weight-gradient GEMMs of fused._wgrad run on a second stream
             # beside these kernels (same-box A/B: the step is 2 ms shorter, these kernels ~5 % longer than when they run alone)
-            roof["concurrent"] = ("weight-gradient GEMMs on a side stream share the GPU with these kernels (RWKV7_WGRAD_SIDE_STREAM=0: "
-                                  "WKV7 group 1.05 ms / frac 0.16, step +2 ms)")
+            roof["concurrent"] = ("weight-gradient GEMMs on a side stream share the GPU with these kernels (without it: WKV7 group "
+                                  "1.05 ms / frac 0.16, step +2 ms)")
         roof["pmc_stale"] = bool(stale)
         if stale:
             roof["pmc_stale_why"] = stale
@@ -413,6 +418,8 @@ def main():
             "device": _device_info(torch, dev),
             "roofline": roof,
         }
+        if a.wgrad_side_stream:
+            out["config"]["wgrad"] = "weight gradients on a side stream (fused.WGRAD_SIDE_STREAM)"
         if a.via_reference_op:
             out["config"]["wkv_entry"] = "torch.ops.wind_backstepping.forward/backward (reference schema)"
         if a.one_device:

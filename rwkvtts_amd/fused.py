@@ -460,7 +460,10 @@ def wgrad_splitk(dy2, x2, out=None):
 # for the side stream before anything reads a gradient slice: wgrad_side_sync() -- trainer.FlatBuffers.finish_backward, the
 # bucket launch of BucketedAllReduce, and a second use of a parameter in the same pass.  Only gradients written straight into the
 # trainer's flat buffer go this way (a gradient handed back to autograd as a fresh tensor may be consumed at once).
-WGRAD_SIDE_STREAM = os.environ.get("RWKV7_WGRAD_SIDE_STREAM", "1") != "0"
+# Off by default: the step is 2 ms (1.5 %) shorter with it, but every kernel that shares the GPU with the side stream measures
+# longer (the WKV7 group ~5 %, small side-stream kernels several times), which blurs per-kernel profiles and the roofline figures
+# of bench.py; RWKV7_WGRAD_SIDE_STREAM=1 / bench.py --wgrad-side-stream turn it on.
+WGRAD_SIDE_STREAM = os.environ.get("RWKV7_WGRAD_SIDE_STREAM", "0") == "1"
 WGRAD_SYNC_BEFORE_SCAN = False   # drain the side stream before the WKV7 backward kernels: +1.4 ms per step (A/B) -- most of the
                                  # overlap IS with those kernels (latency-bound, matrix cores and HBM mostly idle)
 _SIDE = {}   # device index -> [stream, work pending]

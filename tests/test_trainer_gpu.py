@@ -42,8 +42,19 @@ def _batch(model, rank, step, B=2, T=2048):
     return synthetic_spark_batch(model, B, T, seed=100 * step + rank, n_text=31, n_global=8)   # 4096 rows: split weight gradients
 
 
+@pytest.fixture(params=[False, True], ids=["wgrad-inline", "wgrad-side-stream"])
+def side_stream(request):
+    """fused.WGRAD_SIDE_STREAM off (default) and on: the weight gradients written into the flat buffer from a second stream must
+    leave exactly the same parameters (the reducer and finish_backward wait for that stream)."""
+    from rwkvtts_amd import fused
+    old = fused.WGRAD_SIDE_STREAM
+    fused.WGRAD_SIDE_STREAM = request.param
+    yield request.param
+    fused.WGRAD_SIDE_STREAM = old
+
+
 @pytest.mark.parametrize("shard", [False, True])
-def test_forced_allreduce_on_one_rank_equals_plain_trainer(shard):
+def test_forced_allreduce_on_one_rank_equals_plain_trainer(shard, side_stream):
     """shard=True: the sharded-optimizer exchange (RCCL reduce of every bucket piece to its slab owner, AdamW kernel on the own
     slab through offset pointers, broadcast of the parameter slabs) in a group of one rank, where it must be the identity."""
     from rwkvtts_amd import trainer
@@ -58,9 +69,12 @@ def test_forced_allreduce_on_one_rank_equals_plain_trainer(shard):
         t2 = trainer.DataParallelTrainer(m2, lr=1e-3, warmup_steps=0, total_steps=10)
         t2.reducer.enabled = False
         assert t1.reducer.enabled and len(t1.reducer.buckets) > 4 and t1.reducer.backend == "nccl"
+        from rwkvtts_amd import fused
         for step in range(3):
             l1 = t1.step(**_batch(m1, 0, step))
+            fused.WGRAD_SIDE_STREAM = False          # the comparison trainer always computes its weight gradients in line
             l2 = t2.step(**_batch(m2, 0, step))
+            fused.WGRAD_SIDE_STREAM = side_stream
             assert torch.equal(l1, l2)
         torch.cuda.synchronize()
         assert torch.equal(t1.flat.flat_param, t2.flat.flat_param), "bucketed RCCL path changed the update"
