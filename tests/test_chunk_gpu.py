@@ -25,8 +25,8 @@ def test_mfma_fragment_layout_and_transposed_writeback():
     assert (DT.cpu().double() - want.t()).abs().max().item() < 2e-4 * want.abs().max().item()
 
 
-def test_prep_inverse_matches_torch():
-    B, T, H = 2, 64, 3
+@pytest.mark.parametrize("B,T,H", [(2, 64, 3), (1, 96, 1), (3, 32, 5)])   # one wave per PAIR of chunks: even, odd (3, 15) chunk counts
+def test_prep_inverse_matches_torch(B, T, H):
     w, q, k, v, a, b = make_wkv_inputs(B, T, H, 3, torch.float32)
     tinv = ops.wkv7_chunk_prep(w.to(DEV), a.to(DEV), b.to(DEV)).cpu()
     lw = -torch.exp(w.double())
