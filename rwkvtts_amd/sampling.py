@@ -90,17 +90,24 @@ class RowSampler:
         return (lo, hi), [t for t in sup if lo <= t < hi]
 
     def __init__(self, device, seg_len: Sequence[int], allow=None, suppress=None, do_sample=False, top_k=0, top_p=1.0, temperature=1.0,
-                 seed: Optional[int] = None, min_eos: Optional[tuple] = None):
-        """min_eos = (id, n): `id` cannot be drawn while the step counter is below n (min_new_tokens)."""
+                 seed: Optional[int] = None, min_eos: Optional[tuple] = None, seg_off: Optional[Sequence[int]] = None):
+        """min_eos = (id, n): `id` cannot be drawn while the step counter is below n (min_new_tokens).
+        seg_off: where each segment's id 0 sits in a logits row (default: the segments back to back).  An offset may be negative
+        when the row holds only the allowed part of a segment: segment s with allow = (lo, hi) stored at column c has
+        seg_off = c - lo, so that ids keep their vocabulary values (XY channel 0: the audio range of a 66 661-id head)."""
         self.min_id, self.min_until = (-1, 0) if min_eos is None else (int(min_eos[0]), int(min_eos[1]))
         why = self.supported(device, seg_len, allow, suppress, do_sample, top_k, top_p, temperature)
         if why:
             raise ValueError("rwkv7_sample_rows_f32: " + why)
         self.nseg = len(seg_len)
-        off = [0]
-        for n in seg_len[:-1]:
-            off.append(off[-1] + int(n))
-        self.width = off[-1] + int(seg_len[-1])
+        if seg_off is None:
+            off = [0]
+            for n in seg_len[:-1]:
+                off.append(off[-1] + int(n))
+        else:
+            off = [int(o) for o in seg_off]
+        ends = [(allow[i][1] if allow is not None else int(seg_len[i])) for i in range(len(seg_len))]
+        self.width = max(o + e for o, e in zip(off, ends))   # columns a logits row must have
         i32 = dict(dtype=torch.int32, device=device)
         self.seg_off, self.seg_len = torch.tensor(off, **i32), torch.tensor([int(n) for n in seg_len], **i32)
         self.allow_lo = self.allow_hi = None

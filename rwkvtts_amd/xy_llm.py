@@ -155,18 +155,31 @@ class RWKV7XYLM(HFModelMixin, nn.Module):
         # T = 1 steps: the whole stack + the eight heads (as one concatenated projection) through rwkv7_decode_step_bf16
         # when the model is covered (bf16, B <= 32); else module by module
         step_kernel, sizes = None, [h.weight.shape[0] for h in self.heads]
+        st = _XYFrameState(self, input_ids, total, eos, do_sample, top_k, top_p, temperature, generator, reference_termination)
+        # Channel 0 may only emit audio ids (xy_llm.py:82-86): with the fused draw (which applies that range itself) the step kernel
+        # projects onto the 1 025 audio rows of the 66 661-row head only -- 134 of the 151 MB of head weights are never read
+        lo0, hi0 = cfg.text_shift_size, cfg.text_shift_size + cfg.speech_vocab_size
+        audio_only = (getattr(self, "use_step_kernel", True) and st.sampler_supported(sizes, getattr(self, "fused_sampling", True))
+                      and hi0 <= sizes[0])
+        w0, b0 = (self.heads[0].weight[lo0:hi0], self.heads[0].bias[lo0:hi0]) if audio_only else (self.heads[0].weight, self.heads[0].bias)
         if getattr(self, "use_step_kernel", True):
             from types import SimpleNamespace
             from .decode import DecodeStep
-            head = SimpleNamespace(weight=torch.cat([h.weight for h in self.heads], 0).contiguous(),
-                                   bias=torch.cat([h.bias for h in self.heads], 0).contiguous())
+            head = SimpleNamespace(weight=torch.cat([w0] + [h.weight for h in self.heads[1:]], 0).contiguous(),
+                                   bias=torch.cat([b0] + [h.bias for h in self.heads[1:]], 0).contiguous())
             if DecodeStep.supported(self.model, head, cache) is None:
                 step_kernel = DecodeStep(self.model, head, cache)
-        st = _XYFrameState(self, input_ids, total, eos, do_sample, top_k, top_p, temperature, generator, reference_termination)
-        # the frame's logits as ONE [B, V0 + 7 V1] buffer (the step kernel's layout); st.logits are views of its eight segments
-        st.logits_cat = torch.cat([l[:, -1, :].float() for l in out.logits], 1).contiguous()
-        st.logits = list(torch.split(st.logits_cat, sizes, dim=1))
-        st.make_sampler(sizes, getattr(self, "fused_sampling", True))
+        audio_only = audio_only and step_kernel is not None
+        # the frame's logits as ONE buffer (the step kernel's layout); st.logits are views of its eight segments
+        first = [l[:, -1, :].float() for l in out.logits]
+        if audio_only:
+            first[0] = first[0][:, lo0:hi0]
+            st.logits_cat = torch.cat(first, 1).contiguous()
+            st.make_sampler(sizes, True, col0=[0] + [hi0 - lo0 + sum(sizes[1:i]) for i in range(1, len(sizes))])
+        else:
+            st.logits_cat = torch.cat(first, 1).contiguous()
+            st.logits = list(torch.split(st.logits_cat, sizes, dim=1))
+            st.make_sampler(sizes, getattr(self, "fused_sampling", True))
 
         embed_k = None   # the embedding sum of the previous row as one launch (bf16 tables)
         if step_kernel is not None and getattr(self, "fused_frame", True) and input_ids.dtype == torch.int64:
@@ -286,19 +299,30 @@ class _XYFrameState:
         # the frame's bookkeeping as one launch (csrc/sampling.hip xy_frame_kernel) instead of the ~45 tensor operations below
         self.fused_frame = getattr(model, "fused_frame", True) and input_ids.dtype == torch.int64 and input_ids.is_cuda and B <= 64
 
-    def make_sampler(self, sizes, enabled=True):
-        """The eight draws of a frame as ONE launch (csrc/sampling.hip: channel 0 restricted to the audio ids, xy_llm.py:82-86) when
-        the request is covered -- default generator, the stock sample_next, top-k <= 64 ...; as torch operations the eight warper
-        chains are ~120 launches, 1.8 ms of a 3.1 ms frame."""
+    def _sampler_args(self, sizes):
+        cfg, sm = self.cfg, self.sample
+        allow = [(cfg.text_shift_size, cfg.text_shift_size + cfg.speech_vocab_size)] + [(0, n) for n in sizes[1:]]
+        return allow, dict(do_sample=sm["do_sample"], top_k=sm["top_k"], top_p=sm["top_p"], temperature=sm["temperature"])
+
+    def sampler_supported(self, sizes, enabled=True) -> bool:
         from . import spark_llm
         from .sampling import RowSampler
-        cfg, sm = self.cfg, self.sample
-        if not enabled or sm["generator"] is not None or spark_llm.sample_next is not spark_llm._STOCK_SAMPLE_NEXT:
+        if not enabled or self.sample["generator"] is not None or spark_llm.sample_next is not spark_llm._STOCK_SAMPLE_NEXT:
+            return False
+        allow, kw = self._sampler_args(sizes)
+        return RowSampler.supported(self.out.device, sizes, allow, None, **kw) is None
+
+    def make_sampler(self, sizes, enabled=True, col0=None):
+        """The eight draws of a frame as ONE launch (csrc/sampling.hip: channel 0 restricted to the audio ids, xy_llm.py:82-86) when
+        the request is covered -- default generator, the stock sample_next, top-k <= 64 ...; as torch operations the eight warper
+        chains are ~120 launches, 1.8 ms of a 3.1 ms frame.  col0: the column at which each channel's logits start when the row
+        holds only the audio range of channel 0 (ids keep their vocabulary values)."""
+        from .sampling import RowSampler
+        if not self.sampler_supported(sizes, enabled):
             return
-        allow = [(cfg.text_shift_size, cfg.text_shift_size + cfg.speech_vocab_size)] + [(0, n) for n in sizes[1:]]
-        kw = dict(do_sample=sm["do_sample"], top_k=sm["top_k"], top_p=sm["top_p"], temperature=sm["temperature"])
-        if RowSampler.supported(self.logits_cat.device, sizes, allow, None, **kw) is None:
-            self.sampler = RowSampler(self.logits_cat.device, sizes, allow, None, **kw)
+        allow, kw = self._sampler_args(sizes)
+        seg_off = None if col0 is None else [c - a[0] for c, a in zip(col0, allow)]
+        self.sampler = RowSampler(self.out.device, sizes, allow, None, seg_off=seg_off, **kw)
 
     def need_rows(self, frames_after):
         return self.cur_len + frames_after > self.out.shape[1]
