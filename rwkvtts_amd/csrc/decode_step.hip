@@ -385,8 +385,11 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, con
                     }
                     if (n < d.B) *reinterpret_cast<uint2 *>(ob + c) = make_uint2(cvt_pk(v[0], v[1]), cvt_pk(v[2], v[3]));  // F % 64 == 0
                 } else if (n < d.B) {
-                    if (vec && c0 + c + 3 < sg.ncols) {
-                        *reinterpret_cast<float4 *>(op + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (vec && c0 + c + 3 < sg.ncols) {   // write-through, like the state rows: read next by workgroups on other XCDs
+                        f32x4v t4;
+                        t4.x = v[0]; t4.y = v[1]; t4.z = v[2]; t4.w = v[3];
+                        const unsigned long long sp = (unsigned long long)(op + c);
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(sp), "v"(t4) : "memory");
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; i++)
@@ -616,7 +619,10 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
                 if (liveD) {
                     f32x4v t;
                     t.x = st[i].x; t.y = st[i].y; t.z = st[i].z; t.w = st[i].w;
-                    *(f32x4v __attribute__((address_space(1))) *)(S + (vr + 8 * i) * 64 + k4) = t;
+                    // write-through (sc1): the 8 MB of state rows are not left dirty in the L2s at the kernel boundary (a boundary costs
+                    // its predecessor's dirty bytes / 6 TB/s on top, MI355X_MICROARCH.md: 1.3 us here)
+                    const unsigned long long sp = (unsigned long long)(S + (vr + 8 * i) * 64 + k4);
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(sp), "v"(t) : "memory");
                 }
                 const float y = sum16(st[i].x * rr.x + st[i].y * rr.y + st[i].z * rr.z + st[i].w * rr.w);
                 if ((tt & 15) == 0) sm.y[bbD][vr + 8 * i] = y;
