@@ -70,8 +70,14 @@ def ras_sampling_device(logp, recent, ignore_eos, eos: int, top_p=0.8, top_k=25,
                  the accepted draw is the candidate set's distribution with EOS removed, which is what is sampled here directly
                  (if the nucleus is EOS alone: the full distribution without EOS, where the reference would give up after 100
                  rejections).
-    Same distribution as the host functions, different consumption of the random stream (the pinned id-for-id comparison with
-    the reference's functions, tests/test_sampling.py, is on the host pair)."""
+    Different consumption of the random stream (the pinned id-for-id comparison with the reference's functions,
+    tests/test_sampling.py, is on the host pair).  Distribution: identical to the host functions when `ignore_eos` is off or EOS has
+    no mass; while `ignore_eos` is on it is an APPROXIMATION of the reference's rejection loop -- the reference re-runs the WHOLE
+    sampler (nucleus draw, repeat check, full-distribution fallback) after an EOS result, so its accepted law is proportional to
+    N(x)[x not repeated] + N(R)F(x) over x != EOS renormalised ONCE (N nucleus law, F full law, R the repeated ids), while removing
+    EOS per stage gives N'(x)[x not repeated] + N'(R)F(x)/(1 - F(EOS)).  The two differ only when a repeat fallback is possible AND
+    F(EOS) > 0, by a factor (1 - F(EOS))^-1 on the fallback term relative to the nucleus term: total variation
+    <= N(R) F(EOS) / (1 - N(EOS)) (tests/test_sampling.py::test_eos_rejection_laws_reference_vs_per_stage_bound_and_host_sampler)."""
     probs = logp.softmax(dim=0)
     sv, si = probs.sort(descending=True, stable=True)
     cum_before = torch.cumsum(sv, 0) - sv

@@ -452,7 +452,9 @@ __global__ __launch_bounds__(kSmpThreads) void sample_rows_kernel(int nseg, cons
                 nk = (int)block_scan(keep ? 1.f : 0.f, f, sm);
                 nk = (int)f;
             }
-            if (tid == 0) sm.pick[0] = sm.cand_i[min(sm.pick[1], nk - 1)];
+            // no candidate survived (every allowed logit is -inf / NaN, or suppression + min_eos cover the allowed range): the torch
+            // chain would raise; here the draw falls back to the first allowed id instead of reading cand_i[-1]
+            if (tid == 0) sm.pick[0] = nk > 0 ? sm.cand_i[min(sm.pick[1], nk - 1)] : 0;
             __syncthreads();
             choice = sm.pick[0];
         } else {   // plain multinomial over the whole segment
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(kSmpThreads) void sample_rows_kernel(int nseg, cons
             choice = i0 >= 0 ? i0 : key_idx(k);
         }
     }
+    choice = min(max(choice, 0), m - 1);   // an id outside [lo, lo + m) never reaches the output or the embedding lookup below
     if (tid == 0) out[(long)row * nseg + seg] = lo + choice;
     if (tail.ids) {   // nseg == 1
         __syncthreads();

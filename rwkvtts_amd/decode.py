@@ -205,14 +205,30 @@ class GraphDecoder:
         self.prepare(inputs_embeds=inputs_embeds, input_ids=input_ids, attention_mask=attention_mask, max_new_tokens=max_new_tokens,
                      eos_token_id=eos_token_id, pad_token_id=pad_token_id, suppress_tokens=suppress_tokens, do_sample=do_sample,
                      temperature=temperature, top_k=top_k, top_p=top_p, seed=seed, min_new_tokens=min_new_tokens)
-        for _ in range(self.steps_left):
-            self.graph.replay()
+        ran = 0
+        while ran < self.steps_left:
+            n = min(self.EOS_CHECK_EVERY if self.eos is not None else self.steps_left, self.steps_left - ran)
+            for _ in range(n):
+                self.graph.replay()
+            ran += n
+            # the host loop leaves with the step in which the last sequence meets EOS (the reference's scripts ask for 1 024..3 000 new
+            # tokens and an utterance ends after a few hundred): one read-back per EOS_CHECK_EVERY replays, as XY generate does per 8 frames
+            if self.eos is not None and ran < self.steps_left and not bool(self.unfinished.any()):
+                break
+        self.steps_run = ran
         return self.finish()
 
+    EOS_CHECK_EVERY = 16
+
     def finish(self):
-        """After the last replay: bookkeeping, the barrier-timeout check of the step kernel, the ids."""
+        """After the last replay: bookkeeping, the barrier-timeout check of the step kernel, the ids.  After an early exit (every
+        sequence met EOS) the columns that were not run carry the pad id, and `cache.seen_tokens` counts the steps actually run (the
+        state has been advanced through at most EOS_CHECK_EVERY - 1 pad tokens past the last EOS)."""
         if self.graph is not None:
-            self.cache.seen_tokens = self._seen0 + self.max_new_tokens - 1
+            ran = getattr(self, "steps_run", self.steps_left)
+            self.cache.seen_tokens = self._seen0 + ran
+            if ran < self.steps_left:
+                self.out[:, 1 + ran:self.max_new_tokens] = self.pad_t
         if self.step is not None and self.step.barrier_timed_out():
             raise _lib.Rwkv7HipError("rwkv7_decode_step_bf16: a grid barrier timed out; the generated ids are invalid")
         return self.out[:, :self.max_new_tokens]
@@ -336,6 +352,11 @@ class MultiGroupDecoder:
             d.seed_offset = gi
         while len(self.streams) < len(cuts):
             self.streams.append(torch.cuda.Stream())
+        # model.eval() in GraphDecoder.__init__ reset the lazily built parameter caches (backbone._stacked_mix): rebuild them HERE, on
+        # `main`, so that no group's stream reads what another group's stream is still writing (each group waits only on `main`)
+        for mod in self.model.modules():
+            if hasattr(mod, "_stacked_mix"):
+                mod._stacked_mix(self.model.dtype)
         seed = kw.get("seed", None)   # handed to every group: their draws differ by seed_offset
         if seed is not None:
             torch.cuda.manual_seed(seed)
@@ -344,11 +365,20 @@ class MultiGroupDecoder:
             with torch.cuda.stream(st):   # prefill + capture of each group on its own stream
                 d.prepare(inputs_embeds=sl(inputs_embeds, a), input_ids=sl(input_ids, a), attention_mask=sl(attention_mask, a),
                           max_new_tokens=max_new_tokens, **kw)
-        for _ in range(max(0, max_new_tokens - 1)):
+        live = [d for d in self.decoders if d.graph is not None]
+        for d in live:
+            d.steps_run = 0
+        for it in range(max(0, max_new_tokens - 1)):
             for d, st in zip(self.decoders, self.streams):
-                if d.graph is not None:
+                if d in live:
                     with torch.cuda.stream(st):
                         d.graph.replay()
+                    d.steps_run += 1
+            # groups whose sequences have all met EOS drop out (one read-back per group every EOS_CHECK_EVERY rounds)
+            if (it + 1) % GraphDecoder.EOS_CHECK_EVERY == 0 and live and live[0].eos is not None:
+                live = [d for d in live if bool(d.unfinished.any())]
+                if not live:
+                    break
         outs = []
         for d, st in zip(self.decoders, self.streams):
             main.wait_stream(st)

@@ -308,6 +308,11 @@ class DataParallelTrainer:
         if param_groups == "reference":
             param_groups = reference_param_groups(model, weight_decay)
         if param_groups is None:
+            if weight_decay:
+                import warnings
+                warnings.warn("DataParallelTrainer(param_groups=None) decays nothing, like the Spark trainer's single group "
+                              "(train_spark_rwkv7speech.py:188); weight_decay=%g is ignored -- pass param_groups='all' (decay every "
+                              "parameter) or 'reference' (the Cosy trainer's lr_decay group)" % weight_decay, stacklevel=2)
             param_groups = [("all", 1.0, 0.0)] * len(self.flat.params)
         elif param_groups == "all":
             param_groups = [("all", 1.0, float(weight_decay))] * len(self.flat.params)

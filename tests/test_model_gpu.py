@@ -555,6 +555,18 @@ def test_generate_replays_the_loop_from_a_graph_when_covered_and_equals_the_host
     a2 = model.generate(inputs_embeds=same, max_new_tokens=NEW, eos_token_id=eos, pad_token_id=0)
     first = int((ref[0] == eos).nonzero()[0, 0])
     assert h2.shape == (B, first + 1) and torch.equal(h2, a2)
+    # ... and the replay loop itself leaves early (round-3 advice: the reference's scripts ask for 1 024..3 000 new tokens while an
+    # utterance ends after a few hundred): EOS at step `first` of 400 -> at most one check interval of surplus replays, the columns
+    # never run carry the pad id, seen_tokens counts the steps actually run
+    from rwkvtts_amd.decode import GraphDecoder, MultiGroupDecoder
+    dec = GraphDecoder(model, B, step_kernel=True)
+    long_run = dec.generate(inputs_embeds=same, max_new_tokens=400, eos_token_id=eos, pad_token_id=0)
+    assert dec.steps_run <= first + GraphDecoder.EOS_CHECK_EVERY and dec.steps_run < 399
+    assert long_run.shape == (B, 400) and torch.equal(long_run[:, :first + 1], h2) and (long_run[:, first + 1:] == 0).all()
+    assert dec.cache.seen_tokens == P + dec.steps_run
+    mg = MultiGroupDecoder(model, 2, step_kernel=True)   # three groups (2 + 2 + 1 sequences), all finish at `first`
+    long_mg = mg.generate(inputs_embeds=same, max_new_tokens=400, eos_token_id=eos, pad_token_id=0)
+    assert torch.equal(long_mg, long_run) and all(d.steps_run <= first + GraphDecoder.EOS_CHECK_EVERY for d in mg.decoders)
     # mixed: one sequence with another prompt may or may not reach the EOS -> padded rows, same shape either way
     mixed = torch.cat([same[:2], x[2:4]], 0)
     h3 = model.generate(inputs_embeds=mixed, max_new_tokens=NEW, eos_token_id=eos, pad_token_id=0, use_graph=False)
