@@ -333,9 +333,9 @@ def main():
         value = world * B * T * a.steps / dt
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items() if v}
         th = B * T * H
-        chunk_parts = [k for k in ("wkv7c_bwd_pre", "wkv7c_state", "wkv7c_bseq", "wkv7c_bwd_out") if k in kern]
+        chunk_parts = [k for k in ("wkv7c_bseq", "wkv7c_bwd_out") if k in kern]
         if "wkv7c_op_bwd" in kern:   # --via-reference-op: the op's launches are timed as one unit each way
-            bwd_ms, bwd_name = kern["wkv7c_op_bwd"], f"torch.ops.wind_backstepping.backward -> wkv7c_bseq + wkv7c_bwd_out8 ({cfg.num_hidden_layers}x per step)"
+            bwd_ms, bwd_name = kern["wkv7c_op_bwd"], f"torch.ops.wind_backstepping.backward -> wkv7c_bseq + wkv7c_bwd_out9 ({cfg.num_hidden_layers}x per step)"
             fwd_ms, fwd_name = kern["wkv7c_op_fwd"], "torch.ops.wind_backstepping.forward -> wkv7c_prep + wkv7c_fwd9"
             pmc_bwd, pmc_fwd = "wkv7c_bwd", "wkv7c_fwd"
         elif "wkv7c_bwd_out" in kern:

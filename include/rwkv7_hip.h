@@ -85,7 +85,7 @@ int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_b
  *   cols_per_lane : state columns per lane of the scalar forward kernel -- 0 automatic by B*H (what the plain entry does), 4, 8
  *   wide          : row-split backward -- 0 = 256 threads, 2 state rows per lane tile (plain entry); 1 = 512 threads, 1 row
  *   waves         : chunked bf16 forward -- 9 = producer/consumer kernel, two dependent products per chunk (plain entry),
- *                   8 = three dependent products per chunk, 4 = the 4-wave kernel */
+ *                   4 = the 4-wave kernel (the one fp32 tensors run) */
 int rwkv7_wkv_fwd_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                const void *a, const void *b, void *y, float *s, float *sa, int cols_per_lane, rwkv7_stream_t stream);
 int rwkv7_wkv_fwd_variant_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
@@ -299,39 +299,24 @@ int rwkv7_wkv_chunk_fwd_seq_bf16(int B, int T, int H, const void *w, const void 
 int rwkv7_wkv_chunk_fwd_seq_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                 const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                                 const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
-/* ---- chunked backward, bf16 (csrc/wkv7_chunk_bwd.hip, wkv7_chunk_bwd8.hip).  With H = S^T and the chunk quantities above, the
- *      adjoint state obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
- *   bwd_pre : parallel over chunks.  mt  = M_c^T and np = N'_c, one q15 record per chunk each (int16 [4 tiles][64 lanes][16] +
- *                                    fp32 scale [4][64]; RWKV7_Q15_REC uint16 units per record): N' in MFMA accumulator
- *                                    order, M^T as the A fragments the state kernel multiplies with (tile = (k-tile, k'-tile),
- *                                    lane = (row k % 32, half h), values k' = 32 k'-tile + 16 i + 8 h + j, i = 0..1, j = 0..7)
- *   state   : sequential over chunks (reverse), one workgroup per (head, half of the value columns).
- *             e_vk[b,h,c][v][k] = E_{c+1}, what chunk c receives from its future, as bf16 (the recurrence itself carries
- *             ~16 mantissa bits; the per-chunk kernel reads this rounded copy once). ---- */
-int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
-                                 const void *dy, const float *tinv, void *mt, void *np, rwkv7_stream_t stream);
-int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const void *np, void *e_vk, rwkv7_stream_t stream);
-int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const void *np, void *e_vk, const int *seq_chunk_off,
-                                   int nseq, rwkv7_stream_t stream);   /* packed rows: see rwkv7_wkv_chunk_fwd_seq_bf16 */
-/*   bseq    : `bwd_pre` + `state` as ONE sequential kernel (csrc/wkv7_chunk_bseq.hip; what ops.wkv7_chunk_backward launches): the
- *             recurrence in factored form, E_c = E' + A~^T Z + Q~^T dY with Z = (T^T B^) E' + (T^T A_qb^T) dY, E' = g_C E_{c+1} --
- *             M_c^T and N'_c are never formed and never reach HBM.  Same e_vk records as `state`; seq_chunk_off / nseq as in
- *             rwkv7_wkv_chunk_fwd_seq_bf16 (NULL / 0 for plain rows). */
+/* ---- chunked backward, bf16 (csrc/wkv7_chunk_bseq.hip, wkv7_chunk_bwd9.hip; reference wkv7_cuda.cu:54-130).  With H = S^T and the
+ *      chunk quantities above, the adjoint state obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
+ *   bseq    : sequential over chunks (reverse), one workgroup per (head, half of the value columns): the recurrence in factored
+ *             form, E_c = E' + A~^T Z + Q~^T dY with Z = (T^T B^) E' + (T^T A_qb^T) dY, E' = g_C E_{c+1} -- M_c^T and N'_c are
+ *             never formed and never reach HBM.  e_vk[b,h,c] = E_{c+1}, what chunk c receives from its future, one q15 record
+ *             per chunk (int16 [4 tiles][64 lanes][16] + fp32 scale [4][64]; RWKV7_Q15_REC uint16 units; the recurrence itself
+ *             carries ~16 mantissa bits, the per-chunk kernel reads this rounded copy once); seq_chunk_off / nseq as in
+ *             rwkv7_wkv_chunk_fwd_seq_bf16 (NULL / 0 for plain rows). ---- */
 int rwkv7_wkv_chunk_bseq_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
                               const float *tinv, void *e_vk, float *z, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
 /*             z (may be NULL): fp32 [B,T,H,64], Z_t = dL/du_t (u = sa), which the recurrence forms anyway.  With it the per-chunk
- *             gradient kernel needs neither T^-1 nor the A_qb -> G1 -> Z chain: rwkv7_wkv_chunk_bwd_out_z_bf16 (two matrix
- *             phases instead of five; csrc/wkv7_chunk_bwd9.hip). */
+ *             gradient kernel needs neither T^-1 nor an A_qb -> G1 -> Z chain of its own.
+ *   bwd_out_z : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from what the chunked
+ *             forward saved (hs, sa) and e_vk, z of `bseq`; two matrix phases per chunk (csrc/wkv7_chunk_bwd9.hip). */
 int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                    const void *a, const void *b, const void *dy, const void *hs, const float *sa,
                                    const float *z, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
                                    void *da, void *db, rwkv7_stream_t stream);
-/*   bwd_out : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from what the chunked
- *             forward saved (hs, sa, tinv) and the adjoint states e_vk of `state`. */
-int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                 const void *a, const void *b, const void *dy, const void *hs, const float *sa,
-                                 const float *tinv, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
-                                 void *da, void *db, rwkv7_stream_t stream);
 /* ---- head loss: softmax cross-entropy of a chunk of bf16 logits [rows,V], forward and backward in one pass
  *      (spark_llm.py:146-160, FusedLinearCrossEntropyLoss).  labels int64 [rows]; rows with label == ignore_index give 0.
  *      loss_rows[rows] = logsumexp - logit[label]; logits are REPLACED by (softmax - onehot) * scale. ---- */

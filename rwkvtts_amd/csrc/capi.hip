@@ -37,18 +37,12 @@ int ce_fwd_bwd(long, int, void *, const long *, long, float, float *, hipStream_
 int adamw_step(long, float *, const void *, float *, float *, void *, const uint8_t *, const float *, const float *, float, float, float, float,
                float, float, float, hipStream_t);
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
-int chunk_bwd_pre_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
-                       void *, hipStream_t);
-int chunk_state_bf16(int, int, int, const void *, const void *, void *, const int *, int, hipStream_t);
 int chunk_bseq_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                     float *, const int *, int, hipStream_t);
 int gemm_nt_bf16(int, int, int, const void *, const void *, void *, int, hipStream_t);
 int gemm_nt_bf16_variant(int, int, int, const void *, const void *, void *, int, int, hipStream_t);
 int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
-int chunk_bwd_out8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
-                        const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *,
-                        hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
 int sample_rows_f32(int, int, const float *, long, const int *, const int *, const int *, const int *, const int *, int, int, int, int, float,
@@ -395,35 +389,18 @@ EW_DEFINE(f32, float)
 #define RWKV7_COMMA ,
 CHUNK_DEFINE(bf16, 9 RWKV7_COMMA)
 CHUNK_DEFINE(f32, )
-// A/B and cross-check: the 4-wave kernel (waves = 4), the 8-wave producer/consumer kernel with three dependent products per
-// chunk (8) or with two (9, what the plain entry launches)
+// A/B and cross-check: the 4-wave kernel (waves = 4) or the 8-wave producer/consumer kernel (9, what the plain entry launches)
 int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                          const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                                          const int *seq_chunk_off, int nseq, int waves, rwkv7_stream_t stream) {
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;
     if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;
     if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;
-    if (waves != 4 && waves != 8 && waves != 9) return RWKV7_ESHAPE;
+    if (waves != 4 && waves != 9) return RWKV7_ESHAPE;
     return rwkv7::chunk_fwd_bf16(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, waves, (hipStream_t)stream);
 }
 
-// chunked backward (bf16): see csrc/wkv7_chunk_bwd.hip
-int rwkv7_wkv_chunk_bwd_pre_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b,
-                                 const void *dy, const float *tinv, void *mt, void *np, rwkv7_stream_t stream) {
-    if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, a, b, dy, (const void *)tinv, mt, (const void *)np})) return RWKV7_EINVAL;
-    if (T % 32 != 0) return RWKV7_ECHUNK;
-    return rwkv7::chunk_bwd_pre_bf16(B, T, H, w, q, a, b, dy, tinv, mt, np, (hipStream_t)stream);
-}
-int rwkv7_wkv_chunk_state_bf16(int BH, int nchunks, const void *mt, const void *np, void *e_vk, rwkv7_stream_t stream) {
-    if (BH <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk})) return RWKV7_EINVAL;
-    return rwkv7::chunk_state_bf16(BH, nchunks, 1, mt, np, e_vk, nullptr, 0, (hipStream_t)stream);
-}
-int rwkv7_wkv_chunk_state_seq_bf16(int B, int H, int nchunks, const void *mt, const void *np, void *e_vk, const int *seq_chunk_off,
-                                   int nseq, rwkv7_stream_t stream) {
-    if (B <= 0 || H <= 0 || nchunks <= 0 || any_null({mt, (const void *)np, (const void *)e_vk})) return RWKV7_EINVAL;
-    if (seq_chunk_off != nullptr && nseq <= 0) return RWKV7_EINVAL;
-    return rwkv7::chunk_state_bf16(B * H, nchunks, H, mt, np, e_vk, seq_chunk_off, nseq, (hipStream_t)stream);
-}
+// chunked backward (bf16): csrc/wkv7_chunk_bseq.hip (adjoint recurrence, writes E and Z) + csrc/wkv7_chunk_bwd9.hip (per-chunk gradients)
 int rwkv7_wkv_chunk_bseq_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
                               const float *tinv, void *e_vk, float *z, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream) {
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, a, b, dy, (const void *)tinv, (const void *)e_vk})) return RWKV7_EINVAL;
@@ -440,16 +417,6 @@ int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const voi
         return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
     return rwkv7::chunk_bwd_out9_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
-}
-int rwkv7_wkv_chunk_bwd_out_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                 const void *a, const void *b, const void *dy, const void *hs, const float *sa,
-                                 const float *tinv, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
-                                 void *da, void *db, rwkv7_stream_t stream) {
-    if (B <= 0 || T <= 0 || H <= 0 ||
-        any_null({w, q, k, v, a, b, dy, hs, (const void *)sa, (const void *)tinv, e_vk, dw, dq, dk, dv, da, db}))
-        return RWKV7_EINVAL;
-    if (T % 32 != 0) return RWKV7_ECHUNK;
-    return rwkv7::chunk_bwd_out8_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, tinv, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
 int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, rwkv7_stream_t stream) {
     if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;

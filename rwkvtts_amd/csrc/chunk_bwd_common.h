@@ -1,5 +1,4 @@
-// rwkvtts_amd/csrc/chunk_bwd_common.h -- helpers shared by the chunked WKV7 backward kernels (wkv7_chunk_bwd.hip: pre, state
-// and the 4-wave per-chunk gradient kernel; wkv7_chunk_bwd8.hip: the 8-wave per-chunk gradient kernel).
+// rwkvtts_amd/csrc/chunk_bwd_common.h -- helpers of the chunked WKV7 per-chunk gradient kernel (wkv7_chunk_bwd9.hip).
 #pragma once
 #include "chunk_common.h"
 

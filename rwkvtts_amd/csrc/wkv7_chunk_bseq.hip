@@ -1,6 +1,7 @@
 // rwkvtts_amd/csrc/wkv7_chunk_bseq.hip -- adjoint-state recurrence of the chunked (MFMA) WKV7 backward in ONE kernel, bf16 tensors.
 //
-// Replaces wkv7c_bwd_pre_kernel + wkv7c_state_kernel (wkv7_chunk_bwd.hip; reference wkv7_cuda.cu:54-130).  Those two materialise
+// Reference: wkv7_cuda.cu:54-130.  Replaced round 2's wkv7c_bwd_pre_kernel + wkv7c_state_kernel (removed in round 4: git log --
+// rwkvtts_amd/csrc/wkv7_chunk_bwd.hip).  Those two materialised
 // M_c^T and N'_c (two 64 x 64 matrices per chunk, 18 KB of q15 records written by one kernel and read by the next: 0.6 GB per layer
 // at B=8, T=4096, H=16) so that the sequential kernel is one product per chunk.  Here the recurrence
 //     E_c = M_c^T E_{c+1} + N'_c ,   M_c = diag(g_C)(I + B^^T T A~) ,   N'_c = Q~^T dY + (T A~)^T (A_qb^T dY)

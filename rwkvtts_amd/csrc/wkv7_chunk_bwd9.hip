@@ -1,6 +1,7 @@
 // rwkvtts_amd/csrc/wkv7_chunk_bwd9.hip -- per-chunk gradients of the chunked (MFMA) WKV7 backward from Z, bf16 tensors, 8 waves.
 //
-// Same mathematics, inputs and outputs as wkv7c_bwd_out8_kernel (wkv7_chunk_bwd8.hip; reference wkv7_cuda.cu:54-130), except that
+// Reference: wkv7_cuda.cu:54-130.  Successor of round 2's wkv7c_bwd_out8_kernel (removed in round 4: git log -- rwkvtts_amd/csrc/wkv7_chunk_bwd8.hip;
+// the compiler traps found there -- hoisted LDS addresses, divergent wave ids, conditional loads -- are recorded in DESIGN.md section 4), except that
 // Z (Z_t = dL/du_t) is an INPUT: the adjoint-state kernel wkv7c_bseq_kernel forms Z = (T^T B^) E' + (T^T A_qb^T) dY on its chain
 // anyway and writes it (fp32 [B,T,H,64], like sa).  With Z given, the only dependency chain of the 8-wave kernel
 // (A_qb -> G1 -> Z -> {P_vz, P_uz} -> last terms: five barrier-separated phases) is gone -- every tile product of the chunk depends
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
     using L = Out9Smem;
     float *sh_gC = reinterpret_cast<float *>(sm + L::gC), *sh_dterm = reinterpret_cast<float *>(sm + L::dterm);
     const int nc = T_ / kC;
-    // wave and half are wave-uniform, and the compiler must know it (see wkv7_chunk_bwd8.hip)
+    // wave and half are wave-uniform, and the compiler must know it (compiler traps)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int pt = tid & 31, pk = (tid >> 5) * 4;                        // compute mapping: step pt, channels pk .. pk+3
     const int half = wave >> 2, ltid = tid & 255, lt = ltid >> 3, lk = (ltid & 7) * 8;   // global mapping: step lt, channels lk .. lk+7
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
         float4 sc;           // threads 0-63: 4 of the 256 scales of E; threads 64-127: of H_C
     };
     // The same six 16-byte loads in both halves, through per-half pointers (wave-uniform selects), no branch, never skipped
-    // (`valid` = false: every lane reads offset 0): the reasons are in wkv7_chunk_bwd8.hip.
+    // (`valid` = false: every lane reads offset 0): the reasons are in DESIGN.md section 4 (compiler traps).
     auto load_rows = [&](int chunk, bool valid) {
         const int bh = chunk / nc, c = chunk - bh * nc;
         const int bb = bh / H, hh = bh - bb * H;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
     const int chunk0 = blockIdx.x * kOut9ChunksPerWG;
     Rows cur = load_rows(chunk0, true);
     Mats curm = load_mats(chunk0, true);
-    // H0 of a chunk = H_C of the chunk before it (see wkv7_chunk_bwd8.hip)
+    // H0 of a chunk = H_C of the chunk before it (a workgroup walks consecutive chunks, so the record is fetched once)
     float *sh_sE = reinterpret_cast<float *>(sm + L::sclE), *sh_sH = reinterpret_cast<float *>(sm + L::sclH);
     uint2 h0[2];
     q15_load8(hs_ + (long)chunk0 * kQRec, st_v, st_k8, h0[0], h0[1]);

@@ -504,18 +504,14 @@ int chunk_prep_bf16(int B, int T_, int H, const void *w, const void *a, const vo
 int chunk_prep_f32(int B, int T_, int H, const void *w, const void *a, const void *b, float *tinv, hipStream_t st) {
     return launch_prep<float>(B, T_, H, w, a, b, tinv, st);
 }
-// bf16 tensors run the 8-wave producer / consumer kernel (wkv7_chunk_fwd8.hip: 335 us against 495 us for this 4-wave kernel at
+// bf16 tensors run the 8-wave producer / consumer kernel (wkv7_chunk_fwd9.hip: 278 us against 495 us for this 4-wave kernel at
 // B=8, T=4096, H=16); waves == 4 (rwkv7_wkv_chunk_fwd_seq_variant_bf16) selects this one (A/B, cross-check).  fp32 tensors always run here.
-int chunk_fwd8_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const float *,
-                    void *, float *, void *, const int *, int, hipStream_t);
-// waves == 9: the 8-wave kernel with two dependent products per chunk (wkv7_chunk_fwd9.hip)
 int chunk_fwd9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const float *,
                     void *, float *, void *, const int *, int, hipStream_t);
 
 int chunk_fwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                    const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, int waves, hipStream_t st) {
     if (waves == 9) return chunk_fwd9_bf16(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st);
-    if (waves != 4) return chunk_fwd8_bf16(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st);
     return (sa && hs) ? launch_fwd_t<bf16_t, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st)
                       : launch_fwd_t<bf16_t, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, seq_off, nseq, st);
 }

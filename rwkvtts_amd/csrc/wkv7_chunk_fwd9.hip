@@ -1,7 +1,7 @@
 // rwkvtts_amd/csrc/wkv7_chunk_fwd9.hip -- chunked (MFMA) WKV7 forward, bf16 tensors, 8 waves, TWO dependent products per chunk.
 //
-// Same mathematics, inputs and outputs as wkv7c_fwd8_kernel (wkv7_chunk_fwd8.hip; reference wkv7_cuda.cu:10-52).  That kernel
-// walks a chunk in four barrier-separated intervals, three of them on the state's dependency chain:
+// Reference: wkv7_cuda.cu:10-52.  Its predecessor (round 2's wkv7c_fwd8_kernel, removed in round 4: git log -- rwkvtts_amd/csrc/wkv7_chunk_fwd8.hip)
+// walked a chunk in four barrier-separated intervals, three of them on the state's dependency chain:
 //     S -> R = A~ S + A_ak V -> U = T R -> S' = g_C (S + B^^T U + K^^T V)
 // (6.2k cycles per chunk, sequential over T/32 chunks, one workgroup per CU: the whole kernel is this chain).  Here the chain is
 // cut to TWO products by moving T to the state-independent side:
@@ -18,7 +18,7 @@
 //                  0: U -> staging (sa); A_ak, X' of the next chunk
 //                  waves 4-7: rows of the chunk after the next in the compute mapping: exp, prefix sums, scaling, q~ / a~ splits
 // Two barriers per chunk.  LDS: 2 x 38.5 KB operand planes + 48 KB matrices + 9.5 KB fp32 + 25 KB staging = 159.5 KB.
-// Measured (tools/bench_chunk_fwd_waves.py, B=8, T=4096, H=16): 278 us against 335 us for wkv7c_fwd8_kernel; interval stamps
+// Measured (tools/bench_chunk_fwd_waves.py, B=8, T=4096, H=16): 278 us against 335 us for the three-product kernel; interval stamps
 // (tools/cfwd9_timing.py): 4.5k cycles per chunk = 2.25k + 2.25k, every wave within 10 % of the interval in both -- the chain
 // waves' own work is 1.5k + 1.5k.  A fragment fetch of one 32x32x64 product (16 ds_read_b128) takes ~790 cycles with all eight
 // waves on the LDS: the ~120 KB of LDS stores per chunk (operand planes 37, staging 25, split intermediates and fp32 tiles 55)
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
         // raw rows, global -> registers (row-contiguous mapping) -> LDS staging -> registers (compute mapping, one barrier later)
         uint4 gw, gq, gk, ga, gb;
         Raw4<bf16_t> gv;
-        auto issue = [&](int c) {   // unconditional: the chunk index is clamped by the caller (see the notes on conditional loads in wkv7_chunk_bwd8.hip)
+        auto issue = [&](int c) {   // unconditional: the chunk index is clamped by the caller (the notes on conditional loads: DESIGN.md section 4, "compiler traps")
             const long off = head_base + (long)(c * kC + lt) * tstride;
             gw = *reinterpret_cast<const uint4 *>(w_ + off + lk);
             gq = *reinterpret_cast<const uint4 *>(q_ + off + lk);

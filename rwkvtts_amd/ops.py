@@ -344,34 +344,10 @@ def _seq_args(seq_off):
     return _p(seq_off), seq_off.numel() - 1
 
 
-def wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off=None):
-    """First two stages of the chunked backward (bf16): per-chunk M^T / N' (parallel) and the adjoint-state recurrence
-    E_c = M_c^T E_{c+1} + N'_c (sequential over chunks).  Returns (mt, np, e_vk): e_vk[b,h,c] = E_{c+1} as q15 records."""
-    B, T, H, C = w.shape
-    if w.dtype != torch.bfloat16:
-        raise TypeError("the chunked backward is bf16 only")
-    if T % CHUNK_T != 0:
-        raise ValueError(f"chunked WKV7 needs T % {CHUNK_T} == 0, got T={T}")
-    nc = T // CHUNK_T
-    dev = w.device
-    mt = torch.empty(B, H, nc, Q15_REC, dtype=torch.int16, device=dev)
-    np_ = torch.empty(B, H, nc, Q15_REC, dtype=torch.int16, device=dev)
-    e_vk = torch.empty(B, H, nc, Q15_REC, dtype=torch.int16, device=dev)
-    with torch.cuda.device_of(w):
-        with _timed("wkv7c_bwd_pre", w):
-            rc = _lib.lib().rwkv7_wkv_chunk_bwd_pre_bf16(B, T, H, _p(w), _p(q), _p(a), _p(b), _p(dy), _p(tinv), _p(mt), _p(np_),
-                                                         _stream(w))
-        _lib.check(rc, "wkv7_chunk_bwd_pre")
-        with _timed("wkv7c_state", w):
-            rc = _lib.lib().rwkv7_wkv_chunk_state_seq_bf16(B, H, nc, _p(mt), _p(np_), _p(e_vk), *_seq_args(seq_off), _stream(w))
-        _lib.check(rc, "wkv7_chunk_state")
-    return mt, np_, e_vk
-
-
 def wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off=None, want_z=False):
     """The adjoint-state recurrence of the chunked backward as ONE sequential kernel (csrc/wkv7_chunk_bseq.hip): the factored
     form E_c = E' + A~^T Z + Q~^T dY, Z = (T^T B^) E' + (T^T A_qb^T) dY -- M_c^T / N'_c are not materialised.  Returns e_vk
-    (e_vk[b,h,c] = E_{c+1} as q15 records), the same records wkv7_chunk_bwd_state returns; with want_z also Z (fp32 [B,T,H,64],
+    (e_vk[b,h,c] = E_{c+1} as q15 records); with want_z also Z (fp32 [B,T,H,64],
     Z_t = dL/du_t) as (e_vk, z)."""
     B, T, H, C = w.shape
     if w.dtype != torch.bfloat16:
@@ -388,31 +364,19 @@ def wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off=None, want_z=False):
     return (e_vk, z) if want_z else e_vk
 
 
-def wkv7_chunk_backward(w, q, k, v, a, b, dy, hs, sa, tinv, seq_off=None, two_kernel_state=False, from_z=True):
+def wkv7_chunk_backward(w, q, k, v, a, b, dy, hs, sa, tinv, seq_off=None):
     """Chunked (MFMA) WKV7 backward, bf16: same gradients as torch.ops.wind_backstepping.backward, T % 32 == 0, from what
-    wkv7_chunk_forward saved (hs, sa, tinv).  Launches: adjoint-state recurrence (one kernel, which also writes Z = dL/du;
-    two_kernel_state=True: the M^T/N' kernel + the one-product recurrence, kept for A/B and cross-checks), per-chunk gradients
-    (from Z: two matrix phases; from_z=False or two_kernel_state: the kernel that rebuilds Z from T^-1 itself, five phases).
+    wkv7_chunk_forward saved (hs, sa, tinv).  Two launches: the adjoint-state recurrence (csrc/wkv7_chunk_bseq.hip, which also
+    writes Z = dL/du) and the per-chunk gradients from Z (csrc/wkv7_chunk_bwd9.hip, two matrix phases).
     Returns (dw, dq, dk, dv, da, db)."""
     B, T, H, C = w.shape
     if hs.dtype != torch.int16 or hs.shape[-1] != Q15_REC or sa.dtype != torch.float32 or tinv.dtype != torch.float32:
         raise TypeError("wkv7_chunk_backward takes hs (q15 records), sa and tinv (fp32) as saved by wkv7_chunk_forward")
-    z = None
-    if two_kernel_state:
-        mt, np_, e_vk = wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, seq_off)
-        del mt, np_
-    elif from_z:
-        e_vk, z = wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off, want_z=True)
-    else:
-        e_vk = wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off)
+    e_vk, z = wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off, want_z=True)
     grads = [torch.empty_like(w) for _ in range(6)]
     with torch.cuda.device_of(w), _timed("wkv7c_bwd_out", w):
-        if z is not None:
-            rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_z_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(hs), _p(sa),
-                                                           _p(z), _p(e_vk), *[_p(g) for g in grads], _stream(w))
-        else:
-            rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(hs), _p(sa),
-                                                         _p(tinv), _p(e_vk), *[_p(g) for g in grads], _stream(w))
+        rc = _lib.lib().rwkv7_wkv_chunk_bwd_out_z_bf16(B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(dy), _p(hs), _p(sa),
+                                                       _p(z), _p(e_vk), *[_p(g) for g in grads], _stream(w))
     _lib.check(rc, "wkv7_chunk_bwd_out")
     return tuple(grads)
 

@@ -63,21 +63,10 @@ def test_chunk_forward_vs_oracle(c_oracle, B, T, H, seed, dtype):
     assert hsf[:, :, 0].abs().max().item() == 0.0
 
 
-def _untile(np_tiles):
-    """[4 tiles][64 lanes][16 regs] (MFMA accumulator layout, tile = 2*mt + nt) -> [64 (m)][64 (n)]."""
-    out = torch.zeros(64, 64)
-    for tile in range(4):
-        mt, nt = tile >> 1, tile & 1
-        for lane in range(64):
-            for r in range(16):
-                m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-                out[mt * 32 + m, nt * 32 + (lane & 31)] = np_tiles[tile, lane, r]
-    return out
-
-
 def test_chunked_backward_state_recurrence_vs_prototype():
-    """wkv7c_bwd_pre + wkv7c_state: M_c^T, N'_c and the adjoint states E against the CPU prototype of the same algebra
-    (tests/chunked_proto2.py, fp32), which itself is checked against the scalar oracle."""
+    """wkv7c_bseq (the factored adjoint recurrence E_c = E' + A~^T Z + Q~^T dY, M_c^T / N'_c never formed): the adjoint states E
+    against the CPU prototype of the unfactored algebra E_c = M_c^T E_{c+1} + N'_c (tests/chunked_proto2.py, fp32), which itself is
+    checked against the scalar oracle; plain rows, and packed rows (a cut inside the row restarts the recurrence from E = 0)."""
     import chunked_proto2 as P2
     B, T, H = 1, 128, 2
     ins = make_wkv_inputs(B, T, H, 21, torch.bfloat16)
@@ -85,44 +74,25 @@ def test_chunked_backward_state_recurrence_vs_prototype():
     d = [t.to(DEV) for t in ins]
     w, q, k, v, a, b = d
     tinv = ops.wkv7_chunk_prep(w, a, b)
-    mt, np_, e_vk = ops.wkv7_chunk_bwd_state(w, q, a, b, dy.to(DEV), tinv)
-    e_f = ops.q15_decode(e_vk)
-    torch.cuda.synchronize()
-    # M^T is a q15 record whose tiles are MFMA A fragments: tile = (k-tile, k'-tile), lane = k % 32 + 32 h, value 8 i + j =
-    # M^T[k][32 k'-tile + 16 i + 8 h + j]; one fp32 scale per (tile, lane)
-    rec = mt.cpu()
-    frag = rec[..., :4096].float().view(B, H, T // 32, 2, 2, 64, 2, 8) * \
-        rec[..., 4096:].contiguous().view(torch.float32).view(B, H, T // 32, 2, 2, 64, 1, 1)
-    mt = torch.zeros(B, H, T // 32, 64, 64)
-    for kt in range(2):
-        for kpt in range(2):
-            for i in range(2):
-                for half in range(2):
-                    c0 = 32 * kpt + 16 * i + 8 * half
-                    mt[:, :, :, kt * 32:(kt + 1) * 32, c0:c0 + 8] = frag[:, :, :, kt, kpt, 32 * half:32 * half + 32, i, :]
     nc = T // 32
-    for h in range(H):
-        one = [t[0, :, h].float() for t in ins]
-        y, U, hs, L, Ms = P2.fwd3(*one, 32, torch.float32, 0)
-        dyh = dy[0, :, h].float()
-        S = lambda x: x
-        Np = [l["Qt"].T @ dyh[c * 32:c * 32 + 32] + l["W"].T @ (l["A_qb"].T @ dyh[c * 32:c * 32 + 32]) for c, l in enumerate(L)]
-        E = torch.zeros(64, 64)
-        Es = [None] * nc
-        for c in range(nc - 1, -1, -1):
-            Es[c] = E
-            E = Ms[c].T @ E + Np[c]
-        for c in range(nc):
-            ref = Ms[c].T
-            assert (mt[0, h, c] - ref).abs().max() <= 4e-5 * ref.abs().max(), ("M^T", h, c)   # 2^-16 of a lane group's maximum + fp32-level error
-            # N' travels as a q15 record in accumulator order: tiles [mt*2+nt][lane][16], one scale per (tile, lane)
-            rec = np_[0, h, c].cpu()
-            tiles = rec[:4096].float().view(4, 64, 16) * rec[4096:].contiguous().view(torch.float32).view(4, 64, 1)
-            got = _untile(tiles)
-            assert (got - Np[c]).abs().max() <= 6e-5 * Np[c].abs().max() + 1e-6, ("N'", h, c)
-            scale = max(Es[c].abs().max().item(), 1e-3)
-            # e_vk: q15 record of the recurrence's E ([v][k], 2^-15 of each column's maximum) on top of the fp32-level error
-            assert (e_f[0, h, c].cpu().t() - Es[c]).abs().max() <= 1.5e-4 * scale, ("E[v][k]", h, c)
+    for cuts in (None, [0, 3, nc]):
+        so = None if cuts is None else torch.tensor(cuts, dtype=torch.int32, device=DEV)
+        e_f = ops.q15_decode(ops.wkv7_chunk_bwd_seq(w, q, a, b, dy.to(DEV), tinv, so))
+        torch.cuda.synchronize()
+        segs = [(0, nc)] if cuts is None else list(zip(cuts[:-1], cuts[1:]))
+        for h in range(H):
+            for (c0, c1) in segs:
+                one = [t[0, c0 * 32:c1 * 32, h].float() for t in ins]
+                y, U, hs, L, Ms = P2.fwd3(*one, 32, torch.float32, 0)
+                dyh = dy[0, c0 * 32:c1 * 32, h].float()
+                n = c1 - c0
+                Np = [l["Qt"].T @ dyh[c * 32:c * 32 + 32] + l["W"].T @ (l["A_qb"].T @ dyh[c * 32:c * 32 + 32]) for c, l in enumerate(L)]
+                E = torch.zeros(64, 64)
+                for c in range(n - 1, -1, -1):
+                    scale = max(E.abs().max().item(), 1e-3)
+                    # e_vk: q15 record of the recurrence's E ([v][k], 2^-15 of each lane's maximum) on top of the fp32-level error
+                    assert (e_f[0, h, c0 + c].cpu().t() - E).abs().max() <= 3e-4 * scale, ("E[v][k]", cuts, h, c0 + c)
+                    E = Ms[c].T @ E + Np[c]
 
 
 @pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2)])
@@ -180,7 +150,7 @@ def test_full_size_config2_chunked_pair_vs_oracle_slices(c_oracle):
 
 
 def test_packed_sequences_equal_separate_sequences_vs_oracle(c_oracle):
-    """Packed rows (rwkv7_wkv_chunk_fwd_seq_bf16 / rwkv7_wkv_chunk_state_seq_bf16, fla chunk_rwkv7's cu_seqlens): rows whose
+    """Packed rows (rwkv7_wkv_chunk_fwd_seq_bf16 / rwkv7_wkv_chunk_bseq_bf16, fla chunk_rwkv7's cu_seqlens): rows whose
     chunks 0, 2, 3 (row 0) and 0, 1 (row 1) start new sequences must give, segment by segment, exactly what the C oracle gives
     for each segment run on its own from the zero state -- outputs and all six gradients, same bars as the plain tests."""
     B, T, H, seed = 2, 160, 3, 7
@@ -209,11 +179,11 @@ def test_packed_sequences_equal_separate_sequences_vs_oracle(c_oracle):
 DEFAULT_FWD_WAVES = 9   # what the plain entry point rwkv7_wkv_chunk_fwd_seq_bf16 launches
 
 
-@pytest.mark.parametrize("waves", [8, 9])
+@pytest.mark.parametrize("waves", [9])
 @pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
 def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T, H, seed, waves):
-    """wkv7_chunk_fwd8.hip (producer / consumer split, three dependent products per chunk) and wkv7_chunk_fwd9.hip (W = T A~ and
-    X' = T A_ak made beside the chain, two dependent products per chunk; `waves` = 8 / 9 of rwkv7_wkv_chunk_fwd_seq_variant_bf16):
+    """wkv7_chunk_fwd9.hip (producer / consumer split; W = T A~ and X' = T A_ak made beside the chain, two dependent products per
+    chunk; `waves` = 9 of rwkv7_wkv_chunk_fwd_seq_variant_bf16):
     the same bars against the C oracle as the 4-wave kernel, feeding the chunked backward; and against the 4-wave kernel itself the
     fp32 outputs agree to rounding (hipcc contracts the split prologue differently: last-ulp differences of the scaled operands;
     the two-product form associates U = T(A~ S + A_ak V) as (T A~) S + (T A_ak) V), also on packed rows."""
@@ -254,39 +224,3 @@ def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T
         _assert_f32_close(ops.q15_decode(b[3]), ops.q15_decode(a[3]).cpu(), "hs 8 vs 4", 1e-4)
 
 
-@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
-def test_one_kernel_adjoint_recurrence_vs_two_kernel_pair(B, T, H, seed):
-    """wkv7_chunk_bseq.hip (the factored recurrence E_c = E' + A~^T Z + Q~^T dY, what wkv7_chunk_backward launches) against
-    wkv7c_bwd_pre + wkv7c_state (M_c^T / N'_c materialised, checked against the CPU prototype above): the same E records up to
-    the q15 rounding of M^T / N' in the pair (2^-15 of a lane's maximum) and the different association of the products, plain
-    and packed rows; and the six gradients that come out of either."""
-    ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
-    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 7))).bfloat16().to(DEV)
-    d = [t.to(DEV) for t in ins]
-    w, q, k, v, a, b = d
-    nc = T // 32
-    cuts = {0, B * nc}
-    for bi in range(B):
-        cuts.add(bi * nc + nc)
-        if nc > 1:
-            cuts.add(bi * nc + (nc + bi) // 2)
-    seq_off = torch.tensor(sorted(cuts), dtype=torch.int32, device=DEV)
-    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
-    for so in (None, seq_off):
-        _, _, e_pair = ops.wkv7_chunk_bwd_state(w, q, a, b, dy, tinv, so)
-        e_one = ops.wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, so)
-        torch.cuda.synchronize()
-        ep, eo = ops.q15_decode(e_pair).cpu(), ops.q15_decode(e_one)
-        for bi in range(B):
-            for hi in range(H):
-                for c in range(nc):
-                    ref = ep[bi, hi, c]
-                    err = (eo[bi, hi, c].cpu() - ref).abs().max().item()
-                    assert err <= 3e-4 * max(ref.abs().max().item(), 1e-3), (so is not None, bi, hi, c, err, ref.abs().max().item())
-    g_pair = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv, two_kernel_state=True)
-    g_one = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv, from_z=False)
-    g_z = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv)      # default: Z from the recurrence kernel, two-phase gradient kernel
-    torch.cuda.synchronize()
-    for n, g1, g2, g3 in zip(NAMES, g_one, g_pair, g_z):
-        _assert_bf16_close(g1, g2.float().cpu(), f"{n}: one-kernel vs pair", ulps=1.0)
-        _assert_bf16_close(g3, g2.float().cpu(), f"{n}: from Z vs pair", ulps=1.0)

@@ -408,7 +408,7 @@ def test_trainer_fast_gradient_path_equals_accumulate_path():
 @pytest.mark.parametrize("lens", [[70, 33, 128, 5], [32, 64], [1, 1, 200]])
 def test_packed_rows_native_sequence_ranges(lens):
     """cu_seqlens batches in bf16 run on the chunked WKV7 kernels' per-sequence chunk ranges (32-aligned re-layout; forward
-    recurrence in rwkv7_wkv_chunk_fwd_seq_bf16 and adjoint recurrence in rwkv7_wkv_chunk_state_seq_bf16 per sequence) instead
+    recurrence in rwkv7_wkv_chunk_fwd_seq_bf16 and adjoint recurrence in rwkv7_wkv_chunk_bseq_bf16 per sequence) instead
     of being unpacked into a padded batch.  Both ways must agree -- hidden states, loss, every parameter gradient, the input gradient -- and each
     sequence must come out as if it had been run alone (state and token shift restart at the boundaries, including lengths
     that are exact multiples of 32 and lengths of 1)."""

@@ -1,4 +1,4 @@
-"""Per-kernel times of the chunked WKV7 backward (pre / state / out) at several grid sizes: does the sequential state kernel's
+"""Per-kernel times of the chunked WKV7 backward (bseq / bwd_out) at several grid sizes: does the sequential kernel's
 step time depend on how many workgroups run beside it (shared HBM / fabric) or not (per-CU latency chain)?"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,4 +20,4 @@ for B, T, H in ((8, 4096, 16), (8, 4096, 8), (4, 4096, 8), (2, 4096, 8), (8, 204
     med = {k: sorted(s.elapsed_time(e) for s, e in v)[len(v) // 2] * 1e3 for k, v in ops.KERNEL_TIMERS.items()}
     ops.KERNEL_TIMERS = None
     nc = T // 32
-    print(f"B={B} T={T} H={H}: " + "  ".join(f"{k} {v:6.1f} us" for k, v in med.items()) + f"  | state {med['wkv7c_state'] / nc * 1e3:6.0f} ns/step, {B * H * 2} workgroups", flush=True)
+    print(f"B={B} T={T} H={H}: " + "  ".join(f"{k} {v:6.1f} us" for k, v in med.items()) + f"  | bseq {med['wkv7c_bseq'] / nc * 1e3:6.0f} ns/chunk, {B * H * 2} workgroups", flush=True)

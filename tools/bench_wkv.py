@@ -78,9 +78,9 @@ def main():
     if a.dtype == "bf16":
         _, _, sa2, hs16 = ops.wkv7_chunk_forward(w, q, k, v, aa, b)
     cb = (lambda: ops.wkv7_chunk_backward(w, q, k, v, aa, b, dy, hs16, sa2, tinv)) if a.dtype == "bf16" else None
-    cb_state = (lambda: ops.wkv7_chunk_bwd_state(w, q, aa, b, dy, tinv)) if a.dtype == "bf16" else None
-    cb_seq = (lambda: ops.wkv7_chunk_bwd_seq(w, q, aa, b, dy, tinv)) if a.dtype == "bf16" else None
-    cb_pair = (lambda: ops.wkv7_chunk_backward(w, q, k, v, aa, b, dy, hs16, sa2, tinv, two_kernel_state=True)) if a.dtype == "bf16" else None
+    # every bseq launch of this script writes Z, as the training step's does: a PMC pass over this script (tools/pmc_wkv.sh) averages
+    # the counters of all launches of a kernel, and a Z-less launch in the mix would understate the kernel's WRITE_SIZE
+    cb_seq = (lambda: ops.wkv7_chunk_bwd_seq(w, q, aa, b, dy, tinv, want_z=True)) if a.dtype == "bf16" else None
     for name, fn, bytes_per in (("wkv7_fwd(save s,sa)", fwd, 7 * 64 * esz),
                                 ("wkv7_fwd 8 col/lane", shaped(8, fwd), 7 * 64 * esz),
                                 ("wkv7_fwd 4 col/lane", shaped(4, fwd), 7 * 64 * esz),
@@ -90,9 +90,7 @@ def main():
                                 ("wkv7_bwd row-split 512 thr", (lambda: ops.wkv7_backward_split(w, q, k, v, aa, b, dy, s, sa, wide=1)) if a.dtype == "bf16" else None, 13 * 64 * esz),
                                 ("wkv7_state_fwd", sfw, 7 * 64 * esz), ("wkv7c_prep (T inverse)", prep, 3 * 64 * esz),
                                 ("wkv7c_fwd (chunked, save)", cf, 7 * 64 * esz),
-                                ("wkv7c bwd pre+state (2 launches)", cb_state, 13 * 64 * esz),
-                                ("wkv7c bseq (adjoint recurrence, 1 launch)", cb_seq, 13 * 64 * esz),
-                                ("wkv7c bwd total, pre+state+out", cb_pair, 13 * 64 * esz),
+                                ("wkv7c bseq (adjoint recurrence + Z, 1 launch)", cb_seq, 13 * 64 * esz),
                                 ("wkv7c bwd total, bseq+out (default)", cb, 13 * 64 * esz)):
         if fn is None:
             continue
