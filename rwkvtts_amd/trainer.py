@@ -145,25 +145,57 @@ class BucketedAllReduce:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
-        esz = flat.flat_grad.element_size()
-        # buckets follow backward order: last parameters first
-        self.buckets: List[List[int]] = []  # each: [start, end, n_params]
-        self.param_bucket = [0] * len(flat.params)
-        cur_end, cur_start, cnt = flat.numel, flat.numel, 0
-        for i in range(len(flat.params) - 1, -1, -1):
-            cur_start = flat.offsets[i]
-            self.param_bucket[i] = len(self.buckets)
-            cnt += 1
-            if (cur_end - cur_start) * esz >= bucket_bytes or i == 0:
-                self.buckets.append([cur_start, cur_end, cnt])
-                cur_end, cnt = cur_start, 0
-        self.pending = [b[2] for b in self.buckets]
+        self.bucket_bytes = bucket_bytes
+        # First pass: buckets follow REGISTRATION order backwards (last parameters first), the usual proxy for gradient-ready order.
+        # It is wrong where registration and use differ -- the Spark model registers its three input-side embedding tables AFTER
+        # lm_head, so they sat in bucket 0 (136 MiB) although their gradients arrive at the very end of backward, and the bucket
+        # that should open the exchange was the last to fire.  The order the hooks actually fire in is recorded during the first
+        # backward pass and the buckets are re-cut along it once (`rebuild_from_ready_order`, what DDP does after its first
+        # iteration).  The flat buffers are NOT re-laid-out: a bucket is a list of contiguous runs of the flat gradient buffer
+        # (normally one; the embedding-side bucket has one run per end of the buffer), each run one collective.
+        self._cut(list(range(len(flat.params) - 1, -1, -1)))
+        self.ready_order: List[int] = []
+        self.rebuilt = False
         self.works = []
         self.use_avg, self.summed = True, []
         self.measure, self.wait_events = False, []
         self.enabled = self.world > 1 or (force and dist.is_initialized())
         if self.enabled:
             flat.on_ready = self._ready
+
+    def _cut(self, order):
+        """Buckets of >= bucket_bytes along `order` (parameter indices, first-ready first).  self.buckets[b] = [start, end, n_params]
+        with [start, end) the span of the bucket's runs (what bench.py prints); self.runs[b] = the contiguous [s, e) pieces."""
+        flat, esz = self.flat, self.flat.flat_grad.element_size()
+        size = lambda i: ((flat.params[i].numel() + 127) // 128 * 128)
+        self.buckets, self.runs = [], []
+        self.param_bucket = [0] * len(flat.params)
+        cur, nbytes = [], 0
+        for n, i in enumerate(order):
+            cur.append(i)
+            nbytes += size(i) * esz
+            self.param_bucket[i] = len(self.buckets)
+            if nbytes >= self.bucket_bytes or n == len(order) - 1:
+                pieces = sorted((flat.offsets[j], flat.offsets[j] + size(j)) for j in cur)
+                runs = [list(pieces[0])]
+                for s_, e_ in pieces[1:]:
+                    if s_ == runs[-1][1]:
+                        runs[-1][1] = e_
+                    else:
+                        runs.append([s_, e_])
+                self.buckets.append([runs[0][0], runs[-1][1], len(cur)])
+                self.runs.append([tuple(r) for r in runs])
+                cur, nbytes = [], 0
+        self.pending = [b[2] for b in self.buckets]
+
+    def rebuild_from_ready_order(self):
+        """Re-cut the buckets along the order in which the gradient hooks fired in the pass just finished (once; parameters whose
+        hook did not fire go last).  Every rank runs the same model, so every rank records the same order and cuts the same buckets
+        -- a precondition of the collectives, asserted in tests/test_trainer_dist.py."""
+        seen = set(self.ready_order)
+        order = self.ready_order + [i for i in range(len(self.flat.params) - 1, -1, -1) if i not in seen]
+        self._cut(order)
+        self.rebuilt = True
 
     def slab(self, r):
         """[start, end) of rank r's slab of the flat buffers (128-element aligned, the last one may be shorter or empty)."""
@@ -172,6 +204,8 @@ class BucketedAllReduce:
         return min(r * size, n), min((r + 1) * size, n)
 
     def _ready(self, i):
+        if not self.rebuilt:
+            self.ready_order.append(i)
         b = self.param_bucket[i]
         self.pending[b] -= 1
         if self.pending[b] == 0:
@@ -181,9 +215,12 @@ class BucketedAllReduce:
         from . import fused
         fused.wgrad_side_sync()   # ... including the weight gradients still running on fused's side stream
         self.flat.flush()   # the bucket's slices must hold the final gradients
-        s, e, _ = self.buckets[b]
+        for s, e in self.runs[b]:
+            self._exchange(s, e)
+
+    def _exchange(self, s, e):
         if self.shard:
-            for r in range(self.world):   # the bucket's intersection with every rank's slab goes to that rank only
+            for r in range(self.world):   # the run's intersection with every rank's slab goes to that rank only
                 lo, hi = self.slab(r)
                 lo, hi = max(lo, s), min(hi, e)
                 if lo >= hi:
@@ -238,7 +275,10 @@ class BucketedAllReduce:
         for s, e in self.summed:
             self.flat.flat_grad[s:e].mul_(1.0 / self.world)
         self.summed = []
-        self.pending = [b[2] for b in self.buckets]
+        if not self.rebuilt and self.ready_order:
+            self.rebuild_from_ready_order()   # once, after the first backward pass (also resets `pending`)
+        else:
+            self.pending = [b[2] for b in self.buckets]
 
 
 def linear_warmup_decay(step, total_steps, warmup_steps, lr, lr_final):

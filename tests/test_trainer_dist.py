@@ -61,13 +61,30 @@ def _worker(rank, world, port, q, shard=False):
         assert any(s < a1 < e for s, e, _ in tr.reducer.buckets)
     assert len(tr.reducer.buckets) > 2  # several buckets -> hooks fire in backward order
     losses = []
+    names = [n for n, p_ in model.named_parameters() if p_.requires_grad]
+    first_cut = [list(r) for r in tr.reducer.runs]
     for step in range(3):
         x, y = _data(rank, step)
         losses.append(float(tr.step(x=x, y=y)))
+        if step == 0:
+            # after the first backward pass the buckets are re-cut along the order the gradient hooks fired in (trainer.BucketedAllReduce.
+            # rebuild_from_ready_order): the LoRA is registered AFTER `c` but used BEFORE it, so registration order put its gradients
+            # (ready late) into the bucket that should open the exchange.  Now: `c` first, `a` last among the used ones, the never-used
+            # parameter at the very end; runs tile the flat buffer exactly once.
+            r = tr.reducer
+            assert r.rebuilt and [list(x_) for x_ in r.runs] != first_cut
+            order = [names[i] for i in r.ready_order]
+            assert order[0].startswith("c.") and order[-1].startswith("a.") and "unused" not in order
+            assert names[[i for i in range(len(names)) if r.param_bucket[i] == 0][0]].split(".")[0] in ("c", "b", "attn")
+            assert r.param_bucket[names.index("c.bias")] == 0 and r.param_bucket[names.index("unused")] == len(r.buckets) - 1
+            pieces = sorted(x_ for runs in r.runs for x_ in runs)
+            assert pieces[0][0] == 0 and pieces[-1][1] == tr.flat.numel and all(a_[1] == b_[0] for a_, b_ in zip(pieces, pieces[1:]))
+            assert any(len(runs) > 1 for runs in r.runs)   # a bucket of several runs (non-adjacent slices) is exercised
+    cut = [list(x_) for runs in tr.reducer.runs for x_ in runs]
     before = tr.flat.flat_param.clone()
     x, y = _data(rank, 3)
     tr.step(x=x, y=y, poison=(rank == 1))  # NaN on ONE rank: flag all_reduce(MAX) -> both ranks take the zero-grad step
-    q.put((rank, tr.flat.flat_param.numpy().copy(), before.numpy().copy(), losses))  # by value, not shared-memory handles
+    q.put((rank, tr.flat.flat_param.numpy().copy(), before.numpy().copy(), losses, cut))  # by value, not shared-memory handles
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,8 +105,9 @@ def test_two_rank_gloo_matches_single_process_average(shard):
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    (_, p0, b0, _), (_, p1, b1, _) = [(r, torch.from_numpy(a), torch.from_numpy(b), l) for r, a, b, l in res]
+    (_, p0, b0, _), (_, p1, b1, _) = [(r, torch.from_numpy(a), torch.from_numpy(b), l) for r, a, b, l, _ in res]
     assert torch.equal(p0, p1) and torch.equal(b0, b1), "replicas diverged"
+    assert res[0][4] == res[1][4], "the ranks re-cut their buckets differently"
     # single-process reference: torch.optim.AdamW on an untouched copy of the model, fed the gradient of the mean of the two
     # ranks' losses (= the average of the two ranks' gradients)
     model = Toy()
