@@ -559,12 +559,12 @@ def test_generate_replays_the_loop_from_a_graph_when_covered_and_equals_the_host
     # utterance ends after a few hundred): EOS at step `first` of 400 -> at most one check interval of surplus replays, the columns
     # never run carry the pad id, seen_tokens counts the steps actually run
     from rwkvtts_amd.decode import GraphDecoder, MultiGroupDecoder
-    dec = GraphDecoder(model, B, step_kernel=True)
+    dec = GraphDecoder(model, B)
     long_run = dec.generate(inputs_embeds=same, max_new_tokens=400, eos_token_id=eos, pad_token_id=0)
     assert dec.steps_run <= first + GraphDecoder.EOS_CHECK_EVERY and dec.steps_run < 399
     assert long_run.shape == (B, 400) and torch.equal(long_run[:, :first + 1], h2) and (long_run[:, first + 1:] == 0).all()
     assert dec.cache.seen_tokens == P + dec.steps_run
-    mg = MultiGroupDecoder(model, 2, step_kernel=True)   # three groups (2 + 2 + 1 sequences), all finish at `first`
+    mg = MultiGroupDecoder(model, 2)   # three groups (2 + 2 + 1 sequences), all finish at `first`
     long_mg = mg.generate(inputs_embeds=same, max_new_tokens=400, eos_token_id=eos, pad_token_id=0)
     assert torch.equal(long_mg, long_run) and all(d.steps_run <= first + GraphDecoder.EOS_CHECK_EVERY for d in mg.decoders)
     # mixed: one sequence with another prompt may or may not reach the EOS -> padded rows, same shape either way
