@@ -336,7 +336,10 @@ class DataParallelTrainer:
         the slab's new bf16 parameters (reduce-scatter + sharded optimizer + all-gather, ZeRO-1 style: the reference's DeepSpeed
         ZeRO-2 engine does the same exchange, train_spark_rwkv7speech.py:483-516).  Same parameters after every step as the
         default (all-reduce + replicated AdamW) up to the rounding of the reduction; the optimizer pass is 1/N as long.  One flag:
-        for the case that the 8-GPU scaling run shows an exposed all-reduce tail."""
+        for the case that the 8-GPU scaling run shows an exposed all-reduce tail.
+        NOTE for code that reads gradients after step(): in shard mode only the slices of a rank's OWN slab hold the reduced (mean)
+        gradient; `p.grad` of parameters in foreign slabs holds this rank's local, unreduced gradient (gradient-norm logging or
+        clipping must all-reduce its own partial over the own slab, `reducer.slab(rank)`)."""
         self.model = model
         self.flat = FlatBuffers(model)
         self.reducer = BucketedAllReduce(self.flat, bucket_bytes, force=force_allreduce, shard=shard_optimizer)

@@ -157,3 +157,32 @@ def test_eos_rejection_laws_reference_vs_per_stage_bound_and_host_sampler():
         assert ((freq - ref).abs() <= 5 * sigma + 1e-9).all(), (case, (freq - ref).abs().max().item())
         print(f"[ras EOS rejection, {case}] N(R)={rho:.3f} F(EOS)={f:.3f} N(EOS)={n:.3f}: TV(reference law, per-stage law) = {tv:.4f} "
               f"(bound {rho * f / (1 - n):.4f})")
+
+
+def test_float64_warper_chain_used_by_the_gpu_tests_equals_the_hf_warpers():
+    """tests/sampling_laws.exact_probs -- the yardstick of the fused draw's distribution tests on the GPU -- against the HF warpers
+    themselves in float64: the same support and the same probabilities (ties at the k-th value and at the nucleus boundary included)."""
+    import pytest
+    pytest.importorskip("transformers")
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from sampling_laws import exact_probs
+    g = torch.Generator().manual_seed(9)
+    cases = [(8193, 1.0, 50, 0.95), (8193, 0.8, 50, 1.0), (300, 1.3, 20, 0.7), (64, 0.7, 5, 0.5), (1025, 1.0, 64, 0.9)]
+    for V, temp, k, p in cases:
+        logits = (torch.randn(V, generator=g) * 3).double()
+        logits[7] = logits[3]                      # an exact tie somewhere
+        if k:
+            kth = torch.topk(logits, k).values[-1]
+            logits[(logits < kth).nonzero()[0]] = kth   # ... and one AT the k-th value (both warpers keep ties of the k-th)
+        ids = torch.zeros(1, 1, dtype=torch.long)
+        x = logits.clone()[None]
+        if temp != 1.0:
+            x = TemperatureLogitsWarper(temp)(ids, x)
+        if k:
+            x = TopKLogitsWarper(k)(ids, x)
+        if p < 1.0:
+            x = TopPLogitsWarper(p)(ids, x)
+        want = torch.softmax(x[0], -1)
+        got = exact_probs(logits, k, p, temp)
+        assert torch.equal(got > 0, want > 0), (V, temp, k, p)
+        assert (got - want).abs().max().item() < 1e-12

@@ -8,24 +8,10 @@ import pytest
 import torch
 
 from rwkvtts_amd.sampling import RowSampler, ras_step
+from sampling_laws import exact_probs as _exact_probs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-
-
-def _exact_probs(logits64, top_k, top_p, temperature):
-    """the warper chain in float64 on one row -> probability of every id"""
-    x = logits64 / temperature
-    if top_k > 0:
-        kth = torch.topk(x, min(top_k, x.numel())).values[-1]
-        x = x.masked_fill(x < kth, float("-inf"))
-    if top_p < 1.0:
-        sv, si = torch.sort(x, descending=False)
-        cum = sv.softmax(-1).cumsum(-1)
-        rem = cum <= (1 - top_p)
-        rem[-1] = False
-        x = x.masked_fill(torch.zeros_like(rem).scatter(0, si, rem), float("-inf"))
-    return x.softmax(-1)
 
 
 def _check_freq(ids, p, what):
