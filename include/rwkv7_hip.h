@@ -193,6 +193,21 @@ int rwkv7_tmix_prepare_bwd_sum_f32(long rows, int D, const void *w_pre, const vo
                                    const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre, void *d_k,
                                    void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, void *d_r,
                                    float *dparams_partial, int nblocks, rwkv7_stream_t stream);
+/* The same with the COMPACT hand-off from rwkv7_tmix_post_bwd_compact_* (what bf16 training runs since round 4): the bonus term of
+ * tmix_post contributes rank-1 per head -- d_v2 += dt * dot_h, d_k2 += ds_h r r_k, d_r += ds_h k2 r_k -- so the post backward writes
+ * one tensor and two scalars per (row, head) instead of three tensors, and this kernel rebuilds them (k2 recomputed from k, a_pre,
+ * k_a as the forward did).  gsum: HOST array of 19 device pointers = the 15 above (entries 4, 6, 13 -- the post tensors -- unused,
+ * may be NULL) + {dt [rows,D], r [rows,D], r_k [D], hscal fp32 [rows][D/64][2] = (dot_h, ds_h)}. */
+int rwkv7_tmix_prepare_bwd_sum_compact_bf16(long rows, int D, const void *w_pre, const void *k, const void *v,
+                                            const void *a_pre, const void *v_pre, const void *v_first, const void *mask,
+                                            const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre, void *d_k,
+                                            void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, void *d_r,
+                                            float *dparams_partial, int nblocks, rwkv7_stream_t stream);
+int rwkv7_tmix_prepare_bwd_sum_compact_f32(long rows, int D, const void *w_pre, const void *k, const void *v,
+                                           const void *a_pre, const void *v_pre, const void *v_first, const void *mask,
+                                           const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre, void *d_k,
+                                           void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, void *d_r,
+                                           float *dparams_partial, int nblocks, rwkv7_stream_t stream);
 
 /* ---- residual add + LayerNorm (block wiring of rwkv_s2s_single_ffn.py:262-276: x = x + att(ln1(x)); x = x + ffn(ln2(x));
  *      rwkvfla RWKV7Block attn_norm / ffn_norm / pre_norm, model-level norm) ----
@@ -250,6 +265,16 @@ int rwkv7_tmix_post_bwd_f32(long rows, int D, const void *dout, const void *y, c
                             const void *v, const void *g, const void *gn_w, const void *gn_b, const void *r_k,
                             float eps, void *d_y, void *d_r, void *d_k, void *d_v, void *d_g, float *dparams_partial,
                             int nblocks, rwkv7_stream_t stream);
+/* compact form: d_y, d_g as above; dt = dL/d(GroupNorm(y) + bonus) [rows,D] and hscal fp32 [rows][D/64][2] = (sum_head r k r_k,
+ * sum_head dt v) instead of d_r, d_k, d_v (rebuilt by rwkv7_tmix_prepare_bwd_sum_compact_*) */
+int rwkv7_tmix_post_bwd_compact_bf16(long rows, int D, const void *dout, const void *y, const void *r, const void *k,
+                                     const void *v, const void *g, const void *gn_w, const void *gn_b, const void *r_k,
+                                     float eps, void *d_y, void *dt, void *d_g, float *hscal, float *dparams_partial,
+                                     int nblocks, rwkv7_stream_t stream);
+int rwkv7_tmix_post_bwd_compact_f32(long rows, int D, const void *dout, const void *y, const void *r, const void *k,
+                                    const void *v, const void *g, const void *gn_w, const void *gn_b, const void *r_k,
+                                    float eps, void *d_y, void *dt, void *d_g, float *hscal, float *dparams_partial,
+                                    int nblocks, rwkv7_stream_t stream);
 
 /* channel-mix activation relu(x)^2 (rwkv_s2s_single_ffn.py:228) and dx = 2 relu(x) dy; n % 8 == 0 */
 int rwkv7_relusq_fwd_bf16(long n, const void *x, void *y, rwkv7_stream_t stream);

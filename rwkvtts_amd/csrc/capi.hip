@@ -60,9 +60,9 @@ template <typename T> int mix_fwd(int, int, int, int, const void *, const void *
 template <typename T> int mix_bwd(int, int, int, int, const void *const *, const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t);
 template <typename T> int tmix_prepare_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, int, hipStream_t);
 template <typename T> int tmix_prepare_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
-template <typename T> int tmix_prepare_bwd_sum(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *const *, void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
+template <typename T> int tmix_prepare_bwd_sum(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *const *, int, void *, void *, void *, void *, void *, void *, void *, float *, int, hipStream_t);
 template <typename T> int tmix_post_fwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, int, hipStream_t);
-template <typename T> int tmix_post_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, void *, void *, void *, void *, float *, int, hipStream_t);
+template <typename T> int tmix_post_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, void *, void *, void *, void *, float *, float *, int, hipStream_t);
 template <typename T> int add_ln_fwd(long, int, const void *, const void *, const void *, const void *, float, void *, void *, float *, float *, int, hipStream_t);
 template <typename T> int add_ln_bwd(long, int, const void *, const void *, const void *, const float *, const float *, const void *, void *, float *, int, hipStream_t);
 template <typename T> int add_ln_mix_fwd(int, int, int, int, const void *, const void *, const void *, const void *, float, const void *, const void *, void *, void *, float *, float *, int, int, hipStream_t);
@@ -273,7 +273,25 @@ int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, c
         if ((v_pre == nullptr) != (v_first == nullptr)) return RWKV7_EINVAL;                                          \
         if (v_pre && (!d_vpre || !d_vfirst)) return RWKV7_EINVAL;                                                     \
         if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
-        return rwkv7::tmix_prepare_bwd_sum<TY>(rows, D, w_pre, k, v, a_pre, v_pre, v_first, mask, k_k, k_a, gsum,     \
+        return rwkv7::tmix_prepare_bwd_sum<TY>(rows, D, w_pre, k, v, a_pre, v_pre, v_first, mask, k_k, k_a, gsum, 15, \
+                                               d_wpre, d_k, d_v, d_apre, d_vpre, d_vfirst, d_r, dpart, nblocks,       \
+                                               (hipStream_t)stream);                                                  \
+    }                                                                                                                 \
+    int rwkv7_tmix_prepare_bwd_sum_compact_##SFX(long rows, int D, const void *w_pre, const void *k, const void *v,   \
+                                         const void *a_pre, const void *v_pre, const void *v_first, const void *mask, \
+                                         const void *k_k, const void *k_a, const void *const *gsum, void *d_wpre,     \
+                                         void *d_k, void *d_v, void *d_apre, void *d_vpre, void *d_vfirst, void *d_r, \
+                                         float *dpart, int nblocks, rwkv7_stream_t stream) {                          \
+        if (rows <= 0 || nblocks <= 0 ||                                                                              \
+            any_null({w_pre, k, v, a_pre, k_k, k_a, (const void *)gsum, d_wpre, d_k, d_v, d_apre, d_r, dpart}))       \
+            return RWKV7_EINVAL;                                                                                      \
+        /* gsum: 19 pointers; {0,2,5,7,9,11} and the hand-off {15..18} are required, the post tensors {4,6,13} are unused */ \
+        for (int i : {0, 2, 5, 7, 9, 11, 15, 16, 17, 18})                                                             \
+            if (!gsum[i]) return RWKV7_EINVAL;                                                                        \
+        if ((v_pre == nullptr) != (v_first == nullptr)) return RWKV7_EINVAL;                                          \
+        if (v_pre && (!d_vpre || !d_vfirst)) return RWKV7_EINVAL;                                                     \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::tmix_prepare_bwd_sum<TY>(rows, D, w_pre, k, v, a_pre, v_pre, v_first, mask, k_k, k_a, gsum, 19, \
                                                d_wpre, d_k, d_v, d_apre, d_vpre, d_vfirst, d_r, dpart, nblocks,       \
                                                (hipStream_t)stream);                                                  \
     }                                                                                                                 \
@@ -340,7 +358,18 @@ int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, c
             return RWKV7_EINVAL;                                                                                      \
         if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
         return rwkv7::tmix_post_bwd<TY>(rows, D, dout, y, r, k, v, g, gn_w, gn_b, r_k, eps, d_y, d_r, d_k, d_v, d_g,  \
-                                        dpart, nblocks, (hipStream_t)stream);                                         \
+                                        dpart, nullptr, nblocks, (hipStream_t)stream);                                \
+    }                                                                                                                 \
+    int rwkv7_tmix_post_bwd_compact_##SFX(long rows, int D, const void *dout, const void *y, const void *r,           \
+                                  const void *k, const void *v, const void *g, const void *gn_w, const void *gn_b,    \
+                                  const void *r_k, float eps, void *d_y, void *dt, void *d_g, float *hscal,           \
+                                  float *dpart, int nblocks, rwkv7_stream_t stream) {                                 \
+        if (rows <= 0 || nblocks <= 0 ||                                                                              \
+            any_null({dout, y, r, k, v, g, gn_w, gn_b, r_k, d_y, dt, d_g, (const void *)hscal, (const void *)dpart})) \
+            return RWKV7_EINVAL;                                                                                      \
+        if (!SHAPE_OK(D)) return RWKV7_ESHAPE;                                                                        \
+        return rwkv7::tmix_post_bwd<TY>(rows, D, dout, y, r, k, v, g, gn_w, gn_b, r_k, eps, d_y, nullptr, nullptr,    \
+                                        dt, d_g, dpart, hscal, nblocks, (hipStream_t)stream);                         \
     }                                                                                                                 \
     int rwkv7_relusq_fwd_##SFX(long n, const void *x, void *y, rwkv7_stream_t stream) {                               \
         if (n <= 0 || any_null({x, y})) return RWKV7_EINVAL;                                                          \

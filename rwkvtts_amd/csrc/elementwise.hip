@@ -256,6 +256,12 @@ struct PrepBwdExtra {
     const T *d_r_a, *d_r_b, *d_r_c;                              // d_r = a + b + c
     T *d_r;
     const T *d_vfirst_in;   // may be NULL: what the layers after this one contributed to d v_first, added before d_vfirst is stored
+    // compact hand-off from tmix_post's backward (round 4; all NULL = the three full tensors d_k2_c, d_v2_b, d_r_c above): the bonus
+    // term's contributions are rank-1 per head -- d_v2 += dt * dot_h, d_k2 += ds_h r r_k, d_r += ds_h k2 r_k -- so the post backward
+    // writes ONE tensor (dt = dL/d(GroupNorm + bonus)) and two scalars per (row, head) instead of three tensors, and they are
+    // rebuilt here from r (one more stream in) and k2 (recomputed from k, a, k_a as the forward did): 3 x [rows, D] fewer streams
+    const T *dt, *r, *r_k;
+    const float *hscal;     // [rows][H][2]: dot_h = sum_head r k2 r_k, ds_h = sum_head dt v2
 };
 
 template <typename T, bool MULTI>
@@ -309,6 +315,20 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
             V8<T>::ld(ex.d_r_a + o, r3);
             add(ex.d_r_b, r3);
             add(ex.d_r_c, r3);
+            if (ex.dt) {   // compact hand-off: the bonus term's contributions, rebuilt (a head = this thread's 8 channels' group of 8 lanes)
+                float dtv[8], rr[8], rk[8];
+                V8<T>::ld(ex.dt + o, dtv);
+                V8<T>::ld(ex.r + o, rr);
+                V8<T>::ld(ex.r_k + c, rk);
+                const float2 hs = *reinterpret_cast<const float2 *>(ex.hscal + (row * (D >> 6) + (threadIdx.x >> 3)) * 2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float k2 = kx[j] * m * fmaf(sigmoidf_(ap[j]) - 1.f, ka_p[j], 1.f);   // what tmix_prepare's forward stored
+                    gv2[j] = fmaf(dtv[j], hs.x, gv2[j]);
+                    gk2[j] = fmaf(hs.y * rr[j], rk[j], gk2[j]);
+                    r3[j] = fmaf(hs.y * k2, rk[j], r3[j]);
+                }
+            }
             V8<T>::st(ex.d_r + o, r3);
         }
         float kkr[8], a[8], du[8], u[8], o1[8], o2[8];
@@ -432,13 +452,16 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_post_fwd_kernel(long rows,
     }
 }
 
-template <typename T>
+// COMPACT (round 4): d_v receives dt = dL/d(GroupNorm + bonus) instead of dt * dot, d_r / d_k are not written, and (dot_h, ds_h)
+// go to hscal[rows][H][2]: tmix_prepare_bwd_kernel rebuilds the three bonus contributions from them (PrepBwdExtra)
+template <typename T, bool COMPACT>
 __global__ __launch_bounds__(kEwMaxThreads) void tmix_post_bwd_kernel(long rows, int D, const T *__restrict__ dout, const T *__restrict__ y,
                                      const T *__restrict__ r, const T *__restrict__ k, const T *__restrict__ v,
                                      const T *__restrict__ g, const T *__restrict__ gn_w, const T *__restrict__ gn_b,
                                      const T *__restrict__ r_k, float eps, T *__restrict__ d_y, T *__restrict__ d_r,
                                      T *__restrict__ d_k, T *__restrict__ d_v, T *__restrict__ d_g,
-                                     float *__restrict__ dpart /* [nblk][3][D]: d gn_w, d gn_b, d r_k */) {
+                                     float *__restrict__ dpart /* [nblk][3][D]: d gn_w, d gn_b, d r_k */,
+                                     float *__restrict__ hscal) {
     const int c = threadIdx.x * 8;
     float gw[8], gb[8], rk[8], a_w[8], a_b[8], a_rk[8];
     V8<T>::ld(gn_w + c, gw);
@@ -492,7 +515,7 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_post_bwd_kernel(long rows,
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             o1[j] = rstd * (dxh[j] - m1 - xh[j] * m2);  // d_y
-            o2[j] = dt[j] * dot;                        // d_v
+            o2[j] = COMPACT ? dt[j] : dt[j] * dot;      // d_v (COMPACT: dt itself)
         }
         V8<T>::st(d_y + o, o1);
         V8<T>::st(d_v + o, o2);
@@ -502,8 +525,12 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_post_bwd_kernel(long rows,
             o2[j] = ds * rr[j] * rk[j];  // d_k
             a_rk[j] = fmaf(ds, rr[j] * kk[j], a_rk[j]);
         }
-        V8<T>::st(d_r + o, o1);
-        V8<T>::st(d_k + o, o2);
+        if (COMPACT) {
+            if ((threadIdx.x & 7) == 0) *reinterpret_cast<float2 *>(hscal + (row * (D >> 6) + (threadIdx.x >> 3)) * 2) = make_float2(dot, ds);
+        } else {
+            V8<T>::st(d_r + o, o1);
+            V8<T>::st(d_k + o, o2);
+        }
     }
     V8<float>::st(dpart + ((long)blockIdx.x * 3 + 0) * D + c, a_w);
     V8<float>::st(dpart + ((long)blockIdx.x * 3 + 1) * D + c, a_b);
@@ -1202,11 +1229,14 @@ int tmix_prepare_bwd(long rows, int D, const void *w_pre, const void *k, const v
 template <typename T>
 int tmix_prepare_bwd_sum(long rows, int D, const void *w_pre, const void *k, const void *v, const void *a_pre,
                          const void *v_pre, const void *v_first, const void *mask, const void *k_k, const void *k_a,
-                         const void *const *gsum, void *d_wpre, void *d_k, void *d_v, void *d_apre, void *d_vpre,
+                         const void *const *gsum, int ngsum, void *d_wpre, void *d_k, void *d_v, void *d_apre, void *d_vpre,
                          void *d_vfirst, void *d_r, float *dpart, int nblocks, hipStream_t st) {
     (void)hipGetLastError();
     const T *const *g = reinterpret_cast<const T *const *>(gsum);
-    PrepBwdExtra<T> ex{g[1], g[3], g[4], g[6], g[8], g[10], g[11], g[12], g[13], (T *)d_r, g[14]};
+    // gsum[15..18] (compact hand-off, see PrepBwdExtra): dt, r, r_k, hscal (fp32); ngsum = 15 without them
+    PrepBwdExtra<T> ex{g[1], g[3], g[4], g[6], g[8], g[10], g[11], g[12], g[13], (T *)d_r, g[14],
+                       ngsum > 15 ? g[15] : nullptr, ngsum > 15 ? g[16] : nullptr, ngsum > 15 ? g[17] : nullptr,
+                       ngsum > 15 ? reinterpret_cast<const float *>(gsum[18]) : nullptr};
     hipLaunchKernelGGL((tmix_prepare_bwd_kernel<T, true>), dim3(nblocks), dim3(D / 8), 0, st, rows, D,
                        (const T *)w_pre, (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre,
                        (const T *)v_first, (const T *)mask, (const T *)k_k, (const T *)k_a, g[0], g[2], g[5], g[7],
@@ -1226,12 +1256,18 @@ int tmix_post_fwd(long rows, int D, const void *y, const void *r, const void *k,
 template <typename T>
 int tmix_post_bwd(long rows, int D, const void *dout, const void *y, const void *r, const void *k, const void *v,
                   const void *g, const void *gn_w, const void *gn_b, const void *r_k, float eps, void *d_y, void *d_r,
-                  void *d_k, void *d_v, void *d_g, float *dpart, int nblocks, hipStream_t st) {
+                  void *d_k, void *d_v, void *d_g, float *dpart, float *hscal, int nblocks, hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL((tmix_post_bwd_kernel<T>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)dout,
-                       (const T *)y, (const T *)r, (const T *)k, (const T *)v, (const T *)g, (const T *)gn_w,
-                       (const T *)gn_b, (const T *)r_k, eps, (T *)d_y, (T *)d_r, (T *)d_k, (T *)d_v, (T *)d_g,
-                       dpart);
+    if (hscal)   // compact: d_v receives dt, d_r / d_k are not written
+        hipLaunchKernelGGL((tmix_post_bwd_kernel<T, true>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)dout,
+                           (const T *)y, (const T *)r, (const T *)k, (const T *)v, (const T *)g, (const T *)gn_w,
+                           (const T *)gn_b, (const T *)r_k, eps, (T *)d_y, (T *)d_r, (T *)d_k, (T *)d_v, (T *)d_g,
+                           dpart, hscal);
+    else
+        hipLaunchKernelGGL((tmix_post_bwd_kernel<T, false>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)dout,
+                           (const T *)y, (const T *)r, (const T *)k, (const T *)v, (const T *)g, (const T *)gn_w,
+                           (const T *)gn_b, (const T *)r_k, eps, (T *)d_y, (T *)d_r, (T *)d_k, (T *)d_v, (T *)d_g,
+                           dpart, hscal);
     return finish();
 }
 template <typename T>
@@ -1293,7 +1329,7 @@ int relusq_bwd_s(long n, const void *x, const void *dy, void *dx, hipStream_t st
                                    const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t); \
     template int tmix_prepare_bwd_sum<T>(long, int, const void *, const void *, const void *, const void *,          \
                                          const void *, const void *, const void *, const void *, const void *,       \
-                                         const void *const *, void *, void *, void *, void *, void *, void *, void *, \
+                                         const void *const *, int, void *, void *, void *, void *, void *, void *, void *, \
                                          float *, int, hipStream_t);                                                 \
     template int tmix_prepare_bwd<T>(long, int, const void *, const void *, const void *, const void *, const void *, \
                                      const void *, const void *, const void *, const void *, const void *,          \
@@ -1303,7 +1339,7 @@ int relusq_bwd_s(long n, const void *x, const void *dy, void *dx, hipStream_t st
                                   const void *, const void *, const void *, float, void *, int, hipStream_t);       \
     template int tmix_post_bwd<T>(long, int, const void *, const void *, const void *, const void *, const void *,  \
                                   const void *, const void *, const void *, const void *, float, void *, void *,    \
-                                  void *, void *, void *, float *, int, hipStream_t);                               \
+                                  void *, void *, void *, float *, float *, int, hipStream_t);                               \
     template int relusq_fwd<T>(long, const void *, void *, hipStream_t);                                            \
     template int relusq_bwd<T>(long, const void *, const void *, void *, hipStream_t);                              \
     template int relusq_bwd_s<T>(long, const void *, const void *, void *, hipStream_t);

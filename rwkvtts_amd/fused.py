@@ -324,11 +324,21 @@ class _TmixCore(torch.autograd.Function):
         nb = min(rows, _BWD_BLOCKS)
         dout = _c(dout)
         # 1. GroupNorm / bonus / gate
-        d_y, d_r_post, d_k2_post, d_v2_post, d_g = [torch.empty_like(k) for _ in range(5)]
         part_post = torch.empty(nb, 3, D, dtype=torch.float32, device=k.device)
-        _call("tmix_post_bwd", k, ctypes.c_long(rows), D, _p(dout), _p(y), _p(r), _p(k2), _p(v2), _p(g), _p(gn_w), _p(gn_b),
-              _p(r_k), ctypes.c_float(ctx.eps), _p(d_y), _p(d_r_post), _p(d_k2_post), _p(d_v2_post), _p(d_g),
-              _p(part_post), nb)
+        compact = COMPACT_POST_BWD
+        if compact:
+            # the bonus term's contributions to r, k2, v2 are rank-1 per head: one tensor (dt) + two scalars per (row, head) leave
+            # this stage instead of three tensors, and stage 3 rebuilds them (three [rows, D] streams fewer per layer)
+            d_y, dt_post, d_g = [torch.empty_like(k) for _ in range(3)]
+            hscal = torch.empty(rows, H, 2, dtype=torch.float32, device=k.device)
+            d_r_post = d_k2_post = d_v2_post = None
+            _call("tmix_post_bwd_compact", k, ctypes.c_long(rows), D, _p(dout), _p(y), _p(r), _p(k2), _p(v2), _p(g), _p(gn_w),
+                  _p(gn_b), _p(r_k), ctypes.c_float(ctx.eps), _p(d_y), _p(dt_post), _p(d_g), _p(hscal), _p(part_post), nb)
+        else:
+            d_y, d_r_post, d_k2_post, d_v2_post, d_g = [torch.empty_like(k) for _ in range(5)]
+            _call("tmix_post_bwd", k, ctypes.c_long(rows), D, _p(dout), _p(y), _p(r), _p(k2), _p(v2), _p(g), _p(gn_w), _p(gn_b),
+                  _p(r_k), ctypes.c_float(ctx.eps), _p(d_y), _p(d_r_post), _p(d_k2_post), _p(d_v2_post), _p(d_g),
+                  _p(part_post), nb)
         # 2. scan: chunked MFMA backward (bf16, T % 32 == 0) or the scalar kernel with two workgroups per head
         if WGRAD_SYNC_BEFORE_SCAN:
             wgrad_side_sync(k.device)
@@ -352,8 +362,10 @@ class _TmixCore(torch.autograd.Function):
         d_vf_next = None if (d_vf_next is None or v_pre is None) else _c(d_vf_next)
         gsum = [dw2[0], dw2[1], dk2[0], dk2[1], d_k2_post, dv, d_v2_post, da2[0], da2[1], db2[0], db2[1],
                 dq2[0], dq2[1], d_r_post, d_vf_next]
-        ptrs = (ctypes.c_void_p * 15)(*[None if t is None else t.data_ptr() for t in gsum])
-        _call("tmix_prepare_bwd_sum", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
+        if compact:
+            gsum += [dt_post, r, r_k, hscal]
+        ptrs = (ctypes.c_void_p * len(gsum))(*[None if t is None else t.data_ptr() for t in gsum])
+        _call("tmix_prepare_bwd_sum_compact" if compact else "tmix_prepare_bwd_sum", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
               _p(mask), _p(k_k), _p(k_a), ptrs, _p(d_wpre), _p(d_k), _p(d_v), _p(d_apre), _p(d_vpre), _p(d_vf),
               _p(d_r), _p(part), nb)
         dp = part.sum(0).to(k.dtype)
@@ -405,6 +417,8 @@ def lora_decode(x, w1, w2, bias, activation):
 # ------------------------------------------------------------------------------------------------------
 WGRAD_MIN_ROWS = 4096
 WGRAD_SLABS_SMALL, WGRAD_SLABS_BIG = 8, 4   # row slabs of the batched weight-gradient GEMM: outputs up to 1024 x 1024 / larger
+COMPACT_POST_BWD = True   # tmix_post's backward hands dt + (dot, ds) per head to tmix_prepare's backward instead of d_r, d_k2, d_v2
+                          # (A/B switch for tools/ab_step.py)
 SKINNY_WGRAD = True   # low-rank weight gradients through rwkv7_wgrad_skinny_bf16 (A/B switch for tools/ab_step.py)
 
 

@@ -214,12 +214,15 @@ def test_graph_decoder_matches_eager_generate():
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("compact", [True, False])   # round 4: tmix_post's backward hands dt + (dot, ds) per head to the prepare backward
 @pytest.mark.parametrize("T", [48, 64])   # 64: the bf16 run takes the chunked MFMA backward (T % 32 == 0)
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
-def test_fused_tmix_core_equals_separate_nodes(dtype, tol, T):
-    """fused._TmixCore (row-split scan backward + gradient sums folded into the prepare backward) against the
-    three separate autograd nodes, with a padding mask, on every parameter gradient."""
-    from rwkvtts_amd import backbone
+def test_fused_tmix_core_equals_separate_nodes(dtype, tol, T, compact, monkeypatch):
+    """fused._TmixCore (row-split scan backward + gradient sums folded into the prepare backward; the bonus term's contributions
+    to r, k2, v2 rebuilt there from one tensor and two scalars per head when `compact`) against the three separate autograd nodes,
+    with a padding mask, on every parameter gradient."""
+    from rwkvtts_amd import backbone, fused
+    monkeypatch.setattr(fused, "COMPACT_POST_BWD", compact)
     cfg = RWKV7Config(hidden_size=128, num_hidden_layers=3, vocab_size=64, decay_low_rank_dim=32, a_low_rank_dim=32,
                       v_low_rank_dim=16, gate_low_rank_dim=32)
     torch.manual_seed(5)
