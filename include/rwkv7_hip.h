@@ -240,6 +240,15 @@ int rwkv7_add_ln_mix_fwd_bf16(int B, int T, int D, int nmix, const void *x, cons
 int rwkv7_add_ln_mix_fwd_f32(int B, int T, int D, int nmix, const void *x, const void *branch, const void *gamma,
                              const void *beta, float eps, const void *mask, const void *params, void *x_out, void *out,
                              float *mean, float *rstd, int nblocks, int run_len, rwkv7_stream_t stream);
+/*   fwd_h: the same forward that ALSO stores h [rows][D] (unmasked), for callers whose backward runs as the two separate kernels
+ *        rwkv7_mix_bwd_* + rwkv7_add_ln_bwd_* (the six-lerp side: its one-pass backward carries 6 x 3 x 8 values per thread and
+ *        spills; the one-pass forward is 18 us per layer ahead of the two stages even with the extra store). */
+int rwkv7_add_ln_mix_fwd_h_bf16(int B, int T, int D, int nmix, const void *x, const void *branch, const void *gamma,
+                                const void *beta, float eps, const void *mask, const void *params, void *x_out, void *out, void *h,
+                                float *mean, float *rstd, int nblocks, int run_len, rwkv7_stream_t stream);
+int rwkv7_add_ln_mix_fwd_h_f32(int B, int T, int D, int nmix, const void *x, const void *branch, const void *gamma,
+                               const void *beta, float eps, const void *mask, const void *params, void *x_out, void *out, void *h,
+                               float *mean, float *rstd, int nblocks, int run_len, rwkv7_stream_t stream);
 int rwkv7_mix_add_ln_bwd_bf16(int B, int T, int D, int nmix, const void *const *grad_outs, const void *d_resid, const void *x1,
                               const float *mean, const float *rstd, const void *gamma, const void *beta, const void *mask,
                               const void *params, void *dx, float *dparams_partial, int nblocks, int run_len,

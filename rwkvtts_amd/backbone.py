@@ -198,6 +198,10 @@ FUSED_TMIX_CORE = True
 FUSED_ADD_LN_MIX1 = True
 DUAL_LINEAR_XV = True   # training: value projection + value-residual down projection as one autograd node (fused._DualLinear)
 FUSED_ADD_LN_MIX6 = False
+# round 4: the six-lerp side's one-pass FORWARD alone (rwkv7_add_ln_mix_fwd_h: it also stores h, the backward runs as the two separate
+# kernels).  Measured in the same-box A/B (tools/ab_step.py): +0.15 ms per step -- the extra 64 MiB store eats the 30 us the one-pass
+# forward is ahead; off.
+FUSED_ADD_LN_MIX6_FWD = False
 # cu_seqlens batches run on the chunked kernels' sequence flags (bf16); False: always unpack into a padded masked batch
 PACKED_NATIVE = True
 
@@ -357,8 +361,8 @@ class RWKV7Block(nn.Module):
                 delta = None
             x = fused.layer_norm(x, self.pre_norm)
         one_pass = fused.add_ln_mix_supported(x, state)
-        if one_pass and FUSED_ADD_LN_MIX6:
-            x, mixed = fused.add_layer_norm_mix(x, delta, self.attn_norm, mask, self.attn.mix_params())
+        if one_pass and (FUSED_ADD_LN_MIX6 or FUSED_ADD_LN_MIX6_FWD):
+            x, mixed = fused.add_layer_norm_mix(x, delta, self.attn_norm, mask, self.attn.mix_params(), fwd_only=not FUSED_ADD_LN_MIX6)
             att, v_first = self.attn.forward_mixed(mixed, None, mask, v_first, None, seq_start)
         else:
             if delta is None:

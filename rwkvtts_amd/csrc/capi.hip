@@ -65,7 +65,7 @@ template <typename T> int tmix_post_fwd(long, int, const void *, const void *, c
 template <typename T> int tmix_post_bwd(long, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, const void *, float, void *, void *, void *, void *, void *, float *, float *, int, hipStream_t);
 template <typename T> int add_ln_fwd(long, int, const void *, const void *, const void *, const void *, float, void *, void *, float *, float *, int, hipStream_t);
 template <typename T> int add_ln_bwd(long, int, const void *, const void *, const void *, const float *, const float *, const void *, void *, float *, int, hipStream_t);
-template <typename T> int add_ln_mix_fwd(int, int, int, int, const void *, const void *, const void *, const void *, float, const void *, const void *, void *, void *, float *, float *, int, int, hipStream_t);
+template <typename T> int add_ln_mix_fwd(int, int, int, int, void *, const void *, const void *, const void *, const void *, float, const void *, const void *, void *, void *, float *, float *, int, int, hipStream_t);
 template <typename T> int mix_add_ln_bwd(int, int, int, int, const void *const *, const void *, const void *, const float *, const float *, const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t);
 template <typename T> int relusq_fwd(long, const void *, void *, hipStream_t);
 template <typename T> int relusq_bwd(long, const void *, const void *, void *, hipStream_t);
@@ -324,8 +324,20 @@ int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, c
             return RWKV7_EINVAL;                                                                                      \
         if (branch && !x_out) return RWKV7_EINVAL;                                                                    \
         if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
-        return rwkv7::add_ln_mix_fwd<TY>(B, T, D, nmix, x, branch, gamma, beta, eps, mask, params, x_out, out, mean,  \
-                                         rstd, nblocks, run_len, (hipStream_t)stream);                                \
+        return rwkv7::add_ln_mix_fwd<TY>(B, T, D, nmix, nullptr, x, branch, gamma, beta, eps, mask, params, x_out,    \
+                                         out, mean, rstd, nblocks, run_len, (hipStream_t)stream);                     \
+    }                                                                                                                 \
+    int rwkv7_add_ln_mix_fwd_h_##SFX(int B, int T, int D, int nmix, const void *x, const void *branch,                \
+                                     const void *gamma, const void *beta, float eps, const void *mask,                \
+                                     const void *params, void *x_out, void *out, void *h, float *mean, float *rstd,   \
+                                     int nblocks, int run_len, rwkv7_stream_t stream) {                               \
+        if (B <= 0 || T <= 0 || nblocks <= 0 || run_len <= 0 ||                                                       \
+            any_null({x, gamma, params, out, (const void *)h, (const void *)mean, (const void *)rstd}))                \
+            return RWKV7_EINVAL;                                                                                      \
+        if (branch && !x_out) return RWKV7_EINVAL;                                                                    \
+        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
+        return rwkv7::add_ln_mix_fwd<TY>(B, T, D, nmix, h, x, branch, gamma, beta, eps, mask, params, x_out, out,     \
+                                         mean, rstd, nblocks, run_len, (hipStream_t)stream);                          \
     }                                                                                                                 \
     int rwkv7_mix_add_ln_bwd_##SFX(int B, int T, int D, int nmix, const void *const *g, const void *d_resid,          \
                                    const void *x1, const float *mean, const float *rstd, const void *gamma,           \

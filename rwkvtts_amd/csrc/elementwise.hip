@@ -752,7 +752,8 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_mix_fwd_kernel(int B, in
                                                                        const T *__restrict__ beta, float eps, const T *__restrict__ mask,
                                                                        const T *__restrict__ params, T *__restrict__ x_out,
                                                                        T *__restrict__ out, float *__restrict__ mean,
-                                                                       float *__restrict__ rstd) {
+                                                                       float *__restrict__ rstd, T *__restrict__ h_out) {
+    // h_out (may be NULL): also store h = LayerNorm(x1) (unmasked), for a backward that runs as the two separate kernels
     __shared__ float red[4][kEwMaxThreads / 8];
     const int c = threadIdx.x * 8, ng = D / 64;
     const long rows = (long)B * T_;
@@ -798,7 +799,10 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_mix_fwd_kernel(int B, in
         const float rs = rsqrtf(q * inv_d + eps);
         const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) hm[j] = round_to<T>(fmaf(v[j] * rs, gm[j], bt[j])) * m;
+        for (int j = 0; j < 8; j++) hm[j] = round_to<T>(fmaf(v[j] * rs, gm[j], bt[j]));
+        if (write && h_out) V8<T>::st(h_out + o, hm);
+#pragma unroll
+        for (int j = 0; j < 8; j++) hm[j] *= m;
         if (write && threadIdx.x == 0) {
             mean[row] = mu;
             rstd[row] = rs;
@@ -1169,17 +1173,17 @@ int mix_bwd(int B, int T_, int D, int nmix, const void *const *g, const void *x,
     return finish();
 }
 template <typename T>
-int add_ln_mix_fwd(int B, int T_, int D, int nmix, const void *x, const void *branch, const void *gamma, const void *beta, float eps,
+int add_ln_mix_fwd(int B, int T_, int D, int nmix, void *h_out, const void *x, const void *branch, const void *gamma, const void *beta, float eps,
                    const void *mask, const void *params, void *x_out, void *out, float *mean, float *rstd, int nblocks, int run_len,
                    hipStream_t st) {
     (void)hipGetLastError();
     const dim3 grid(nblocks), block(D / 8);
     if (nmix == 6)
         hipLaunchKernelGGL((add_ln_mix_fwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, run_len, (const T *)x, (const T *)branch,
-                           (const T *)gamma, (const T *)beta, eps, (const T *)mask, (const T *)params, (T *)x_out, (T *)out, mean, rstd);
+                           (const T *)gamma, (const T *)beta, eps, (const T *)mask, (const T *)params, (T *)x_out, (T *)out, mean, rstd, (T *)h_out);
     else
         hipLaunchKernelGGL((add_ln_mix_fwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, run_len, (const T *)x, (const T *)branch,
-                           (const T *)gamma, (const T *)beta, eps, (const T *)mask, (const T *)params, (T *)x_out, (T *)out, mean, rstd);
+                           (const T *)gamma, (const T *)beta, eps, (const T *)mask, (const T *)params, (T *)x_out, (T *)out, mean, rstd, (T *)h_out);
     return finish();
 }
 template <typename T>
@@ -1323,7 +1327,7 @@ int relusq_bwd_s(long n, const void *x, const void *dy, void *dx, hipStream_t st
                                float *, float *, int, hipStream_t);                                                 \
     template int add_ln_bwd<T>(long, int, const void *, const void *, const void *, const float *, const float *,    \
                                const void *, void *, float *, int, hipStream_t);                                     \
-    template int add_ln_mix_fwd<T>(int, int, int, int, const void *, const void *, const void *, const void *, float, const void *, \
+    template int add_ln_mix_fwd<T>(int, int, int, int, void *, const void *, const void *, const void *, const void *, float, const void *, \
                                    const void *, void *, void *, float *, float *, int, int, hipStream_t);           \
     template int mix_add_ln_bwd<T>(int, int, int, int, const void *const *, const void *, const void *, const float *, const float *, \
                                    const void *, const void *, const void *, const void *, void *, float *, int, int, hipStream_t); \

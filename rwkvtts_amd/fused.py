@@ -743,16 +743,69 @@ class _AddLNMix(torch.autograd.Function):
                 None, None, dp[:nmix].to(params.dtype))
 
 
+class _AddLNMixFwd(torch.autograd.Function):
+    """Forward of _AddLNMix (one pass: residual add + LayerNorm + lerps, rwkv7_add_ln_mix_fwd_h, which also stores h), backward as
+    the two SEPARATE kernels (rwkv7_mix_bwd, rwkv7_add_ln_bwd).  For the time-mix side: its one-pass backward spills (backbone.py,
+    FUSED_ADD_LN_MIX6), its one-pass forward does not."""
+
+    @staticmethod
+    def forward(ctx, x, branch, gamma, beta, eps, mask, params):
+        B, T, D = x.shape
+        x, params = _c(x), _c(params)
+        nmix = params.shape[0]
+        gamma_c = _c(gamma.to(x.dtype))
+        beta_c = None if beta is None else _c(beta.to(x.dtype))
+        rows = B * T
+        out = torch.empty(nmix, B, T, D, dtype=x.dtype, device=x.device)
+        h = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        if branch is not None:
+            branch = _c(branch)
+            x1 = torch.empty_like(x)
+        else:
+            x1 = None
+        nb = max(1, min(-(-rows // _ADD_LN_MIX_RUN), _ADD_LN_MIX_BLOCKS))
+        _call("add_ln_mix_fwd_h", x, B, T, D, nmix, _p(x), _p(branch), _p(gamma_c), _p(beta_c), ctypes.c_float(eps), _p(mask),
+              _p(params), _p(x1), _p(out), _p(h), _p(mean), _p(rstd), nb, _ADD_LN_MIX_RUN)
+        ctx.has_branch, ctx.has_beta = branch is not None, beta is not None
+        ctx.save_for_backward(x1 if branch is not None else x, h, mean, rstd, gamma_c, mask, params)
+        return (x1 if branch is not None else x,) + tuple(out[i] for i in range(nmix))
+
+    @staticmethod
+    def backward(ctx, d_x1, *gs):
+        xs, h, mean, rstd, gamma, mask, params = ctx.saved_tensors
+        B, T, D = xs.shape
+        nmix = params.shape[0]
+        rows = B * T
+        gs = [torch.zeros_like(xs) if g is None else _c(g) for g in gs]
+        nb = max(1, min(-(-rows // _MIX_BWD_ROWS), _MIX_BWD_BLOCKS))
+        dh = torch.empty_like(xs)
+        part_m = torch.empty(nb, nmix, D, dtype=torch.float32, device=xs.device)
+        ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])
+        _call("mix_bwd", xs, B, T, D, nmix, ptrs, _p(h), _p(None), _p(mask), _p(params), _p(dh), _p(part_m), nb, _MIX_BWD_ROWS)
+        d_x1 = None if d_x1 is None else _c(d_x1)
+        nb2 = min(rows, _BWD_BLOCKS)
+        dx = torch.empty_like(xs)
+        part = torch.empty(nb2, 2, D, dtype=torch.float32, device=xs.device)
+        _call("add_ln_bwd", xs, ctypes.c_long(rows), D, _p(dh), _p(d_x1), _p(xs), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(part), nb2)
+        dp = part.sum(0)
+        return (dx, (dx if ctx.has_branch else None), dp[0].to(xs.dtype), (dp[1].to(xs.dtype) if ctx.has_beta else None),
+                None, None, part_m.sum(0).to(params.dtype))
+
+
 def add_ln_mix_supported(x, state):
     return x.is_cuda and state is None and x.dim() == 3 and x.dtype in (torch.bfloat16, torch.float32) and torch.is_grad_enabled()
 
 
-def add_layer_norm_mix(x, branch, norm, mask, mix_params):
+def add_layer_norm_mix(x, branch, norm, mask, mix_params, fwd_only=False):
     """(x + branch, [token-shift lerps of norm(x + branch) * mask]); branch may be None.  mix_params: the lerp coefficient
-    vectors (6 for the time-mix block, 1 for the channel-mix block)."""
+    vectors (6 for the time-mix block, 1 for the channel-mix block).  fwd_only: one-pass forward, the backward as the two separate
+    kernels (_AddLNMixFwd)."""
     D = x.shape[-1]
     params = torch.cat([p.reshape(1, D) for p in mix_params], 0).to(x.dtype) if len(mix_params) > 1 else mix_params[0].reshape(1, D).to(x.dtype)
-    res = _AddLNMix.apply(x, branch, norm.weight, norm.bias, norm.eps, _mask_rows(mask, x), params)
+    node = _AddLNMixFwd if (fwd_only and len(mix_params) > 1) else _AddLNMix
+    res = node.apply(x, branch, norm.weight, norm.bias, norm.eps, _mask_rows(mask, x), params)
     return res[0], res[1:]
 
 

@@ -181,10 +181,11 @@ def test_linear_split_wgrad_vs_fp32_reference(N, K):
     _cmp(bd.grad, br.grad, 1e-2, "db")
 
 
+@pytest.mark.parametrize("fwd_only", [False, True])   # True: one-pass forward that also stores h, backward as the two separate kernels
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("nmix,with_branch,with_mask,D", [(6, True, True, 256), (6, False, False, 1024), (1, True, False, 1024),
                                                           (1, True, True, 128), (6, True, False, 2048)])
-def test_add_layer_norm_mix_equals_the_two_separate_stages(dtype, nmix, with_branch, with_mask, D):
+def test_add_layer_norm_mix_equals_the_two_separate_stages(dtype, nmix, with_branch, with_mask, D, fwd_only):
     """rwkv7_add_ln_mix_fwd / rwkv7_mix_add_ln_bwd (one pass each way) against rwkv7_add_ln_* followed by rwkv7_mix_* (which
     have their own checks against torch above): the same values -- h is rounded to the tensor type before it is mixed and dh
     before it enters the LayerNorm backward, exactly as the separate path stores them.  Several sequences, a length that is not
@@ -215,7 +216,7 @@ def test_add_layer_norm_mix_equals_the_two_separate_stages(dtype, nmix, with_bra
         for p_ in list(norm.parameters()) + mixp:
             p_.grad = None
         if fused_path:
-            x1, outs = fused.add_layer_norm_mix(xd, bd, norm, mask, tuple(mixp))
+            x1, outs = fused.add_layer_norm_mix(xd, bd, norm, mask, tuple(mixp), fwd_only=fwd_only)
         else:
             if bd is None:
                 x1, h = xd, fused.layer_norm(xd, norm)
