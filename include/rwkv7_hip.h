@@ -387,6 +387,10 @@ int rwkv7_wgrad_skinny_bf16(long M, int N, int K, int S, const void *dy, const v
  *      LDS-DMA (csrc/gemm_relusq.hip); M, N multiples of 256, K of 64 (RWKV7_ESHAPE otherwise).  A measured experiment against
  *      the library GEMM + rwkv7_relusq_fwd pair (tools/bench_gemm_relusq.py). ---- */
 int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, rwkv7_stream_t stream);
+/*      the backward of the activation as the epilogue of the value projection's input-gradient GEMM (round 4):
+ *      C[M][N] = bf16(A[M][K] . W[N][K]^T) * 2 relu(aux[M][N]) -- A = dy, W = value.weight^T (contiguous [N = F][K = D]), aux = the key
+ *      projection's output h: dh without ds ever reaching HBM and without rwkv7_relusq_bwd_*. */
+int rwkv7_gemm_nt_relusq_bwd_bf16(int M, int N, int K, const void *A, const void *W, const void *aux, void *C, rwkv7_stream_t stream);
 /*      variant (A/B): 0 = K tile 64, two LDS buffers (the plain entry); 1 = K tile 32, four buffers, three tiles in flight */
 int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant,
                                rwkv7_stream_t stream);

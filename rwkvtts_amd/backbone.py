@@ -335,7 +335,12 @@ class RWKV7FeedForward(nn.Module):
     def forward_mixed(self, kx):
         s = fused.key_relu_sq(kx, self.key.weight) if self.key.bias is None else None   # GEMM with the activation as epilogue
         if s is None:
-            s = fused.relu_sq(self.key(kx))
+            h = self.key(kx)
+            if self.value.bias is None:
+                out = fused.relu_sq_value(h, self.value.weight)   # training: the activation's backward rides in the value dgrad GEMM
+                if out is not None:
+                    return out
+            s = fused.relu_sq(h)
         return self.value(s)
 
 

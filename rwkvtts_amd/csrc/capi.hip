@@ -41,6 +41,7 @@ int chunk_bseq_bf16(int, int, int, const void *, const void *, const void *, con
                     float *, const int *, int, hipStream_t);
 int gemm_nt_bf16(int, int, int, const void *, const void *, void *, int, hipStream_t);
 int gemm_nt_bf16_variant(int, int, int, const void *, const void *, void *, int, int, hipStream_t);
+int gemm_nt_relusq_bwd_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
@@ -463,6 +464,11 @@ int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *
     if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || epilogue < 0 || epilogue > 1) return RWKV7_ESHAPE;
     return rwkv7::gemm_nt_bf16(M, N, K, A, W, C, epilogue, (hipStream_t)stream);
+}
+int rwkv7_gemm_nt_relusq_bwd_bf16(int M, int N, int K, const void *A, const void *W, const void *aux, void *C, rwkv7_stream_t stream) {
+    if (any_null({A, W, aux, (const void *)C})) return RWKV7_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0) return RWKV7_ESHAPE;
+    return rwkv7::gemm_nt_relusq_bwd_bf16(M, N, K, A, W, aux, C, (hipStream_t)stream);
 }
 int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant, rwkv7_stream_t stream) {
     if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;

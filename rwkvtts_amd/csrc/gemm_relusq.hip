@@ -70,9 +70,12 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 }  // namespace
 
+// EPI: 0 plain; 1 relu(.)^2 (channel-mix key, forward); 2 (round 4) C = bf16(A W^T) * 2 relu(aux) -- the backward of the activation
+// as the epilogue of the value projection's input-gradient GEMM (ds = dy W_value, dh = ds * 2 relu(h), rwkv_s2s_single_ffn.py:228
+// differentiated): ds never reaches HBM and rwkv7_relusq_bwd (805 MB, 140 us per layer) is not launched.  aux = h, [M][N] like C.
 template <int EPI, int BK, int NBUF>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(int M, int N, int K, const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
-                                                           uint16_t *__restrict__ C) {
+                                                           uint16_t *__restrict__ C, const uint16_t *__restrict__ aux) {
     using Cfg = GemmCfg<BK, NBUF>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,20 +159,40 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(int M, int N, int K, 
             }
         }
         // epilogue: lane = output row inside the m tile, registers 4 g .. 4 g + 3 = columns 8 g + 4 h + (0..3) of the n tile
+        uint2 ax[2][8];   // EPI 2: the aux values of row block j, requested one block ahead
+        auto load_aux = [&](int j, uint2 (&dst)[8]) {
+            const uint16_t *arow = aux + (long)(row0 + wm * 128 + j * 32 + rl) * N + col0 + wn * 64 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) dst[i * 4 + g] = *reinterpret_cast<const uint2 *>(arow + i * 32 + 8 * g);
+        };
+        if (EPI == 2) load_aux(0, ax[0]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            if (EPI == 2 && j + 1 < 4) load_aux(j + 1, ax[(j + 1) & 1]);
             uint16_t *crow = C + (long)(row0 + wm * 128 + j * 32 + rl) * N + col0 + wn * 64 + 4 * h;
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     float x[4];
+                    float hx[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (EPI == 2) {
+                        const uint2 a2 = ax[j & 1][i * 4 + g];
+                        hx[0] = __uint_as_float(a2.x << 16); hx[1] = __uint_as_float(a2.x & 0xffff0000u);
+                        hx[2] = __uint_as_float(a2.y << 16); hx[3] = __uint_as_float(a2.y & 0xffff0000u);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         float v = acc[i][j][4 * g + e];
                         if (EPI == 1) {          // relu(bf16(x))^2, rounded again: what the two separate kernels produce
                             v = bf2f(f2bf(v));
                             v = v > 0.f ? v * v : 0.f;
+                        }
+                        if (EPI == 2) {          // bf16(ds) * 2 relu(h): what the library GEMM + rwkv7_relusq_bwd produce
+                            v = bf2f(f2bf(v));
+                            v = hx[e] > 0.f ? 2.f * hx[e] * v : 0.f;
                         }
                         x[e] = v;
                     }
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(int M, int N, int K, 
 
 namespace {
 template <int EPI, int BK, int NBUF>
-int launch_gemm(int M, int N, int K, const void *A, const void *W, void *C, hipStream_t st) {
+int launch_gemm(int M, int N, int K, const void *A, const void *W, void *C, hipStream_t st, const void *aux = nullptr) {
     static bool attr = false;
     auto kern = &gemm_nt_bf16_kernel<EPI, BK, NBUF>;
     constexpr size_t lds_bytes = GemmCfg<BK, NBUF>::lds;
@@ -192,7 +215,8 @@ int launch_gemm(int M, int N, int K, const void *A, const void *W, void *C, hipS
     }
     (void)hipGetLastError();
     const int ntiles = (M / GBM) * (N / GBN);
-    kern<<<dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds_bytes, st>>>(M, N, K, (const uint16_t *)A, (const uint16_t *)W, (uint16_t *)C);
+    kern<<<dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds_bytes, st>>>(M, N, K, (const uint16_t *)A, (const uint16_t *)W, (uint16_t *)C,
+                                                                          (const uint16_t *)aux);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -202,6 +226,10 @@ int gemm_nt_bf16_variant(int M, int N, int K, const void *A, const void *W, void
     if (variant == 0)
         return epilogue ? launch_gemm<1, 64, 2>(M, N, K, A, W, C, st) : launch_gemm<0, 64, 2>(M, N, K, A, W, C, st);
     return epilogue ? launch_gemm<1, 32, 4>(M, N, K, A, W, C, st) : launch_gemm<0, 32, 4>(M, N, K, A, W, C, st);
+}
+
+int gemm_nt_relusq_bwd_bf16(int M, int N, int K, const void *A, const void *W, const void *aux, void *C, hipStream_t st) {
+    return launch_gemm<2, 64, 2>(M, N, K, A, W, C, st, aux);
 }
 
 int gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, hipStream_t st) {

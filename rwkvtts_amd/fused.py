@@ -168,6 +168,62 @@ class _KeyReluSq(torch.autograd.Function):
         return dx, dw
 
 
+# Round 4: the OTHER end of the activation.  value(relu(h)^2): forward unchanged (rwkv7_relusq_fwd + library GEMM); backward: the
+# input gradient of the value projection and the activation's backward as ONE launch -- dh = bf16(dy W_value) * 2 relu(h) through the
+# own MFMA GEMM with h as an auxiliary epilogue operand (rwkv7_gemm_nt_relusq_bwd_bf16): ds (256 MiB per layer) is neither written nor
+# read back and rwkv7_relusq_bwd (140 us per layer) is not launched; the own GEMM is slower than the library's on this shape
+# (0.30 against 0.22-0.25 ms), the pair it replaces is 0.39 ms on paper.  Measured (tools/ab_step.py, "relu^2 backward in the value
+# dgrad", same box, 132.98 ms without / 133.09 ms with): a tie, like the forward twin above -- what the launch saves, the slower GEMM
+# and the transposed copy of the weight give back.  Off; RWKV7_FUSED_RELUSQ_VALUE_BWD=1 switches it on.
+FUSED_RELUSQ_VALUE_BWD = os.environ.get("RWKV7_FUSED_RELUSQ_VALUE_BWD", "0") == "1"
+
+
+def relusq_value_eligible(h, weight):
+    M = h.numel() // h.shape[-1]
+    return (FUSED_RELUSQ_VALUE_BWD and h.is_cuda and h.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and M % 256 == 0
+            and weight.shape[1] % 256 == 0 and weight.shape[0] % 64 == 0 and torch.is_grad_enabled())
+
+
+class _ReluSqValue(torch.autograd.Function):
+    """out = relu(h)^2 @ weight^T  (weight = value.weight [D, F])."""
+
+    @staticmethod
+    def forward(ctx, h, weight):
+        h2 = _c(h).view(-1, h.shape[-1])
+        s = torch.empty_like(h2)
+        _call("relusq_fwd", h2, ctypes.c_long(h2.numel()), _p(h2), _p(s))
+        out = torch.nn.functional.linear(s, weight)
+        ctx.save_for_backward(h2, s, weight)
+        ctx.wparam = weight
+        ctx.shape = h.shape
+        return out.view(*h.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2, s, weight = ctx.saved_tensors
+        d2 = _c(dout).view(-1, dout.shape[-1])
+        M, F = h2.shape
+        D = weight.shape[0]
+        dh = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().t().contiguous()     # [F, D]: the NT operand (8 MiB at 0.4B, one copy per layer and step)
+            dh = torch.empty_like(h2)
+            with torch.cuda.device_of(h2):
+                rc = _lib.lib().rwkv7_gemm_nt_relusq_bwd_bf16(M, F, D, _p(d2), _p(wt), _p(h2), _p(dh), _stream(h2))
+            _lib.check(rc, "gemm_nt_relusq_bwd")
+            dh = dh.view(ctx.shape)
+        dw = _wgrad(d2, s, ctx.wparam) if ctx.needs_input_grad[1] else None
+        return dh, dw
+
+
+def relu_sq_value(h, weight):
+    """value(relu(h)^2) with the activation's backward inside the value projection's input-gradient GEMM, or None (shapes / dtype
+    outside the own GEMM's range: the caller runs relu_sq + Linear)."""
+    if relusq_value_eligible(h, weight):
+        return _ReluSqValue.apply(h, weight)
+    return None
+
+
 def key_relu_sq(x, weight):
     """relu(x @ weight^T)^2 -- one kernel when the shapes allow it (see above), the library GEMM + relu_sq otherwise."""
     if key_relusq_eligible(x, weight):

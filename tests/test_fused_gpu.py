@@ -509,3 +509,37 @@ def _key_relusq_case(fused, M, N, K):
             e = (a_.float() - b_.float()).norm().item() / max(b_.float().norm().item(), 1e-9)
             assert e < 8e-3, (n, e)
     assert fused.key_relu_sq(x[:100], w) is None and fused.key_relu_sq(x.float(), w.float()) is None
+
+
+@pytest.mark.parametrize("M,F,D", [(256, 256, 64), (512, 768, 128), (2048, 4096, 1024)])
+def test_relu_squared_backward_inside_the_value_dgrad_gemm(M, F, D, monkeypatch):
+    """fused.relu_sq_value (round 4): value(relu(h)^2) whose backward forms dh = bf16(dy W_value) * 2 relu(h) in ONE launch
+    (rwkv7_gemm_nt_relusq_bwd_bf16: the own MFMA GEMM with h as an auxiliary epilogue operand) against the separate nodes (library
+    GEMM, rwkv7_relusq_bwd): the forward is the same two launches, bit for bit; dh agrees to the bf16 rounding of ds (the two GEMMs
+    accumulate K in different orders: <= 1 ulp of ds, i.e. 2^-7 of |dh|, with the floor of the parity bars); the weight gradient is
+    the same call on the same operands."""
+    from rwkvtts_amd import fused
+    monkeypatch.setattr(fused, "FUSED_RELUSQ_VALUE_BWD", True)   # off by default (a tie in the step): switched on for the test
+    g = torch.Generator().manual_seed(M + F)
+    h = (torch.randn(M, F, generator=g) * 0.7).to(DEV, torch.bfloat16)
+    w = (torch.randn(D, F, generator=g) * (F ** -0.5)).to(DEV, torch.bfloat16)
+    dy = torch.randn(M, D, generator=g).to(DEV, torch.bfloat16)
+    res = []
+    for fusedp in (True, False):
+        hi, wi = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        if fusedp:
+            out = fused.relu_sq_value(hi, wi)
+            assert out is not None
+        else:
+            out = fused.linear(fused.relu_sq(hi), wi, None)
+        out.backward(dy)
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), hi.grad.clone(), wi.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert (res[0][1][h <= 0] == 0).all()                              # relu: no gradient where h <= 0
+    a, b = res[0][1].float(), res[1][1].float()
+    tol = 2.0 ** -7 * torch.clamp(b.abs(), min=0.25 * b.abs().mean().item())
+    assert ((a - b).abs() <= tol).all(), (a - b).abs().max().item()
+    assert (res[0][2].float() - res[1][2].float()).abs().max().item() <= 1e-2 * res[1][2].float().abs().max().item()
+    # shapes outside the tile grid: the caller falls back
+    assert fused.relu_sq_value(torch.zeros(100, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True), w[:, :256].contiguous()) is None
