@@ -145,6 +145,7 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
             *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(y_) + o) = make_uint2(cvt_pk(yv.x, yv.y), cvt_pk(yv.z, yv.w));
             if (SAVE) *reinterpret_cast<float4 *>(sa_ + o) = *reinterpret_cast<const float4 *>(&sh_U[pt * kStageLD + pv]);
         };
+        if (SAVE && (wave == 1 || wave == 2)) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + c0) * kQRec, vh, wave - 1, lane);   // S = 0
         lds_barrier();
         lds_barrier();
         for (int it = c0 - 1; it < c1; it++) {
@@ -160,15 +161,11 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
                     mma_gen<kC, false, true, true, false>(accA, sm + L::XPh, sm + L::XPl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
                     store_T_split(accA, sm + L::Uh, sm + L::Ul, LDC, lane);
                 } else if (wave == 1) {  // D[m = s][n = t] = b^_s . q~_t = A_qb[t][s], s <= t
-                    // state at the START of chunk cc = the backward's checkpoint: q15 record straight from the accumulator tile
-                    // (in this interval: the record is not on the chain, and waves 1, 2 finish before the producer here)
-                    if (SAVE) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + cc) * kQRec, vh, 0, lane);
                     f32x16 acc = zero16();
                     mma_tile3<kN>(acc, bufc + L::BHh, bufc + L::BHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
                     mask_lower_T<false>(acc, lane);
                     store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
                 } else if (wave == 2) {  // k^_s . q~_t = A_qk[t][s], s <= t
-                    if (SAVE) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + cc) * kQRec, vh, 1, lane);
                     f32x16 acc = zero16();
                     mma_tile3<kN>(acc, bufc + L::KHh, bufc + L::KHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
                     mask_lower_T<false>(acc, lane);
@@ -191,6 +188,11 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
                     for (int r = 0; r < 16; r++) Smaster[r] = gCc[kt * 32 + d_row(r, lane)] * (Smaster[r] + acc[r]);
                     // new state planes S[v][k]: read by waves 0 and 3 in the next interval a (one barrier away)
                     store_T_split(Smaster, sm + L::Sh + kt * 32, sm + L::Sl + kt * 32, LDK, lane);
+                    // the state at the START of chunk cc + 1 = the backward's checkpoint: q15 record straight from the accumulator
+                    // tile.  Here, behind the state planes (round 4; round 3 wrote it at the top of the next interval a): the interval
+                    // stamps put waves 1, 2 at 2.1k of interval a's 2.26k cycles (the A_qb / A_qk products + this record, sharing their
+                    // SIMDs with producer waves that are as long) and at 1.2k of interval b's -- the record moves to where the slack is
+                    if (SAVE && cc + 1 < c1) q15_encode_tile(Smaster, hs_ + ((long)bh * nc + cc + 1) * kQRec, vh, kt, lane);
                 } else if (wave == 3) {
                     mma_gen<kC, false, true, true, false>(accA, sm + L::QKh, sm + L::QKl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
                     mma_tile3<kC>(accA, sm + L::QBh, sm + L::QBl, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
