@@ -13,8 +13,11 @@
 //   dlw_t = sum_{s >= t} (q dQ - k dK - b dB)_s + sum_{s > t} (a dA)_s + rowsum(E * H_C) ;  dw = dlw * lw
 // TWO matrix phases:
 //     phase  wave 0               1              2        3        4        5        6        7
-//       A    dQ0: dY H0^T; P_vy   dQ1: dY H0^T   A_qk     A_ak     P_uz     P_uy     P_vz     -
-//       B    dK0; dQ0 +=          dK1; dQ1 +=    dB0      dB1      dA0      dA1      dV[0]    dV[1]     (all three terms each)
+//       A    dQ0: dY H0^T         dQ1: dY H0^T   A_qk     A_ak     P_uz     P_uy     P_vz     P_vy
+//       B    dK0; dQ0 +=          dK1; dQ1 +=    dA0      dA1      dV[0]    dV[1]    dB0      dB1       (all three terms each)
+// (round 4: waves w and w + 4 share a SIMD; phase B's MFMA counts per SIMD were 56 / 56 / 46 / 46 with dB on 2-3, dA on 4-5, dV on
+// 6-7 -- now 54 / 54 / 48 / 48, the heavier dA on the older waves, which win the VALU arbitration -- and P_vy moved from wave 0 to
+// the wave that had nothing in phase A)
 // then the ten accumulator tiles are staged (fp32, over the dead operand planes) and the epilogue runs as before.  T^-1, A_qb and
 // G1 are not needed at all: 28 (rows) + 8 (u) + 8 (z) + 8.5 (E) + 8.5 (H_C) KB in, 24 KB out per chunk; LDS 133 KB.
 #include "chunk_bwd_common.h"
@@ -354,18 +357,17 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
         B9STAMP(4);
         // ---- phase A --------------------------------------------------------------------------------------------------------------
         const int lnA = fresh(lane);
-        // acc1: waves 0,1 dQ (A, B); waves 4,5 dA (B).  acc2: waves 0,1 dK; 2,3 dB; 6,7 dV (B).   D[m = t][n = k] / D[m = s][n = v]
+        // acc1: waves 0,1 dQ (A, B); waves 2,3 dA (B).  acc2: waves 0,1 dK; 6,7 dB; 4,5 dV (B).   D[m = t][n = k] / D[m = s][n = v]
         // (waves 0-3, dispatched first, win the VALU arbitration against their SIMD partners 4-7: they get the longer jobs)
         f32x16 acc1 = zero16(), acc2 = zero16();
         if (wave <= 1) {
             const int kt = wave;   // D[t][k] = sum_v dY[t][v] H0[v][k]
             mma_xe_yks_k64(acc1, sm + L::DYp, LDK, sm + L::HTh, sm + L::HTl, LDK, kt * 32, lnA);
-            if (wave == 0) {
-                f32x16 acc = zero16();  // D[m = s][n = t] = dy_s . v_t, s >= t -> P_vy[t][s]
-                mma_tile<kN>(acc, sm + L::DYp, LDK, sm + L::Vp, LDK, lnA);
-                mask_upper_T<false>(acc, lnA);
-                store_T_split(acc, sm + L::P0 + 0 * 2 * L::A1, sm + L::P0 + 0 * 2 * L::A1 + L::A1, LDC, lnA);
-            }
+        } else if (wave == 7) {   // (round 4: was wave 0's second job; wave 7 had none)
+            f32x16 acc = zero16();  // D[m = s][n = t] = dy_s . v_t, s >= t -> P_vy[t][s]
+            mma_tile<kN>(acc, sm + L::DYp, LDK, sm + L::Vp, LDK, lnA);
+            mask_upper_T<false>(acc, lnA);
+            store_T_split(acc, sm + L::P0 + 0 * 2 * L::A1, sm + L::P0 + 0 * 2 * L::A1 + L::A1, LDC, lnA);
         } else if (wave == 2) {
             f32x16 acc = zero16();  // q~_t . k^_s, t >= s -> QKT[s][t]
             mma3_k64(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::KHh, sm + L::KHl, LDK, lnA);
@@ -408,22 +410,22 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
             mma_gen<kC, true, true, true, true>(acc1, sm + L::P0, sm + L::P0 + L::A1, LDC, 0, sm + L::KHh, sm + L::KHl, LDK, kt * 32, lnB);
             mma_gen<kC, true, true, true, true>(acc1, sm + L::P0 + 2 * 2 * L::A1, sm + L::P0 + 2 * 2 * L::A1 + L::A1, LDC, 0, sm + L::BHh,
                                                 sm + L::BHl, LDK, kt * 32, lnB);
-        } else if (wave <= 3) {
-            const int kt = wave - 2;   // dB: U E'^T + P_uy Q~ + P_uz A~
+        } else if (wave >= 6) {
+            const int kt = wave - 6;   // dB: U E'^T + P_uy Q~ + P_uz A~
             mma3_xr_yk_k64(acc2, sm + L::Uh, sm + L::Ul, LDK, sm + L::XTh, sm + L::XTl, LDK, kt * 32, lnB);
             mma_tile3_yK<kC>(acc2, sm + L::P0 + 2 * 2 * L::A1, sm + L::P0 + 2 * 2 * L::A1 + L::A1, LDC, sm + L::QTh, sm + L::QTl, LDK,
                              kt * 32, lnB);
             mma_tile3_yK<kC>(acc2, sm + L::P0 + 3 * 2 * L::A1, sm + L::P0 + 3 * 2 * L::A1 + L::A1, LDC, sm + L::ATh, sm + L::ATl, LDK, kt * 32,
                              lnB);
-        } else if (wave <= 5) {
-            const int kt = wave - 4;    // dA: Z H0^T + P_vz^T K^ + P_uz^T B^
+        } else if (wave <= 3) {
+            const int kt = wave - 2;    // dA: Z H0^T + P_vz^T K^ + P_uz^T B^
             mma3_xr_yk_k64(acc1, sm + L::Zh, sm + L::Zl, LDK, sm + L::HTh, sm + L::HTl, LDK, kt * 32, lnB);
             mma_gen<kC, true, true, true, true>(acc1, sm + L::P0 + 1 * 2 * L::A1, sm + L::P0 + 1 * 2 * L::A1 + L::A1, LDC, 0, sm + L::KHh,
                                                 sm + L::KHl, LDK, kt * 32, lnB);
             mma_gen<kC, true, true, true, true>(acc1, sm + L::P0 + 3 * 2 * L::A1, sm + L::P0 + 3 * 2 * L::A1 + L::A1, LDC, 0, sm + L::BHh,
                                                 sm + L::BHl, LDK, kt * 32, lnB);
         } else {
-            const int vt = wave - 6;   // dV[s][v] = sum_t A_qk[t][s] dY[t][v] + sum_k k^[s][k] E'[k][v] + sum_t A_ak[t][s] Z[t][v]
+            const int vt = wave - 4;   // dV[s][v] = sum_t A_qk[t][s] dY[t][v] + sum_k k^[s][k] E'[k][v] + sum_t A_ak[t][s] Z[t][v]
             mma_xs_yeK<kC>(acc2, sm + L::QKTh, sm + L::QKTl, LDC, sm + L::DYp, LDK, vt * 32, lnB);
             mma3_k64(acc2, sm + L::KHh, sm + L::KHl, LDK, sm + L::XTh + vt * 32 * LDK, sm + L::XTl + vt * 32 * LDK, LDK, lnB);
             mma_tile3_yK<kC>(acc2, sm + L::AKTh, sm + L::AKTl, LDC, sm + L::Zh, sm + L::Zl, LDK, vt * 32, lnB);
@@ -439,9 +441,9 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
             if (wave <= 1) {
                 stage_tile9(acc2, reinterpret_cast<float *>(sm + L::sK), wave, lnS);
                 stage_tile9(acc1, reinterpret_cast<float *>(sm + L::sQ), wave, lnS);
-            } else if (wave <= 3) stage_tile9(acc2, reinterpret_cast<float *>(sm + L::sB), wave - 2, lnS);
-            else if (wave <= 5) stage_tile9(acc1, reinterpret_cast<float *>(sm + L::sA), wave - 4, lnS);
-            else stage_tile9(acc2, reinterpret_cast<float *>(sm + L::sV), wave - 6, lnS);
+            } else if (wave <= 3) stage_tile9(acc1, reinterpret_cast<float *>(sm + L::sA), wave - 2, lnS);
+            else if (wave <= 5) stage_tile9(acc2, reinterpret_cast<float *>(sm + L::sV), wave - 4, lnS);
+            else stage_tile9(acc2, reinterpret_cast<float *>(sm + L::sB), wave - 6, lnS);
         }
         B9STAMP(9);
         lds_barrier();
