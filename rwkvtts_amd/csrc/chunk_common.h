@@ -276,6 +276,12 @@ __device__ __forceinline__ float scan32(float x) {
     x += dpp0<0x142, 0xa, false>(x);  // row_bcast:15 into rows 1 and 3: lane 15 / 47 carries the first 16 steps
     return x;
 }
+// value of the previous lane (previous time step) inside the half-wave; `first` for step 0.  One DPP move (wave_shr:1) + one select:
+// gamma_{t-1} from gamma_t without a second exponential (v_exp_f32 is a quarter-rate instruction)
+__device__ __forceinline__ float prev32(float x, float first, int lane) {
+    const float y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));   // wave_shr:1
+    return (lane & 31) == 0 ? first : y;
+}
 // value of lane 31 (63) for every lane of the half-wave
 __device__ __forceinline__ float last32(float x, int lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) << 2, __float_as_int(x)));

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
             for (int j = 0; j < 8; j++) Gc[j] = scan32(lw[j]);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float gam = fast_exp(Gc[j]), gprev = fast_exp(Gc[j] - lw[j]), ig = fast_exp(-Gc[j]);
+                const float gam = fast_exp(Gc[j]), gprev = prev32(gam, 1.f, ltid), ig = fast_exp(-Gc[j]);
                 qsL[j] = qv[j] * gam;
                 asL[j] = av[j] * gprev;
                 bsL[j] = bv[j] * ig;

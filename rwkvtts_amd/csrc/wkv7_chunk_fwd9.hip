@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
             float qs[8], as_[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float gam = fast_exp(Gc[j]), gprev = fast_exp(Gc[j] - lw[j]), ig = fast_exp(-Gc[j]);
+                const float gam = fast_exp(Gc[j]), gprev = prev32(gam, 1.f, ltid), ig = fast_exp(-Gc[j]);
                 qs[j] = qv[j] * gam;
                 as_[j] = av[j] * gprev;
                 ksL[j] = kv[j] * ig;
