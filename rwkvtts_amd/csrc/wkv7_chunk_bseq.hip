@@ -51,12 +51,15 @@ struct BSSmem {  // offsets in uint16 units; every plane 16-byte aligned
     static constexpr int QTh = 0, QTl = PL, ATh = 2 * PL, ATl = 3 * PL, BHh = 4 * PL, BHl = 5 * PL, DYt = 6 * PL;
     static constexpr int BUF = 6 * PL + PS;
     // single: state planes E'[v][k], B"[r][k], and the 32 x 32 matrices X"[r][t], A_qb[t][s], T[t][r], Z[v][r]
-    static constexpr int Eh = 2 * BUF, El = Eh + VH * LDK;
+    // THREE producer buffers (round 4: the planes of a chunk land one iteration earlier, so that A_qb of the next chunk can be formed in
+    // interval a -- by wave 3, idle there until now -- and only X" is left behind it in interval b)
+    static constexpr int NBUF = 3;
+    static constexpr int Eh = NBUF * BUF, El = Eh + VH * LDK;
     static constexpr int BBh = El + VH * LDK, BBl = BBh + PL;
     static constexpr int XPh = BBl + PL, XPl = XPh + PS, QBh = XPl + PS, QBl = QBh + PS, TMh = QBl + PS, TMl = TMh + PS;
     static constexpr int Zh = TMl + PS, Zl = Zh + VH * LDC;
     static constexpr int end16 = Zl + VH * LDC;
-    static constexpr int fGC = 0, fZ = 2 * kN, fend = fZ + kC * 36;   // fp32: g_C of both buffers; Z staging tile [32][36]
+    static constexpr int fGC = 0, fZ = NBUF * kN, fend = fZ + kC * 36;   // fp32: g_C of the three buffers; Z staging tile [32][36]
     // raw input staging (bf16): 4 planes [32][64 + 8] and dY [32][32 + 8]
     static constexpr int RS = kN + 8, RSV = VH + 8;
     static constexpr size_t bytes = (size_t)end16 * 2 + (size_t)fend * 4 + (size_t)(4 * kC * RS + kC * RSV) * 2;
@@ -122,10 +125,13 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
         f32x16 Emaster = zero16();  // waves 1, 2: D-layout tile (32 keys x 32 value columns) of E_{cc+1}, fp32, not yet decayed
         lds_barrier();
         lds_barrier();
+        lds_barrier();
+        lds_barrier();
         for (int it = c1; it >= c0; it--) {
             const int cc = it, pc = it - 1;
-            const uint16_t *bufc = sm + (cc & 1) * L::BUF, *bufp = sm + (pc & 1) * L::BUF;
-            const float *gCc = sh_gC2 + (cc & 1) * kN, *gCp = sh_gC2 + (pc & 1) * kN;
+            const int bc = cc % L::NBUF, bp = (pc + L::NBUF) % L::NBUF;
+            const uint16_t *bufc = sm + bc * L::BUF, *bufp = sm + bp * L::BUF;
+            const float *gCc = sh_gC2 + bc * kN, *gCp = sh_gC2 + bp * kN;
             // ----------------------------------------------------------------------------------------------- interval a
             if (z_ && cc + 1 < c1) {
                 // Z of the previous chunk (staged in its interval b) -> HBM, fp32 [B,T,H,64] like sa: thread (pt, pv) owns 4 value
@@ -141,6 +147,14 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
                 mma_tile3<kN>(accZ, sm + L::BBh, sm + L::BBl, LDK, sm + L::Eh, sm + L::El, LDK, lane);
                 mma_gen<kC, false, true, true, false>(accZ, sm + L::XPh, sm + L::XPl, LDC, 0, bufc + L::DYt, bufc + L::DYt, LDC, 0, lane);
                 store_T_split(accZ, sm + L::Zh, sm + L::Zl, LDC, lane);
+            }
+            if (wave == 3 && pc >= c0) {
+                // next chunk: A_qb[t][s] (s <= t) from its planes, which landed an iteration ago (X" = T^T A_qb^T follows in interval b,
+                // when T of that chunk has landed)
+                f32x16 acc = zero16();  // D[m = s][n = t] = b^_s . q~_t
+                mma_tile3<kN, 2>(acc, bufp + L::BHh, bufp + L::BHl, LDK, bufp + L::QTh, bufp + L::QTl, LDK, lane);
+                mask_lower_T<false>(acc, lane);
+                store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
             }
             BSSTAMP(0);
             lds_barrier();
@@ -168,23 +182,19 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
                     for (int r = 0; r < 16; r++) sh_Z[d_row(r, lane) * kStageLD + (lane & 31)] = accZ[r];
                 }
                 if (pc >= c0) {
-                // B" = T^T B^ of the next chunk: D[m = k][n = r] = sum_s b^[s][k] T[s][r] -> B"[r][k], two key tiles
-#pragma unroll
-                for (int kt = 0; kt < 2; kt++) {
+                    // B" = T^T B^ of the next chunk, key tile 0: D[m = k][n = r] = sum_s b^[s][k] T[s][r] -> B"[r][k]
                     f32x16 acc = zero16();
-                    mma_gen<kC, true, true, true, true>(acc, bufp + L::BHh, bufp + L::BHl, LDK, kt * 32, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
-                    store_T_split(acc, sm + L::BBh + kt * 32, sm + L::BBl + kt * 32, LDK, lane);
-                }
+                    mma_gen<kC, true, true, true, true>(acc, bufp + L::BHh, bufp + L::BHl, LDK, 0, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
+                    store_T_split(acc, sm + L::BBh, sm + L::BBl, LDK, lane);
                 }
             } else if (wave == 3 && pc >= c0) {
-                // next chunk: A_qb[t][s] (s <= t), then X"[r][t] = sum_s T[s][r] A_qb[t][s] (this wave reads back what it wrote)
-                f32x16 acc = zero16();  // D[m = s][n = t] = b^_s . q~_t
-                mma_tile3<kN, 2>(acc, bufp + L::BHh, bufp + L::BHl, LDK, bufp + L::QTh, bufp + L::QTl, LDK, lane);
-                mask_lower_T<false>(acc, lane);
-                store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
+                // next chunk: X"[r][t] = sum_s T[s][r] A_qb[t][s] (A_qb: this wave, interval a) and key tile 1 of B"
                 f32x16 acx = zero16();  // D[m = t][n = r]
                 mma_gen<kC, false, true, true, true>(acx, sm + L::QBh, sm + L::QBl, LDC, 0, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
                 store_T_split(acx, sm + L::XPh, sm + L::XPl, LDC, lane);
+                f32x16 acb = zero16();
+                mma_gen<kC, true, true, true, true>(acb, bufp + L::BHh, bufp + L::BHl, LDK, 32, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
+                store_T_split(acb, sm + L::BBh + 32, sm + L::BBl + 32, LDK, lane);
             }
             BSSTAMP(2);
             lds_barrier();
@@ -248,35 +258,46 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
                 gamL[j] = gam;
             }
         };
+        // operand planes, dY and g_C of chunk c (whose scaled rows first_half() left in registers) -> buffer c % 3
+        auto write_planes = [&](int c) {
+            uint16_t *bufw = sm + (c % L::NBUF) * L::BUF;
+            float *gCw = sh_gC2 + (c % L::NBUF) * kN;
+            const int o = pt * LDK + pk;
+            auto put = [&](const float (&x)[8], int ph, int pl) {
+                uint32_t h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], h[j], l[j]);
+                *reinterpret_cast<uint4 *>(&bufw[ph + o]) = make_uint4(h[0], h[1], h[2], h[3]);
+                *reinterpret_cast<uint4 *>(&bufw[pl + o]) = make_uint4(l[0], l[1], l[2], l[3]);
+            };
+            put(qsL, L::QTh, L::QTl);
+            put(asL, L::ATh, L::ATl);
+            put(bsL, L::BHh, L::BHl);
+            *reinterpret_cast<RawVec *>(&bufw[L::DYt + pt * LDC + pv]) = rdy;  // bf16 dY: exact
+            if (pt == kC - 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) gCw[pk + j] = gamL[j];
+            }
+        };
+        // Two chunks of lead (four barriers before the loop, like the consumer): planes of c1 - 1 written, rows of c1 - 2 scaled
         issue(c1 - 1);
         stage_raw();
         issue(clampc(c1 - 2));
         float4 tmreg = load_tm(c1 - 1);
         lds_barrier();
         first_half();   // chunk c1 - 1
-        lds_barrier();  // staging is rewritten in the first interval a
+        lds_barrier();  // staging is rewritten below
+        write_planes(c1 - 1);
+        stage_raw();    // rows of chunk c1 - 2
+        issue(clampc(c1 - 3));
+        lds_barrier();
+        if (c1 - 2 >= c0) first_half();   // chunk c1 - 2
+        lds_barrier();
         for (int it = c1; it >= c0; it--) {
-            const int pc = it - 1;
-            uint16_t *bufp = sm + (pc & 1) * L::BUF;
-            float *gCp = sh_gC2 + (pc & 1) * kN;
+            const int pc = it - 1, pp = it - 2;   // T planes of pc, operand planes of pp land in this interval a
             // ----------------------------------------------------------------------------------------------- interval a
+            if (pp >= c0) write_planes(pp);
             if (pc >= c0) {
-                const int o = pt * LDK + pk;
-                auto put = [&](const float (&x)[8], int ph, int pl) {
-                    uint32_t h[4], l[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) split_pk(x[2 * j], x[2 * j + 1], h[j], l[j]);
-                    *reinterpret_cast<uint4 *>(&bufp[ph + o]) = make_uint4(h[0], h[1], h[2], h[3]);
-                    *reinterpret_cast<uint4 *>(&bufp[pl + o]) = make_uint4(l[0], l[1], l[2], l[3]);
-                };
-                put(qsL, L::QTh, L::QTl);
-                put(asL, L::ATh, L::ATl);
-                put(bsL, L::BHh, L::BHl);
-                *reinterpret_cast<RawVec *>(&bufp[L::DYt + pt * LDC + pv]) = rdy;  // bf16 dY: exact
-                if (pt == kC - 1) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) gCp[pk + j] = gamL[j];
-                }
                 {   // T planes Tm[t][r] of chunk pc: thread = row ltid >> 3, columns 4 (ltid & 7) .. +4
                     uint32_t h0, l0, h1, l1;
                     split_pk(tmreg.x, tmreg.y, h0, l0);
@@ -286,16 +307,16 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
                     *reinterpret_cast<uint2 *>(&sm[L::TMl + ot]) = make_uint2(l0, l1);
                 }
             }
-            stage_raw();   // rows of chunk pc - 1 (requested one iteration ago)
+            stage_raw();   // rows of chunk pp - 1 (requested one iteration ago)
             __builtin_amdgcn_sched_barrier(0);
             tmreg = load_tm(pc - 1);
-            issue(clampc(pc - 2));
+            issue(clampc(pp - 2));
             __builtin_amdgcn_sched_barrier(0);
             BSSTAMP(0);
             lds_barrier();
             BSSTAMP(1);
             // ----------------------------------------------------------------------------------------------- interval b
-            if (pc - 1 >= c0) first_half();   // chunk pc - 1
+            if (pp - 1 >= c0) first_half();   // chunk pp - 1
             BSSTAMP(2);
             lds_barrier();
             BSSTAMP(3);
