@@ -87,7 +87,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(int M, int N, int K, 
     // patch, so that every k-slice of A is fetched once for 8 workgroups and every slice of W once for 4 while they walk K together
     // (a 2 x 16 patch streamed all of W through every L2 once per pair of row panels: 811 instead of 872 TFLOP/s)
     const int nbn = N / GBN, nbm = M / GBM, ntiles = nbn * nbm;
-    const bool patched = (gridDim.x & 7) == 0 && nbm % 32 == 0 && nbn % 8 == 0;
+    // (round 4) narrow outputs (N = 1024: four column tiles): the patch is 8 row panels x 4 column tiles, so that the four workgroups
+    // that share an A panel still sit on one XCD (id % nbn as the column put them on four different L2s: A fetched four times)
+    const int pc = nbn % 8 == 0 ? 8 : 4, pr = 32 / pc;      // patch: pr row panels x pc column tiles
+    const bool patched = (gridDim.x & 7) == 0 && nbm % (8 * pr) == 0 && nbn % pc == 0;
     const int nk = K / BK;
     const int rl = lane & 31, h = lane >> 5;
     constexpr int NP = 2 * Cfg::G;              // DMA instructions per thread and K tile
@@ -97,10 +100,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(int M, int N, int K, 
         int bm, bn;
         if (patched) {
             const int xcd = id & 7, j = id >> 3;
-            const int nround_n = nbn / 8;
+            const int nround_n = nbn / pc;
             const int r = j / 32, i = j % 32;
-            bn = 8 * (r % nround_n) + (i & 7);
-            bm = xcd + 8 * (4 * (r / nround_n) + (i >> 3));
+            bn = pc * (r % nround_n) + (i % pc);
+            bm = xcd + 8 * (pr * (r / nround_n) + (i / pc));
         } else {
             bn = id % nbn;
             bm = id / nbn;

@@ -12,18 +12,24 @@
 // (Z_t = dL/du_t, the same Z the per-chunk gradient kernel uses).  Two dependent products per chunk, nothing but the raw rows read
 // and nothing but the E records written: 20 KB in (16 of them shared by the two workgroups of a head through L2) + 9 KB out per
 // chunk against 43 + 28.
-//     interval a   wave 0: Z = B" E' + X" dY -> Z planes
-//                  waves 4-7 (producer): hi/lo splits; operand planes q~, a~, b^, dY, g_C, T planes of the NEXT chunk (c - 1); raw rows
-//                                        of the chunk after it -> LDS staging; next global prefetch
-//     interval b   waves 1,2: record of E_{c+1} -> e_vk[c]; E_c (two key tiles); E' planes of the next chunk
-//                  wave 0: B" of the next chunk          wave 3: A_qb, X" of the next chunk
-//                  waves 4-7: rows of the chunk after the next in the compute mapping: exp, prefix sums, scaling
+//     interval a   wave 0: Z = B" E' + X" dY -> Z planes            wave 3: A_qb of the NEXT chunk (c - 1)
+//                  waves 1,2: record of E_{c+1} -> e_vk[c] (and the Z tile of the previous chunk -> global)
+//                  waves 4-7 (producer): hi/lo splits; operand planes q~, a~, b^, dY, g_C of the chunk after the next (c - 2): THREE
+//                                        plane buffers since round 4, so that A_qb no longer waits for planes written in the same
+//                                        interval; T planes of c - 1; raw rows -> LDS staging; next global prefetch
+//     interval b   waves 1,2: E_c (two key tiles); E' planes of the next chunk
+//                  wave 0: Z -> staging tile, B" key tile 0 of the next chunk      wave 3: X", B" key tile 1 of the next chunk
+//                  waves 4-7: rows of chunk c - 2 in the compute mapping: exp, prefix sums, scaling
 // One workgroup per (head, half of the value columns): the value columns of E never mix.
-// Measured (tools/cbseq_timing.py, B=8, T=4096, H=16): 3.8k cycles per chunk = 1.9k + 1.9k, 0.21 ms (0.22-0.24 with the Z store)
-// against 0.29 ms for the pair it replaces.  Tried and dropped: eight producer waves (768 threads, 4 channels per producer thread,
+// Measured (tools/cbseq_timing.py, B=8, T=4096, H=16): round 3: 3.8k cycles per chunk = 1.9k + 1.9k, 0.22-0.24 ms with the Z store
+// (0.29 ms for the pair of round 2).  Round 4 (same-box A/B, tools/ab_kernel.py): -6.3 % from the three-buffer pipeline above -- the
+// intervals are bounded by the wave with the most state-INDEPENDENT work and its SIMD partner (waves w and w + 4 share a SIMD and the
+// older wave wins the VALU arbitration), not by the chain product, so work was moved until the SIMDs are even.
+// Tried and dropped: eight producer waves (768 threads, 4 channels per producer thread,
 // three waves per SIMD, K = 64 products in two halves to stay inside 168 registers) -- the producer's share of each interval
 // shrinks (1.5-1.9k -> 1.1-1.7k) but the chain waves, now sharing their SIMD with two producer waves, slow down by as much:
-// 3.9k cycles per chunk; B" on the waves that compute E_c instead of wave 0: no change.
+// 3.9k cycles per chunk; B" on the waves that compute E_c instead of wave 0: no change; an LDS flag instead of the barrier for the
+// X" hand-off inside interval b: +4.2 % (profiles/experiments_r04/bseq_xpp_relocation.patch).
 #include "chunk_common.h"
 
 namespace rwkv7 {

@@ -1,47 +1,53 @@
-"""GEMM shapes of the training step, timed hot (same operands every call) and cold (cycling through 24 operand sets, as the
-24 layers of the step do).  python tools/bench_gemm_cold.py"""
-import os
-import sys
+"""Library GEMM (hipBLASLt through torch) against the own MFMA GEMM (csrc/gemm_relusq.hip, rwkv7_gemm_nt_bf16), HOT (same operands every
+call: they sit in the 256 MB infinity cache) and COLD (operands rotate through R buffer sets larger than the cache together -- what the
+training step sees).  HIP events, same process.
 
-sys.path.insert(0, os.getcwd())
+    python tools/bench_gemm_cold.py [M N K] [R]      default 32768 1024 1024, R = 8"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from rwkvtts_amd import _lib
 
-M = 32768
+M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (32768, 1024, 1024)
+R = int(sys.argv[4]) if len(sys.argv) >= 5 else 8
 dev = "cuda:0"
+g = torch.Generator(device=dev).manual_seed(0)
+As = [(torch.randn(M, K, device=dev, generator=g) * 0.5).bfloat16() for _ in range(R)]
+W = (torch.randn(N, K, device=dev, generator=g) * 0.05).bfloat16()
+Cs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(R)]
+lib = _lib.lib()
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def timeit(fn, n):
-    for i in range(3):
-        fn(i)
+def own(i):
+    rc = lib.rwkv7_gemm_nt_bf16(M, N, K, P(As[i]), P(W), P(Cs[i]), 0, st())
+    assert rc == 0, rc
+
+
+def library(i):
+    torch.nn.functional.linear(As[i], W, out=None) if False else torch.mm(As[i], W.t(), out=Cs[i])
+
+
+def timeit(fn, rotate, n=48):
+    for i in range(R):
+        fn(i if rotate else 0)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(n):
-        fn(i)
-    e1.record()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for j, (s, e) in enumerate(ev):
+        s.record(); fn(j % R if rotate else 0); e.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    ts = sorted(s.elapsed_time(e) for s, e in ev)
+    return ts[len(ts) // 2]
 
 
-def main():
-    torch.manual_seed(0)
-    for N, K in ((1024, 1024), (4096, 1024), (1024, 4096)):
-        S = 24
-        xs = [torch.randn(M, K, device=dev, dtype=torch.bfloat16) for _ in range(S)]
-        ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(S)]
-        dys = [torch.randn(M, N, device=dev, dtype=torch.bfloat16) for _ in range(S)]
-        outs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(S)]
-        dxs = [torch.empty(M, K, device=dev, dtype=torch.bfloat16) for _ in range(S)]
-        fl = 2.0 * M * N * K
-        for name, hot, cold in (
-            ("fwd   x @ W^T", lambda i: torch.mm(xs[0], ws[0].t(), out=outs[0]), lambda i: torch.mm(xs[i % S], ws[i % S].t(), out=outs[i % S])),
-            ("dgrad dy @ W ", lambda i: torch.mm(dys[0], ws[0], out=dxs[0]), lambda i: torch.mm(dys[i % S], ws[i % S], out=dxs[i % S])),
-        ):
-            th, tc = timeit(hot, 48), timeit(cold, 48)
-            print(f"N={N:5d} K={K:5d} {name}: hot {th:7.1f} us ({fl / th / 1e9:6.3f} PF/s)   cold {tc:7.1f} us ({fl / tc / 1e9:6.3f} PF/s)", flush=True)
-        del xs, ws, dys, outs, dxs
-        torch.cuda.empty_cache()
-
-
-if __name__ == "__main__":
-    main()
+library(0)
+ref = Cs[0].clone()
+Cs[0].zero_()
+own(0)
+print(f"own vs library: max|d| {(Cs[0].float() - ref.float()).abs().max().item():.3e} (max|ref| {ref.float().abs().max().item():.3e})")
+flops = 2.0 * M * N * K
+for name, fn in (("library", library), ("own", own)):
+    for rot in (False, True):
+        t = timeit(fn, rot)
+        print(f"{name:8s} {'cold' if rot else 'hot ':4s} {t * 1e3:8.1f} us  {flops / t / 1e9:8.1f} TFLOP/s")
