@@ -391,7 +391,15 @@ int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *
  *      C[M][N] = bf16(A[M][K] . W[N][K]^T) * 2 relu(aux[M][N]) -- A = dy, W = value.weight^T (contiguous [N = F][K = D]), aux = the key
  *      projection's output h: dh without ds ever reaching HBM and without rwkv7_relusq_bwd_*. */
 int rwkv7_gemm_nt_relusq_bwd_bf16(int M, int N, int K, const void *A, const void *W, const void *aux, void *C, rwkv7_stream_t stream);
-/*      variant (A/B): 0 = K tile 64, two LDS buffers (the plain entry); 1 = K tile 32, four buffers, three tiles in flight */
+/*      the same from the activation's OUTPUT: C[M][N] = bf16(A . W^T) * 2 sqrt(s[M][N]), s = relu(h)^2 as written by rwkv7_gemm_nt_bf16 with
+ *      epilogue 1 (what the library GEMM + rwkv7_relusq_bwd_s_* produce, bit for bit): with it the channel mix never materialises h or
+ *      ds (fused.channel_mix).  csrc/gemm_nt4.hip only: K % 1024 == 0. */
+int rwkv7_gemm_nt_relusq_bwd_s_bf16(int M, int N, int K, const void *A, const void *W, const void *s, void *C, rwkv7_stream_t stream);
+/*      which own GEMM the two entries above run (A/B knob, process-wide): 4 (default) = csrc/gemm_nt4.hip (four waves, quadrant phases,
+ *      ring of eight half-tile slots; K % 1024 == 0, other K fall back to generation 1), 1 = csrc/gemm_relusq.hip.  Returns the
+ *      previous value; other arguments leave it unchanged. */
+int rwkv7_set_gemm_generation(int generation);
+/*      variant (A/B) of generation 1: 0 = K tile 64, two LDS buffers (the plain entry); 1 = K tile 32, four buffers, three tiles in flight */
 int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant,
                                rwkv7_stream_t stream);
 

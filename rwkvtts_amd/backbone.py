@@ -333,6 +333,10 @@ class RWKV7FeedForward(nn.Module):
         return self.forward_mixed(kx)
 
     def forward_mixed(self, kx):
+        if self.key.bias is None and self.value.bias is None:
+            out = fused.channel_mix(kx, self.key.weight, self.value.weight)   # the activation inside both GEMMs (own MFMA kernel)
+            if out is not None:
+                return out
         s = fused.key_relu_sq(kx, self.key.weight) if self.key.bias is None else None   # GEMM with the activation as epilogue
         if s is None:
             h = self.key(kx)

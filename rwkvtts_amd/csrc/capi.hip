@@ -42,6 +42,7 @@ int chunk_bseq_bf16(int, int, int, const void *, const void *, const void *, con
 int gemm_nt_bf16(int, int, int, const void *, const void *, void *, int, hipStream_t);
 int gemm_nt_bf16_variant(int, int, int, const void *, const void *, void *, int, int, hipStream_t);
 int gemm_nt_relusq_bwd_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
+int gemm_nt4_bf16(int, int, int, const void *, const void *, void *, const void *, int, hipStream_t);
 int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
@@ -460,15 +461,28 @@ int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const voi
     if (T % 32 != 0) return RWKV7_ECHUNK;
     return rwkv7::chunk_bwd_out9_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
+static int g_gemm_generation = 4;   // 4: csrc/gemm_nt4.hip (K % 1024 == 0), 1: csrc/gemm_relusq.hip
+int rwkv7_set_gemm_generation(int gen) {
+    const int prev = g_gemm_generation;
+    if (gen == 1 || gen == 4) g_gemm_generation = gen;
+    return prev;
+}
 int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, rwkv7_stream_t stream) {
     if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || epilogue < 0 || epilogue > 1) return RWKV7_ESHAPE;
+    if (g_gemm_generation == 4 && K % 1024 == 0) return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, nullptr, epilogue, (hipStream_t)stream);
     return rwkv7::gemm_nt_bf16(M, N, K, A, W, C, epilogue, (hipStream_t)stream);
 }
 int rwkv7_gemm_nt_relusq_bwd_bf16(int M, int N, int K, const void *A, const void *W, const void *aux, void *C, rwkv7_stream_t stream) {
     if (any_null({A, W, aux, (const void *)C})) return RWKV7_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0) return RWKV7_ESHAPE;
+    if (g_gemm_generation == 4 && K % 1024 == 0) return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, aux, 2, (hipStream_t)stream);
     return rwkv7::gemm_nt_relusq_bwd_bf16(M, N, K, A, W, aux, C, (hipStream_t)stream);
+}
+int rwkv7_gemm_nt_relusq_bwd_s_bf16(int M, int N, int K, const void *A, const void *W, const void *s, void *C, rwkv7_stream_t stream) {
+    if (any_null({A, W, s, (const void *)C})) return RWKV7_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 1024 != 0) return RWKV7_ESHAPE;
+    return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, s, 3, (hipStream_t)stream);
 }
 int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant, rwkv7_stream_t stream) {
     if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;

@@ -216,6 +216,65 @@ class _ReluSqValue(torch.autograd.Function):
         return dh, dw
 
 
+# Round 4, second half: BOTH ends at once on the second-generation own GEMM (csrc/gemm_nt4.hip: four waves, quadrant phases, ring of
+# half-tile slots; 0.89 of the library's rate as a plain GEMM, but the activation rides for free).  forward: s = relu(x W_key^T)^2 as
+# the key GEMM's epilogue (h never written), out = s W_value^T (library); backward: dk = bf16(dout W_value) * 2 sqrt(s) as the epilogue of
+# the value projection's input-gradient GEMM (ds never written), then the key projection's gradients as before.  Neither rwkv7_relusq_fwd
+# nor rwkv7_relusq_bwd runs, and one [rows, F] activation less is kept per layer.  Same-box A/B (tools/ab_step.py): see DESIGN.md section 4.
+FUSED_CMIX = os.environ.get("RWKV7_FUSED_CMIX", "1") == "1"
+FUSED_CMIX_HITS = [0]
+
+
+def cmix_eligible(x, wk, wv):
+    M = x.numel() // x.shape[-1]
+    return (FUSED_CMIX and x.is_cuda and x.dtype == torch.bfloat16 and wk.dtype == torch.bfloat16 and wv.dtype == torch.bfloat16
+            and M % 256 == 0 and wk.shape[0] % 256 == 0 and wk.shape[1] % 1024 == 0 and wv.shape[0] == wk.shape[1] and wv.shape[1] == wk.shape[0])
+
+
+class _ChannelMix(torch.autograd.Function):
+    """out = relu(x @ wk^T)^2 @ wv^T   (wk = key.weight [F, D], wv = value.weight [D, F]); rwkv_s2s_single_ffn.py:226-229."""
+
+    @staticmethod
+    def forward(ctx, x, wk, wv):
+        x2 = _c(x).view(-1, x.shape[-1])
+        wkc = _c(wk)
+        M, D = x2.shape
+        F = wkc.shape[0]
+        s = torch.empty(M, F, dtype=x.dtype, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = _lib.lib().rwkv7_gemm_nt_bf16(M, F, D, _p(x2), _p(wkc), _p(s), 1, _stream(x))
+        _lib.check(rc, "gemm_nt_relusq")
+        FUSED_CMIX_HITS[0] += 1
+        out = torch.nn.functional.linear(s, wv)
+        ctx.save_for_backward(x2, s, wk, wv)
+        ctx.wk, ctx.wv = wk, wv
+        ctx.shape = x.shape
+        return out.view(*x.shape[:-1], wv.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, s, wk, wv = ctx.saved_tensors
+        d2 = _c(dout).view(-1, dout.shape[-1])
+        M, F = s.shape
+        D = wv.shape[0]
+        wt = wv.detach().t().contiguous()     # [F, D]: the NT operand (8 MiB at 0.4B, one copy per layer and step)
+        dk = torch.empty_like(s)
+        with torch.cuda.device_of(s):
+            rc = _lib.lib().rwkv7_gemm_nt_relusq_bwd_s_bf16(M, F, D, _p(d2), _p(wt), _p(s), _p(dk), _stream(s))
+        _lib.check(rc, "gemm_nt_relusq_bwd_s")
+        dx = torch.mm(dk, wk).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        dwk = _wgrad(dk, x2, ctx.wk) if ctx.needs_input_grad[1] else None
+        dwv = _wgrad(d2, s, ctx.wv) if ctx.needs_input_grad[2] else None
+        return dx, dwk, dwv
+
+
+def channel_mix(x, wk, wv):
+    """value(relu(key(x))^2) with the activation inside both GEMMs, or None (shapes / dtype outside the own GEMM's range)."""
+    if cmix_eligible(x, wk, wv):
+        return _ChannelMix.apply(x, wk, wv)
+    return None
+
+
 def relu_sq_value(h, weight):
     """value(relu(h)^2) with the activation's backward inside the value projection's input-gradient GEMM, or None (shapes / dtype
     outside the own GEMM's range: the caller runs relu_sq + Linear)."""

@@ -543,3 +543,92 @@ def test_relu_squared_backward_inside_the_value_dgrad_gemm(M, F, D, monkeypatch)
     assert (res[0][2].float() - res[1][2].float()).abs().max().item() <= 1e-2 * res[1][2].float().abs().max().item()
     # shapes outside the tile grid: the caller falls back
     assert fused.relu_sq_value(torch.zeros(100, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True), w[:, :256].contiguous()) is None
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (512, 1024, 1024), (2048, 4096, 1024), (1024, 1024, 4096), (256 * 9, 256 * 5, 2048), (256 * 33, 256 * 8, 1024)])
+def test_second_generation_gemm_all_epilogues_against_the_library_compositions(M, N, K):
+    """csrc/gemm_nt4.hip (four waves, quadrant phases over a ring of eight half-tile slots, counted vmcnt, deferred-drain epilogue
+    through LDS) behind the same C entries as csrc/gemm_relusq.hip: epilogue 0 against the library GEMM, 1 against GEMM +
+    rwkv7_relusq_fwd, 2 against GEMM + rwkv7_relusq_bwd (aux = h), 3 against GEMM + rwkv7_relusq_bwd_s (aux = s) -- each bit for
+    bit where the library accumulates K in the same order, within one bf16 ulp of the GEMM result otherwise; several tiles per
+    workgroup and tile counts that are not a multiple of the grid included (ragged persistence); generation 1 gives the same bits."""
+    import ctypes
+    from rwkvtts_amd import _lib, fused
+    lib = _lib.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * (K ** -0.5)).to(DEV, torch.bfloat16)
+    aux = (torch.randn(M, N, generator=g) * 0.7).to(DEV, torch.bfloat16)
+    ref = torch.nn.functional.linear(A, W)
+    ulp = 2.0 ** -7 * torch.clamp(ref.float().abs(), min=1e-3)
+
+    def close(got, want, scale=None):
+        tol = ulp if scale is None else 2.0 ** -6 * torch.clamp(want.float().abs(), min=scale)
+        d = (got.float() - want.float()).abs()
+        assert (d <= tol).all(), d.max().item()
+
+    prev = lib.rwkv7_set_gemm_generation(4)
+    try:
+        outs = {}
+        for gen in (4, 1):
+            lib.rwkv7_set_gemm_generation(gen)
+            C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C), 0, st) == 0
+            close(C, ref)
+            outs[gen] = C.clone()
+            C1 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C1), 1, st) == 0
+            assert torch.equal(C1, fused.relu_sq(C))                       # the activation of the kernel's own product, bit for bit
+            C2 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            assert lib.rwkv7_gemm_nt_relusq_bwd_bf16(M, N, K, P(A), P(W), P(aux), P(C2), st) == 0
+            want2 = torch.empty_like(C)
+            fused._call("relusq_bwd", aux, ctypes.c_long(aux.numel()), P(aux), P(C), P(want2))
+            assert torch.equal(C2, want2)
+        assert torch.equal(outs[4], outs[1])
+        lib.rwkv7_set_gemm_generation(4)
+        s_act = fused.relu_sq(aux)
+        C3 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        assert lib.rwkv7_gemm_nt_relusq_bwd_s_bf16(M, N, K, P(A), P(W), P(s_act), P(C3), st) == 0
+        want3 = torch.empty_like(C3)
+        fused._call("relusq_bwd_s", s_act, ctypes.c_long(s_act.numel()), P(s_act), P(outs[4]), P(want3))
+        assert torch.equal(C3, want3)
+        # repeated launches give the same bits (a race in the slot ring would come and go)
+        for _ in range(5):
+            C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C), 0, st) == 0
+            assert torch.equal(C, outs[4])
+        assert lib.rwkv7_gemm_nt_relusq_bwd_s_bf16(M, N, 960, P(A), P(W), P(s_act), P(C3), st) == -4      # K % 1024: RWKV7_ESHAPE
+    finally:
+        lib.rwkv7_set_gemm_generation(prev)
+
+
+@pytest.mark.parametrize("M,F,D", [(512, 1024, 1024), (2048, 4096, 1024)])
+def test_channel_mix_with_the_activation_inside_both_gemms(M, F, D, monkeypatch):
+    """fused.channel_mix (rwkv_s2s_single_ffn.py:226-229): relu(x W_k^T)^2 W_v^T with s as the key GEMM's epilogue and
+    dk = bf16(dout W_v) * 2 sqrt(s) as the epilogue of the value projection's input-gradient GEMM, against the separate nodes
+    (library GEMMs, rwkv7_relusq_fwd / rwkv7_relusq_bwd): output within the bf16 rounding of s, gradients to the parity bars."""
+    from rwkvtts_amd import fused
+    monkeypatch.setattr(fused, "FUSED_CMIX", True)
+    g = torch.Generator().manual_seed(M + F)
+    x = (torch.randn(M, D, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    wk = (torch.randn(F, D, generator=g) * (D ** -0.5)).to(DEV, torch.bfloat16)
+    wv = (torch.randn(D, F, generator=g) * (F ** -0.5)).to(DEV, torch.bfloat16)
+    dy = torch.randn(M, D, generator=g).to(DEV, torch.bfloat16)
+    res = []
+    for fusedp in (True, False):
+        xi, ki, vi = x.clone().requires_grad_(True), wk.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+        if fusedp:
+            hits = fused.FUSED_CMIX_HITS[0]
+            out = fused.channel_mix(xi, ki, vi)
+            assert out is not None and fused.FUSED_CMIX_HITS[0] == hits + 1
+        else:
+            out = fused.linear(fused.relu_sq(fused.linear(xi, ki, None)), vi, None)
+        out.backward(dy)
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), xi.grad.clone(), ki.grad.clone(), vi.grad.clone()))
+    for a_, b_, n in zip(res[0], res[1], ("out", "dx", "dwk", "dwv")):
+        e = (a_.float() - b_.float()).norm().item() / max(b_.float().norm().item(), 1e-9)
+        assert e < 8e-3, (n, e)
+    assert fused.channel_mix(x[:100], wk, wv) is None and fused.channel_mix(x.float(), wk.float(), wv.float()) is None
