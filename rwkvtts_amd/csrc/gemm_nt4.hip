@@ -25,6 +25,9 @@
 #ifndef GEMM4_EXP
 #define GEMM4_EXP 0
 #endif
+#ifndef GEMM4_SCHED
+#define GEMM4_SCHED 0
+#endif
 
 namespace rwkv7 {
 namespace {
@@ -33,7 +36,10 @@ constexpr int kRowB4 = BK4 * 2;            // bytes per LDS row
 constexpr int kSlotB4 = 128 * kRowB4;      // a half tile: 128 rows x 64 k = 16 KB
 constexpr int kStageB4 = 32 * 256;         // per wave: 32 rows x 128 columns bf16
 constexpr size_t kLds4 = 8 * kSlotB4 + 4 * kStageB4;   // 160 KB
-constexpr int kAhead = 6;                  // half tiles requested ahead of the one being read
+#ifndef GEMM4_AHEAD
+#define GEMM4_AHEAD 6
+#endif
+constexpr int kAhead = GEMM4_AHEAD;                  // half tiles requested ahead of the one being read
 constexpr int kDmaPerPhase = 4;            // DMA instructions per wave and half tile
 
 __device__ __forceinline__ int swz4(int row) { return (row >> 1) & 7; }
@@ -160,6 +166,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
 #define G4STAMP(i)
 #endif
     constexpr int kInFlight = (kAhead - 1) * kDmaPerPhase;   // DMA instructions younger than the half tile a phase needs
+    constexpr int kInFlight2 = (kAhead - 2) * kDmaPerPhase;  // ... than the half tiles a PAIR of phases needs
     constexpr int kStores = 32;                               // epilogue stores per thread
     bool stores_behind = false;   // the previous tile's stores are younger than the DMA the first six phases wait for
 
@@ -175,11 +182,15 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
                     constexpr int p = decltype(P)::value;
                     constexpr int slot_r = (s0 + p) % 8, slot_w = (s0 + p + kAhead) % 8;
                     G4STAMP(1)
-                    if (kt == 0 || (kt == 1 && p < 2)) {
-                        if (stores_behind) wait_vm4<kInFlight + kStores>();
-                        else wait_vm4<kInFlight>();
-                    } else {
-                        wait_vm4<kInFlight>();
+                    // one barrier per TWO phases: the half tiles of this phase and the next have landed (everybody's pieces), everybody is
+                    // done with the slots the two phases' DMA will overwrite (read in the previous pair of phases)
+                    if (p % 2 == 0) {
+                        if (kt == 0 || (kt == 1 && p == 0)) {
+                            if (stores_behind) wait_vm4<kInFlight2 + kStores>();
+                            else wait_vm4<kInFlight2>();
+                        } else {
+                            wait_vm4<kInFlight2>();
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     G4STAMP(0)
@@ -199,6 +210,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
                     if (p == 1) quadrant(FA[0], FB[1 - e], 0, 1);
                     if (p == 2) quadrant(FA[1], FB[1 - e], 1, 1);
                     if (p == 3) quadrant(FA[1], FB[e], 1, 0);
+#if GEMM4_SCHED == 0
                     // issue order: MFMA, ds_read (x 8), MFMA, DMA (x 4), 4 MFMAs -- the reads and the DMA go out in the shadow of the MFMAs
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -211,6 +223,57 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
                         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#elif GEMM4_SCHED == 1
+                    // four groups of (MFMA, ds_read, MFMA, ds_read, MFMA, DMA, MFMA)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+#elif GEMM4_SCHED == 2
+                    // DMA first (longest latency), one per two MFMAs, then the reads
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#elif GEMM4_SCHED == 3
+                    // four groups of (MFMA, DMA, MFMA, ds_read, MFMA, ds_read, MFMA)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+#elif GEMM4_SCHED == 4
+                    // DMA: one per three MFMAs; reads in pairs behind
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 phase(IC<0>{});
