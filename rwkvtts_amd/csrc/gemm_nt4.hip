@@ -17,16 +17,24 @@
 //     slots, a slot is free again one phase after its only read, the DMA is issued 4 instructions per wave and phase between the
 //     MFMAs instead of 16 in a burst, and every load has 1.5 K tiles of latency budget (counted vmcnt, never 0 inside the loop);
 //   * ONE software pipeline over all K tiles of all tiles of a workgroup (persistent, XCD-aware tile patches as before);
+//   * one barrier per TWO phases;
 //   * epilogue through a wave-private LDS staging tile: full 128-byte lines leave, 8 lines per store instruction (2.5k instead of
 //     10k address cycles per tile).  vmcnt is in order on gfx9 (loads and stores retire in issue order), so the DMA requested before
 //     the epilogue is awaited with the epilogue's stores still in flight (vmcnt(20 + 32)); nothing waits for a store before the
 //     seventh phase of the next tile.
+// Measured (tools/gemm_lab/bench.py: operands rotating through 2 GB, variants interleaved in one process; 32768 x 4096 x 1024):
+// library (hipBLASLt) 215-219 us, this kernel 231 us, the first generation 320 us; 32768 x 1024 x 1024: 59-62 / 64.6 / 80-90 us.  As a plain
+// GEMM it stays 7 % behind the library; with the activation as epilogue it replaces GEMM + elementwise kernel pairs (fused.channel_mix).
+// What bounds it (interval stamps, GEMM4_TIMING): 3.4k cycles per K tile for 2.0k of MFMA.  On a LONE wave nothing issues in the
+// shadow of an MFMA -- two dummy VALU instructions behind every MFMA cost +12 %, four +41 % -- so the 32 fragment reads (~14 cycles),
+// the 16 DMA instructions with their address arithmetic (~30), two barriers and the epilogue (5.2k cycles per tile) all ADD to the
+// MFMA time.  Tried: other interleavings of reads / DMA / MFMAs (within 2 %); one barrier per two phases (-1.3 %, kept); the same ring
+// with EIGHT waves of 128 x 64 (two per SIMD, so that one wave's issue hides behind the other's MFMAs): bit-identical, 267 us -- the
+// 192 KB of fragment reads per K tile saturate the LDS (profiles/experiments_r04/gemm_nt8_ring_8waves.hip); the DMA in its scalar-base form
+// (inline asm, no 64-bit VALU add per instruction): +-0.
 #include "chunk_common.h"
 #ifndef GEMM4_EXP
 #define GEMM4_EXP 0
-#endif
-#ifndef GEMM4_SCHED
-#define GEMM4_SCHED 0
 #endif
 
 namespace rwkv7 {
@@ -36,10 +44,7 @@ constexpr int kRowB4 = BK4 * 2;            // bytes per LDS row
 constexpr int kSlotB4 = 128 * kRowB4;      // a half tile: 128 rows x 64 k = 16 KB
 constexpr int kStageB4 = 32 * 256;         // per wave: 32 rows x 128 columns bf16
 constexpr size_t kLds4 = 8 * kSlotB4 + 4 * kStageB4;   // 160 KB
-#ifndef GEMM4_AHEAD
-#define GEMM4_AHEAD 6
-#endif
-constexpr int kAhead = GEMM4_AHEAD;                  // half tiles requested ahead of the one being read
+constexpr int kAhead = 6;                  // half tiles requested ahead of the one being read
 constexpr int kDmaPerPhase = 4;            // DMA instructions per wave and half tile
 
 __device__ __forceinline__ int swz4(int row) { return (row >> 1) & 7; }
@@ -210,7 +215,6 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
                     if (p == 1) quadrant(FA[0], FB[1 - e], 0, 1);
                     if (p == 2) quadrant(FA[1], FB[1 - e], 1, 1);
                     if (p == 3) quadrant(FA[1], FB[e], 1, 0);
-#if GEMM4_SCHED == 0
                     // issue order: MFMA, ds_read (x 8), MFMA, DMA (x 4), 4 MFMAs -- the reads and the DMA go out in the shadow of the MFMAs
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -223,57 +227,6 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
                         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#elif GEMM4_SCHED == 1
-                    // four groups of (MFMA, ds_read, MFMA, ds_read, MFMA, DMA, MFMA)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    }
-#elif GEMM4_SCHED == 2
-                    // DMA first (longest latency), one per two MFMAs, then the reads
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-#elif GEMM4_SCHED == 3
-                    // four groups of (MFMA, DMA, MFMA, ds_read, MFMA, ds_read, MFMA)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    }
-#elif GEMM4_SCHED == 4
-                    // DMA: one per three MFMAs; reads in pairs behind
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    }
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 phase(IC<0>{});
