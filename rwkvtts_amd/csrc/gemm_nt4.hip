@@ -311,7 +311,12 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
                             const float x0 = __uint_as_float(pv[e2] << 16), x1 = __uint_as_float(pv[e2] & 0xffff0000u);
                             const float h0 = __uint_as_float(au << 16), h1 = __uint_as_float(au & 0xffff0000u);
                             if (EPI == 2) pv[e2] = cvt_pk(h0 > 0.f ? 2.f * h0 * x0 : 0.f, h1 > 0.f ? 2.f * h1 * x1 : 0.f);
-                            else pv[e2] = cvt_pk(2.f * __builtin_sqrtf(fmaxf(h0, 0.f)) * x0, 2.f * __builtin_sqrtf(fmaxf(h1, 0.f)) * x1);
+                            else {
+                                // s = bf16(relu(h)^2) >= 0: no clamp (the four v_max per pair that fmaxf costs are paid for on a lone wave).
+                                // (the factor 2 as the square root's output modifier does not work: IEEE mode ignores omod)
+                                const float q0 = 2.f * __builtin_sqrtf(h0), q1 = 2.f * __builtin_sqrtf(h1);
+                                pv[e2] = cvt_pk(q0 * x0, q1 * x1);
+                            }
                         }
                     }
                     if (!(GEMM4_EXP & 4) || v.x == 0x12345u) *reinterpret_cast<uint4 *>(cblk + (long)row * N + seg * 8) = v;
