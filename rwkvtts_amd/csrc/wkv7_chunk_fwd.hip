@@ -76,40 +76,54 @@ __global__ __launch_bounds__(64) void wkv7c_prep_kernel(int T_, int H, const T *
     f32x16 acc = zero16();
     mma_tile3<kN>(acc, BHh, BHl, LD, ATh, ATl, LD, lane);  // D[m = s][n = t] = b^_s . a~_t = A_ab[t][s]
     mask_lower_T<true>(acc, lane);
-    // every lane (and its twin lane^32) gathers the whole row t = lane&31 of A_ab
-    const int h = lane >> 5;
-    float Arow[kC];
+    // T = I + T A  =>  T[t][r] = delta(t,r) + sum_{q>r} T[t][q] A[q][r], r = 31..0, row t on lane t AND its twin t + 32: the twins
+    // split the sum by the parity of q (round 4; before, both computed the whole row with A[q][r] fetched by v_readlane: 496 readlane
+    // + 496 fma per lane, half the wave redundant -- 1k of the kernel's 2.1k instructions).  A goes through LDS, transposed and
+    // parity-split, AtP[r][h][i] = A[2 i + h][r] (over the dead operand planes: same wave, LDS is in order), so that the 16-byte read
+    // of four consecutive i is a two-address broadcast; lane (t, h) keeps Tq[i] = T[t][2 i + h].  272 fma + 80 reads + 32 exchanges.
+    const int t = lane & 31, h = lane >> 5;
+    float *AtP = reinterpret_cast<float *>(ATh);   // [32][2][16] floats = 4 KB
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const float other = __shfl_xor(acc[r], 32);
-        const int s0 = (r & 3) + 8 * (r >> 2);
-        Arow[s0] = h == 0 ? acc[r] : other;
-        Arow[s0 + 4] = h == 0 ? other : acc[r];
+        const int s0 = (r & 3) + 8 * (r >> 2) + 4 * h;   // acc[r] = A[t][s0]
+        AtP[(s0 * 2 + (t & 1)) * 16 + (t >> 1)] = acc[r];
     }
-    // T = I + T A  =>  T[t][r] = delta(t,r) + sum_{q>r} T[t][q] A[q][r], r = 31..0; A[q][r] is a wave-uniform scalar
-    const int t = lane & 31;
-    float Trow[kC];
+    float Tq[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) Tq[i] = 0.f;
 #pragma unroll
     for (int r = kC - 1; r >= 0; r--) {
-        float s0 = (t == r) ? 1.f : 0.f, s1 = 0.f;
+        // terms i >= r / 2 (for even r and h = 0 that includes q = r: A[r][r] = 0 times the still-zero Tq[r / 2])
+        const int i0 = r >> 1;
+        float s0 = 0.f, s1 = 0.f;
+        const float *ap = AtP + (r * 2 + h) * 16;
+        // oldest columns first: the term with the column finished one step ago is the LAST link of its chain, not the first
 #pragma unroll
-        for (int q = r + 1; q < kC; q++) {
-            const float aqr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Arow[r]), q));
-            if ((q - r) & 1) s0 = fmaf(Trow[q], aqr, s0);
-            else s1 = fmaf(Trow[q], aqr, s1);
+        for (int i4 = 12; i4 >= (i0 & ~3); i4 -= 4) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(ap + i4);
+            if (i4 + 3 >= i0) s1 = fmaf(Tq[i4 + 3], a4.w, s1);
+            if (i4 + 2 >= i0) s0 = fmaf(Tq[i4 + 2], a4.z, s0);
+            if (i4 + 1 >= i0) s1 = fmaf(Tq[i4 + 1], a4.y, s1);
+            if (i4 + 0 >= i0) s0 = fmaf(Tq[i4 + 0], a4.x, s0);
         }
-        Trow[r] = s0 + s1;
+        const float part = s0 + s1;
+        const float tot = part + __shfl_xor(part, 32) + ((t == r) ? 1.f : 0.f);
+        Tq[i0] = ((r & 1) == h) ? tot : Tq[i0];
     }
-    // lane t stores columns [16h, 16h+16) of its row
+    // lane (t, 0) stores columns 0..15 of its row, its twin 16..31: the twins exchange the halves they do not store
     float *out = tinv_ + ((long)blockIdx.x * kC + t) * kC + 16 * h;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        float4 v4;
-        v4.x = h == 0 ? Trow[4 * j + 0] : Trow[16 + 4 * j + 0];
-        v4.y = h == 0 ? Trow[4 * j + 1] : Trow[16 + 4 * j + 1];
-        v4.z = h == 0 ? Trow[4 * j + 2] : Trow[16 + 4 * j + 2];
-        v4.w = h == 0 ? Trow[4 * j + 3] : Trow[16 + 4 * j + 3];
-        *reinterpret_cast<float4 *>(out + 4 * j) = v4;
+        float c[4];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int i = 2 * j + e;
+            // h = 0 holds T[t][2 i] (keeps) and T[t][16 + 2 i] (gives); h = 1 holds T[t][2 i + 1] (gives) and T[t][17 + 2 i] (keeps)
+            const float got = __shfl_xor(h == 0 ? Tq[8 + i] : Tq[i], 32);
+            c[2 * e] = h == 0 ? Tq[i] : got;
+            c[2 * e + 1] = h == 0 ? got : Tq[8 + i];
+        }
+        *reinterpret_cast<float4 *>(out + 4 * j) = make_float4(c[0], c[1], c[2], c[3]);
     }
 }
 
