@@ -30,7 +30,9 @@
 // the 16 DMA instructions with their address arithmetic (~30), two barriers and the epilogue (5.2k cycles per tile) all ADD to the
 // MFMA time.  Tried: other interleavings of reads / DMA / MFMAs (within 2 %); one barrier per two phases (-1.3 %, kept); the same ring
 // with EIGHT waves of 128 x 64 (two per SIMD, so that one wave's issue hides behind the other's MFMAs): bit-identical, 267 us -- the
-// 192 KB of fragment reads per K tile saturate the LDS (profiles/experiments_r04/gemm_nt8_ring_8waves.hip); the DMA in its scalar-base form
+// 192 KB of fragment reads per K tile saturate the LDS (profiles/experiments_r04/gemm_nt8_ring_8waves.hip); the same eight waves as two
+// groups staggered by one step, one reading fragments while the other runs MFMAs: 320 us (gemm_nt8s_staggered_groups.hip: a load step
+// moves 64 KB through the LDS, as long as the MFMAs beside it, plus latency and a barrier); the DMA in its scalar-base form
 // (inline asm, no 64-bit VALU add per instruction): +-0.
 #include "chunk_common.h"
 #ifndef GEMM4_EXP
