@@ -22,6 +22,12 @@
 // G1 are not needed at all: 28 (rows) + 8 (u) + 8 (z) + 8.5 (E) + 8.5 (H_C) KB in, 24 KB out per chunk; LDS 133 KB.
 #include "chunk_bwd_common.h"
 
+// experiment ("measure operand by operand"): bit i set = the lo plane of operand i is written as zeros, i.e. that
+// operand enters its products as ONE bf16 plane.  0 Q~  1 A~  2 K^  3 B^  4 U  5 Z  6 E'  7 H0  8 P_vy  9 P_vz  10 P_uy  11 P_uz  12 A_qk  13 A_ak
+#ifndef WKV7C_B9_SINGLE
+#define WKV7C_B9_SINGLE 0
+#endif
+#define B9S(bit) (((WKV7C_B9_SINGLE) >> (bit)) & 1)
 #ifndef WKV7C_B9_YOUNG_PRIO
 #define WKV7C_B9_YOUNG_PRIO 0   // measured: the two halves of the workgroup swap places, the chunk takes the same 14.3-14.6k cycles
 #endif
@@ -80,6 +86,12 @@ static_assert(8 * kN * 2 <= 2 * Out9Smem::A1, "DT8 must fit in the P_vy planes")
 static_assert(Out9Smem::XTh % 8 == 0 && Out9Smem::P0 % 8 == 0 && Out9Smem::AKTh % 8 == 0 && Out9Smem::gC % 8 == 0 && Out9Smem::ST % 8 == 0,
               "16-byte alignment");
 
+// experiment helper: the lo plane of a transposed D tile as zeros (same addresses as store_T_split)
+__device__ __forceinline__ void zero_T_lo(uint16_t *Ol, int ld, int lane) {
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; j++) *reinterpret_cast<uint2 *>(Ol + n * ld + 8 * j + 4 * h) = make_uint2(0u, 0u);
+}
 // D tile -> fp32 staging [32][64 + 4], columns [32 ct, 32 ct + 32)
 __device__ __forceinline__ void stage_tile9(const f32x16 &acc, float *stg, int ct, int lane) {
 #pragma unroll
@@ -300,11 +312,17 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
         {
             const int o = pt * LDK + pk;
             put_row4(sm + L::QTh, sm + L::QTl, o, qv[0] * gam[0], qv[1] * gam[1], qv[2] * gam[2], qv[3] * gam[3]);
+            if (B9S(0)) *reinterpret_cast<uint2 *>(sm + L::QTl + o) = make_uint2(0u, 0u);
             put_row4(sm + L::ATh, sm + L::ATl, o, av[0] * gprev[0], av[1] * gprev[1], av[2] * gprev[2], av[3] * gprev[3]);
+            if (B9S(1)) *reinterpret_cast<uint2 *>(sm + L::ATl + o) = make_uint2(0u, 0u);
             put_row4(sm + L::KHh, sm + L::KHl, o, kv[0] * igam[0], kv[1] * igam[1], kv[2] * igam[2], kv[3] * igam[3]);
+            if (B9S(2)) *reinterpret_cast<uint2 *>(sm + L::KHl + o) = make_uint2(0u, 0u);
             put_row4(sm + L::BHh, sm + L::BHl, o, bv[0] * igam[0], bv[1] * igam[1], bv[2] * igam[2], bv[3] * igam[3]);
+            if (B9S(3)) *reinterpret_cast<uint2 *>(sm + L::BHl + o) = make_uint2(0u, 0u);
             put_row4(sm + L::Uh, sm + L::Ul, o, ru.x, ru.y, ru.z, ru.w);
+            if (B9S(4)) *reinterpret_cast<uint2 *>(sm + L::Ul + o) = make_uint2(0u, 0u);
             put_row4(sm + L::Zh, sm + L::Zl, o, rz.x, rz.y, rz.z, rz.w);
+            if (B9S(5)) *reinterpret_cast<uint2 *>(sm + L::Zl + o) = make_uint2(0u, 0u);
             *reinterpret_cast<uint2 *>(sm + L::Vp + o) = rv;     // bf16 inputs are exact: single planes
             *reinterpret_cast<uint2 *>(sm + L::DYp + o) = rdy;
         }
@@ -330,8 +348,10 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
             }
             uint32_t hi[4], lo[4];
             put_row8(sm + L::XTh, sm + L::XTl, row * LDK + k8, x, hi, lo);
+            if (B9S(6)) *reinterpret_cast<uint4 *>(sm + L::XTl + row * LDK + k8) = make_uint4(0u, 0u, 0u, 0u);
             q15_decode8(h0[0], h0[1], sH0[slot], sH0[slot + 32], x);
             put_row8(sm + L::HTh, sm + L::HTl, row * LDK + k8, x, hi, lo);
+            if (B9S(7)) *reinterpret_cast<uint4 *>(sm + L::HTl + row * LDK + k8) = make_uint4(0u, 0u, 0u, 0u);
             h0[0] = curm.hc[0];   // H_C of this chunk = H0 of the next (zeros across a head / sequence boundary on both sides);
             h0[1] = curm.hc[1];   // copied here, while no load is in flight
             // rowsum over v (= over the 8 lanes of this wave with the same tid & 7, then over the 8 waves): transposing pair sums
@@ -368,31 +388,37 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
             mma_tile<kN>(acc, sm + L::DYp, LDK, sm + L::Vp, LDK, lnA);
             mask_upper_T<false>(acc, lnA);
             store_T_split(acc, sm + L::P0 + 0 * 2 * L::A1, sm + L::P0 + 0 * 2 * L::A1 + L::A1, LDC, lnA);
+            if (B9S(8)) zero_T_lo(sm + L::P0 + 0 * 2 * L::A1 + L::A1, LDC, lnA);
         } else if (wave == 2) {
             f32x16 acc = zero16();  // q~_t . k^_s, t >= s -> QKT[s][t]
             mma3_k64(acc, sm + L::QTh, sm + L::QTl, LDK, sm + L::KHh, sm + L::KHl, LDK, lnA);
             mask_upper_T<false>(acc, lnA);
             store_T_split(acc, sm + L::QKTh, sm + L::QKTl, LDC, lnA);
+            if (B9S(12)) zero_T_lo(sm + L::QKTl, LDC, lnA);
         } else if (wave == 3) {
             f32x16 acc = zero16();  // a~_t . k^_s, t > s -> AKT[s][t]
             mma3_k64(acc, sm + L::ATh, sm + L::ATl, LDK, sm + L::KHh, sm + L::KHl, LDK, lnA);
             mask_upper_T<true>(acc, lnA);
             store_T_split(acc, sm + L::AKTh, sm + L::AKTl, LDC, lnA);
+            if (B9S(13)) zero_T_lo(sm + L::AKTl, LDC, lnA);
         } else if (wave == 4) {
             f32x16 acc = zero16();  // z_s . u_t, s > t -> P_uz[t][s]
             mma3_k64(acc, sm + L::Zh, sm + L::Zl, LDK, sm + L::Uh, sm + L::Ul, LDK, lnA);
             mask_upper_T<true>(acc, lnA);
             store_T_split(acc, sm + L::P0 + 3 * 2 * L::A1, sm + L::P0 + 3 * 2 * L::A1 + L::A1, LDC, lnA);
+            if (B9S(11)) zero_T_lo(sm + L::P0 + 3 * 2 * L::A1 + L::A1, LDC, lnA);
         } else if (wave == 5) {
             f32x16 acc = zero16();  // dy_s . u_t, s >= t -> P_uy[t][s]
             mma2y_k64(acc, sm + L::DYp, LDK, sm + L::Uh, sm + L::Ul, LDK, lnA);
             mask_upper_T<false>(acc, lnA);
             store_T_split(acc, sm + L::P0 + 2 * 2 * L::A1, sm + L::P0 + 2 * 2 * L::A1 + L::A1, LDC, lnA);
+            if (B9S(10)) zero_T_lo(sm + L::P0 + 2 * 2 * L::A1 + L::A1, LDC, lnA);
         } else if (wave == 6) {
             f32x16 acz = zero16();  // z_s . v_t, s > t -> P_vz[t][s]
             mma_xs_ye_k64(acz, sm + L::Zh, sm + L::Zl, LDK, sm + L::Vp, LDK, lnA);
             mask_upper_T<true>(acz, lnA);
             store_T_split(acz, sm + L::P0 + 1 * 2 * L::A1, sm + L::P0 + 1 * 2 * L::A1 + L::A1, LDC, lnA);
+            if (B9S(9)) zero_T_lo(sm + L::P0 + 1 * 2 * L::A1 + L::A1, LDC, lnA);
         }
         B9STAMP(5);
         lds_barrier();
