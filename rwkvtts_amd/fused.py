@@ -127,6 +127,8 @@ def relu_sq(x):
 # -- but inside the training step the library runs this GEMM at 223 us (1.23 PFLOP/s; other kernel / other clocks than in the
 # loop benchmark) and the own kernel at 313 us (0.88 PFLOP/s): 313 against 310 us per layer, -0.13 ms per step in the same-box A/B
 # (tools/ab_step.py) -- no gain, so the pair stays.  The bar was the library's rate on this shape in the same process.
+# Round 4: the entry now runs the second-generation kernel (csrc/gemm_nt4.hip) for K % 1024 == 0 and the pair of fusions lives in
+# channel_mix below (on by default); this stand-alone node stays as the A/B switch of the forward half (-1.02 ms on its own).
 # bf16, M and N multiples of 256, K of 64; RWKV7_FUSED_KEY_RELUSQ=1 (or the attribute) switches it on.
 FUSED_KEY_RELUSQ = os.environ.get("RWKV7_FUSED_KEY_RELUSQ", "0") == "1"
 FUSED_KEY_RELUSQ_HITS = [0]
@@ -174,7 +176,8 @@ class _KeyReluSq(torch.autograd.Function):
 # read back and rwkv7_relusq_bwd (140 us per layer) is not launched; the own GEMM is slower than the library's on this shape
 # (0.30 against 0.22-0.25 ms), the pair it replaces is 0.39 ms on paper.  Measured (tools/ab_step.py, "relu^2 backward in the value
 # dgrad", same box, 132.98 ms without / 133.09 ms with): a tie, like the forward twin above -- what the launch saves, the slower GEMM
-# and the transposed copy of the weight give back.  Off; RWKV7_FUSED_RELUSQ_VALUE_BWD=1 switches it on.
+# and the transposed copy of the weight give back.  On the second-generation GEMM (round 4, later) the same switch is -2.18 ms; it is
+# subsumed by channel_mix below and stays as the A/B switch of the backward half.  Off; RWKV7_FUSED_RELUSQ_VALUE_BWD=1 switches it on.
 FUSED_RELUSQ_VALUE_BWD = os.environ.get("RWKV7_FUSED_RELUSQ_VALUE_BWD", "0") == "1"
 
 
