@@ -395,6 +395,10 @@ int rwkv7_gemm_nt_relusq_bwd_bf16(int M, int N, int K, const void *A, const void
  *      epilogue 1 (what the library GEMM + rwkv7_relusq_bwd_s_* produce, bit for bit): with it the channel mix never materialises h or
  *      ds (fused.channel_mix).  csrc/gemm_nt4.hip only: K % 1024 == 0. */
 int rwkv7_gemm_nt_relusq_bwd_s_bf16(int M, int N, int K, const void *A, const void *W, const void *s, void *C, rwkv7_stream_t stream);
+/*      a projection with the residual add that follows it as the epilogue: C[M][N] = bf16(bf16(A . W^T) + resid[M][N]) -- the block wiring
+ *      x = x + att(...) of rwkv_s2s_single_ffn.py:262-276 for the output projection (fused.linear_add); what nn.Linear followed by the
+ *      add of the two bf16 tensors produces, bit for bit.  csrc/gemm_nt4.hip only: K % 1024 == 0.  C must not alias resid. */
+int rwkv7_gemm_nt_add_bf16(int M, int N, int K, const void *A, const void *W, const void *resid, void *C, rwkv7_stream_t stream);
 /*      which own GEMM the two entries above run (A/B knob, process-wide): 4 (default) = csrc/gemm_nt4.hip (four waves, quadrant phases,
  *      ring of eight half-tile slots; K % 1024 == 0, other K fall back to generation 1), 1 = csrc/gemm_relusq.hip.  Returns the
  *      previous value; other arguments leave it unchanged. */

@@ -254,21 +254,22 @@ class RWKV7Attention(nn.Module):
             self._mix_key = key
         return self._mix_cache
 
-    def forward(self, x, mask, v_first, state: Optional[LayerState] = None, seq_start=None):
-        """x [B,T,D] (LayerNorm'ed), mask [B,T,1] or None.  Returns (out, v_first).
+    def forward(self, x, mask, v_first, state: Optional[LayerState] = None, seq_start=None, resid=None):
+        """x [B,T,D] (LayerNorm'ed), mask [B,T,1] or None.  Returns (out, v_first); resid: see forward_mixed.
         With `state`, token shift and the WKV state are carried (and updated in place).
         seq_start (int32 [nseq+1] chunk offsets): packed rows, see RWKV7Model._forward_packed."""
         x_prev = None if state is None else state.att_x_prev
         mixed = fused.token_shift_mix6(x, x_prev, self.x_r, self.x_w, self.x_k, self.x_v,
                                        self.x_a, self.x_g, mask, self._stacked_mix(x.dtype))
-        return self.forward_mixed(mixed, x, mask, v_first, state, seq_start)
+        return self.forward_mixed(mixed, x, mask, v_first, state, seq_start, resid)
 
     def mix_params(self):
         return (self.x_r, self.x_w, self.x_k, self.x_v, self.x_a, self.x_g)
 
-    def forward_mixed(self, mixed, x, mask, v_first, state: Optional[LayerState] = None, seq_start=None):
+    def forward_mixed(self, mixed, x, mask, v_first, state: Optional[LayerState] = None, seq_start=None, resid=None):
         """The block after the token-shift lerps (`mixed` = xr, xw, xk, xv, xa, xg); x (the LayerNorm'ed input) is only read for
-        the carried state and may be None without one."""
+        the carried state and may be None without one.  resid (training one-pass path): the residual stream; if the output
+        projection can take the add as its epilogue the first return value is a pair (resid + out, True)."""
         xr, xw, xk, xv, xa, xg = mixed
         B, T, D = xr.shape
         H, N = self.num_heads, self.head_dim
@@ -298,6 +299,10 @@ class RWKV7Attention(nn.Module):
                                      and FUSED_TMIX_CORE):
             y, vf_next = fused.tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, self.k_k, self.k_a, self.g_norm.weight,
                                          self.g_norm.bias, self.r_k, mask, H, self.g_norm.eps, self.layer_idx == 0, seq_start)
+            if resid is not None and self.o_proj.bias is None:
+                x1 = fused.linear_add(y, self.o_proj.weight, resid)
+                if x1 is not None:
+                    return (x1, True), (v_first if vf_next is None else vf_next)
             return self.o_proj(y), (v_first if vf_next is None else vf_next)
         w, k2, v2, a_in, b_in = fused.tmix_prepare(w_pre, k, v, a_pre, v_pre, v_first, self.k_k, self.k_a, mask,
                                                    H, self.layer_idx == 0)
@@ -372,16 +377,20 @@ class RWKV7Block(nn.Module):
         one_pass = fused.add_ln_mix_supported(x, state)
         if one_pass and (FUSED_ADD_LN_MIX6 or FUSED_ADD_LN_MIX6_FWD):
             x, mixed = fused.add_layer_norm_mix(x, delta, self.attn_norm, mask, self.attn.mix_params(), fwd_only=not FUSED_ADD_LN_MIX6)
-            att, v_first = self.attn.forward_mixed(mixed, None, mask, v_first, None, seq_start)
+            att, v_first = self.attn.forward_mixed(mixed, None, mask, v_first, None, seq_start,
+                                                   resid=x if FUSED_ADD_LN_MIX1 else None)
         else:
             if delta is None:
                 h = fused.layer_norm(x, self.attn_norm)
             else:
                 x, h = fused.add_layer_norm(x, delta, self.attn_norm)
-            att, v_first = self.attn(h, mask, v_first, state, seq_start)
+            att, v_first = self.attn(h, mask, v_first, state, seq_start, resid=x if (one_pass and FUSED_ADD_LN_MIX1) else None)
         if one_pass and FUSED_ADD_LN_MIX1:
             # training path: add + LayerNorm + token-shift lerp in one pass each way (h / dh never reach HBM)
-            x, (kx,) = fused.add_layer_norm_mix(x, att, self.ffn_norm, mask, (self.ffn.x_k,))
+            if isinstance(att, tuple):   # the add already happened in the output projection's epilogue
+                x, (kx,) = fused.add_layer_norm_mix(att[0], None, self.ffn_norm, mask, (self.ffn.x_k,))
+            else:
+                x, (kx,) = fused.add_layer_norm_mix(x, att, self.ffn_norm, mask, (self.ffn.x_k,))
             return x, self.ffn.forward_mixed(kx), v_first
         x, h = fused.add_layer_norm(x, att, self.ffn_norm)
         return x, self.ffn(h, mask, state), v_first

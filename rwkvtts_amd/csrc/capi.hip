@@ -484,6 +484,11 @@ int rwkv7_gemm_nt_relusq_bwd_s_bf16(int M, int N, int K, const void *A, const vo
     if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 1024 != 0) return RWKV7_ESHAPE;
     return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, s, 3, (hipStream_t)stream);
 }
+int rwkv7_gemm_nt_add_bf16(int M, int N, int K, const void *A, const void *W, const void *resid, void *C, rwkv7_stream_t stream) {
+    if (any_null({A, W, resid, (const void *)C})) return RWKV7_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 1024 != 0) return RWKV7_ESHAPE;
+    return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, resid, 4, (hipStream_t)stream);
+}
 int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant, rwkv7_stream_t stream) {
     if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || epilogue < 0 || epilogue > 1 || variant < 0 || variant > 1)

@@ -1,7 +1,7 @@
 // rwkvtts_amd/csrc/gemm_nt4.hip -- bf16 GEMM  C[M][N] = epi(A[M][K] . W[N][K]^T), second generation (round 4) of the own MFMA GEMM
 // (csrc/gemm_relusq.hip is the first).  Same problem and epilogues (0 plain, 1 relu(.)^2 = the channel-mix key activation,
 // rwkv_s2s_single_ffn.py:228, 2 its backward as the epilogue of the value projection's input-gradient GEMM from the pre-activation h,
-// 3 the same from the activation's output s).
+// 3 the same from the activation's output s, 4 the residual add behind a projection).
 //
 // What the first kernel's ablation and interval stamps showed (tools/gemm_lab, 32768 x 4096 x 1024): (i) the texture-address path
 // costs ~2.5 cycles per distinct 128-byte line and instruction (64 B/clk of L1): 1280 cycles for the 64 KB of a 256 x 256 x 64 K
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
                             const float x0 = __uint_as_float(pv[e2] << 16), x1 = __uint_as_float(pv[e2] & 0xffff0000u);
                             const float h0 = __uint_as_float(au << 16), h1 = __uint_as_float(au & 0xffff0000u);
                             if (EPI == 2) pv[e2] = cvt_pk(h0 > 0.f ? 2.f * h0 * x0 : 0.f, h1 > 0.f ? 2.f * h1 * x1 : 0.f);
+                            else if (EPI == 4) pv[e2] = cvt_pk(x0 + h0, x1 + h1);   // residual add: bf16(bf16(A W^T) + aux), what Linear + add produce
                             else {
                                 // s = bf16(relu(h)^2) >= 0: no clamp (the four v_max per pair that fmaxf costs are paid for on a lone wave).
                                 // (the factor 2 as the square root's output modifier does not work: IEEE mode ignores omod)
@@ -364,6 +365,7 @@ int gemm_nt4_bf16(int M, int N, int K, const void *A, const void *W, void *C, co
     if (epilogue == 1) return launch_gemm4<1>(M, N, K, A, W, C, nullptr, st);
     if (epilogue == 2 && aux) return launch_gemm4<2>(M, N, K, A, W, C, aux, st);
     if (epilogue == 3 && aux) return launch_gemm4<3>(M, N, K, A, W, C, aux, st);
+    if (epilogue == 4 && aux) return launch_gemm4<4>(M, N, K, A, W, C, aux, st);
     return -1;
 }
 

@@ -756,6 +756,54 @@ def linear(x, weight, bias=None):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+# Round 4: a projection with the residual add that follows it as the GEMM's epilogue (csrc/gemm_nt4.hip epilogue 4): x1 = x + y W^T leaves
+# the GEMM, so the add + LayerNorm (+ lerp) stage behind it reads one [rows, D] stream less and does not write x1.  Used for the output
+# projection of the time-mix block (K = D = 1024: the own GEMM is 5 us behind the library there, the stage saves two streams); the
+# channel-mix value projection (K = 4096) stays with the library, where the own kernel is 25 us behind.  RWKV7_FUSED_OPROJ_ADD=0: off.
+FUSED_OPROJ_ADD = os.environ.get("RWKV7_FUSED_OPROJ_ADD", "1") == "1"
+
+
+def linear_add_eligible(y, weight, resid):
+    M = y.numel() // y.shape[-1]
+    return (FUSED_OPROJ_ADD and y.is_cuda and y.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and resid.dtype == torch.bfloat16
+            and M % 256 == 0 and weight.shape[0] % 256 == 0 and weight.shape[1] % 1024 == 0 and resid.shape == (*y.shape[:-1], weight.shape[0]))
+
+
+class _LinearAdd(torch.autograd.Function):
+    """x1 = resid + y @ weight^T  (bf16(bf16(y W^T) + resid): the bits of nn.Linear followed by the add)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, resid):
+        y2 = _c(y).view(-1, y.shape[-1])
+        w = _c(weight)
+        r2 = _c(resid).view(-1, resid.shape[-1])
+        M, K = y2.shape
+        N = w.shape[0]
+        out = torch.empty(M, N, dtype=y.dtype, device=y.device)
+        with torch.cuda.device_of(y):
+            rc = _lib.lib().rwkv7_gemm_nt_add_bf16(M, N, K, _p(y2), _p(w), _p(r2), _p(out), _stream(y))
+        _lib.check(rc, "gemm_nt_add")
+        ctx.save_for_backward(y2, weight)
+        ctx.wparam = weight
+        ctx.yshape = y.shape
+        return out.view(resid.shape)
+
+    @staticmethod
+    def backward(ctx, d1):
+        y2, weight = ctx.saved_tensors
+        d2 = _c(d1).view(-1, d1.shape[-1])
+        dy = torch.mm(d2, weight).view(ctx.yshape) if ctx.needs_input_grad[0] else None
+        dw = _wgrad(d2, y2, ctx.wparam) if ctx.needs_input_grad[1] else None
+        return dy, dw, (d1 if ctx.needs_input_grad[2] else None)
+
+
+def linear_add(y, weight, resid):
+    """resid + y @ weight^T as one GEMM, or None (shapes / dtype outside the own GEMM's range: the caller adds)."""
+    if linear_add_eligible(y, weight, resid):
+        return _LinearAdd.apply(y, weight, resid)
+    return None
+
+
 # ------------------------------------------------------------------------------------------------------
 # residual add + LayerNorm
 # ------------------------------------------------------------------------------------------------------

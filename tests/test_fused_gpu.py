@@ -632,3 +632,31 @@ def test_channel_mix_with_the_activation_inside_both_gemms(M, F, D, monkeypatch)
         e = (a_.float() - b_.float()).norm().item() / max(b_.float().norm().item(), 1e-9)
         assert e < 8e-3, (n, e)
     assert fused.channel_mix(x[:100], wk, wv) is None and fused.channel_mix(x.float(), wk.float(), wv.float()) is None
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 1024), (8192, 1024, 1024), (256 * 33, 256 * 8, 2048)])
+def test_projection_with_the_residual_add_as_its_epilogue(M, N, K, monkeypatch):
+    """fused.linear_add (rwkv7_gemm_nt_add_bf16, csrc/gemm_nt4.hip epilogue 4): resid + y W^T as one GEMM against nn.Linear followed by
+    the add -- bit for bit forward (bf16(bf16(y W^T) + resid)); the three gradients to the parity bars of the linear layers (the input and
+    weight gradients are the same library / slab calls on the same operands, the residual gradient is the incoming one)."""
+    from rwkvtts_amd import fused
+    monkeypatch.setattr(fused, "FUSED_OPROJ_ADD", True)
+    g = torch.Generator().manual_seed(M + N + K)
+    y = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * (K ** -0.5)).to(DEV, torch.bfloat16)
+    r = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+    d = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+    res = []
+    for fusedp in (True, False):
+        yi, wi, ri = y.clone().requires_grad_(True), w.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        out = fused.linear_add(yi, wi, ri) if fusedp else ri + fused.linear(yi, wi, None)
+        assert out is not None
+        out.backward(d)
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), yi.grad.clone(), wi.grad.clone(), ri.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][3], res[1][3])
+    for a_, b_, n in ((res[0][1], res[1][1], "dy"), (res[0][2], res[1][2], "dw")):
+        e = (a_.float() - b_.float()).norm().item() / max(b_.float().norm().item(), 1e-9)
+        assert e < 8e-3, (n, e)
+    assert fused.linear_add(y[:100], w, r[:100]) is None
