@@ -131,7 +131,8 @@ int rwkv7_wkv_state_fwd_f32(int B, int T, int C, int H, float *state, const void
  * the caller sums over the first axis.
  * ===================================================================================================== */
 
-/* token shift + nmix lerps (nmix = 6: x_r,x_w,x_k,x_v,x_a,x_g -- rwkv_s2s_single_ffn.py:160-169;
+/* token shift + nmix lerps (nmix = 6: x_r,x_w,x_k,x_v,x_a,x_g -- rwkv_s2s_single_ffn.py:160-169; nmix = 3: x_r,x_k,x_v when the
+ * low-rank branches take their inputs through the lerp, fused.mix_lora;
  * nmix = 1: channel-mix x_k -- :224-227):  xm = x*mask ; out[i] = xm + (shift(xm) - xm) * params[i].
  * x_prev [B,D] (carried token-shift state, rwkv_asr_cuda_whisper.py:185) or NULL = zeros.
  * out is [nmix][rows][D]. */
@@ -406,6 +407,24 @@ int rwkv7_set_gemm_generation(int generation);
 /*      variant (A/B) of generation 1: 0 = K tile 64, two LDS buffers (the plain entry); 1 = K tile 32, four buffers, three tiles in flight */
 int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant,
                                rwkv7_stream_t stream);
+
+/* ---- the low-rank branches of the time-mix block taken THROUGH the token-shift lerp (fused.mix_lora; rwkv_s2s_single_ffn.py:160-190):
+ *      (xm (1 - mu) + shift(xm) mu) W1^T = xm (W1 * (1 - mu))^T + shift(xm) (W1 * mu)^T, so one GEMM G = x [W_a ; W_b]^T on the LayerNorm
+ *      output ([M, D] x [D, 2 R]) replaces the mixed inputs x_w, x_a, x_v, x_g and their four Linear(D, r_i).  nb <= 4 branches with ranks
+ *      r_i (multiples of 8, R = sum r_i), HOST arrays of device pointers, bf16.
+ *   wcat_fwd:     wcat [2 R][D]: rows off_i .. = W1_i * (1 - mu_i), rows R + off_i .. = W1_i * mu_i           (W1_i [r_i][D], mu_i [D])
+ *   wcat_bwd:     dW1_i = dW_a (1 - mu_i) + dW_b mu_i ;  dmu_i[c] = sum_rows W1_i (dW_b - dW_a)                from dwcat [2 R][D]
+ *   combine_fwd:  out_i[t] = act_i(bf16(m_t G[t][off_i ..] + m_{t-1} G[t - 1][R + off_i ..])), nothing from t - 1 at the first step of a
+ *                 sequence (rows are [B][T]); acts: 0 none, 1 tanh, 2 sigmoid; mask [M] or NULL; out_i [M][r_i]
+ *   combine_bwd:  dG [M][2 R] from the activation OUTPUTS y_i and their gradients dy_i ---- */
+int rwkv7_mix_lora_wcat_fwd_bf16(int nb, const int *ranks, const void *const *w1, const void *const *mu, int D, void *wcat,
+                                 rwkv7_stream_t stream);
+int rwkv7_mix_lora_wcat_bwd_bf16(int nb, const int *ranks, const void *const *w1, const void *const *mu, int D, const void *dwcat,
+                                 void *const *dw1, void *const *dmu, rwkv7_stream_t stream);
+int rwkv7_mix_lora_combine_fwd_bf16(int nb, const int *ranks, const int *acts, long M, int T, const void *G, const void *mask,
+                                    void *const *out, rwkv7_stream_t stream);
+int rwkv7_mix_lora_combine_bwd_bf16(int nb, const int *ranks, const int *acts, long M, int T, const void *mask, const void *const *y,
+                                    const void *const *dy, void *dG, rwkv7_stream_t stream);
 
 /* ---- decode-step linear layers: y[M,N] = x[M,K] @ w[N,K]^T (+ bias[N]), bf16, M <= 32 rows (one token per sequence and
  *      step), K % 64 == 0.  Replaces the nn.Linear calls of the per-token path (rwkv_s2s_single_ffn.py:482-506,545-549)

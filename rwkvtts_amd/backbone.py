@@ -259,6 +259,15 @@ class RWKV7Attention(nn.Module):
         With `state`, token shift and the WKV state are carried (and updated in place).
         seq_start (int32 [nseq+1] chunk offsets): packed rows, see RWKV7Model._forward_packed."""
         x_prev = None if state is None else state.att_x_prev
+        if fused.mix_lora_supported(x, state, seq_start) and FUSED_TMIX_CORE:
+            # training: the four low-rank branches' down projections taken THROUGH the lerp (fused.mix_lora): x_w, x_a, x_g and the
+            # branch copy of x_v are never formed
+            loras = [self.w_lora, self.a_lora] + ([self.v_lora] if self.layer_idx != 0 else []) + [self.g_lora]
+            mus = [self.x_w, self.x_a] + ([self.x_v] if self.layer_idx != 0 else []) + [self.x_g]
+            xr, xk, xv, hs = fused.mix_lora(x, mask, self.x_r, self.x_k, self.x_v, mus, [l.lora[0].weight for l in loras],
+                                            [l.activation for l in loras])
+            hid = dict(zip(("w", "a") + (("v",) if self.layer_idx != 0 else ()) + ("g",), hs))
+            return self.forward_mixed((xr, None, xk, xv, None, None), x, mask, v_first, state, seq_start, resid, hid)
         mixed = fused.token_shift_mix6(x, x_prev, self.x_r, self.x_w, self.x_k, self.x_v,
                                        self.x_a, self.x_g, mask, self._stacked_mix(x.dtype))
         return self.forward_mixed(mixed, x, mask, v_first, state, seq_start, resid)
@@ -266,8 +275,9 @@ class RWKV7Attention(nn.Module):
     def mix_params(self):
         return (self.x_r, self.x_w, self.x_k, self.x_v, self.x_a, self.x_g)
 
-    def forward_mixed(self, mixed, x, mask, v_first, state: Optional[LayerState] = None, seq_start=None, resid=None):
-        """The block after the token-shift lerps (`mixed` = xr, xw, xk, xv, xa, xg); x (the LayerNorm'ed input) is only read for
+    def forward_mixed(self, mixed, x, mask, v_first, state: Optional[LayerState] = None, seq_start=None, resid=None, hid=None):
+        """The block after the token-shift lerps (`mixed` = xr, xw, xk, xv, xa, xg; with `hid` -- the low-rank branches' hidden
+        pre-activations from fused.mix_lora -- only xr, xk, xv are given); x (the LayerNorm'ed input) is only read for
         the carried state and may be None without one.  resid (training one-pass path): the residual stream; if the output
         projection can take the add as its epilogue the first return value is a pair (resid + out, True)."""
         xr, xw, xk, xv, xa, xg = mixed
@@ -276,6 +286,25 @@ class RWKV7Attention(nn.Module):
         r = self.r_proj(xr)
         k = self.k_proj(xk)
         v_lo = None
+        if hid is not None:   # the branches' hidden pre-activations came through the lerp (fused.mix_lora)
+            v = self.v_proj(xv)
+            w_pre = self.w_lora.lora[2](hid["w"])     # hid: the branches' hidden states, activation applied
+            a_pre = self.a_lora.lora[2](hid["a"])
+            g = self.g_lora.lora[2](hid["g"])
+            v_pre = None if self.layer_idx == 0 else self.v_lora.lora[2](hid["v"])
+            if self.layer_idx == 0:
+                if mask is not None:
+                    v = v * mask
+                v_first = v
+            if mask is not None:
+                r = r * mask
+            y, vf_next = fused.tmix_core(r, w_pre, k, v, a_pre, g, v_pre, v_first, self.k_k, self.k_a, self.g_norm.weight,
+                                         self.g_norm.bias, self.r_k, mask, H, self.g_norm.eps, self.layer_idx == 0, seq_start)
+            if resid is not None and self.o_proj.bias is None:
+                x1 = fused.linear_add(y, self.o_proj.weight, resid)
+                if x1 is not None:
+                    return (x1, True), (v_first if vf_next is None else vf_next)
+            return self.o_proj(y), (v_first if vf_next is None else vf_next)
         if (self.layer_idx != 0 and DUAL_LINEAR_XV and self.v_proj.bias is None
                 and fused.dual_linear_supported(xv, self.v_proj.weight, self.v_lora.lora[0].weight)):
             # xv feeds the value projection AND the value-residual branch: one autograd node, the input gradient without an add pass

@@ -43,6 +43,19 @@ int gemm_nt_bf16(int, int, int, const void *, const void *, void *, int, hipStre
 int gemm_nt_bf16_variant(int, int, int, const void *, const void *, void *, int, int, hipStream_t);
 int gemm_nt_relusq_bwd_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 int gemm_nt4_bf16(int, int, int, const void *, const void *, void *, const void *, int, hipStream_t);
+struct MixLoraDesc {
+    int nb;
+    int r[4], off[4];
+    int act[4];
+    const void *w1[4];
+    const void *mu[4];
+    void *out[4];
+    void *out2[4];
+};
+int mix_lora_wcat_fwd(const MixLoraDesc &, int, int, void *, hipStream_t);
+int mix_lora_wcat_bwd(const MixLoraDesc &, int, int, const void *, hipStream_t);
+int mix_lora_combine_fwd(const MixLoraDesc &, long, int, int, const void *, const void *, hipStream_t);
+int mix_lora_combine_bwd(const MixLoraDesc &, long, int, int, const void *, void *, hipStream_t);
 int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
@@ -221,7 +234,7 @@ int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, c
     int rwkv7_mix_fwd_##SFX(int B, int T, int D, int nmix, const void *x, const void *x_prev, const void *mask,       \
                             const void *params, void *out, int nblocks, rwkv7_stream_t stream) {                      \
         if (B <= 0 || T <= 0 || nblocks <= 0 || any_null({x, params, out})) return RWKV7_EINVAL;                      \
-        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
+        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 3 && nmix != 6)) return RWKV7_ESHAPE;                                            \
         return rwkv7::mix_fwd<TY>(B, T, D, nmix, x, x_prev, mask, params, out, nblocks, (hipStream_t)stream);         \
     }                                                                                                                 \
     int rwkv7_mix_bwd_##SFX(int B, int T, int D, int nmix, const void *const *g, const void *x, const void *x_prev,   \
@@ -229,7 +242,7 @@ int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, c
                             int run_len, rwkv7_stream_t stream) {                                                     \
         if (B <= 0 || T <= 0 || nblocks <= 0 || run_len <= 0 || any_null({g, x, params, dx, dpart}))                  \
             return RWKV7_EINVAL;                                                                                      \
-        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
+        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 3 && nmix != 6)) return RWKV7_ESHAPE;                                            \
         for (int i = 0; i < nmix; i++)                                                                                \
             if (!g[i]) return RWKV7_EINVAL;                                                                           \
         return rwkv7::mix_bwd<TY>(B, T, D, nmix, g, x, x_prev, mask, params, dx, dpart, nblocks, run_len,            \
@@ -488,6 +501,84 @@ int rwkv7_gemm_nt_add_bf16(int M, int N, int K, const void *A, const void *W, co
     if (any_null({A, W, resid, (const void *)C})) return RWKV7_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 1024 != 0) return RWKV7_ESHAPE;
     return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, resid, 4, (hipStream_t)stream);
+}
+namespace {
+// ranks: multiples of 8, 1 <= nb <= 4; fills nb, r, off; returns R or a negative error
+int mix_lora_desc(rwkv7::MixLoraDesc &d, int nb, const int *ranks) {
+    if (nb < 1 || nb > 4 || ranks == nullptr) return RWKV7_EINVAL;
+    d.nb = nb;
+    int R = 0;
+    for (int i = 0; i < 4; i++) {
+        d.r[i] = i < nb ? ranks[i] : 0;
+        d.off[i] = R;
+        d.act[i] = 0;
+        d.w1[i] = d.mu[i] = nullptr;
+        d.out[i] = d.out2[i] = nullptr;
+        if (i < nb) {
+            if (ranks[i] <= 0 || ranks[i] % 8 != 0) return RWKV7_ESHAPE;
+            R += ranks[i];
+        }
+    }
+    return R;
+}
+}  // namespace
+int rwkv7_mix_lora_wcat_fwd_bf16(int nb, const int *ranks, const void *const *w1, const void *const *mu, int D, void *wcat, rwkv7_stream_t stream) {
+    rwkv7::MixLoraDesc d;
+    const int R = mix_lora_desc(d, nb, ranks);
+    if (R < 0) return R;
+    if (w1 == nullptr || mu == nullptr || wcat == nullptr) return RWKV7_EINVAL;
+    if (D <= 0) return RWKV7_ESHAPE;
+    for (int i = 0; i < nb; i++) {
+        if (w1[i] == nullptr || mu[i] == nullptr) return RWKV7_EINVAL;
+        d.w1[i] = w1[i];
+        d.mu[i] = mu[i];
+    }
+    return rwkv7::mix_lora_wcat_fwd(d, R, D, wcat, (hipStream_t)stream);
+}
+int rwkv7_mix_lora_wcat_bwd_bf16(int nb, const int *ranks, const void *const *w1, const void *const *mu, int D, const void *dwcat,
+                                 void *const *dw1, void *const *dmu, rwkv7_stream_t stream) {
+    rwkv7::MixLoraDesc d;
+    const int R = mix_lora_desc(d, nb, ranks);
+    if (R < 0) return R;
+    if (w1 == nullptr || mu == nullptr || dwcat == nullptr || dw1 == nullptr || dmu == nullptr) return RWKV7_EINVAL;
+    if (D <= 0) return RWKV7_ESHAPE;
+    for (int i = 0; i < nb; i++) {
+        if (w1[i] == nullptr || mu[i] == nullptr || dw1[i] == nullptr || dmu[i] == nullptr) return RWKV7_EINVAL;
+        d.w1[i] = w1[i];
+        d.mu[i] = mu[i];
+        d.out[i] = dw1[i];
+        d.out2[i] = dmu[i];
+    }
+    return rwkv7::mix_lora_wcat_bwd(d, R, D, dwcat, (hipStream_t)stream);
+}
+int rwkv7_mix_lora_combine_fwd_bf16(int nb, const int *ranks, const int *acts, long M, int T, const void *G, const void *mask,
+                                    void *const *out, rwkv7_stream_t stream) {
+    rwkv7::MixLoraDesc d;
+    const int R = mix_lora_desc(d, nb, ranks);
+    if (R < 0) return R;
+    if (acts == nullptr || G == nullptr || out == nullptr) return RWKV7_EINVAL;
+    if (M <= 0 || T <= 0 || M % T != 0) return RWKV7_ESHAPE;
+    for (int i = 0; i < nb; i++) {
+        if (out[i] == nullptr || acts[i] < 0 || acts[i] > 2) return RWKV7_EINVAL;
+        d.act[i] = acts[i];
+        d.out[i] = out[i];
+    }
+    return rwkv7::mix_lora_combine_fwd(d, M, T, R, G, mask, (hipStream_t)stream);
+}
+int rwkv7_mix_lora_combine_bwd_bf16(int nb, const int *ranks, const int *acts, long M, int T, const void *mask, const void *const *y,
+                                    const void *const *dy, void *dG, rwkv7_stream_t stream) {
+    rwkv7::MixLoraDesc d;
+    const int R = mix_lora_desc(d, nb, ranks);
+    if (R < 0) return R;
+    if (acts == nullptr || y == nullptr || dy == nullptr || dG == nullptr) return RWKV7_EINVAL;
+    if (M <= 0 || T <= 0 || M % T != 0) return RWKV7_ESHAPE;
+    for (int i = 0; i < nb; i++) {
+        if (y[i] == nullptr || dy[i] == nullptr || acts[i] < 0 || acts[i] > 2) return RWKV7_EINVAL;
+        d.act[i] = acts[i];
+        d.out[i] = const_cast<void *>(y[i]);
+        d.out2[i] = const_cast<void *>(dy[i]);
+    }
+    return rwkv7::mix_lora_combine_bwd(d, M, T, R, mask, dG, (hipStream_t)stream);
 }
 int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant, rwkv7_stream_t stream) {
     if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;

@@ -1147,6 +1147,9 @@ int mix_fwd(int B, int T_, int D, int nmix, const void *x, const void *x_prev, c
     if (nmix == 6)
         hipLaunchKernelGGL((mix_fwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, (const T *)x, (const T *)x_prev,
                            (const T *)mask, (const T *)params, (T *)out);
+    else if (nmix == 3)   // x_r, x_k, x_v only: the low-rank branches take their inputs through the lerp (fused.mix_lora)
+        hipLaunchKernelGGL((mix_fwd_kernel<T, 3>), grid, block, 0, st, B, T_, D, (const T *)x, (const T *)x_prev,
+                           (const T *)mask, (const T *)params, (T *)out);
     else
         hipLaunchKernelGGL((mix_fwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, (const T *)x, (const T *)x_prev,
                            (const T *)mask, (const T *)params, (T *)out);
@@ -1161,6 +1164,12 @@ int mix_bwd(int B, int T_, int D, int nmix, const void *const *g, const void *x,
         MixGrads<6> gs;
         for (int i = 0; i < 6; i++) gs.g[i] = g[i];
         hipLaunchKernelGGL((mix_bwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, run_len, gs, (const T *)x,
+                           (const T *)x_prev,
+                           (const T *)mask, (const T *)params, (T *)dx, dpart);
+    } else if (nmix == 3) {
+        MixGrads<3> gs;
+        for (int i = 0; i < 3; i++) gs.g[i] = g[i];
+        hipLaunchKernelGGL((mix_bwd_kernel<T, 3>), grid, block, 0, st, B, T_, D, run_len, gs, (const T *)x,
                            (const T *)x_prev,
                            (const T *)mask, (const T *)params, (T *)dx, dpart);
     } else {

@@ -86,6 +86,149 @@ class _Mix(torch.autograd.Function):
         return dx, None, None, part.sum(0).to(params.dtype)
 
 
+# Round 4: the low-rank branches' DOWN projections commute with the token-shift lerp,
+#     (xm (1 - mu) + shift(xm) mu) W1^T = xm (W1 * (1 - mu))^T + shift(xm) (W1 * mu)^T ,
+# so the four mixed inputs x_w, x_a, x_v(branch), x_g (rwkv_s2s_single_ffn.py:160-169, consumed only by Linear(D, r) of the w / a / v / g
+# branches, :171-190) never have to exist: ONE GEMM G = x [W_a ; W_b]^T ([M, D] x [D, 2 R], R = 64 + 64 + 32 + 128) on the LayerNorm
+# output, then h_i[t] = m_t G_a[t] + m_{t-1} G_b[t - 1] on the small side (the shift, the mask and the sequence start are applied to
+# [M, R] instead of [M, D]).  Per layer, forward: three lerp outputs instead of six, one projection GEMM instead of four; backward: the
+# lerp stage reads three gradients instead of six, one input-gradient GEMM accumulating into the lerp stage's dx (beta = 1) instead of
+# four that each write [M, D], one weight-gradient reduction over M instead of four.  The gradients of W1 and mu come out of
+# d[W_a ; W_b] through the two small products above (autograd).  The mixed inputs are not rounded to bf16 on the way (the reference
+# rounds x_i, then projects): one rounding less, inside the parity bars of tests/test_model_gpu.py.  RWKV7_FUSED_MIX_LORA=0: off.
+FUSED_MIX_LORA = os.environ.get("RWKV7_FUSED_MIX_LORA", "1") == "1"
+FUSED_MIX_LORA_HITS = [0]
+WGRAD_SLABS_WCAT = 32
+
+
+class _MixLora(torch.autograd.Function):
+    """(x_r, x_k, x_v, G) = (the three token-shift lerps that feed full projections, x @ wcat^T)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, params, wcat):
+        B, T, D = x.shape
+        x, params, wcat = _c(x), _c(params), _c(wcat)
+        nmix = params.shape[0]
+        out = torch.empty(nmix, B, T, D, dtype=x.dtype, device=x.device)
+        _call("mix_fwd", x, B, T, D, nmix, _p(x), _p(None), _p(mask), _p(params), _p(out), min(B * T, _MIX_FWD_BLOCKS))
+        G = torch.mm(x.view(-1, D), wcat.t())
+        ctx.save_for_backward(x, mask, params, wcat)
+        FUSED_MIX_LORA_HITS[0] += 1
+        return (*[out[i] for i in range(nmix)], G.view(B, T, -1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, mask, params, wcat = ctx.saved_tensors
+        B, T, D = x.shape
+        nmix = params.shape[0]
+        dG = gs[nmix]
+        gs = [torch.zeros_like(x) if g is None else _c(g) for g in gs[:nmix]]
+        nb = max(1, min(-(-B * T // _MIX_BWD_ROWS), _MIX_BWD_BLOCKS))
+        dx = torch.empty_like(x)
+        part = torch.empty(nb, nmix, D, dtype=torch.float32, device=x.device)
+        ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])
+        _call("mix_bwd", x, B, T, D, nmix, ptrs, _p(x), _p(None), _p(mask), _p(params), _p(dx), _p(part), nb, _MIX_BWD_ROWS)
+        dwcat = None
+        if dG is not None:
+            dG2 = _c(dG).view(-1, dG.shape[-1])
+            dx.view(-1, D).addmm_(dG2, wcat)          # the branches' input gradient accumulates into the lerp stage's dx
+            dwcat = wgrad_splitk(dG2, x.view(-1, D), slabs=WGRAD_SLABS_WCAT)   # [2 R, D] = [576, 1024]: 69 us with 32 slabs, 100 with 8
+        return dx, None, part.sum(0).to(params.dtype), dwcat
+
+
+def mix_lora_supported(x, state, seq_start):
+    return (FUSED_MIX_LORA and state is None and seq_start is None and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
+            and x.requires_grad and x.dim() == 3 and x.shape[0] * x.shape[1] >= WGRAD_MIN_ROWS and x.shape[-1] % 8 == 0)
+
+
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+class _WcatBuild(torch.autograd.Function):
+    """wcat [2 R, D] = [W1_i * (1 - mu_i) ; W1_i * mu_i] of all branches (rwkv7_mix_lora_wcat_*: one small kernel each way instead of
+    a dozen tensor ops per branch)."""
+
+    @staticmethod
+    def forward(ctx, nb, *ts):
+        w1s, mus = [_c(t) for t in ts[:nb]], [_c(t) for t in ts[nb:]]
+        D = w1s[0].shape[1]
+        ranks = (ctypes.c_int * nb)(*[w.shape[0] for w in w1s])
+        R = sum(w.shape[0] for w in w1s)
+        wcat = torch.empty(2 * R, D, dtype=w1s[0].dtype, device=w1s[0].device)
+        with torch.cuda.device_of(wcat):
+            rc = _lib.lib().rwkv7_mix_lora_wcat_fwd_bf16(nb, ranks, _ptr_array(w1s), _ptr_array(mus), D, _p(wcat), _stream(wcat))
+        _lib.check(rc, "mix_lora_wcat_fwd")
+        ctx.save_for_backward(*w1s, *mus)
+        ctx.nb = nb
+        ctx.mu_shapes = [t.shape for t in ts[nb:]]
+        return wcat
+
+    @staticmethod
+    def backward(ctx, dwcat):
+        nb = ctx.nb
+        ts = ctx.saved_tensors
+        w1s, mus = ts[:nb], ts[nb:]
+        D = w1s[0].shape[1]
+        ranks = (ctypes.c_int * nb)(*[w.shape[0] for w in w1s])
+        dwcat = _c(dwcat)
+        dw1 = [torch.empty_like(w) for w in w1s]
+        dmu = [torch.empty(D, dtype=w1s[0].dtype, device=w1s[0].device) for _ in range(nb)]
+        with torch.cuda.device_of(dwcat):
+            rc = _lib.lib().rwkv7_mix_lora_wcat_bwd_bf16(nb, ranks, _ptr_array(w1s), _ptr_array(mus), D, _p(dwcat), _ptr_array(dw1),
+                                                         _ptr_array(dmu), _stream(dwcat))
+        _lib.check(rc, "mix_lora_wcat_bwd")
+        return (None, *dw1, *[g.view(sh) for g, sh in zip(dmu, ctx.mu_shapes)])
+
+
+_ACT_CODE = {None: 0, "tanh": 1, "sigmoid": 2}
+
+
+class _CombineAct(torch.autograd.Function):
+    """a_i[t] = act_i(bf16(m_t G_a[t] + m_{t-1} G_b[t - 1])) per branch, contiguous [B, T, r_i] (rwkv7_mix_lora_combine_*)."""
+
+    @staticmethod
+    def forward(ctx, G, mask, ranks, acts):
+        B, T, R2 = G.shape
+        G = _c(G)
+        nb = len(ranks)
+        outs = [torch.empty(B, T, r, dtype=G.dtype, device=G.device) for r in ranks]
+        cr, ca = (ctypes.c_int * nb)(*ranks), (ctypes.c_int * nb)(*acts)
+        with torch.cuda.device_of(G):
+            rc = _lib.lib().rwkv7_mix_lora_combine_fwd_bf16(nb, cr, ca, ctypes.c_long(B * T), T, _p(G), _p(mask), _ptr_array(outs), _stream(G))
+        _lib.check(rc, "mix_lora_combine_fwd")
+        ctx.save_for_backward(mask, *outs)
+        ctx.ranks, ctx.acts, ctx.shape = ranks, acts, (B, T, R2)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *das):
+        mask, *outs = ctx.saved_tensors
+        B, T, R2 = ctx.shape
+        nb = len(ctx.ranks)
+        das = [torch.zeros_like(o) if g is None else _c(g) for g, o in zip(das, outs)]
+        dG = torch.empty(B, T, R2, dtype=outs[0].dtype, device=outs[0].device)
+        cr, ca = (ctypes.c_int * nb)(*ctx.ranks), (ctypes.c_int * nb)(*ctx.acts)
+        with torch.cuda.device_of(dG):
+            rc = _lib.lib().rwkv7_mix_lora_combine_bwd_bf16(nb, cr, ca, ctypes.c_long(B * T), T, _p(mask), _ptr_array(outs), _ptr_array(das),
+                                                            _p(dG), _stream(dG))
+        _lib.check(rc, "mix_lora_combine_bwd")
+        return dG, None, None, None
+
+
+def mix_lora(x, mask, x_r, x_k, x_v, mus, w1s, acts):
+    """x [B,T,D] (LayerNorm output); mus / w1s / acts: the lerp coefficient, Linear(D, r_i) weight and activation name of each low-rank
+    branch.  Returns (x_r, x_k, x_v, [a_i]): the three lerps that feed full projections and the branches' ACTIVATED hidden states
+    [B,T,r_i] (the inputs of their Linear(r_i, D))."""
+    B, T, D = x.shape
+    params = torch.cat([p.reshape(1, D) for p in (x_r, x_k, x_v)], 0).to(x.dtype)
+    wcat = _WcatBuild.apply(len(w1s), *w1s, *mus)
+    mr = _mask_rows(mask, x)
+    xr, xk, xv, G = _MixLora.apply(x, mr, params, wcat)
+    hs = _CombineAct.apply(G, mr, tuple(w.shape[0] for w in w1s), tuple(_ACT_CODE[a] for a in acts))
+    return xr, xk, xv, list(hs)
+
+
 def token_shift_mix6(x, x_prev, x_r, x_w, x_k, x_v, x_a, x_g, mask=None, stacked=None):
     """xm = x*mask ; xx = shift(xm) - xm ; returns xm + xx*x_? for ? in r,w,k,v,a,g  (6 tensors [B,T,D]).
     stacked: the six coefficient vectors already stacked [6,D] (inference caches it; one launch less per call)."""
@@ -540,7 +683,7 @@ COMPACT_POST_BWD = True   # tmix_post's backward hands dt + (dot, ds) per head t
 SKINNY_WGRAD = True   # low-rank weight gradients through rwkv7_wgrad_skinny_bf16 (A/B switch for tools/ab_step.py)
 
 
-def wgrad_splitk(dy2, x2, out=None):
+def wgrad_splitk(dy2, x2, out=None, slabs=None):
     """dy2[M,N]^T @ x2[M,K] -> [N,K].  The reduction runs over M = B*T rows (32768 at BASELINE configs[1]) while the
     result is at most a few 256x256 tiles, so one BLAS call leaves most CUs idle (measured on MI355X, tools/
     bench_wgrad_splitk.py: 1024x1024 209 us, 64x1024 115 us).  Batched over S slabs of rows with fp32 partials,
@@ -562,7 +705,7 @@ def wgrad_splitk(dy2, x2, out=None):
             rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(N * K), S, _p(part), _p(out), 0, _stream(part))
         _lib.check(rc, "sum_slabs")
         return out
-    S = WGRAD_SLABS_SMALL if N * K <= 1024 * 1024 else WGRAD_SLABS_BIG
+    S = slabs if slabs else (WGRAD_SLABS_SMALL if N * K <= 1024 * 1024 else WGRAD_SLABS_BIG)
     if M < WGRAD_MIN_ROWS or M % (S * 8) != 0:
         res = torch.mm(dy2.t(), x2)
         if out is not None:

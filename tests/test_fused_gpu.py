@@ -660,3 +660,59 @@ def test_projection_with_the_residual_add_as_its_epilogue(M, N, K, monkeypatch):
         e = (a_.float() - b_.float()).norm().item() / max(b_.float().norm().item(), 1e-9)
         assert e < 8e-3, (n, e)
     assert fused.linear_add(y[:100], w, r[:100]) is None
+
+
+@pytest.mark.parametrize("B,T,nb,masked", [(2, 2048, 4, False), (4, 1024, 3, True), (8, 1024, 4, True)])
+def test_low_rank_branches_through_the_lerp(B, T, nb, masked, monkeypatch):
+    """fused.mix_lora (rwkv_s2s_single_ffn.py:160-190): the w / a / v / g branches' Linear(D, r) taken through the token-shift lerp --
+    one GEMM on the LayerNorm output + rwkv7_mix_lora_combine_* on [M, 2 R] -- against the separate nodes (six lerps, four projections,
+    activations): the three remaining lerps bit for bit, the branches' activated hidden states and every gradient (input, lerp
+    coefficients, Linear weights) to the parity bars of the fused stages (the mixed inputs are not rounded to bf16 on the way)."""
+    from rwkvtts_amd import fused
+    monkeypatch.setattr(fused, "FUSED_MIX_LORA", True)
+    D = 1024
+    g = torch.Generator().manual_seed(B + T + nb)
+    x = torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16)
+    mask = None
+    if masked:
+        mask = (torch.rand(B, T, 1, generator=g) > 0.2).to(DEV, torch.bfloat16)
+        mask[:, :3] = 1
+    ranks = [64, 64, 32, 128][:nb] if nb == 4 else [64, 64, 128]
+    acts = ["tanh", None, None, "sigmoid"] if nb == 4 else ["tanh", None, "sigmoid"]
+    mus6 = [(torch.rand(1, 1, D, generator=g)).to(DEV, torch.bfloat16) for _ in range(6)]          # r w k v a g
+    w1s = [(torch.randn(r, D, generator=g) * D ** -0.5).to(DEV, torch.bfloat16) for r in ranks]
+    douts = [torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16) for _ in range(3)]
+    dhs = [torch.randn(B, T, r, generator=g).to(DEV, torch.bfloat16) for r in ranks]
+    act_fn = {None: lambda t: t, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+    res = []
+    for fusedp in (True, False):
+        xi = x.clone().requires_grad_(True)
+        mi = [m.clone().requires_grad_(True) for m in mus6]
+        wi = [w.clone().requires_grad_(True) for w in w1s]
+        x_r, x_w, x_k, x_v, x_a, x_g = mi
+        bm = [x_w, x_a, x_v, x_g] if nb == 4 else [x_w, x_a, x_g]
+        if fusedp:
+            assert fused.mix_lora_supported(xi, None, None)
+            xr, xk, xv, hs = fused.mix_lora(xi, mask, x_r, x_k, x_v, bm, wi, acts)
+        else:
+            xr, xw, xk, xv, xa, xg = fused.token_shift_mix6(xi, None, x_r, x_w, x_k, x_v, x_a, x_g, mask)
+            ins = [xw, xa, xv, xg] if nb == 4 else [xw, xa, xg]
+            hs = [act_fn[a](torch.nn.functional.linear(t, w)) for t, w, a in zip(ins, wi, acts)]
+        loss_terms = [(o.float() * d.float()).sum() for o, d in zip((xr, xk, xv), douts)] + [(h.float() * d.float()).sum() for h, d in zip(hs, dhs)]
+        sum(loss_terms).backward()
+        torch.cuda.synchronize()
+        used = [0, 2, 3] + ([1, 4, 3, 5] if nb == 4 else [1, 4, 5])
+        res.append(dict(outs=[t.detach().clone() for t in (xr, xk, xv)], hs=[h.detach().clone() for h in hs], dx=xi.grad.clone(),
+                        dmu=[mi[j].grad.clone() for j in sorted(set(used))], dw=[w.grad.clone() for w in wi]))
+    a_, b_ = res
+    for o1, o0 in zip(a_["outs"], b_["outs"]):
+        assert torch.equal(o1, o0)
+    def rel(u, v):
+        return (u.float() - v.float()).norm().item() / max(v.float().norm().item(), 1e-9)
+    for h1, h0 in zip(a_["hs"], b_["hs"]):
+        assert rel(h1, h0) < 8e-3, rel(h1, h0)
+    assert rel(a_["dx"], b_["dx"]) < 8e-3, rel(a_["dx"], b_["dx"])
+    for u, v in zip(a_["dw"], b_["dw"]):
+        assert rel(u, v) < 1.5e-2, rel(u, v)
+    for u, v in zip(a_["dmu"], b_["dmu"]):
+        assert rel(u, v) < 2e-2, rel(u, v)

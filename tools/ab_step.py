@@ -25,7 +25,8 @@ def steps(n):
     return ts
 
 
-switches = [("output projection with the residual add as its epilogue (own kernel)", fused, "FUSED_OPROJ_ADD", False, True),
+switches = [("low-rank branches: down projections through the lerp (one GEMM on the LayerNorm output)", fused, "FUSED_MIX_LORA", False, True),
+            ("output projection with the residual add as its epilogue (own kernel)", fused, "FUSED_OPROJ_ADD", False, True),
             ("channel mix: activation inside both GEMMs (own kernel, generation 4)", fused, "FUSED_CMIX", False, True),
             ("relu^2 backward in the value dgrad GEMM (own kernel)", fused, "FUSED_RELUSQ_VALUE_BWD", False, True),
             ("add+LN+six lerps: one-pass forward (backward as two kernels)", backbone, "FUSED_ADD_LN_MIX6_FWD", False, True),
