@@ -377,6 +377,9 @@ int rwkv7_adamw_groups_bf16(long n, float *p32, const void *g16, float *m, float
  *      228-229, reduced over B*T in S row slabs with fp32 partials): out[n] (bf16) = (accumulate ? out[n] : 0) +
  *      sum_s parts[s][n].  out may be the parameter's slice of the flat gradient buffer.  n % 4 == 0. ---- */
 int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, rwkv7_stream_t stream);
+/*   out[C][R] = in[R][C]^T, 16-bit elements, R % 64 == 0 and C % 64 == 0: the NT operand W_value^T of the channel-mix backward's
+ *   input-gradient GEMM (rwkv7_gemm_nt_relusq_bwd_s_bf16; autograd of rwkv_s2s_single_ffn.py:229). */
+int rwkv7_transpose_bf16(int R, int C, const void *in, void *out, rwkv7_stream_t stream);
 /*   Weight gradient of a low-rank projection (rwkv_s2s_single_ffn.py:172-184, autograd of x @ w1 / h @ w2): for y = x W^T,
  *   parts[s][N][K] (fp32) = dy[slab s][N]^T x[slab s][K], slab = M / S consecutive rows (a multiple of 128); one of N, K is the
  *   rank (32, 64 or 128), the other a multiple of 256.  bf16 operands, fp32 accumulation on MFMA; finish with

@@ -262,15 +262,19 @@ class RWKV7Attention(nn.Module):
         if fused.mix_lora_supported(x, state, seq_start) and FUSED_TMIX_CORE:
             # training: the four low-rank branches' down projections taken THROUGH the lerp (fused.mix_lora): x_w, x_a, x_g and the
             # branch copy of x_v are never formed
-            loras = [self.w_lora, self.a_lora] + ([self.v_lora] if self.layer_idx != 0 else []) + [self.g_lora]
-            mus = [self.x_w, self.x_a] + ([self.x_v] if self.layer_idx != 0 else []) + [self.x_g]
-            xr, xk, xv, hs = fused.mix_lora(x, mask, self.x_r, self.x_k, self.x_v, mus, [l.lora[0].weight for l in loras],
-                                            [l.activation for l in loras])
-            hid = dict(zip(("w", "a") + (("v",) if self.layer_idx != 0 else ()) + ("g",), hs))
-            return self.forward_mixed((xr, None, xk, xv, None, None), x, mask, v_first, state, seq_start, resid, hid)
+            mus, w1s, acts, names = self.lora_branches()
+            xr, xk, xv, hs = fused.mix_lora(x, mask, self.x_r, self.x_k, self.x_v, mus, w1s, acts)
+            return self.forward_mixed((xr, None, xk, xv, None, None), x, mask, v_first, state, seq_start, resid, dict(zip(names, hs)))
         mixed = fused.token_shift_mix6(x, x_prev, self.x_r, self.x_w, self.x_k, self.x_v,
                                        self.x_a, self.x_g, mask, self._stacked_mix(x.dtype))
         return self.forward_mixed(mixed, x, mask, v_first, state, seq_start, resid)
+
+    def lora_branches(self):
+        """(lerp coefficients, Linear(D, r) weights, activation names, keys) of the low-rank branches, in fused.mix_lora's order."""
+        loras = [self.w_lora, self.a_lora] + ([self.v_lora] if self.layer_idx != 0 else []) + [self.g_lora]
+        mus = [self.x_w, self.x_a] + ([self.x_v] if self.layer_idx != 0 else []) + [self.x_g]
+        names = ("w", "a") + (("v",) if self.layer_idx != 0 else ()) + ("g",)
+        return mus, [l.lora[0].weight for l in loras], [l.activation for l in loras], names
 
     def mix_params(self):
         return (self.x_r, self.x_w, self.x_k, self.x_v, self.x_a, self.x_g)
@@ -408,6 +412,15 @@ class RWKV7Block(nn.Module):
             x, mixed = fused.add_layer_norm_mix(x, delta, self.attn_norm, mask, self.attn.mix_params(), fwd_only=not FUSED_ADD_LN_MIX6)
             att, v_first = self.attn.forward_mixed(mixed, None, mask, v_first, None, seq_start,
                                                    resid=x if FUSED_ADD_LN_MIX1 else None)
+        elif (one_pass and FUSED_TMIX_CORE and fused.FUSED_ADD_LN_MIX_LORA_FWD and x.requires_grad
+              and fused.mix_lora_supported(x, state, seq_start)):
+            # residual add + LayerNorm + the three lerps of the full projections in one forward kernel; the low-rank branches take
+            # their inputs through the lerp from the stored LayerNorm output (fused.add_layer_norm_mix_lora)
+            a = self.attn
+            mus, w1s, acts, names = a.lora_branches()
+            x, xr, xk, xv, hs = fused.add_layer_norm_mix_lora(x, delta, self.attn_norm, mask, a.x_r, a.x_k, a.x_v, mus, w1s, acts)
+            att, v_first = a.forward_mixed((xr, None, xk, xv, None, None), None, mask, v_first, None, seq_start,
+                                           x if FUSED_ADD_LN_MIX1 else None, dict(zip(names, hs)))
         else:
             if delta is None:
                 h = fused.layer_norm(x, self.attn_norm)

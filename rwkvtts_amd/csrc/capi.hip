@@ -59,6 +59,7 @@ int mix_lora_combine_bwd(const MixLoraDesc &, long, int, int, const void *, void
 int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
+int transpose_bf16(int, int, const void *, void *, hipStream_t);
 int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
 int sample_rows_f32(int, int, const float *, long, const int *, const int *, const int *, const int *, const int *, int, int, int, int, float,
                     float, unsigned long long, const long *, long *, const void *, int, long, hipStream_t);
@@ -338,7 +339,7 @@ int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, c
             any_null({x, gamma, params, out, (const void *)mean, (const void *)rstd}))                                \
             return RWKV7_EINVAL;                                                                                      \
         if (branch && !x_out) return RWKV7_EINVAL;                                                                    \
-        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
+        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 3 && nmix != 6)) return RWKV7_ESHAPE;                               \
         return rwkv7::add_ln_mix_fwd<TY>(B, T, D, nmix, nullptr, x, branch, gamma, beta, eps, mask, params, x_out,    \
                                          out, mean, rstd, nblocks, run_len, (hipStream_t)stream);                     \
     }                                                                                                                 \
@@ -350,7 +351,7 @@ int rwkv7_wkv_state_fwd_variant_bf16(int B, int T, int C, int H, float *state, c
             any_null({x, gamma, params, out, (const void *)h, (const void *)mean, (const void *)rstd}))                \
             return RWKV7_EINVAL;                                                                                      \
         if (branch && !x_out) return RWKV7_EINVAL;                                                                    \
-        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 6)) return RWKV7_ESHAPE;                                            \
+        if (!SHAPE_OK(D) || (nmix != 1 && nmix != 3 && nmix != 6)) return RWKV7_ESHAPE;                               \
         return rwkv7::add_ln_mix_fwd<TY>(B, T, D, nmix, h, x, branch, gamma, beta, eps, mask, params, x_out, out,     \
                                          mean, rstd, nblocks, run_len, (hipStream_t)stream);                          \
     }                                                                                                                 \
@@ -632,6 +633,11 @@ int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accum
     if (n <= 0 || S <= 0 || any_null({(const void *)parts, (const void *)out})) return RWKV7_EINVAL;
     if (n % 4 != 0) return RWKV7_ESHAPE;
     return rwkv7::sum_slabs_bf16(n, S, parts, out, accumulate, (hipStream_t)stream);
+}
+int rwkv7_transpose_bf16(int R, int C, const void *in, void *out, rwkv7_stream_t stream) {
+    if (R <= 0 || C <= 0 || any_null({in, (const void *)out})) return RWKV7_EINVAL;
+    if (R % 64 != 0 || C % 64 != 0) return RWKV7_ESHAPE;
+    return rwkv7::transpose_bf16(R, C, in, out, (hipStream_t)stream);
 }
 int rwkv7_decode_layer_ptrs(void) { return rwkv7::decode_layer_ptrs(); }
 size_t rwkv7_decode_workspace_bytes(const rwkv7_decode_dims *dm) {

@@ -1125,15 +1125,94 @@ __global__ __launch_bounds__(256) void sum_slabs_wide_kernel(long n4, int S, con
     }
 }
 
+// many slabs over a SHORT vector, S in the hundreds or thousands (round 4: the column sums of the fused stages' parameter-gradient
+// partials, [S = 1024..2048 workgroup rows][2..8 x D] fp32 -- torch's reduce + cast pair was 15 + 5 us, 122 times per step): a
+// workgroup owns 32 columns (one 128-byte line per slab row) and walks ALL slabs, thread = (float4 column, slab lane of 64), 16
+// independent loads in flight per thread, then a fixed-order tree over the 64 slab lanes in LDS -- one launch, deterministic
+__global__ __launch_bounds__(512) void sum_slabs_tall_kernel(long n4, int S, const float *__restrict__ parts, bf16_t *__restrict__ out,
+                                                             int accumulate) {
+    __shared__ float4 red[64][8];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const long i = (long)blockIdx.x * 8 + cl;
+    const long ic = i < n4 ? i : n4 - 1;   // clamped, never skipped (a guarded load is waited for at its issue)
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = rl; s0 < S; s0 += 64 * 16) {
+        float4 t[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int s = s0 + 64 * u;
+            t[u] = *reinterpret_cast<const float4 *>(parts + ((long)(s < S ? s : S - 1) * n4 + ic) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const float m = s0 + 64 * u < S ? 1.f : 0.f;
+            a.x = fmaf(t[u].x, m, a.x); a.y = fmaf(t[u].y, m, a.y); a.z = fmaf(t[u].z, m, a.z); a.w = fmaf(t[u].w, m, a.w);
+        }
+    }
+    red[rl][cl] = a;
+    __syncthreads();
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) {
+        if (rl < h) {
+            const float4 b = red[rl + h][cl];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            red[rl][cl] = a;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && i < n4) {
+        if (accumulate) {
+            const float4 o = cvt4(ld4<bf16_t>(out + i * 4, true));
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        st4(out + i * 4, a);
+    }
+}
+
 int sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, hipStream_t st) {
     (void)hipGetLastError();
     const long n4 = n / 4;
+    if (S >= 256 && n4 <= 8192) {
+        hipLaunchKernelGGL(sum_slabs_tall_kernel, dim3((int)((n4 + 7) / 8)), dim3(512), 0, st, n4, S, parts, (bf16_t *)out, accumulate);
+        return (int)hipGetLastError();
+    }
     if (S >= 16 && n4 <= 64L * 4096) {
         hipLaunchKernelGGL(sum_slabs_wide_kernel, dim3((int)((n4 + 63) / 64)), dim3(256), 0, st, n4, S, parts, (bf16_t *)out, accumulate);
         return (int)hipGetLastError();
     }
     const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid), dim3(256), 0, st, n4, S, parts, (bf16_t *)out, accumulate);
+    return (int)hipGetLastError();
+}
+
+// out[c][r] = in[r][c] for a row-major [R][C] matrix of 16-bit elements: 64 x 64 tiles through LDS, 16-byte global accesses both ways
+// (round 4: the channel-mix backward's NT operand W_value^T, 8 MiB per layer and step -- torch's strided copy took 27 us)
+__global__ __launch_bounds__(256) void transpose16_kernel(int R, int C, const uint16_t *__restrict__ in, uint16_t *__restrict__ out) {
+    __shared__ uint16_t tile[64][64 + 2];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;   // 32 rows x 8 pieces of 8 elements per pass
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int r = tr + 32 * p;
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + (long)(r0 + r) * C + c0 + tc);
+        const uint16_t *e = reinterpret_cast<const uint16_t *>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) tile[r][tc + j] = e[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int c = tr + 32 * p;   // output row = input column
+        uint4 v;
+        uint16_t *e = reinterpret_cast<uint16_t *>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[j] = tile[tc + j][c];
+        *reinterpret_cast<uint4 *>(out + (long)(c0 + c) * R + r0 + tc) = v;
+    }
+}
+int transpose_bf16(int R, int C, const void *in, void *out, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(transpose16_kernel, dim3(C / 64, R / 64), dim3(256), 0, st, R, C, (const uint16_t *)in, (uint16_t *)out);
     return (int)hipGetLastError();
 }
 
@@ -1189,6 +1268,9 @@ int add_ln_mix_fwd(int B, int T_, int D, int nmix, void *h_out, const void *x, c
     const dim3 grid(nblocks), block(D / 8);
     if (nmix == 6)
         hipLaunchKernelGGL((add_ln_mix_fwd_kernel<T, 6>), grid, block, 0, st, B, T_, D, run_len, (const T *)x, (const T *)branch,
+                           (const T *)gamma, (const T *)beta, eps, (const T *)mask, (const T *)params, (T *)x_out, (T *)out, mean, rstd, (T *)h_out);
+    else if (nmix == 3)   // x_r, x_k, x_v: the time-mix side when the low-rank branches go through the lerp (fused.add_layer_norm_mix_lora)
+        hipLaunchKernelGGL((add_ln_mix_fwd_kernel<T, 3>), grid, block, 0, st, B, T_, D, run_len, (const T *)x, (const T *)branch,
                            (const T *)gamma, (const T *)beta, eps, (const T *)mask, (const T *)params, (T *)x_out, (T *)out, mean, rstd, (T *)h_out);
     else
         hipLaunchKernelGGL((add_ln_mix_fwd_kernel<T, 1>), grid, block, 0, st, B, T_, D, run_len, (const T *)x, (const T *)branch,

@@ -49,6 +49,22 @@ def _call(name, ref, *args):
     _lib.check(rc, name)
 
 
+COLSUM_KERNEL = os.environ.get("RWKV7_COLSUM_KERNEL", "1") == "1"
+
+
+def _colsum(part, dtype):
+    """Column sums of a stage's parameter-gradient partials, [nb, ..., D] fp32 -> [..., D] `dtype`.  bf16 on the device: one launch
+    (rwkv7_sum_slabs_bf16's tall shape, fixed summation order) instead of torch's reduce + cast pair (15 + 5 us, ~120 per step)."""
+    if COLSUM_KERNEL and part.is_cuda and dtype == torch.bfloat16 and part.dtype == torch.float32 and part.shape[0] >= 256:
+        n = part[0].numel()
+        if n % 4 == 0 and n <= 32768:
+            out = torch.empty(part.shape[1:], dtype=dtype, device=part.device)
+            rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(n), part.shape[0], _p(part), _p(out), 0, _stream(part))
+            _lib.check(rc, "sum_slabs(colsum)")
+            return out
+    return part.sum(0).to(dtype)
+
+
 def _mask_rows(mask, like):
     """mask [B,T,1] / [B,T] / None  ->  contiguous [B*T] tensor of like.dtype, or None."""
     if mask is None:
@@ -83,7 +99,7 @@ class _Mix(torch.autograd.Function):
         part = torch.empty(nb, nmix, D, dtype=torch.float32, device=x.device)
         ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])
         _call("mix_bwd", x, B, T, D, nmix, ptrs, _p(x), _p(xp), _p(mask), _p(params), _p(dx), _p(part), nb, _MIX_BWD_ROWS)
-        return dx, None, None, part.sum(0).to(params.dtype)
+        return dx, None, None, _colsum(part, params.dtype)
 
 
 # Round 4: the low-rank branches' DOWN projections commute with the token-shift lerp,
@@ -133,7 +149,7 @@ class _MixLora(torch.autograd.Function):
             dG2 = _c(dG).view(-1, dG.shape[-1])
             dx.view(-1, D).addmm_(dG2, wcat)          # the branches' input gradient accumulates into the lerp stage's dx
             dwcat = wgrad_splitk(dG2, x.view(-1, D), slabs=WGRAD_SLABS_WCAT)   # [2 R, D] = [576, 1024]: 69 us with 32 slabs, 100 with 8
-        return dx, None, part.sum(0).to(params.dtype), dwcat
+        return dx, None, _colsum(part, params.dtype), dwcat
 
 
 def mix_lora_supported(x, state, seq_start):
@@ -369,6 +385,7 @@ class _ReluSqValue(torch.autograd.Function):
 # nor rwkv7_relusq_bwd runs, and one [rows, F] activation less is kept per layer.  Same-box A/B (tools/ab_step.py): see DESIGN.md section 4.
 FUSED_CMIX = os.environ.get("RWKV7_FUSED_CMIX", "1") == "1"
 FUSED_CMIX_HITS = [0]
+TRANSPOSE_KERNEL = True   # W_value^T through rwkv7_transpose_bf16 instead of torch's strided copy (27 -> ~6 us per layer)
 
 
 def cmix_eligible(x, wk, wv):
@@ -403,7 +420,13 @@ class _ChannelMix(torch.autograd.Function):
         d2 = _c(dout).view(-1, dout.shape[-1])
         M, F = s.shape
         D = wv.shape[0]
-        wt = wv.detach().t().contiguous()     # [F, D]: the NT operand (8 MiB at 0.4B, one copy per layer and step)
+        if TRANSPOSE_KERNEL and D % 64 == 0 and F % 64 == 0 and wv.is_contiguous():
+            wt = torch.empty(F, D, dtype=wv.dtype, device=wv.device)      # [F, D]: the NT operand (8 MiB at 0.4B, once per layer and step)
+            with torch.cuda.device_of(s):
+                rc = _lib.lib().rwkv7_transpose_bf16(D, F, _p(wv), _p(wt), _stream(s))
+            _lib.check(rc, "transpose")
+        else:
+            wt = wv.detach().t().contiguous()
         dk = torch.empty_like(s)
         with torch.cuda.device_of(s):
             rc = _lib.lib().rwkv7_gemm_nt_relusq_bwd_s_bf16(M, F, D, _p(d2), _p(wt), _p(s), _p(dk), _stream(s))
@@ -465,7 +488,7 @@ class _TmixPrepare(torch.autograd.Function):
         _call("tmix_prepare_bwd", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first), _p(mask),
               _p(k_k), _p(k_a), *[_p(g) for g in gs], _p(d_wpre), _p(d_k), _p(d_v), _p(d_apre), _p(d_vpre), _p(d_vf),
               _p(part), nb)
-        dp = part.sum(0).to(k.dtype)
+        dp = _colsum(part, k.dtype)
         _attach_colsums(dp, d_wpre, d_apre, d_vpre)
         return d_wpre, d_k, d_v, d_apre, d_vpre, d_vf, dp[0], dp[1], None
 
@@ -503,7 +526,7 @@ class _TmixPost(torch.autograd.Function):
         part = torch.empty(nb, 3, D, dtype=torch.float32, device=y.device)
         _call("tmix_post_bwd", y, ctypes.c_long(rows), D, _p(dout), _p(y), _p(r), _p(k), _p(v), _p(g), _p(gn_w), _p(gn_b), _p(r_k),
               ctypes.c_float(ctx.eps), _p(d_y), _p(d_r), _p(d_k), _p(d_v), _p(d_g), _p(part), nb)
-        dp = part.sum(0).to(y.dtype)
+        dp = _colsum(part, y.dtype)
         return d_y, d_r, d_k, d_v, d_g, dp[0], dp[1], dp[2], None
 
 
@@ -629,8 +652,8 @@ class _TmixCore(torch.autograd.Function):
         _call("tmix_prepare_bwd_sum_compact" if compact else "tmix_prepare_bwd_sum", k, ctypes.c_long(rows), D, _p(w_pre), _p(k), _p(v), _p(a_pre), _p(v_pre), _p(v_first),
               _p(mask), _p(k_k), _p(k_a), ptrs, _p(d_wpre), _p(d_k), _p(d_v), _p(d_apre), _p(d_vpre), _p(d_vf),
               _p(d_r), _p(part), nb)
-        dp = part.sum(0).to(k.dtype)
-        dpp = part_post.sum(0).to(k.dtype)
+        dp = _colsum(part, k.dtype)
+        dpp = _colsum(part_post, k.dtype)
         _attach_colsums(dp, d_wpre, d_apre, d_vpre)
         return (d_r, d_wpre, d_k, d_v, d_apre, d_g, d_vpre, d_vf, dp[0], dp[1], dpp[0], dpp[1], dpp[2], None, None,
                 None, None)
@@ -996,7 +1019,7 @@ class _AddLN(torch.autograd.Function):
         part = torch.empty(nb, 2, D, dtype=torch.float32, device=xs.device)
         _call("add_ln_bwd", xs, ctypes.c_long(rows), D, _p(dh), _p(d_x1), _p(xs), _p(mean), _p(rstd), _p(gamma), _p(dx),
               _p(part), nb)
-        dp = part.sum(0).to(xs.dtype)
+        dp = _colsum(part, xs.dtype)
         return dx, (dx if ctx.has_branch else None), dp[0], (dp[1] if ctx.has_beta else None), None
 
 
@@ -1047,7 +1070,7 @@ class _AddLNMix(torch.autograd.Function):
         ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])
         _call("mix_add_ln_bwd", xs, B, T, D, nmix, ptrs, _p(d_x1), _p(xs), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(mask),
               _p(params), _p(dx), _p(part), nb, _ADD_LN_MIX_RUN)
-        dp = part.sum(0)
+        dp = _colsum(part, xs.dtype) if params.dtype == xs.dtype else part.sum(0)
         return (dx, (dx if ctx.has_branch else None), dp[nmix].to(xs.dtype), (dp[nmix + 1].to(xs.dtype) if ctx.has_beta else None),
                 None, None, dp[:nmix].to(params.dtype))
 
@@ -1098,9 +1121,85 @@ class _AddLNMixFwd(torch.autograd.Function):
         dx = torch.empty_like(xs)
         part = torch.empty(nb2, 2, D, dtype=torch.float32, device=xs.device)
         _call("add_ln_bwd", xs, ctypes.c_long(rows), D, _p(dh), _p(d_x1), _p(xs), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(part), nb2)
-        dp = part.sum(0)
-        return (dx, (dx if ctx.has_branch else None), dp[0].to(xs.dtype), (dp[1].to(xs.dtype) if ctx.has_beta else None),
-                None, None, part_m.sum(0).to(params.dtype))
+        dp = _colsum(part, xs.dtype)
+        return (dx, (dx if ctx.has_branch else None), dp[0], (dp[1] if ctx.has_beta else None),
+                None, None, _colsum(part_m, params.dtype))
+
+
+# measured (round 4, same-box A/B, tools/ab_step.py): 126.25 -> 126.83 ms per step, +0.58 ms -- the one-pass kernel re-normalises a
+# neighbour row per run of four and holds two workgroup barriers per row; with five output streams that costs more than the one
+# [rows, D] read it saves.  Off; bit-identical to the two stages (tests/test_fused_gpu.py), kept as the recorded experiment.
+FUSED_ADD_LN_MIX_LORA_FWD = os.environ.get("RWKV7_FUSED_ADD_LN_MIX_LORA_FWD", "0") == "1"
+
+
+class _AddLNMixLora(torch.autograd.Function):
+    """(x1, x_r, x_k, x_v, G): _AddLN followed by _MixLora with ONE forward kernel -- residual add + LayerNorm + the three lerps that
+    feed full projections, h = LayerNorm(x1) stored because the branches' GEMM G = h wcat^T (and the backward) read it anyway
+    (rwkv7_add_ln_mix_fwd_h, nmix = 3).  The backward is the separate stages' own: mix_bwd -> + dG wcat -> add_ln_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, branch, gamma, beta, eps, mask, params, wcat):
+        B, T, D = x.shape
+        x, params, wcat = _c(x), _c(params), _c(wcat)
+        nmix = params.shape[0]
+        gamma_c = _c(gamma.to(x.dtype))
+        beta_c = None if beta is None else _c(beta.to(x.dtype))
+        rows = B * T
+        out = torch.empty(nmix, B, T, D, dtype=x.dtype, device=x.device)
+        h = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        if branch is not None:
+            branch = _c(branch)
+            x1 = torch.empty_like(x)
+        else:
+            x1 = None
+        nb = max(1, min(-(-rows // _ADD_LN_MIX_RUN), _ADD_LN_MIX_BLOCKS))
+        _call("add_ln_mix_fwd_h", x, B, T, D, nmix, _p(x), _p(branch), _p(gamma_c), _p(beta_c), ctypes.c_float(eps), _p(mask),
+              _p(params), _p(x1), _p(out), _p(h), _p(mean), _p(rstd), nb, _ADD_LN_MIX_RUN)
+        G = torch.mm(h.view(-1, D), wcat.t())
+        ctx.has_branch, ctx.has_beta = branch is not None, beta is not None
+        ctx.save_for_backward(x1 if branch is not None else x, h, mean, rstd, gamma_c, mask, params, wcat)
+        FUSED_MIX_LORA_HITS[0] += 1
+        return ((x1 if branch is not None else x), *[out[i] for i in range(nmix)], G.view(B, T, -1))
+
+    @staticmethod
+    def backward(ctx, d_x1, *gs):
+        xs, h, mean, rstd, gamma, mask, params, wcat = ctx.saved_tensors
+        B, T, D = xs.shape
+        nmix = params.shape[0]
+        rows = B * T
+        dG = gs[nmix]
+        gs = [torch.zeros_like(xs) if g is None else _c(g) for g in gs[:nmix]]
+        nb = max(1, min(-(-rows // _MIX_BWD_ROWS), _MIX_BWD_BLOCKS))
+        dh = torch.empty_like(xs)
+        part_m = torch.empty(nb, nmix, D, dtype=torch.float32, device=xs.device)
+        ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in gs])
+        _call("mix_bwd", xs, B, T, D, nmix, ptrs, _p(h), _p(None), _p(mask), _p(params), _p(dh), _p(part_m), nb, _MIX_BWD_ROWS)
+        dwcat = None
+        if dG is not None:
+            dG2 = _c(dG).view(-1, dG.shape[-1])
+            dh.view(-1, D).addmm_(dG2, wcat)
+            dwcat = wgrad_splitk(dG2, h.view(-1, D), slabs=WGRAD_SLABS_WCAT)
+        d_x1 = None if d_x1 is None else _c(d_x1)
+        nb2 = min(rows, _BWD_BLOCKS)
+        dx = torch.empty_like(xs)
+        part = torch.empty(nb2, 2, D, dtype=torch.float32, device=xs.device)
+        _call("add_ln_bwd", xs, ctypes.c_long(rows), D, _p(dh), _p(d_x1), _p(xs), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(part), nb2)
+        dp = _colsum(part, xs.dtype)
+        return (dx, (dx if ctx.has_branch else None), dp[0], (dp[1] if ctx.has_beta else None), None, None,
+                _colsum(part_m, params.dtype), dwcat)
+
+
+def add_layer_norm_mix_lora(x, branch, norm, mask, x_r, x_k, x_v, mus, w1s, acts):
+    """fused.add_layer_norm + fused.mix_lora with one forward kernel.  Returns (x + branch, x_r, x_k, x_v, [a_i])."""
+    D = x.shape[-1]
+    params = torch.cat([p.reshape(1, D) for p in (x_r, x_k, x_v)], 0).to(x.dtype)
+    wcat = _WcatBuild.apply(len(w1s), *w1s, *mus)
+    mr = _mask_rows(mask, x)
+    x1, xr, xk, xv, G = _AddLNMixLora.apply(x, branch, norm.weight, norm.bias, norm.eps, mr, params, wcat)
+    hs = _CombineAct.apply(G, mr, tuple(w.shape[0] for w in w1s), tuple(_ACT_CODE[a] for a in acts))
+    return x1, xr, xk, xv, list(hs)
 
 
 def add_ln_mix_supported(x, state):

@@ -271,6 +271,24 @@ def test_low_rank_weight_gradient_kernel_vs_fp32_reference(M, N, K):
     assert torch.equal(out, got)
 
 
+@pytest.mark.parametrize("S,shape", [(1024, (5, 1024)), (2048, (3, 1024)), (1024, (2, 1024)), (256, (1, 768)), (1000, (3, 100)), (1024, (8, 2048))])
+def test_partials_column_sum_kernel(S, shape):
+    """fused._colsum: the column sums of a stage's parameter-gradient partials ([S workgroup rows][... D] fp32 -> bf16) through
+    rwkv7_sum_slabs_bf16's tall shape, against the float64 sum rounded once; deterministic (two calls, same bits); other dtypes and
+    short partials keep torch's reduce + cast."""
+    g = torch.Generator().manual_seed(S + shape[-1])
+    part = (torch.randn(S, *shape, generator=g) * torch.rand(S, 1, 1, generator=g)).float()
+    want = part.double().sum(0)
+    got = fused._colsum(part.to(DEV), torch.bfloat16)
+    assert got.shape == tuple(shape) and got.dtype == torch.bfloat16
+    again = fused._colsum(part.to(DEV), torch.bfloat16)
+    assert torch.equal(got, again)
+    _cmp_bf16(got, want.float().bfloat16().float(), "column sums", ulps=1.0)
+    ref32 = fused._colsum(part.to(DEV), torch.float32)   # torch path
+    assert ref32.dtype == torch.float32
+    _cmp(ref32, want.float(), 1e-5, "fp32 column sums")
+
+
 def test_low_rank_weight_gradient_argument_errors():
     import ctypes
     from rwkvtts_amd import _lib
@@ -716,3 +734,76 @@ def test_low_rank_branches_through_the_lerp(B, T, nb, masked, monkeypatch):
         assert rel(u, v) < 1.5e-2, rel(u, v)
     for u, v in zip(a_["dmu"], b_["dmu"]):
         assert rel(u, v) < 2e-2, rel(u, v)
+
+
+@pytest.mark.parametrize("B,T,with_branch,masked,layer0", [(2, 2048, True, False, False), (4, 1024, True, True, False), (8, 512, False, False, True)])
+def test_add_layer_norm_mix_lora_one_pass_forward(B, T, with_branch, masked, layer0):
+    """fused.add_layer_norm_mix_lora (rwkv_s2s_single_ffn.py:158-190, 251-259): residual add + LayerNorm + the three remaining lerps as
+    ONE forward kernel (rwkv7_add_ln_mix_fwd_h, nmix = 3) with the branches' GEMM on the stored LayerNorm output, against
+    fused.add_layer_norm followed by fused.mix_lora -- the same arithmetic in the same order, so outputs and every gradient bit for bit."""
+    D = 1024
+    g = torch.Generator().manual_seed(B * T + with_branch)
+    x = torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16)
+    br = torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16) if with_branch else None
+    mask = None
+    if masked:
+        mask = (torch.rand(B, T, 1, generator=g) > 0.2).to(DEV, torch.bfloat16)
+        mask[:, :3] = 1
+    ranks = [64, 64, 128] if layer0 else [64, 64, 32, 128]
+    acts = ["tanh", None, "sigmoid"] if layer0 else ["tanh", None, None, "sigmoid"]
+    nbr = len(ranks)
+    mus = [(torch.rand(1, 1, D, generator=g)).to(DEV, torch.bfloat16) for _ in range(3 + nbr)]
+    w1s = [(torch.randn(r, D, generator=g) * D ** -0.5).to(DEV, torch.bfloat16) for r in ranks]
+    norm = torch.nn.LayerNorm(D, eps=1e-5).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(D, generator=g))
+        norm.bias.copy_(0.1 * torch.randn(D, generator=g))
+    d_x1 = torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16)
+    douts = [torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16) for _ in range(3)]
+    dhs = [torch.randn(B, T, r, generator=g).to(DEV, torch.bfloat16) for r in ranks]
+    res = []
+    for one_pass in (True, False):
+        xi = x.clone().requires_grad_(True)
+        bi = None if br is None else br.clone().requires_grad_(True)
+        mi = [m.clone().requires_grad_(True) for m in mus]
+        wi = [w.clone().requires_grad_(True) for w in w1s]
+        norm.zero_grad(set_to_none=True)
+        if one_pass:
+            x1, xr, xk, xv, hs = fused.add_layer_norm_mix_lora(xi, bi, norm, mask, mi[0], mi[1], mi[2], mi[3:], wi, acts)
+        else:
+            if bi is None:
+                x1, h = xi, fused.layer_norm(xi, norm)
+            else:
+                x1, h = fused.add_layer_norm(xi, bi, norm)
+            xr, xk, xv, hs = fused.mix_lora(h, mask, mi[0], mi[1], mi[2], mi[3:], wi, acts)
+        terms = [(o.float() * d.float()).sum() for o, d in zip((xr, xk, xv), douts)] + [(h_.float() * d.float()).sum() for h_, d in zip(hs, dhs)]
+        if bi is not None:
+            terms.append((x1.float() * d_x1.float()).sum())
+        sum(terms).backward()
+        torch.cuda.synchronize()
+        res.append(dict(outs=[t.detach().clone() for t in (x1, xr, xk, xv, *hs)], dx=xi.grad.clone(), db=None if bi is None else bi.grad.clone(),
+                        dmu=[m.grad.clone() for m in mi], dw=[w.grad.clone() for w in wi], dg=norm.weight.grad.clone(), dbeta=norm.bias.grad.clone()))
+    a_, b_ = res
+    for o1, o0 in zip(a_["outs"], b_["outs"]):
+        assert torch.equal(o1, o0)
+    assert torch.equal(a_["dx"], b_["dx"])
+    if with_branch:
+        assert torch.equal(a_["db"], b_["db"])
+    for u, v in zip(a_["dmu"] + a_["dw"] + [a_["dg"], a_["dbeta"]], b_["dmu"] + b_["dw"] + [b_["dg"], b_["dbeta"]]):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("R,C", [(1024, 4096), (64, 64), (192, 1088)])
+def test_transpose_kernel(R, C):
+    """rwkv7_transpose_bf16 (the channel-mix backward's W_value^T): exact against torch's .t().contiguous(); argument errors."""
+    import ctypes
+    from rwkvtts_amd import _lib
+    x = torch.randn(R, C, generator=torch.Generator().manual_seed(R + C)).to(DEV, torch.bfloat16)
+    out = torch.empty(C, R, dtype=torch.bfloat16, device=DEV)
+    L = _lib.lib()
+    assert L.rwkv7_transpose_bf16(R, C, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, x.t().contiguous())
+    one = ctypes.c_void_p(16)
+    assert L.rwkv7_transpose_bf16(R, C, None, one, None) == -1
+    assert L.rwkv7_transpose_bf16(100, 64, one, one, None) == -4

@@ -25,7 +25,10 @@ def steps(n):
     return ts
 
 
-switches = [("low-rank branches: down projections through the lerp (one GEMM on the LayerNorm output)", fused, "FUSED_MIX_LORA", False, True),
+switches = [("channel-mix backward: W_value^T through the own transpose kernel", fused, "TRANSPOSE_KERNEL", False, True),
+            ("time-mix side: add + LayerNorm + three lerps one-pass forward (with mix_lora)", fused, "FUSED_ADD_LN_MIX_LORA_FWD", False, True),
+            ("parameter-gradient partials: column sums as one launch (sum_slabs tall shape)", fused, "COLSUM_KERNEL", False, True),
+            ("low-rank branches: down projections through the lerp (one GEMM on the LayerNorm output)", fused, "FUSED_MIX_LORA", False, True),
             ("output projection with the residual add as its epilogue (own kernel)", fused, "FUSED_OPROJ_ADD", False, True),
             ("channel mix: activation inside both GEMMs (own kernel, generation 4)", fused, "FUSED_CMIX", False, True),
             ("relu^2 backward in the value dgrad GEMM (own kernel)", fused, "FUSED_RELUSQ_VALUE_BWD", False, True),

@@ -22,3 +22,27 @@ rows = sorted(ka, key=lambda e: -e.count)
 print(f"{'op':60s} {'count':>6s} {'cuda ms':>9s}")
 for e in rows[:60]:
     print(f"{e.key[:60]:60s} {e.count:6d} {getattr(e, 'device_time_total', getattr(e, 'cuda_time_total', 0)) / 1e3:9.2f}")
+
+# second view (round 4): the small ATen launches by input shape and by the first frame of this package on their stack
+if os.environ.get("PROFILE_SITES", "1") == "1":
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof2:
+        step(3)
+        torch.cuda.synchronize()
+    want = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::sum", "aten::cat", "aten::add", "aten::add_", "aten::mul", "aten::mul_",
+            "aten::sigmoid", "aten::tanh", "aten::_foreach_copy_", "aten::index_select", "aten::embedding_dense_backward", "aten::eq", "aten::ne")
+    sites = {}
+    for ev in prof2.events():
+        if ev.name not in want:
+            continue
+        dt = getattr(ev, "device_time_total", getattr(ev, "cuda_time_total", 0))
+        if dt <= 0:
+            continue
+        frame = next((s for s in (ev.stack or []) if "rwkvtts_amd" in s or "bench" in s or "profile_ops" in s), "?")
+        frame = frame.split("rwkvtts_amd/")[-1][:70]
+        key = (ev.name, str(ev.input_shapes)[:60], frame)
+        c = sites.setdefault(key, [0, 0.0])
+        c[0] += 1
+        c[1] += dt
+    print(f"\n{'op':28s} {'shapes':60s} {'site':70s} {'count':>6s} {'dev ms':>8s}")
+    for (name, shp, frame), (n, t) in sorted(sites.items(), key=lambda kv: -kv[1][1])[:70]:
+        print(f"{name:28s} {shp:60s} {frame:70s} {n:6d} {t / 1e3:8.2f}")
