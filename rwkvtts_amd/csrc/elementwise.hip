@@ -34,10 +34,10 @@ struct V8<bf16_t> {
     }
     static __device__ __forceinline__ void st(bf16_t *p, const float (&f)[8]) {
         uint4 r;
-        r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-        r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-        r.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-        r.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+        r.x = pk_bf16(f[0], f[1]);
+        r.y = pk_bf16(f[2], f[3]);
+        r.z = pk_bf16(f[4], f[5]);
+        r.w = pk_bf16(f[6], f[7]);
         *reinterpret_cast<uint4 *>(p) = r;
     }
     static __device__ __forceinline__ float ld1(const bf16_t *p) { return bf2f(p->x); }
@@ -53,6 +53,32 @@ struct V8<float> {
         *reinterpret_cast<float4 *>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
     }
     static __device__ __forceinline__ float ld1(const float *p) { return *p; }
+};
+
+// the 16 (bf16) / 32 (fp32) bytes of 8 consecutive channels as they come from memory: loaded early, converted at the use
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<bf16_t> {
+    uint4 r;
+    __device__ __forceinline__ void load(const bf16_t *p) { r = *reinterpret_cast<const uint4 *>(p); }
+    __device__ __forceinline__ void get(float (&f)[8]) const {
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+};
+template <>
+struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float *p) {
+        a = *reinterpret_cast<const float4 *>(p);
+        b = *reinterpret_cast<const float4 *>(p + 4);
+    }
+    __device__ __forceinline__ void get(float (&f)[8]) const {
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -591,18 +617,38 @@ __global__ void relusq_bwd_s_kernel(long n8, const T *__restrict__ s, const T *_
 template <typename T>
 __device__ __forceinline__ float round_to(float v);
 template <>
-__device__ __forceinline__ float round_to<bf16_t>(float v) { return bf2f(f2bf(v)); }
+__device__ __forceinline__ float round_to<bf16_t>(float v) { return __uint_as_float(pk_bf16(v, v) & 0xffff0000u); }
 template <>
 __device__ __forceinline__ float round_to<float>(float v) { return v; }
 
+// a + b that -ffast-math cannot reassociate: the LayerNorm sums of the one-pass kernels and of the separate stages must come out
+// bit for bit the same (tests/test_fused_gpu.py compares the two routes with torch.equal), whatever shape the compiler gives each loop
+__device__ __forceinline__ float add_pinned(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// red[0 .. ngroups) summed in index order (slots past ngroups hold zeros, red_init: whole float4 groups are read)
+__device__ __forceinline__ float sum_slots(const float *red, int ngroups) {
+    float t = 0.f;
+    for (int i = 0; i < ngroups; i += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(red + i);
+        t = add_pinned(add_pinned(add_pinned(add_pinned(t, v.x), v.y), v.z), v.w);
+    }
+    return t;
+}
 // sum of v over the D/8 threads of the workgroup; red has D/64 slots; every thread gets the total
 __device__ __forceinline__ float block_sum(float v, float *red, int ngroups) {
     v = sum8(v);
     if ((threadIdx.x & 7) == 0) red[threadIdx.x >> 3] = v;
     __syncthreads();
-    float t = 0.f;
-    for (int i = 0; i < ngroups; i++) t += red[i];
-    return t;
+    return sum_slots(red, ngroups);
+}
+// every reduction slot zero before the first block_sum / block_sum2 (they read whole float4 groups)
+template <int ROWS>
+__device__ __forceinline__ void red_init(float (*red)[kEwMaxThreads / 8]) {   // red[ROWS][kEwMaxThreads / 8]
+    for (int i = threadIdx.x; i < ROWS * (kEwMaxThreads / 8); i += blockDim.x) (&red[0][0])[i] = 0.f;
+    __syncthreads();
 }
 
 template <typename T>
@@ -612,7 +658,8 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_fwd_kernel(long rows, in
                                                                    const T *__restrict__ beta, float eps,
                                                                    T *__restrict__ x_out, T *__restrict__ h,
                                                                    float *__restrict__ mean, float *__restrict__ rstd) {
-    __shared__ float red[2][kEwMaxThreads / 8];
+    __shared__ __attribute__((aligned(16))) float red[2][kEwMaxThreads / 8];
+    red_init<2>(red);
     const int c = threadIdx.x * 8, ng = D / 64;
     const float inv_d = 1.0f / (float)D;
     float gm[8], bt[8];
@@ -663,7 +710,8 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_bwd_kernel(long rows, in
                                                                    const float *__restrict__ rstd,
                                                                    const T *__restrict__ gamma, T *__restrict__ dx,
                                                                    float *__restrict__ dpart /* [nblk][2][D] */) {
-    __shared__ float red[4][kEwMaxThreads / 8];
+    __shared__ __attribute__((aligned(16))) float red[4][kEwMaxThreads / 8];
+    red_init<4>(red);
     const int c = threadIdx.x * 8, ng = D / 64;
     const float inv_d = 1.0f / (float)D;
     float gm[8], dg[8], db[8];
@@ -696,11 +744,7 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_bwd_kernel(long rows, in
             red[ph + 1][threadIdx.x >> 3] = s2;
         }
         __syncthreads();
-        float m1 = 0.f, m2 = 0.f;
-        for (int i = 0; i < ng; i++) {
-            m1 += red[ph][i];
-            m2 += red[ph + 1][i];
-        }
+        float m1 = sum_slots(red[ph], ng), m2 = sum_slots(red[ph + 1], ng);
         m1 *= inv_d;
         m2 *= inv_d;
         float r[8];
@@ -737,11 +781,7 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[kEwM
         red[ph + 1][threadIdx.x >> 3] = b;
     }
     __syncthreads();
-    float ta = 0.f, tb = 0.f;
-    for (int i = 0; i < ngroups; i++) {
-        ta += red[ph][i];
-        tb += red[ph + 1][i];
-    }
+    const float ta = sum_slots(red[ph], ngroups), tb = sum_slots(red[ph + 1], ngroups);
     a = ta;
     b = tb;
 }
@@ -754,7 +794,8 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_mix_fwd_kernel(int B, in
                                                                        T *__restrict__ out, float *__restrict__ mean,
                                                                        float *__restrict__ rstd, T *__restrict__ h_out) {
     // h_out (may be NULL): also store h = LayerNorm(x1) (unmasked), for a backward that runs as the two separate kernels
-    __shared__ float red[4][kEwMaxThreads / 8];
+    __shared__ __attribute__((aligned(16))) float red[4][kEwMaxThreads / 8];
+    red_init<4>(red);
     const int c = threadIdx.x * 8, ng = D / 64;
     const long rows = (long)B * T_;
     const float inv_d = 1.0f / (float)D;
@@ -769,14 +810,30 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_mix_fwd_kernel(int B, in
 #pragma unroll
     for (int i = 0; i < NMIX; i++) V8<T>::ld(params + (long)i * D + c, p[i]);
     int ph = 0;
+    // Round 4: unconditional loads issued one row ahead (see mix_add_ln_bwd_kernel below: behind conditions hipcc waited for every load
+    // right behind its issue -- three serialized HBM latencies per row of a run)
+    const bool has_branch = branch != nullptr, has_mask = mask != nullptr;
+    const T *const brq = has_branch ? branch : x;
+    const T *const maskq = has_mask ? mask : gamma;
+    struct Pre {
+        Raw8<T> xv, bv;
+        float m;
+    };
+    auto fetch = [&](long row) {
+        Pre f;
+        f.xv.load(x + row * D + c);
+        f.bv.load(brq + row * D + c);
+        f.m = V8<T>::ld1(maskq + (has_mask ? row : 0));
+        return f;
+    };
     // hm of one row; WRITE: also x1 and the statistics (mean, then the centred squares: two barriers, as add_ln_fwd_kernel)
-    auto ln_row = [&](long row, bool write, float (&hm)[8]) {
+    auto ln_row = [&](const Pre &f, long row, bool write, float (&hm)[8]) {
         const long o = row * D + c;
         float v[8];
-        V8<T>::ld(x + o, v);
-        if (branch) {
+        f.xv.get(v);
+        if (has_branch) {
             float b[8];
-            V8<T>::ld(branch + o, b);
+            f.bv.get(b);
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = round_to<T>(v[j] + b[j]);
             if (write) V8<T>::st(x_out + o, v);
@@ -797,7 +854,7 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_mix_fwd_kernel(int B, in
         block_sum2(q, dummy, red, ph, ng);
         ph ^= 2;
         const float rs = rsqrtf(q * inv_d + eps);
-        const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+        const float m = has_mask ? f.m : 1.f;
 #pragma unroll
         for (int j = 0; j < 8; j++) hm[j] = round_to<T>(fmaf(v[j] * rs, gm[j], bt[j]));
         if (write && h_out) V8<T>::st(h_out + o, hm);
@@ -810,29 +867,35 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_mix_fwd_kernel(int B, in
     };
     for (long r_lo = (long)blockIdx.x * run_len; r_lo < rows; r_lo += (long)gridDim.x * run_len) {
         const long r_hi = r_lo + run_len < rows ? r_lo + run_len : rows;
+        int t = (int)(r_lo % T_);                       // one 64-bit division per run
+        const long first = t != 0 ? r_lo - 1 : r_lo;    // the neighbour row is re-normalised at the start of a run
+        t = t != 0 ? t - 1 : 0;
         float hp[8];
-        if ((r_lo % T_) != 0) {
-            ln_row(r_lo - 1, false, hp);
-        } else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) hp[j] = 0.f;
-        }
-        for (long row = r_lo; row < r_hi; row++) {
+        for (int j = 0; j < 8; j++) hp[j] = 0.f;
+        Pre A = fetch(first);
+        for (long row = first; row < r_hi; row++) {
+            const Pre Bn = fetch(row + 1 < r_hi ? row + 1 : row);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool write = row >= r_lo;
             float hc[8];
-            ln_row(row, true, hc);
-            if ((row % T_) == 0) {
+            ln_row(A, row, write, hc);
+            if (write) {
+                const float keep = t != 0 ? 1.f : 0.f;   // first step of a sequence: shift(x) = 0
 #pragma unroll
-                for (int j = 0; j < 8; j++) hp[j] = 0.f;   // first step of a sequence: shift(x) = 0
-            }
+                for (int j = 0; j < 8; j++) hp[j] *= keep;
 #pragma unroll
-            for (int i = 0; i < NMIX; i++) {
-                float o[8];
+                for (int i = 0; i < NMIX; i++) {
+                    float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) o[j] = fmaf(hp[j] - hc[j], p[i][j], hc[j]);
-                V8<T>::st(out + ((long)i * rows + row) * D + c, o);
+                    for (int j = 0; j < 8; j++) o[j] = fmaf(hp[j] - hc[j], p[i][j], hc[j]);
+                    V8<T>::st(out + ((long)i * rows + row) * D + c, o);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) hp[j] = hc[j];
+            t = t + 1 < T_ ? t + 1 : 0;
+            A = Bn;
         }
     }
 }
@@ -846,7 +909,8 @@ __global__ __launch_bounds__(kEwMaxThreads) void mix_add_ln_bwd_kernel(int B, in
                                                                        const T *__restrict__ gamma, const T *__restrict__ beta,
                                                                        const T *__restrict__ mask, const T *__restrict__ params,
                                                                        T *__restrict__ dx, float *__restrict__ dpart) {
-    __shared__ float red[4][kEwMaxThreads / 8];
+    __shared__ __attribute__((aligned(16))) float red[4][kEwMaxThreads / 8];
+    red_init<4>(red);
     const int c = threadIdx.x * 8, ng = D / 64;
     const long rows = (long)B * T_;
     const float inv_d = 1.0f / (float)D;
@@ -866,56 +930,89 @@ __global__ __launch_bounds__(kEwMaxThreads) void mix_add_ln_bwd_kernel(int B, in
 #pragma unroll
         for (int j = 0; j < 8; j++) dp[i][j] = 0.f;
     }
-    // xhat and hm of a row, from what the forward saved
-    auto renorm = [&](long row, float (&xh)[8], float (&hm)[8], float &rs) {
-        V8<T>::ld(x1 + row * D + c, xh);
-        const float mu = mean[row];
-        rs = rstd[row];
-        const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+    // Round 4: every load of a row iteration is UNCONDITIONAL (clamped rows, NULL pointers replaced by a valid one and the value
+    // dropped by a select) and issued ONE ITERATION AHEAD.  The first form loaded x1[row - 1], the mask, g and d_resid behind
+    // conditions, each merged with "no value" by a phi, so hipcc waited for every one of them right behind its issue (s_waitcnt
+    // vmcnt(0) after each global_load in the ISA): four to five serialized HBM latencies per row and run -- the kernel streamed at
+    // 2.3 TB/s where the one-row-per-workgroup stages reach 4-5.7 by sheer parallelism.
+    const bool has_dr = d_resid != nullptr, has_mask = mask != nullptr;
+    const T *const drq = has_dr ? d_resid : x1;
+    const T *const maskq = has_mask ? mask : gamma;
+    struct Pre {
+        Raw8<T> x1p, dr, g[NMIX];
+        float mu, rs, m_prev, m_cur;
+    };
+    auto fetch = [&](long row) {   // what the iteration of `row` needs: x1 / statistics / mask of row - 1, g, d_resid and mask of row
+        Pre f;
+        const long rp = row > 0 ? row - 1 : 0;
+        f.x1p.load(x1 + rp * D + c);
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            xh[j] = (xh[j] - mu) * rs;
-            hm[j] = round_to<T>(fmaf(xh[j], gm[j], bt[j])) * m;
-        }
+        for (int i = 0; i < NMIX; i++) f.g[i].load(reinterpret_cast<const T *>(gs.g[i]) + row * D + c);
+        f.dr.load(drq + row * D + c);
+        f.mu = mean[rp];
+        f.rs = rstd[rp];
+        f.m_prev = V8<T>::ld1(maskq + (has_mask ? rp : 0));
+        f.m_cur = V8<T>::ld1(maskq + (has_mask ? row : 0));
+        return f;
     };
     int ph = 0;
     for (long r_lo = (long)blockIdx.x * run_len; r_lo < rows; r_lo += (long)gridDim.x * run_len) {
         const long r_hi = r_lo + run_len < rows ? r_lo + run_len : rows;
-        // prime the carried values with row r_hi (the row after this run), if it belongs to the same sequence
-        if (r_hi < rows && (r_hi % T_) != 0) {
-#pragma unroll
-            for (int i = 0; i < NMIX; i++) V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + r_hi * D + c, gn[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NMIX; i++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) gn[i][j] = 0.f;
-        }
+        Pre A = fetch(r_hi - 1);
+        // the carried values: g of row r_hi (the row after this run) if it belongs to the same sequence, xhat / hm of row r_hi - 1
+        const bool has_next = r_hi < rows && (r_hi % T_) != 0;
         float xc[8], hc[8], rs_c;
-        renorm(r_hi - 1, xc, hc, rs_c);
-        for (long row = r_hi - 1; row >= r_lo; row--) {
-            const int t = (int)(row % T_);
-            float xp[8], hp[8], rs_p = 0.f;
-            if (t > 0) {
-                renorm(row - 1, xp, hp, rs_p);
-            } else {
+        {
+            const long rn = has_next ? r_hi : r_hi - 1;
+            Raw8<T> gr[NMIX], xr;
 #pragma unroll
-                for (int j = 0; j < 8; j++) xp[j] = hp[j] = 0.f;
+            for (int i = 0; i < NMIX; i++) gr[i].load(reinterpret_cast<const T *>(gs.g[i]) + rn * D + c);
+            xr.load(x1 + (r_hi - 1) * D + c);
+            const float mu = mean[r_hi - 1], m0 = V8<T>::ld1(maskq + (has_mask ? r_hi - 1 : 0));
+            rs_c = rstd[r_hi - 1];
+            const float m = has_mask ? m0 : 1.f, keep = has_next ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < NMIX; i++) {
+                gr[i].get(gn[i]);
+#pragma unroll
+                for (int j = 0; j < 8; j++) gn[i][j] *= keep;
             }
-            const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+            xr.get(xc);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                xc[j] = (xc[j] - mu) * rs_c;
+                hc[j] = round_to<T>(fmaf(xc[j], gm[j], bt[j])) * m;
+            }
+        }
+        int t = (int)((r_hi - 1) % T_) + 1;                      // one 64-bit division per run, not per row
+        for (long row = r_hi - 1; row >= r_lo; row--) {
+            const Pre Bn = fetch(row > r_lo ? row - 1 : r_lo);   // the next iteration's rows (the last one re-reads row r_lo: dropped)
+            __builtin_amdgcn_sched_barrier(0);                   // the scheduler would sink these loads to their use
+            t = t > 0 ? t - 1 : T_ - 1;
+            // row - 1 from what the forward saved (the row before a sequence start is normalised too: it is the next iteration's row)
+            float xq[8], hq[8], hp[8];
+            A.x1p.get(xq);
+            const float mq = has_mask ? A.m_prev : 1.f, first = t > 0 ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                xq[j] = (xq[j] - A.mu) * A.rs;
+                hq[j] = round_to<T>(fmaf(xq[j], gm[j], bt[j])) * mq;
+                hp[j] = hq[j] * first;                           // first step of a sequence: shift(hm) = 0
+            }
+            const float m = has_mask ? A.m_cur : 1.f;
             float g[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) g[j] = 0.f;
 #pragma unroll
             for (int i = 0; i < NMIX; i++) {
                 float gc[8];
-                V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + row * D + c, gc);
+                A.g[i].get(gc);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     g[j] = fmaf(gc[j], 1.f - p[i][j], g[j]);
                     g[j] = fmaf(gn[i][j], p[i][j], g[j]);     // g_i[t+1] (zero past the end of the sequence)
                     dp[i][j] = fmaf(gc[j], hp[j] - hc[j], dp[i][j]);
-                    gn[i][j] = t > 0 ? gc[j] : 0.f;            // row-1 is the last row of the previous sequence if t == 0
+                    gn[i][j] = gc[j] * first;                  // row - 1 is the last row of the previous sequence if t == 0
                 }
             }
             // dh = g * mask, rounded to the tensor type as the separate mix_bwd kernel stores it
@@ -934,22 +1031,21 @@ __global__ __launch_bounds__(kEwMaxThreads) void mix_add_ln_bwd_kernel(int B, in
             s1 *= inv_d;
             s2 *= inv_d;
             float r[8];
-            if (d_resid) {
-                V8<T>::ld(d_resid + row * D + c, r);
-            } else {
+            A.dr.get(r);
+            const float keep_r = has_dr ? 1.f : 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; j++) r[j] = 0.f;
+            for (int j = 0; j < 8; j++) {
+                r[j] *= keep_r;
+                r[j] += rs_c * (g[j] - s1 - xc[j] * s2);   // (the expression of the first form: same contraction, same bits)
             }
-#pragma unroll
-            for (int j = 0; j < 8; j++) r[j] += rs_c * (g[j] - s1 - xc[j] * s2);
             V8<T>::st(dx + row * D + c, r);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                xc[j] = xp[j];
-                hc[j] = hp[j];
+                xc[j] = xq[j];
+                hc[j] = hq[j];
             }
-            rs_c = rs_p;
-            if (t == 0 && row > r_lo) renorm(row - 1, xc, hc, rs_c);  // the run continues into the previous sequence
+            rs_c = A.rs;
+            A = Bn;
         }
     }
 #pragma unroll

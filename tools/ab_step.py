@@ -28,6 +28,14 @@ def steps(n):
 switches = [("channel-mix backward: W_value^T through the own transpose kernel", fused, "TRANSPOSE_KERNEL", False, True),
             ("time-mix side: add + LayerNorm + three lerps one-pass forward (with mix_lora)", fused, "FUSED_ADD_LN_MIX_LORA_FWD", False, True),
             ("parameter-gradient partials: column sums as one launch (sum_slabs tall shape)", fused, "COLSUM_KERNEL", False, True),
+            ("round 4 knobs: one-pass backward partials 2048 -> 4096 workgroups", fused, "_ADD_LN_MIX_BWD_BLOCKS", 2048, 4096),
+            ("round 4 knobs: one-pass backward partials 2048 -> 8192 workgroups", fused, "_ADD_LN_MIX_BWD_BLOCKS", 2048, 8192),
+            ("round 4 knobs: one-pass stages run of 4 -> 8 rows", fused, "_ADD_LN_MIX_RUN", 4, 8),
+            ("round 4 knobs: one-pass stages run of 4 -> 2 rows", fused, "_ADD_LN_MIX_RUN", 4, 2),
+            ("round 4 knobs: parameter-gradient partials 1024 -> 2048 workgroups", fused, "_BWD_BLOCKS", 1024, 2048),
+            ("round 4 knobs: parameter-gradient partials 1024 -> 4096 workgroups", fused, "_BWD_BLOCKS", 1024, 4096),
+            ("round 4 knobs: mix backward 1024 -> 2048 workgroups", fused, "_MIX_BWD_BLOCKS", 1024, 2048),
+            ("round 4 knobs: mix backward 1024 -> 4096 workgroups", fused, "_MIX_BWD_BLOCKS", 1024, 4096),
             ("low-rank branches: down projections through the lerp (one GEMM on the LayerNorm output)", fused, "FUSED_MIX_LORA", False, True),
             ("output projection with the residual add as its epilogue (own kernel)", fused, "FUSED_OPROJ_ADD", False, True),
             ("channel mix: activation inside both GEMMs (own kernel, generation 4)", fused, "FUSED_CMIX", False, True),
