@@ -435,6 +435,130 @@ __global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_kernel(long ro
     V8<float>::st(dpart + ((long)blockIdx.x * 5 + 4) * D + c, sv_acc);
 }
 
+// Round 4: the SAME arithmetic for the configuration bf16 training runs (chunked scan backward: one gradient set; compact hand-off
+// from tmix_post's backward) with every load of a row issued at the top of the iteration, unconditionally.  In the general kernel
+// above each optional addend sits behind `if (pointer)`, the loads behind it are merged with "no value" by a phi, and hipcc waits
+// for every load right behind its issue: the ISA showed 18 global loads each followed by s_waitcnt vmcnt(0) -- eighteen serialized
+// HBM latencies per row on a kernel with eight waves per CU.  Optional tensors that remain (mask, d_vfirst_in) are read through a
+// valid substitute pointer and dropped by a multiply; HAS_V (layers >= 1) is a template parameter.
+template <typename T, bool HAS_V>
+__global__ __launch_bounds__(kEwMaxThreads) void tmix_prepare_bwd_fast_kernel(
+    long rows, int D, const T *__restrict__ w_pre, const T *__restrict__ k, const T *__restrict__ v, const T *__restrict__ a_pre,
+    const T *__restrict__ v_pre, const T *__restrict__ v_first, const T *__restrict__ mask, const T *__restrict__ k_k,
+    const T *__restrict__ k_a, const T *__restrict__ d_w, const T *__restrict__ d_k2, const T *__restrict__ d_v2,
+    const T *__restrict__ d_ain, const T *__restrict__ d_bin, T *__restrict__ d_wpre, T *__restrict__ d_k, T *__restrict__ d_v,
+    T *__restrict__ d_apre, T *__restrict__ d_vpre, T *__restrict__ d_vfirst, float *__restrict__ dpart, const T *__restrict__ d_r_a,
+    T *__restrict__ d_r, const T *__restrict__ d_vfirst_in, const T *__restrict__ dt_, const T *__restrict__ r_,
+    const T *__restrict__ r_k, const float *__restrict__ hscal) {
+    const int c = threadIdx.x * 8;
+    float kk_p[8], ka_p[8], rk[8], dkk_acc[8], dka_acc[8], sw_acc[8], sa_acc[8], sv_acc[8];
+    V8<T>::ld(k_k + c, kk_p);
+    V8<T>::ld(k_a + c, ka_p);
+    V8<T>::ld(r_k + c, rk);
+#pragma unroll
+    for (int j = 0; j < 8; j++) dkk_acc[j] = dka_acc[j] = sw_acc[j] = sa_acc[j] = sv_acc[j] = 0.f;
+    const bool has_mask = mask != nullptr, has_vin = d_vfirst_in != nullptr;
+    const T *const maskq = has_mask ? mask : k_k;
+    const T *const vinq = has_vin ? d_vfirst_in : d_w;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long o = row * D + c;
+        Raw8<T> q_z, q_k, q_v, q_ap, q_gw, q_gk2, q_gv2, q_ga, q_gb, q_r3, q_dt, q_rr, q_vp, q_vf, q_vin;
+        q_z.load(w_pre + o); q_k.load(k + o); q_v.load(v + o); q_ap.load(a_pre + o);
+        q_gw.load(d_w + o); q_gk2.load(d_k2 + o); q_gv2.load(d_v2 + o); q_ga.load(d_ain + o); q_gb.load(d_bin + o);
+        q_r3.load(d_r_a + o); q_dt.load(dt_ + o); q_rr.load(r_ + o);
+        if constexpr (HAS_V) {
+            q_vp.load(v_pre + o); q_vf.load(v_first + o); q_vin.load(vinq + o);
+        }
+        const float2 hs = *reinterpret_cast<const float2 *>(hscal + (row * (D >> 6) + (threadIdx.x >> 3)) * 2);
+        const float m0 = V8<T>::ld1(maskq + (has_mask ? row : 0));
+        __builtin_amdgcn_sched_barrier(0);
+        const float m = has_mask ? m0 : 1.f;
+        float z[8], kx[8], vx[8], ap[8], gw[8], gk2[8], gv2[8], ga[8], gb[8], r3[8];
+        q_z.get(z); q_k.get(kx); q_v.get(vx); q_ap.get(ap); q_gw.get(gw); q_gk2.get(gk2); q_gv2.get(gv2); q_ga.get(ga); q_gb.get(gb);
+        q_r3.get(r3);
+        {   // compact hand-off: the bonus term's contributions, rebuilt (a head = this thread's 8 channels' group of 8 lanes)
+            float dtv[8], rr[8];
+            q_dt.get(dtv); q_rr.get(rr);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float k2 = kx[j] * m * fmaf(sigmoidf_(ap[j]) - 1.f, ka_p[j], 1.f);   // what tmix_prepare's forward stored
+                gv2[j] = fmaf(dtv[j], hs.x, gv2[j]);
+                gk2[j] = fmaf(hs.y * rr[j], rk[j], gk2[j]);
+                r3[j] = fmaf(hs.y * k2, rk[j], r3[j]);
+            }
+        }
+        V8<T>::st(d_r + o, r3);
+        float kkr[8], a[8], du[8], u[8], o1[8], o2[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            kx[j] *= m;
+            vx[j] *= m;
+            kkr[j] = kx[j] * kk_p[j];
+            ss = fmaf(kkr[j], kkr[j], ss);
+            a[j] = sigmoidf_(ap[j]);
+        }
+        ss = sum8(ss);
+        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            u[j] = kkr[j] * rn;                            // unit vector; kk = u * m
+            du[j] = (gb[j] * a[j] - ga[j]) * m;            // dL/du
+            dot = fmaf(du[j], u[j], dot);
+        }
+        dot = sum8(dot);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            o1[j] = gw[j] * m * sigmoidf_(-z[j]);
+            sw_acc[j] += o1[j];   // the low-rank branches' bias gradients are these column sums
+        }
+        V8<T>::st(d_wpre + o, o1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float dkkr = (du[j] - u[j] * dot) * rn;
+            const float kk = u[j] * m;
+            const float da = gk2[j] * kx[j] * ka_p[j] + gb[j] * kk;
+            const float dkx = gk2[j] * fmaf(a[j] - 1.f, ka_p[j], 1.f) + dkkr * kk_p[j];
+            dkk_acc[j] = fmaf(dkkr, kx[j], dkk_acc[j]);
+            dka_acc[j] = fmaf(gk2[j] * kx[j], a[j] - 1.f, dka_acc[j]);
+            o1[j] = dkx * m;
+            o2[j] = da * a[j] * (1.f - a[j]);
+            sa_acc[j] += o2[j];
+        }
+        V8<T>::st(d_k + o, o1);
+        V8<T>::st(d_apre + o, o2);
+        if constexpr (HAS_V) {
+            float vp[8], vf[8], o3[8], vin[8];
+            q_vp.get(vp); q_vf.get(vf); q_vin.get(vin);
+            const float keep = has_vin ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float s = sigmoidf_(vp[j]);
+                const float g2 = gv2[j] * m;
+                o1[j] = g2 * (1.f - s) * m;              // d_v
+                o2[j] = g2 * (vf[j] - vx[j]) * s * (1.f - s);  // d_vpre
+                o3[j] = g2 * s;                          // d_vfirst
+                sv_acc[j] += o2[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) o3[j] += vin[j] * keep;
+            V8<T>::st(d_v + o, o1);
+            V8<T>::st(d_vpre + o, o2);
+            V8<T>::st(d_vfirst + o, o3);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) o1[j] = gv2[j] * m * m;
+            V8<T>::st(d_v + o, o1);
+        }
+    }
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 0) * D + c, dkk_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 1) * D + c, dka_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 2) * D + c, sw_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 3) * D + c, sa_acc);
+    V8<float>::st(dpart + ((long)blockIdx.x * 5 + 4) * D + c, sv_acc);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // tmix_post (rwkv_s2s_single_ffn.py:192-195): out = (GroupNorm_head(y) + (sum_head r k r_k) v) * g
 // ------------------------------------------------------------------------------------------------------
@@ -1428,6 +1552,23 @@ int tmix_prepare_bwd_sum(long rows, int D, const void *w_pre, const void *k, con
     PrepBwdExtra<T> ex{g[1], g[3], g[4], g[6], g[8], g[10], g[11], g[12], g[13], (T *)d_r, g[14],
                        ngsum > 15 ? g[15] : nullptr, ngsum > 15 ? g[16] : nullptr, ngsum > 15 ? g[17] : nullptr,
                        ngsum > 15 ? reinterpret_cast<const float *>(gsum[18]) : nullptr};
+    const bool one_set = !ex.d_w_b && !ex.d_k2_b && !ex.d_k2_c && !ex.d_v2_b && !ex.d_a_b && !ex.d_b_b && !ex.d_r_b && !ex.d_r_c;
+    if (one_set && ex.dt && ex.r && ex.r_k && ex.hscal && ex.d_r_a && (v_pre == nullptr) == (v_first == nullptr)) {
+        // what bf16 training launches: one gradient set from the chunked scan backward + the compact hand-off (loads hoisted)
+        if (v_pre)
+            hipLaunchKernelGGL((tmix_prepare_bwd_fast_kernel<T, true>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)w_pre,
+                               (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre, (const T *)v_first, (const T *)mask,
+                               (const T *)k_k, (const T *)k_a, g[0], g[2], g[5], g[7], g[9], (T *)d_wpre, (T *)d_k, (T *)d_v,
+                               (T *)d_apre, (T *)d_vpre, (T *)d_vfirst, dpart, ex.d_r_a, ex.d_r, ex.d_vfirst_in, ex.dt, ex.r, ex.r_k,
+                               ex.hscal);
+        else
+            hipLaunchKernelGGL((tmix_prepare_bwd_fast_kernel<T, false>), dim3(nblocks), dim3(D / 8), 0, st, rows, D, (const T *)w_pre,
+                               (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre, (const T *)v_first, (const T *)mask,
+                               (const T *)k_k, (const T *)k_a, g[0], g[2], g[5], g[7], g[9], (T *)d_wpre, (T *)d_k, (T *)d_v,
+                               (T *)d_apre, (T *)d_vpre, (T *)d_vfirst, dpart, ex.d_r_a, ex.d_r, ex.d_vfirst_in, ex.dt, ex.r, ex.r_k,
+                               ex.hscal);
+        return finish();
+    }
     hipLaunchKernelGGL((tmix_prepare_bwd_kernel<T, true>), dim3(nblocks), dim3(D / 8), 0, st, rows, D,
                        (const T *)w_pre, (const T *)k, (const T *)v, (const T *)a_pre, (const T *)v_pre,
                        (const T *)v_first, (const T *)mask, (const T *)k_k, (const T *)k_a, g[0], g[2], g[5], g[7],
