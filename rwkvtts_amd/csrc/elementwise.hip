@@ -21,6 +21,15 @@ namespace rwkv7 {
 // and serialised its loads: 1.1 TB/s).
 constexpr int kEwMaxThreads = 512;
 
+// two fp32 -> packed bf16 pair (low half = a), round-to-nearest-even in ONE v_cvt_pk_bf16_f32 (gfx950) instead of the ~14 integer
+// instructions of two f2bf(): the row-stream kernels below round 8-24 values per thread and row
+typedef __bf16 pkbf2_t __attribute__((ext_vector_type(2)));
+typedef float pkf2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    const pkf2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pkbf2_t));
+}
+
 template <typename T>
 struct V8;
 template <>

@@ -23,15 +23,6 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     return (uint16_t)(x >> 16);
 }
 
-// two fp32 -> packed bf16 pair (low half = a), round-to-nearest-even in ONE v_cvt_pk_bf16_f32 (gfx950) instead of the ~14 integer
-// instructions of two f2bf(): the row-stream kernels of elementwise.hip round 8-24 values per thread and row
-typedef __bf16 pkbf2_t __attribute__((ext_vector_type(2)));
-typedef float pkf2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-    const pkf2_t v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pkbf2_t));
-}
-
 // ---- 4-element vector I/O, templated on the tensor element type -------------------------------
 template <typename T>
 struct Raw4;
