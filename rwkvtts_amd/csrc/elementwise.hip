@@ -103,28 +103,27 @@ __global__ __launch_bounds__(kEwMaxThreads) void mix_fwd_kernel(int B, int T_, i
     float p[NMIX][8];
 #pragma unroll
     for (int i = 0; i < NMIX; i++) V8<T>::ld(params + (long)i * D + c, p[i]);
+    // (round 4) both rows and both mask values are loaded unconditionally at the top -- a load behind `if (t > 0)` / `if (mask)` is
+    // waited for at its issue -- and dropped by a multiply; only the carried-state row x_prev (inference) stays behind its branch
+    const bool has_mask = mask != nullptr;
+    const T *const maskq = has_mask ? mask : params;
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
         const int t = (int)(row % T_);
+        const long rp = row > 0 ? row - 1 : 0;
+        Raw8<T> qc, qp;
+        qc.load(x + row * D + c);
+        qp.load(x + rp * D + c);
+        const float mc0 = V8<T>::ld1(maskq + (has_mask ? row : 0)), mp0 = V8<T>::ld1(maskq + (has_mask ? rp : 0));
         float xc[8], xp[8];
-        V8<T>::ld(x + row * D + c, xc);
-        if (mask) {
-            const float m = V8<T>::ld1(mask + row);
+        qc.get(xc);
+        qp.get(xp);
+        const float mc = has_mask ? mc0 : 1.f, mp = (has_mask ? mp0 : 1.f) * (t > 0 ? 1.f : 0.f);
 #pragma unroll
-            for (int j = 0; j < 8; j++) xc[j] *= m;
+        for (int j = 0; j < 8; j++) {
+            xc[j] *= mc;
+            xp[j] *= mp;
         }
-        if (t > 0) {
-            V8<T>::ld(x + (row - 1) * D + c, xp);
-            if (mask) {
-                const float m = V8<T>::ld1(mask + row - 1);
-#pragma unroll
-                for (int j = 0; j < 8; j++) xp[j] *= m;
-            }
-        } else if (x_prev) {
-            V8<T>::ld(x_prev + (row / T_) * D + c, xp);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) xp[j] = 0.f;
-        }
+        if (t == 0 && x_prev) V8<T>::ld(x_prev + (row / T_) * D + c, xp);
 #pragma unroll
         for (int i = 0; i < NMIX; i++) {
             float o[8];
@@ -161,61 +160,88 @@ __global__ __launch_bounds__(kEwMaxThreads) void mix_bwd_kernel(int B, int T_, i
 #pragma unroll
         for (int j = 0; j < 8; j++) dp[i][j] = 0.f;
     }
-    auto load_xm = [&](long row, float (&o)[8]) {  // xm[row] = x[row] * mask[row]
-        V8<T>::ld(x + row * D + c, o);
-        if (mask) {
-            const float m = V8<T>::ld1(mask + row);
+    // Round 4: the loads of a row iteration are unconditional (clamped rows; a NULL mask is read through a valid pointer and
+    // dropped) and issued one iteration ahead -- behind conditions hipcc waited for each of them at its issue (see
+    // mix_add_ln_bwd_kernel).  Only the carried-state row x_prev (inference) stays behind its branch.
+    const bool has_mask = mask != nullptr;
+    const T *const maskq = has_mask ? mask : params;
+    struct Pre {
+        Raw8<T> xp, g[NMIX];
+        float m_prev, m_cur;
+    };
+    auto fetch = [&](long row) {   // x / mask of row - 1, g and mask of row
+        Pre f;
+        const long rp = row > 0 ? row - 1 : 0;
+        f.xp.load(x + rp * D + c);
 #pragma unroll
-            for (int j = 0; j < 8; j++) o[j] *= m;
-        }
+        for (int i = 0; i < NMIX; i++) f.g[i].load(reinterpret_cast<const T *>(gs.g[i]) + row * D + c);
+        f.m_prev = V8<T>::ld1(maskq + (has_mask ? rp : 0));
+        f.m_cur = V8<T>::ld1(maskq + (has_mask ? row : 0));
+        return f;
     };
     for (long r_lo = (long)blockIdx.x * run_len; r_lo < rows; r_lo += (long)gridDim.x * run_len) {
         const long r_hi = r_lo + run_len < rows ? r_lo + run_len : rows;
-        // prime the carried values with row r_hi (the row after this run), if it belongs to the same sequence
-        if (r_hi < rows && (r_hi % T_) != 0) {
-#pragma unroll
-            for (int i = 0; i < NMIX; i++) V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + r_hi * D + c, gn[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NMIX; i++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) gn[i][j] = 0.f;
-        }
+        Pre A = fetch(r_hi - 1);
+        // the carried values: g of row r_hi (the row after this run) if it belongs to the same sequence, xm of row r_hi - 1
+        const bool has_next = r_hi < rows && (r_hi % T_) != 0;
         float xc[8];
-        load_xm(r_hi - 1, xc);
-        for (long row = r_hi - 1; row >= r_lo; row--) {
-            const int t = (int)(row % T_);
-            float xp[8], acc[8];
-            if (t > 0) {
-                load_xm(row - 1, xp);
-            } else if (x_prev) {
-                V8<T>::ld(x_prev + (row / T_) * D + c, xp);
-            } else {
+        {
+            const long rn = has_next ? r_hi : r_hi - 1;
+            Raw8<T> gr[NMIX], xr;
 #pragma unroll
-                for (int j = 0; j < 8; j++) xp[j] = 0.f;
+            for (int i = 0; i < NMIX; i++) gr[i].load(reinterpret_cast<const T *>(gs.g[i]) + rn * D + c);
+            xr.load(x + (r_hi - 1) * D + c);
+            const float m0 = V8<T>::ld1(maskq + (has_mask ? r_hi - 1 : 0));
+            const float m = has_mask ? m0 : 1.f, keep = has_next ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < NMIX; i++) {
+                gr[i].get(gn[i]);
+#pragma unroll
+                for (int j = 0; j < 8; j++) gn[i][j] *= keep;
             }
-            const float m = mask ? V8<T>::ld1(mask + row) : 1.f;
+            xr.get(xc);
+            if (has_mask) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) xc[j] *= m;
+            }
+        }
+        int t = (int)((r_hi - 1) % T_) + 1;   // one 64-bit division per run
+        for (long row = r_hi - 1; row >= r_lo; row--) {
+            const Pre Bn = fetch(row > r_lo ? row - 1 : r_lo);
+            __builtin_amdgcn_sched_barrier(0);
+            t = t > 0 ? t - 1 : T_ - 1;
+            float xq[8], xp[8], acc[8];
+            A.xp.get(xq);                       // xm[row - 1]: the next iteration's row whatever t is
+            if (has_mask) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) xq[j] *= A.m_prev;
+            }
+            const float first = t > 0 ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) xp[j] = xq[j] * first;
+            if (t == 0 && x_prev) V8<T>::ld(x_prev + (row / T_) * D + c, xp);
+            const float m = has_mask ? A.m_cur : 1.f;
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] = 0.f;
 #pragma unroll
             for (int i = 0; i < NMIX; i++) {
                 float gc[8];
-                V8<T>::ld(reinterpret_cast<const T *>(gs.g[i]) + row * D + c, gc);
+                A.g[i].get(gc);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     acc[j] = fmaf(gc[j], 1.f - p[i][j], acc[j]);
                     acc[j] = fmaf(gn[i][j], p[i][j], acc[j]);  // g_i[t+1] (zero past the end of the sequence)
                     dp[i][j] = fmaf(gc[j], xp[j] - xc[j], dp[i][j]);
-                    gn[i][j] = t > 0 ? gc[j] : 0.f;             // row-1 is the last row of the previous sequence if t == 0
+                    gn[i][j] = gc[j] * first;                   // row-1 is the last row of the previous sequence if t == 0
                 }
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 acc[j] *= m;
-                xc[j] = xp[j];
+                xc[j] = xq[j];
             }
-            if (t == 0 && row > r_lo) load_xm(row - 1, xc);  // the run continues into the previous sequence
             V8<T>::st(dx + row * D + c, acc);
+            A = Bn;
         }
     }
 #pragma unroll
@@ -803,17 +829,20 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_fwd_kernel(long rows, in
 #pragma unroll
         for (int j = 0; j < 8; j++) bt[j] = 0.f;
     }
+    const bool has_branch = branch != nullptr;
+    const T *const brq = has_branch ? branch : x;   // (round 4) both rows loaded unconditionally: no wait between them
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
         const long o = row * D + c;
-        float v[8];
-        V8<T>::ld(x + o, v);
-        if (branch) {
-            float b[8];
-            V8<T>::ld(branch + o, b);
+        Raw8<T> qx, qb;
+        qx.load(x + o);
+        qb.load(brq + o);
+        float v[8], b[8];
+        qx.get(v);
+        qb.get(b);
+        const float keep_b = has_branch ? 1.f : 0.f;   // no branch around the use: the compiler would sink the load into it
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = round_to<T>(v[j] + b[j]);
-            V8<T>::st(x_out + o, v);
-        }
+        for (int j = 0; j < 8; j++) v[j] = round_to<T>(fmaf(b[j], keep_b, v[j]));   // (x is exact in T: the rounding is the identity without a branch)
+        if (has_branch) V8<T>::st(x_out + o, v);
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; j++) s += v[j];
@@ -852,12 +881,31 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_bwd_kernel(long rows, in
 #pragma unroll
     for (int j = 0; j < 8; j++) dg[j] = db[j] = 0.f;
     int ph = 0;
+    const bool has_dr = d_resid != nullptr;
+    const T *const drq = has_dr ? d_resid : dh;   // (round 4) the three rows of an iteration are loaded together, one row ahead
+    struct Pre {
+        Raw8<T> g, x, r;
+        float mu, rs;
+    };
+    auto fetch = [&](long row) {
+        Pre f;
+        const long o = row * D + c;
+        f.g.load(dh + o);
+        f.x.load(x1 + o);
+        f.r.load(drq + o);
+        f.mu = mean[row];
+        f.rs = rstd[row];
+        return f;
+    };
+    Pre A = fetch(blockIdx.x < rows ? blockIdx.x : 0);
     for (long row = blockIdx.x; row < rows; row += gridDim.x, ph ^= 2) {
         const long o = row * D + c;
+        const Pre Bn = fetch(row + gridDim.x < rows ? row + gridDim.x : row);
+        __builtin_amdgcn_sched_barrier(0);
         float g[8], xh[8];
-        V8<T>::ld(dh + o, g);
-        V8<T>::ld(x1 + o, xh);
-        const float mu = mean[row], rs = rstd[row];
+        A.g.get(g);
+        A.x.get(xh);
+        const float mu = A.mu, rs = A.rs;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -881,15 +929,15 @@ __global__ __launch_bounds__(kEwMaxThreads) void add_ln_bwd_kernel(long rows, in
         m1 *= inv_d;
         m2 *= inv_d;
         float r[8];
-        if (d_resid) {
-            V8<T>::ld(d_resid + o, r);
-        } else {
+        A.r.get(r);
+        const float keep_r = has_dr ? 1.f : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; j++) r[j] = 0.f;
+        for (int j = 0; j < 8; j++) {
+            r[j] *= keep_r;
+            r[j] += rs * (g[j] - m1 - xh[j] * m2);
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++) r[j] += rs * (g[j] - m1 - xh[j] * m2);
         V8<T>::st(dx + o, r);
+        A = Bn;
     }
     V8<float>::st(dpart + ((long)blockIdx.x * 2 + 0) * D + c, dg);
     V8<float>::st(dpart + ((long)blockIdx.x * 2 + 1) * D + c, db);
