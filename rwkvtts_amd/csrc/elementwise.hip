@@ -1302,6 +1302,10 @@ int adamw_step(long n, float *p32, const void *g16, float *m, float *v, void *p1
 // no fp32 copy), then the row is rewritten IN PLACE with d loss / d logits = (softmax - onehot(label)) * scale, or 0
 // for ignored rows; loss_rows[row] = (logsumexp - logit[label]) * valid.  Two reads (the second from L2) + one write.
 // ------------------------------------------------------------------------------------------------------
+// Round 4: the row is walked in 16-byte pieces (8 logits per lane and load; V is odd for the Spark head -- 8 193 -- so a row starts
+// on any 2-byte boundary: up to 7 single elements in front of the first aligned piece and behind the last), one running-max rescale per
+// piece instead of one per element (9 exponentials per 8 logits instead of 16), the gradients leave as 16-byte stores through
+// v_cvt_pk_bf16_f32.  The first form read and wrote 2 bytes per lane and instruction: 98 us per 4 096 x 8 193 chunk.
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_t *__restrict__ logits, const long *__restrict__ labels,
                                                          long ignore_index, float scale, float *__restrict__ loss_rows) {
     const int lane = threadIdx.x & 63;
@@ -1310,26 +1314,63 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_
     uint16_t *x = reinterpret_cast<uint16_t *>(logits) + row * V;
     const long lab = labels[row];
     const bool valid = lab != ignore_index;
+    // [0, head) singles, [head, head + 8 nv) aligned pieces, [head + 8 nv, V) singles
+    int head = (int)(((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 1);
+    head = head < V ? head : V;
+    const int nv = (V - head) >> 3, tail0 = head + 8 * nv;
+    const uint4 *xv = reinterpret_cast<const uint4 *>(x + head);
     float m = -INFINITY, ssum = 0.f;
-    for (int j = lane; j < V; j += 64) {
-        const float v = bf2f(x[j]);
+    auto one = [&](float v) {
         const float mn = fmaxf(m, v);
         ssum = ssum * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+    };
+    if (lane < head) one(bf2f(x[lane]));
+    if (tail0 + lane < V) one(bf2f(x[tail0 + lane]));
+    for (int i = lane; i < nv; i += 64) {
+        const uint4 r = xv[i];
+        float f[8];
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+        float mx = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
+        const float mn = fmaxf(m, mx);
+        float e = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) e += __expf(f[j] - mn);
+        ssum = ssum * __expf(m - mn) + e;
         m = mn;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float mo = __shfl_xor(m, off), so = __shfl_xor(ssum, off);
         const float mn = fmaxf(m, mo);
-        ssum = ssum * __expf(m - mn) + so * __expf(mo - mn);
+        // a lane that saw no element carries (m, ssum) = (-inf, 0): exp(-inf - mn) = 0 keeps it out, and two such lanes give exp(nan) * 0
+        ssum = (m == mn ? ssum : ssum * __expf(m - mn)) + (mo == mn ? so : so * __expf(mo - mn));
         m = mn;
     }
     const float lse = m + __logf(ssum);
     if (lane == 0) loss_rows[row] = valid ? lse - bf2f(x[lab < 0 ? 0 : lab]) : 0.f;
     const float sc = valid ? scale : 0.f;
-    for (int j = lane; j < V; j += 64) {
+    auto grad1 = [&](int j) {
         const float p = __expf(bf2f(x[j]) - lse) - (j == lab ? 1.f : 0.f);
-        x[j] = f2bf(p * sc);
+        x[j] = (uint16_t)pk_bf16(p * sc, 0.f);
+    };
+    if (lane < head) grad1(lane);
+    if (tail0 + lane < V) grad1(tail0 + lane);
+    uint4 *xw = reinterpret_cast<uint4 *>(x + head);
+    const int labv = (int)lab - head;   // position of the label among the aligned elements (anything outside [0, 8 nv): no hit)
+    for (int i = lane; i < nv; i += 64) {
+        const uint4 r = xv[i];
+        float f[8];
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) f[j] = (__expf(f[j] - lse) - (8 * i + j == labv ? 1.f : 0.f)) * sc;
+        xw[i] = make_uint4(pk_bf16(f[0], f[1]), pk_bf16(f[2], f[3]), pk_bf16(f[4], f[5]), pk_bf16(f[6], f[7]));
     }
 }
 
