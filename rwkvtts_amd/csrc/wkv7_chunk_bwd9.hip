@@ -52,7 +52,10 @@ __device__ long long g_cbwd9_timing[8 * 16];
 #endif
 
 namespace {
-constexpr int kOut9ChunksPerWG = 8;
+// consecutive chunks per workgroup: a launch argument (round 4).  8 was fixed; with 16 384 chunks the same-box A/B gave 16: -2.2 %,
+// 32: -3.1 %, 64 (one workgroup per CU): -3.8 % -- every workgroup pays one un-prefetched chunk at its start -- and 4: +4.0 %.
+// The host picks the largest power of two in [8, 64] that still leaves >= 256 workgroups.
+constexpr int kOut9MinChunksPerWG = 8, kOut9MaxChunksPerWG = 64;
 
 struct Out9Smem {  // offsets in uint16 units
     static constexpr int kStLD = kN + 4;   // fp32 staging tiles [32][64 + 4]
@@ -174,7 +177,7 @@ __device__ __forceinline__ void cvt4u(const uint2 r, float (&f)[4]) {
 // hs_ = hs of wkv7_chunk_fwd*.hip (state at the START of every 32-step chunk: entries c and c+1), e_vk = E_{c+1} and z_ = Z of
 // wkv7c_bseq_kernel; hs_ / e_vk q15 records [b,h,c] (chunk_common.h), sa_ / z_ fp32 [B,T,H,64].
 __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
-    int T_, int H, int nchunks_total, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
+    int T_, int H, int nchunks_total, int cpw, const bf16_t *__restrict__ w_, const bf16_t *__restrict__ q_, const bf16_t *__restrict__ k_,
     const bf16_t *__restrict__ v_, const bf16_t *__restrict__ a_, const bf16_t *__restrict__ b_, const bf16_t *__restrict__ dy_,
     const uint16_t *__restrict__ hs_, const float *__restrict__ sa_, const float *__restrict__ z_, const uint16_t *__restrict__ e_vk,
     bf16_t *__restrict__ dw_, bf16_t *__restrict__ dq_, bf16_t *__restrict__ dk_, bf16_t *__restrict__ dv_, bf16_t *__restrict__ da_,
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
 #if WKV7C_B9_YOUNG_PRIO
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses the per-SIMD VALU arbitration by age
 #endif
-    const int chunk0 = blockIdx.x * kOut9ChunksPerWG;
+    const int chunk0 = blockIdx.x * cpw;
     Rows cur = load_rows(chunk0, true);
     Mats curm = load_mats(chunk0, true);
     // H0 of a chunk = H_C of the chunk before it (a workgroup walks consecutive chunks, so the record is fetched once)
@@ -247,10 +250,10 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
     if (tid < 64)   // scales of the first H0 -> buffer 1 (chunk ci reads its H0 scales from buffer (ci & 1) ^ 1)
         *reinterpret_cast<float4 *>(sh_sH + 256 + tid * 4) =
             *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(hs_ + (long)chunk0 * kQRec + kQMant) + tid * 4);
-    for (int ci = 0; ci < kOut9ChunksPerWG; ci++) {
+    for (int ci = 0; ci < cpw; ci++) {
         const int chunk = chunk0 + ci;
         if (chunk >= nchunks_total) break;
-        const bool more = ci + 1 < kOut9ChunksPerWG && chunk + 1 < nchunks_total;
+        const bool more = ci + 1 < cpw && chunk + 1 < nchunks_total;
         const long off = cur.off;
         B9STAMP_INIT;
         // ---- raw rows: global mapping -> LDS -> compute mapping ---------------------------------------------------------------
@@ -533,8 +536,10 @@ int chunk_bwd_out9_bf16(int B, int T_, int H, const void *w, const void *q, cons
     }
     (void)hipGetLastError();
     const int total = B * H * (T_ / kC);
-    hipLaunchKernelGGL(wkv7c_bwd_out9_kernel, dim3((total + kOut9ChunksPerWG - 1) / kOut9ChunksPerWG), dim3(512), Out9Smem::bytes, st, T_, H,
-                       total, (const bf16_t *)w, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a,
+    int cpw = kOut9MinChunksPerWG;
+    while (cpw < kOut9MaxChunksPerWG && total / (2 * cpw) >= 256) cpw *= 2;
+    hipLaunchKernelGGL(wkv7c_bwd_out9_kernel, dim3((total + cpw - 1) / cpw), dim3(512), Out9Smem::bytes, st, T_, H,
+                       total, cpw, (const bf16_t *)w, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)a,
                        (const bf16_t *)b, (const bf16_t *)dy, (const uint16_t *)hs, sa, z, (const uint16_t *)e_vk, (bf16_t *)dw,
                        (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv, (bf16_t *)da, (bf16_t *)db);
     return (int)hipGetLastError();
