@@ -357,6 +357,11 @@ int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const voi
  *      loss_rows[rows] = logsumexp - logit[label]; logits are REPLACED by (softmax - onehot) * scale. ---- */
 int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
                           rwkv7_stream_t stream);
+/*      The same with label smoothing (torch.nn.CrossEntropyLoss(label_smoothing = ls), the XY heads: xy_llm.py:233-240):
+ *      loss_rows = (1 - ls)(logsumexp - logit[label]) + ls (logsumexp - mean logit); logits REPLACED by
+ *      (softmax - ls / V - (1 - ls) onehot) * scale.  0 <= ls < 1; ls = 0 is the entry above. */
+int rwkv7_ce_fwd_bwd_ls_bf16(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
+                             float label_smoothing, rwkv7_stream_t stream);
 
 /* ---- optimizer step (train_spark_rwkv7speech.py:178-197; torch.optim.AdamW update rule, decoupled weight decay) on a
  *      flat parameter buffer: fp32 master weights p32 and moments m, v updated in place from bf16 gradients g16; the

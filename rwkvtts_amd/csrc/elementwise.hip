@@ -1306,8 +1306,10 @@ int adamw_step(long n, float *p32, const void *g16, float *m, float *v, void *p1
 // on any 2-byte boundary: up to 7 single elements in front of the first aligned piece and behind the last), one running-max rescale per
 // piece instead of one per element (9 exponentials per 8 logits instead of 16), the gradients leave as 16-byte stores through
 // v_cvt_pk_bf16_f32.  The first form read and wrote 2 bytes per lane and instruction: 98 us per 4 096 x 8 193 chunk.
+// label smoothing ls (torch.nn.CrossEntropyLoss(label_smoothing), xy_llm.py:233-240): loss = (1 - ls)(lse - x[label]) + ls (lse - mean x),
+// d loss / d x_j = softmax_j - ls / V - (1 - ls) [j == label]; ls = 0 is the plain form, bit for bit what it was.
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_t *__restrict__ logits, const long *__restrict__ labels,
-                                                         long ignore_index, float scale, float *__restrict__ loss_rows) {
+                                                         long ignore_index, float scale, float *__restrict__ loss_rows, float ls) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -1319,11 +1321,12 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_
     head = head < V ? head : V;
     const int nv = (V - head) >> 3, tail0 = head + 8 * nv;
     const uint4 *xv = reinterpret_cast<const uint4 *>(x + head);
-    float m = -INFINITY, ssum = 0.f;
+    float m = -INFINITY, ssum = 0.f, xsum = 0.f;   // xsum: sum of the logits (the smoothing term)
     auto one = [&](float v) {
         const float mn = fmaxf(m, v);
         ssum = ssum * __expf(m - mn) + __expf(v - mn);
         m = mn;
+        xsum += v;
     };
     if (lane < head) one(bf2f(x[lane]));
     if (tail0 + lane < V) one(bf2f(x[tail0 + lane]));
@@ -1338,12 +1341,16 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_
         const float mn = fmaxf(m, mx);
         float e = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) e += __expf(f[j] - mn);
+        for (int j = 0; j < 8; j++) {
+            e += __expf(f[j] - mn);
+            xsum += f[j];
+        }
         ssum = ssum * __expf(m - mn) + e;
         m = mn;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
+        xsum += __shfl_xor(xsum, off);
         const float mo = __shfl_xor(m, off), so = __shfl_xor(ssum, off);
         const float mn = fmaxf(m, mo);
         // a lane that saw no element carries (m, ssum) = (-inf, 0): exp(-inf - mn) = 0 keeps it out, and two such lanes give exp(nan) * 0
@@ -1351,10 +1358,13 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_
         m = mn;
     }
     const float lse = m + __logf(ssum);
-    if (lane == 0) loss_rows[row] = valid ? lse - bf2f(x[lab < 0 ? 0 : lab]) : 0.f;
-    const float sc = valid ? scale : 0.f;
+    if (lane == 0) {
+        const float nll = lse - bf2f(x[lab < 0 ? 0 : lab]);
+        loss_rows[row] = valid ? (ls > 0.f ? (1.f - ls) * nll + ls * (lse - xsum / (float)V) : nll) : 0.f;
+    }
+    const float sc = valid ? scale : 0.f, hit = 1.f - ls, off_all = ls / (float)V;
     auto grad1 = [&](int j) {
-        const float p = __expf(bf2f(x[j]) - lse) - (j == lab ? 1.f : 0.f);
+        const float p = __expf(bf2f(x[j]) - lse) - off_all - (j == lab ? hit : 0.f);
         x[j] = (uint16_t)pk_bf16(p * sc, 0.f);
     };
     if (lane < head) grad1(lane);
@@ -1369,15 +1379,16 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_
         f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
         f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
 #pragma unroll
-        for (int j = 0; j < 8; j++) f[j] = (__expf(f[j] - lse) - (8 * i + j == labv ? 1.f : 0.f)) * sc;
+        for (int j = 0; j < 8; j++) f[j] = (__expf(f[j] - lse) - off_all - (8 * i + j == labv ? hit : 0.f)) * sc;
         xw[i] = make_uint4(pk_bf16(f[0], f[1]), pk_bf16(f[2], f[3]), pk_bf16(f[4], f[5]), pk_bf16(f[6], f[7]));
     }
 }
 
-int ce_fwd_bwd(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows, hipStream_t st) {
+int ce_fwd_bwd(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows, float label_smoothing,
+               hipStream_t st) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rows, V, (bf16_t *)logits, labels,
-                       ignore_index, scale, loss_rows);
+                       ignore_index, scale, loss_rows, label_smoothing);
     return (int)hipGetLastError();
 }
 

@@ -376,6 +376,35 @@ def test_fused_linear_ce_hip_kernel_bf16():
     assert h.grad[::5].abs().max().item() == 0      # ignored rows contribute nothing
 
 
+@pytest.mark.parametrize("V,ls,with_bias", [(1025, 0.0, True), (1025, 0.1, True), (8193, 0.05, False), (66661, 0.0, True), (70, 0.2, True)])
+def test_fused_linear_ce_hip_kernel_bias_and_label_smoothing(V, ls, with_bias):
+    """The XY heads (xy_llm.py:233-240: Linear WITH bias, CrossEntropyLoss(label_smoothing, ignore_index = -100)) on
+    rwkv7_ce_fwd_bwd_ls_bf16: against torch's fp32 cross_entropy on the same bf16 logits (the bias inside nn.Linear's GEMM, as the
+    reference's bf16 modules compute them); V = 1025 / 66 661 (the XY channel vocabularies), 70 (shorter than one aligned piece per lane)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(V)
+    N, D = 300, 64
+    h = (torch.randn(N, D, generator=g)).bfloat16().to(DEV).requires_grad_(True)
+    w = (torch.randn(V, D, generator=g) * 0.2).bfloat16().to(DEV).requires_grad_(True)
+    b = (torch.randn(V, generator=g) * 0.5).bfloat16().to(DEV).requires_grad_(True) if with_bias else None
+    lab = torch.randint(0, V, (N,), generator=g).to(DEV)
+    lab[::7] = -100
+    l1 = fused_linear_cross_entropy(h, lab, w, b, -100, chunk=128, label_smoothing=ls)
+    l1.backward()
+    logits = F.linear(h.detach(), w.detach(), None if b is None else b.detach()).float().requires_grad_(True)
+    l2 = F.cross_entropy(logits, lab, ignore_index=-100, label_smoothing=ls)
+    l2.backward()
+    assert abs(l1.item() - l2.item()) < 2e-4 * abs(l2.item()), (l1.item(), l2.item())
+    dh_ref = logits.grad @ w.detach().float()
+    dw_ref = logits.grad.t() @ h.detach().float()
+    assert (h.grad.float() - dh_ref).abs().max().item() <= 2e-2 * dh_ref.abs().max().item()
+    assert (w.grad.float() - dw_ref).abs().max().item() <= 2e-2 * dw_ref.abs().max().item()
+    if with_bias:
+        db_ref = logits.grad.sum(0)
+        assert (b.grad.float() - db_ref).abs().max().item() <= 2e-2 * db_ref.abs().max().item()
+    assert h.grad[::7].abs().max().item() == 0
+
+
 def test_trainer_fast_gradient_path_equals_accumulate_path():
     """DataParallelTrainer.step arms the flat gradient buffer (no zero fill, .grad = None, the split weight gradients are
     written into their slices by rwkv7_sum_slabs_bf16, everything else is adopted and copied by the hook); the result must be
