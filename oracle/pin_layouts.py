@@ -4,7 +4,10 @@ Runs the reference's own batch builders and loss helpers on toy inputs and write
 tests/golden/layouts.npz:
     create_inputs                       inference/rwkv7speech_inference.py:35-67
     process_single_batch / _culens      data/utils/spark_dataset.py:163-239 / 111-162
-    create_inputs_and_labels            utils/multiple_jsonl.py:4-74
+    create_inputs_and_labels[_culens]   utils/multiple_jsonl.py:4-74 / 76-136
+    create_inputs_and_labels_with_properties[_culens]                 utils/multiple_jsonl.py:139-234 / 236-311
+    create_inputs_and_labels_with_properties_global_tokens[_culens]   utils/multiple_jsonl.py:313-400 / 403-478
+    xy_data_collator                    data/utils/collator.py:8-132
     XYDataProcessor.process_batch       utils/xy_data_processor.py:30-130
     collate_fn (Cosy)                   data/utils/llm_dataset.py:118-188
     LabelSmoothingLoss, th_accuracy     cosyvoice/transformer/label_smoothing_loss.py:68-96, cosyvoice/utils/common.py:76-95
@@ -33,6 +36,8 @@ class FakeTok:
     vocab_size = 500
 
     def encode(self, text, add_special_tokens=False):
+        if text.startswith("SPCT_"):   # the property string "SPCT_0SPCT_15SPCT_46..." -> one id (300 + n) per SPCT_n
+            return [300 + int(t) for t in text.split("SPCT_")[1:]]
         return [int(t) for t in text.split()]
 
     def __call__(self, text, return_tensors="pt"):
@@ -112,6 +117,37 @@ def main():
         eq(o[k], r[k], "create_inputs_and_labels." + k)
         gold["cil." + k] = r[k]
 
+    print("[Spark] create_inputs_and_labels_culens")
+    mj = sp.multiple_jsonl
+    dev = torch.device("cpu")
+    r = mj.create_inputs_and_labels_culens({"text": texts, "global_tokens": glob, "semantic_tokens": sem}, tok, duck, 100, dev)
+    o = L.create_inputs_and_labels_culens(text_ids, glob, sem, duck, 100)
+    for k in ("input_embs", "labels", "cu_seqlens"):
+        eq(o[k], r[k], "create_inputs_and_labels_culens." + k)
+        gold["cilc." + k] = r[k]
+    # properties-prefixed layouts: the reference builds the property string and tokenises it; ours takes the ids
+    props = dict(age=["child", "youth-adult", "elderly"], gender=["female", "male", "female"],
+                 emotion=["HAPPY", "neutral", "WHISPER"], pitch=[260.0, 120.0, 230.0], speed=[3.0, 4.2, 5.5])
+    from utils.properties_util import convert_properties_to_tokens
+    prop_ids = [tok.encode(convert_properties_to_tokens(props["age"][i], props["gender"][i], props["emotion"][i],
+                                                        props["pitch"][i], props["speed"][i])) for i in range(3)]
+    for i, pi in enumerate(prop_ids):
+        gold[f"props.ids{i}"] = torch.tensor(pi)
+    pbatch = {"text": texts, "global_tokens": glob, "semantic_tokens": sem, **props}
+    mj.global_debug = False
+    for name, short, keys in (("create_inputs_and_labels_with_properties", "cilp", ("input_embs", "labels", "attention_mask")),
+                              ("create_inputs_and_labels_with_properties_culens", "cilpc", ("input_embs", "labels", "cu_seqlens")),
+                              ("create_inputs_and_labels_with_properties_global_tokens", "cilpg",
+                               ("input_embs", "labels", "attention_mask")),
+                              ("create_inputs_and_labels_with_properties_global_tokens_culens", "cilpgc",
+                               ("input_embs", "labels", "cu_seqlens"))):
+        print(f"[Spark] {name}")
+        r = getattr(mj, name)(pbatch, tok, duck, 100, dev)
+        o = getattr(L, name)(text_ids, glob, sem, prop_ids, duck, 100)
+        for k in keys:
+            eq(o[k], r[k], f"{name}.{k}")
+            gold[f"{short}.{k}"] = r[k]
+
     print("[XY] XYDataProcessor.process_batch")
     from utils.xy_data_processor import XYDataProcessor as RefXY
     C = 4
@@ -124,6 +160,24 @@ def main():
         eq(o[k], r[k], "XY." + k)
         gold["xy." + k] = r[k]
     gold["xy.audio0"], gold["xy.audio1"], gold["xy.audio2"] = [torch.tensor(x) for x in audio]
+
+    print("[XY] xy_data_collator")
+    from data.utils.collator import xy_data_collator as ref_collator
+
+    class FakeCodec:   # stands in for the XY audio tokenizer: the "audio" array already holds the codes
+        def encode(self, wavs, device=None):
+            return {"codes_list": [w.long() for w in wavs]}
+
+    feats = [{"json": {"text": texts[i]}, "audio": {"array": np.asarray(audio[i], dtype=np.int64)}} for i in range(3)]
+    feats.insert(1, {"json": {"text": "1 2"}, "audio": {}})   # no audio: skipped by the collator
+    r = ref_collator(feats, tok, FakeCodec(), C, 450, 16, dev)
+    ours = [{"text": xy_text[i], "codes": audio[i]} for i in range(3)]
+    ours.insert(1, {"text": [400, 1, 2, 401], "codes": None})
+    o = L.xy_data_collator(ours, C, 450, 16, tok.vocab_size)
+    for k in ("input_ids", "labels", "attention_mask"):
+        eq(o[k], r[k], "xy_data_collator." + k)
+        gold["xyc." + k] = r[k]
+    assert ref_collator([], tok, FakeCodec(), C, 450, 16, dev) == {} and L.xy_data_collator([], C, 450, 16, 500) == {}
 
     print("[Cosy] collate_fn")
     from data.utils import llm_dataset

@@ -125,18 +125,34 @@ def process_single_batch_culens(batch, rwkv7speech_model, eos_token_id=8192, max
             "cu_seqlens": torch.tensor(cu, dtype=torch.long, device=device)}
 
 
-def create_inputs_and_labels(text_ids: List[Sequence[int]], global_tokens: List[Sequence[int]],
-                             semantic_tokens: List[Sequence[int]], model, eos_token_id):
-    """utils/multiple_jsonl.py:4-74 with pre-tokenised text: semantic ids + EOS are INPUTS too, labels are
-    aligned with the inputs (the model's forward shifts), right padding, mask of ones over the real length."""
+def _jsonl_sample(model, t, g, s, eos_token_id):
+    """One utterance of the jsonl trainers (utils/multiple_jsonl.py:13-55): inputs [TAG2, text, TAG0, global, TAG1,
+    semantic + EOS] and labels ALIGNED with them (the model's forward shifts): -100 over the prefix, then the
+    semantic ids + EOS."""
     dev = model.device
-    embs, labs = [], []
-    for t, g, s in zip(text_ids, global_tokens, semantic_tokens):
-        s_pred = list(s) + [eos_token_id]
-        embs.append(spark_embed_sample(model, t, g, s_pred)[0])
-        prefix = 1 + len(t) + 1 + len(g) + 1
-        labs.append(torch.cat([torch.full((prefix,), -100, dtype=torch.long, device=dev),
-                               torch.tensor(s_pred, dtype=torch.long, device=dev)]))
+    s_pred = list(s) + [eos_token_id]
+    emb = spark_embed_sample(model, t, g, s_pred)[0]
+    prefix = 1 + len(t) + 1 + len(g) + 1
+    lab = torch.cat([torch.full((prefix,), -100, dtype=torch.long, device=dev),
+                     torch.tensor(s_pred, dtype=torch.long, device=dev)])
+    return emb, lab
+
+
+def _jsonl_sample_with_properties(model, t, g, s, props, eos_token_id, emb, semantic_labels=True):
+    """The controllable-TTS twin of an utterance (utils/multiple_jsonl.py:183-210): the property-token ids go through
+    `text_embedder` in FRONT of the plain sample, and the labels now also cover the global tokens:
+        [-100 x (len(props) + 1 + len(text) + 1), global ids, -100 (TAG1), semantic ids + EOS]
+    (`semantic_labels=False`: the `_global_tokens` variants, :362-374, ignore the semantic part as well)."""
+    dev = model.device
+    p_emb = model.text_embedder(torch.tensor(list(props), dtype=torch.long, device=dev))
+    ign = lambda n: torch.full((n,), -100, dtype=torch.long, device=dev)
+    s_pred = torch.tensor(list(s) + [eos_token_id], dtype=torch.long, device=dev)
+    lab = torch.cat([ign(len(props) + 1 + len(t) + 1), torch.tensor(list(g), dtype=torch.long, device=dev), ign(1),
+                     s_pred if semantic_labels else ign(s_pred.numel())])
+    return torch.cat([p_emb, emb], dim=0), lab
+
+
+def _right_pad(embs, labs, dev):
     lengths = [e.shape[0] for e in embs]
     mask = torch.zeros(len(embs), max(lengths), dtype=torch.long, device=dev)
     for i, n in enumerate(lengths):
@@ -145,6 +161,83 @@ def create_inputs_and_labels(text_ids: List[Sequence[int]], global_tokens: List[
     return {"input_embs": torch.nn.utils.rnn.pad_sequence(embs, batch_first=True, padding_value=0.0),
             "labels": torch.nn.utils.rnn.pad_sequence(labs, batch_first=True, padding_value=-100),
             "attention_mask": mask}
+
+
+def _pack(embs, labs, dev):
+    cu = [0]
+    for e in embs:
+        cu.append(cu[-1] + e.shape[0])
+    return {"input_embs": torch.cat(embs, 0).unsqueeze(0), "labels": torch.cat(labs, 0).unsqueeze(0),
+            "cu_seqlens": torch.tensor(cu, dtype=torch.long, device=dev)}
+
+
+def _jsonl_samples(text_ids, global_tokens, semantic_tokens, model, eos_token_id):
+    embs, labs = [], []
+    for t, g, s in zip(text_ids, global_tokens, semantic_tokens):
+        e, l = _jsonl_sample(model, t, g, s, eos_token_id)
+        embs.append(e)
+        labs.append(l)
+    return embs, labs
+
+
+def create_inputs_and_labels(text_ids: List[Sequence[int]], global_tokens: List[Sequence[int]],
+                             semantic_tokens: List[Sequence[int]], model, eos_token_id):
+    """utils/multiple_jsonl.py:4-74 with pre-tokenised text: semantic ids + EOS are INPUTS too, labels are
+    aligned with the inputs (the model's forward shifts), right padding, mask of ones over the real length."""
+    return _right_pad(*_jsonl_samples(text_ids, global_tokens, semantic_tokens, model, eos_token_id), model.device)
+
+
+def create_inputs_and_labels_culens(text_ids: List[Sequence[int]], global_tokens: List[Sequence[int]],
+                                    semantic_tokens: List[Sequence[int]], model, eos_token_id):
+    """utils/multiple_jsonl.py:76-136: the same samples packed back to back into ONE row [1, sum T, D] with
+    `cu_seqlens` [n+1] (int64) -- what `model(inputs_embeds=, labels=, cu_seqlens=)` trains on without padding
+    (train_spark_rwkv7speech.py:238-239).  No length cap here (unlike spark_dataset's `_culens` twin)."""
+    return _pack(*_jsonl_samples(text_ids, global_tokens, semantic_tokens, model, eos_token_id), model.device)
+
+
+def _properties_samples(text_ids, global_tokens, semantic_tokens, properties_ids, model, eos_token_id, both, semantic_labels):
+    assert len(properties_ids) == len(text_ids)
+    embs, labs = [], []
+    for t, g, s, pr in zip(text_ids, global_tokens, semantic_tokens, properties_ids):
+        e, l = _jsonl_sample(model, t, g, s, eos_token_id)
+        if both:   # sample 1: plain TTS, sample 2: the same utterance behind its property tokens
+            embs.append(e)
+            labs.append(l)
+        e2, l2 = _jsonl_sample_with_properties(model, t, g, s, pr, eos_token_id, e, semantic_labels)
+        embs.append(e2)
+        labs.append(l2)
+    return embs, labs
+
+
+def create_inputs_and_labels_with_properties(text_ids, global_tokens, semantic_tokens, properties_ids, model, eos_token_id):
+    """utils/multiple_jsonl.py:139-234.  `properties_ids[i]` = tokenizer ids of the property string the reference
+    builds with `convert_properties_to_tokens(age, gender, emotion, pitch, speed)` ("SPCT_0SPCT_15..."; string work
+    on the host, outside the path).  TWO rows per utterance, interleaved [plain_0, props_0, plain_1, props_1, ...];
+    right padding; the property rows also carry labels on the 32 global tokens (:198-210)."""
+    return _right_pad(*_properties_samples(text_ids, global_tokens, semantic_tokens, properties_ids, model,
+                                           eos_token_id, True, True), model.device)
+
+
+def create_inputs_and_labels_with_properties_culens(text_ids, global_tokens, semantic_tokens, properties_ids, model,
+                                                    eos_token_id):
+    """utils/multiple_jsonl.py:236-311: the interleaved plain / property rows packed into [1, sum T, D] + cu_seqlens."""
+    return _pack(*_properties_samples(text_ids, global_tokens, semantic_tokens, properties_ids, model,
+                                      eos_token_id, True, True), model.device)
+
+
+def create_inputs_and_labels_with_properties_global_tokens(text_ids, global_tokens, semantic_tokens, properties_ids,
+                                                           model, eos_token_id):
+    """utils/multiple_jsonl.py:313-400: ONE row per utterance (the property row only), labels on the global tokens
+    ONLY (the semantic part is input but ignored by the loss, :362-374); right padding."""
+    return _right_pad(*_properties_samples(text_ids, global_tokens, semantic_tokens, properties_ids, model,
+                                           eos_token_id, False, False), model.device)
+
+
+def create_inputs_and_labels_with_properties_global_tokens_culens(text_ids, global_tokens, semantic_tokens,
+                                                                  properties_ids, model, eos_token_id):
+    """utils/multiple_jsonl.py:403-478: the packed form of the global-token-only property rows."""
+    return _pack(*_properties_samples(text_ids, global_tokens, semantic_tokens, properties_ids, model,
+                                      eos_token_id, False, False), model.device)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -229,6 +322,17 @@ class XYDataProcessor:
                 lab_l[i] = torch.cat([lab_l[i], torch.full((pad, C), ign, dtype=torch.long)], 0)
                 msk_l[i] = torch.cat([msk_l[i], torch.zeros(pad, dtype=torch.long)], 0)
         return {"input_ids": torch.stack(ids_l), "labels": torch.stack(lab_l), "attention_mask": torch.stack(msk_l)}
+
+
+def xy_data_collator(features, num_channels, text_shift_size, speech_vocab_size, text_vocab_size):
+    """data/utils/collator.py:8-132 after tokenisation: `features[i]` = {"text": ids of "[S0]" + text + "[CTL0]",
+    "codes": [num_channels][T2] RVQ codes as the XY codec returns them (channel 0 NOT yet shifted)}; a feature with
+    no text or no codes is skipped (:20-22) and an empty batch returns {} (:40-41).  The reference wrote this collator
+    and `XYDataProcessor.process_batch` independently (and ships `verify_collator_logic.py` to compare them); here both
+    names run the one vectorised builder above, and each is pinned against its own reference function."""
+    kept = [f for f in features if f.get("text") is not None and len(f["text"]) > 0 and f.get("codes") is not None]
+    proc = XYDataProcessor(text_vocab_size, num_channels, text_shift_size, speech_vocab_size)
+    return proc.process_batch([f["text"] for f in kept], [f["codes"] for f in kept])
 
 
 def synthetic_xy_batch(B: int, T1: int = 128, T2: int = 8057, num_channels=8, text_vocab=66661, speech_vocab=1025,

@@ -56,6 +56,74 @@ def test_spark_create_inputs_and_labels_right_pad_aligned():
         assert torch.equal(o[k], g["cil." + k]), k
 
 
+def test_spark_create_inputs_and_labels_culens_packed():
+    """utils/multiple_jsonl.py:76-136 -- the row SURVEY section 8 a10 / N1 cite by name."""
+    g = load_golden("layouts.npz")
+    o = L.create_inputs_and_labels_culens(TEXT, GLOB, SEM, Duck(g), 100)
+    for k in ("input_embs", "labels", "cu_seqlens"):
+        assert torch.equal(o[k], g["cilc." + k]) and o[k].dtype == g["cilc." + k].dtype, k
+    lens = [3 + len(t) + len(gl) + len(s) + 1 for t, gl, s in zip(TEXT, GLOB, SEM)]
+    assert o["cu_seqlens"].tolist() == [0, lens[0], lens[0] + lens[1], sum(lens)]
+    assert o["input_embs"].shape[:2] == (1, sum(lens)) and o["labels"].shape == (1, sum(lens))
+    # packed == the right-padded rows with the padding removed
+    p = L.create_inputs_and_labels(TEXT, GLOB, SEM, Duck(g), 100)
+    keep = p["attention_mask"].bool()
+    assert torch.equal(o["input_embs"][0], p["input_embs"][keep]) and torch.equal(o["labels"][0], p["labels"][keep])
+
+
+def _prop_ids(g):
+    return [g[f"props.ids{i}"].tolist() for i in range(3)]
+
+
+def test_spark_properties_layouts_two_rows_per_utterance():
+    """utils/multiple_jsonl.py:139-311: plain row + property-prefixed row per utterance; the property rows carry
+    labels on the global tokens too (:198-210)."""
+    g = load_golden("layouts.npz")
+    duck, props = Duck(g), _prop_ids(g)
+    o = L.create_inputs_and_labels_with_properties(TEXT, GLOB, SEM, props, duck, 100)
+    for k in ("input_embs", "labels", "attention_mask"):
+        assert torch.equal(o[k], g["cilp." + k]), k
+    assert o["input_embs"].shape[0] == 6
+    P, T0 = len(props[0]), len(TEXT[0])
+    row = o["labels"][1]     # utterance 0 behind its property tokens
+    assert row[:P + 1 + T0 + 1].eq(-100).all()
+    assert row[P + 2 + T0: P + 2 + T0 + 4].tolist() == GLOB[0] and row[P + 2 + T0 + 4] == -100
+    assert row[P + 2 + T0 + 5: P + 2 + T0 + 5 + 6].tolist() == SEM[0] + [100]
+    assert o["labels"][0][: 3 + T0 + 4].eq(-100).all()           # the plain row: nothing before the semantic ids
+    o = L.create_inputs_and_labels_with_properties_culens(TEXT, GLOB, SEM, props, duck, 100)
+    for k in ("input_embs", "labels", "cu_seqlens"):
+        assert torch.equal(o[k], g["cilpc." + k]), k
+    assert o["cu_seqlens"].numel() == 7
+
+
+def test_spark_properties_global_tokens_only_layouts():
+    """utils/multiple_jsonl.py:313-478: one property row per utterance, loss on the global tokens only."""
+    g = load_golden("layouts.npz")
+    duck, props = Duck(g), _prop_ids(g)
+    o = L.create_inputs_and_labels_with_properties_global_tokens(TEXT, GLOB, SEM, props, duck, 100)
+    for k in ("input_embs", "labels", "attention_mask"):
+        assert torch.equal(o[k], g["cilpg." + k]), k
+    assert o["input_embs"].shape[0] == 3
+    assert sorted(o["labels"][0][o["labels"][0] != -100].tolist()) == GLOB[0]
+    o = L.create_inputs_and_labels_with_properties_global_tokens_culens(TEXT, GLOB, SEM, props, duck, 100)
+    for k in ("input_embs", "labels", "cu_seqlens"):
+        assert torch.equal(o[k], g["cilpgc." + k]), k
+
+
+def test_xy_data_collator_pinned_separately():
+    """data/utils/collator.py:8-132 (the reference compares it with XYDataProcessor in verify_collator_logic.py:99-181):
+    its own golden entry, a feature without audio skipped, empty batch -> {}."""
+    g = load_golden("layouts.npz")
+    audio = [g[f"xy.audio{i}"].tolist() for i in range(3)]
+    feats = [{"text": [400] + TEXT[i] + [401], "codes": audio[i]} for i in range(3)]
+    feats.insert(1, {"text": [400, 1, 2, 401], "codes": None})
+    o = L.xy_data_collator(feats, 4, 450, 16, 500)
+    for k in ("input_ids", "labels", "attention_mask"):
+        assert torch.equal(o[k], g["xyc." + k]), k
+        assert torch.equal(g["xyc." + k], g["xy." + k]), k    # the reference's two builders agree on this batch
+    assert L.xy_data_collator([], 4, 450, 16, 500) == {}
+
+
 def test_xy_delay_pattern_and_labels():
     g = load_golden("layouts.npz")
     audio = [g[f"xy.audio{i}"].tolist() for i in range(3)]

@@ -197,6 +197,40 @@ def test_packed_cu_seqlens_equals_per_sequence_forward():
     assert torch.isfinite(out.loss)
 
 
+def test_properties_packed_batch_through_the_spark_head_counts_the_global_token_labels():
+    """a10 + N1: the packed properties layout (utils/multiple_jsonl.py:236-311; two rows per utterance, the second behind
+    its property tokens and with labels on the 32 global tokens as well, :198-210) through RWKV7ForSpeech with cu_seqlens:
+    logits per sequence == the oracle run on each sequence alone, the loss == the oracle's CE over the packed shifted
+    labels (so the global-token positions are in it), == the right-padded form of the same batch."""
+    import torch.nn.functional as F
+    from rwkvtts_amd import layouts as L
+    model, p, rcfg = _spark_pair(seed=17)
+    g = torch.Generator().manual_seed(8)
+    n = 3
+    text = [torch.randint(0, 300, (k,), generator=g).tolist() for k in (5, 11, 2)]
+    glob = [torch.randint(0, 64, (32,), generator=g).tolist() for _ in range(n)]
+    sem = [torch.randint(0, 256, (k,), generator=g).tolist() for k in (40, 17, 29)]
+    props = [torch.randint(0, 300, (6,), generator=g).tolist() for _ in range(n)]
+    with torch.no_grad():
+        packed = L.create_inputs_and_labels_with_properties_culens(text, glob, sem, props, model, 256)
+        padded = L.create_inputs_and_labels_with_properties(text, glob, sem, props, model, 256)
+        cu = packed["cu_seqlens"]
+        assert cu.numel() == 2 * n + 1 and packed["input_embs"].shape[1] == int(cu[-1])
+        out = model(inputs_embeds=packed["input_embs"], labels=packed["labels"], cu_seqlens=cu)
+        out_pad = model(inputs_embeds=padded["input_embs"], labels=padded["labels"], attention_mask=padded["attention_mask"])
+        x = packed["input_embs"][0].cpu()
+        bounds = cu.tolist()
+        oracle = torch.cat([R.spark_forward(p, rcfg, x[a:b][None], None, None)[1][0] for a, b in zip(bounds, bounds[1:])])
+    assert (out.logits[0].cpu() - oracle).abs().max().item() < 1e-3
+    lab = packed["labels"][0].cpu()
+    shifted = torch.cat([lab[1:], torch.tensor([-100])])
+    want = F.cross_entropy(oracle, shifted, ignore_index=-100)
+    n_glob = sum(1 for i in range(n) for _ in glob[i])
+    assert int((shifted != -100).sum()) == 2 * sum(len(s) + 1 for s in sem) + n_glob    # global ids are targets in the property rows
+    assert abs(out.loss.item() - want.item()) < 1e-3, (out.loss.item(), want.item())
+    assert abs(out_pad.loss.item() - want.item()) < 1e-3, (out_pad.loss.item(), want.item())
+
+
 def test_graph_decoder_matches_eager_generate():
     """config 5 machinery: hipGraph-replayed persistent-state decode == the eager generate loop, id for id."""
     from rwkvtts_amd.decode import GraphDecoder
