@@ -259,7 +259,7 @@ class RWKV7Attention(nn.Module):
         With `state`, token shift and the WKV state are carried (and updated in place).
         seq_start (int32 [nseq+1] chunk offsets): packed rows, see RWKV7Model._forward_packed."""
         x_prev = None if state is None else state.att_x_prev
-        if fused.mix_lora_supported(x, state, seq_start) and FUSED_TMIX_CORE:
+        if FUSED_TMIX_CORE and fused.mix_lora_supported(x, state, seq_start, self.lora_branches()[1]):
             # training: the four low-rank branches' down projections taken THROUGH the lerp (fused.mix_lora): x_w, x_a, x_g and the
             # branch copy of x_v are never formed
             mus, w1s, acts, names = self.lora_branches()
@@ -413,7 +413,7 @@ class RWKV7Block(nn.Module):
             att, v_first = self.attn.forward_mixed(mixed, None, mask, v_first, None, seq_start,
                                                    resid=x if FUSED_ADD_LN_MIX1 else None)
         elif (one_pass and FUSED_TMIX_CORE and fused.FUSED_ADD_LN_MIX_LORA_FWD and x.requires_grad
-              and fused.mix_lora_supported(x, state, seq_start)):
+              and fused.mix_lora_supported(x, state, seq_start, self.attn.lora_branches()[1])):
             # residual add + LayerNorm + the three lerps of the full projections in one forward kernel; the low-rank branches take
             # their inputs through the lerp from the stored LayerNorm output (fused.add_layer_norm_mix_lora)
             a = self.attn

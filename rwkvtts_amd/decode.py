@@ -225,7 +225,7 @@ class GraphDecoder:
         sequence met EOS) the columns that were not run carry the pad id, and `cache.seen_tokens` counts the steps actually run (the
         state has been advanced through at most EOS_CHECK_EVERY - 1 pad tokens past the last EOS)."""
         if self.graph is not None:
-            ran = getattr(self, "steps_run", self.steps_left)
+            ran = self.steps_left if getattr(self, "steps_run", None) is None else self.steps_run
             self.cache.seen_tokens = self._seen0 + ran
             if ran < self.steps_left:
                 self.out[:, 1 + ran:self.max_new_tokens] = self.pad_t
@@ -243,6 +243,7 @@ class GraphDecoder:
         `finish()` returns the ids."""
         self.do_sample, self.temperature, self.top_k, self.top_p = bool(do_sample), float(temperature), int(top_k or 0), float(top_p)
         self.max_new_tokens, self.steps_left, self.graph = max_new_tokens, 0, None
+        self.steps_run = None    # None = "every replay ran" (prepare + manual replays + finish); generate() / MultiGroupDecoder set it
         self.min_new_tokens = int(min_new_tokens or 0)   # the EOS id cannot be drawn before that many tokens (fused sampler only)
         if seed is not None:
             torch.cuda.manual_seed(seed)
@@ -376,7 +377,12 @@ class MultiGroupDecoder:
                     d.steps_run += 1
             # groups whose sequences have all met EOS drop out (one read-back per group every EOS_CHECK_EVERY rounds)
             if (it + 1) % GraphDecoder.EOS_CHECK_EVERY == 0 and live and live[0].eos is not None:
-                live = [d for d in live if bool(d.unfinished.any())]
+                flags = []
+                for d, st in zip(self.decoders, self.streams):
+                    if d in live:
+                        with torch.cuda.stream(st):   # on the stream that writes the flag: the read-back waits for the replays queued so far
+                            flags.append((d, d.unfinished.any()))
+                live = [d for d, f in flags if bool(f)]
                 if not live:
                     break
         outs = []

@@ -59,7 +59,8 @@ def _colsum(part, dtype):
         n = part[0].numel()
         if n % 4 == 0 and n <= 32768:
             out = torch.empty(part.shape[1:], dtype=dtype, device=part.device)
-            rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(n), part.shape[0], _p(part), _p(out), 0, _stream(part))
+            with torch.cuda.device_of(part):
+                rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(n), part.shape[0], _p(part), _p(out), 0, _stream(part))
             _lib.check(rc, "sum_slabs(colsum)")
             return out
     return part.sum(0).to(dtype)
@@ -152,7 +153,13 @@ class _MixLora(torch.autograd.Function):
         return dx, None, _colsum(part, params.dtype), dwcat
 
 
-def mix_lora_supported(x, state, seq_start):
+def mix_lora_supported(x, state, seq_start, w1s=None):
+    """w1s: the down-projection weights of the low-rank branches that would ride on the fused path; what the C entry points
+    require of them (rwkv7_mix_lora_wcat_*: at most 4 branches, every rank a multiple of 8, bf16, contiguous) is checked HERE so
+    that an unusual config (rank 20, fp32 LoRA) falls back to token_shift_mix6 instead of raising RWKV7_ESHAPE mid-training."""
+    if w1s is not None and not (0 < len(w1s) <= 4 and all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2
+                                                         and w.shape[0] % 8 == 0 for w in w1s)):
+        return False
     return (FUSED_MIX_LORA and state is None and seq_start is None and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
             and x.requires_grad and x.dim() == 3 and x.shape[0] * x.shape[1] >= WGRAD_MIN_ROWS and x.shape[-1] % 8 == 0)
 

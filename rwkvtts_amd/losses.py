@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 HIP_CE = os.environ.get("RWKV7_HIP_CE", "1") == "1"   # A/B switch: 0 = the torch chain for every head
+CHECK_LABELS = os.environ.get("RWKV7_CHECK_LABELS", "0") == "1"
 
 
 class _FusedLinearCE(torch.autograd.Function):
@@ -29,6 +30,14 @@ class _FusedLinearCE(torch.autograd.Function):
         db = torch.zeros_like(bias, dtype=torch.float32) if (bias is not None and need[2]) else None
         # bias and label smoothing (the XY heads, xy_llm.py:233-240) ride on the same kernel since round 4: at configs[3] the torch
         # chain behind them (fp32 logits, logsumexp, softmax, scatter, casts) was ~40 ms of a 417 ms step
+        # NUMERICS of the HIP path (also for the XY heads since round 4): the logits are the bf16 output of the head GEMM -- logsumexp,
+        # softmax and the smoothing mean term sum(x)/V are computed in fp32 FROM those bf16 logits, where the torch chain below keeps
+        # fp32 logits.  The formula is torch's CrossEntropyLoss(label_smoothing, ignore_index); tests/test_heads_reference.py holds
+        # bias + smoothing to the training tolerance against the reference's own forward.  Labels must be < V or == ignore_index
+        # (the kernel indexes x[label]); RWKV7_CHECK_LABELS=1 asserts it (one host sync per call, debugging only).
+        if CHECK_LABELS:
+            bad = (labels != ignore_index) & ((labels < 0) | (labels >= weight.shape[0]))
+            assert not bool(bad.any()), f"labels outside [0, {weight.shape[0]}) that are not ignore_index={ignore_index}"
         hip_ce = (HIP_CE and hidden.is_cuda and hidden.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
                   and (bias is None or bias.dtype == torch.bfloat16) and 0 <= label_smoothing < 1 and labels.dtype == torch.int64)
         for s in range(0, N, chunk):

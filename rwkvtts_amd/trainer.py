@@ -156,7 +156,9 @@ class BucketedAllReduce:
         self._cut(list(range(len(flat.params) - 1, -1, -1)))
         self.ready_order: List[int] = []
         self.rebuilt = False
-        self.works = []
+        self.order_differs_from_rank0 = False
+        self.works = []          # (bucket, work) in launch order
+        self.launched = []       # buckets in launch order (the order finish() hands them to `on_bucket`)
         self.use_avg, self.summed = True, []
         self.measure, self.wait_events = False, []
         self.enabled = self.world > 1 or (force and dist.is_initialized())
@@ -187,13 +189,31 @@ class BucketedAllReduce:
                 self.runs.append([tuple(r) for r in runs])
                 cur, nbytes = [], 0
         self.pending = [b[2] for b in self.buckets]
+        self.next_bucket = 0
 
     def rebuild_from_ready_order(self):
         """Re-cut the buckets along the order in which the gradient hooks fired in the pass just finished (once; parameters whose
-        hook did not fire go last).  Every rank runs the same model, so every rank records the same order and cuts the same buckets
-        -- a precondition of the collectives, asserted in tests/test_trainer_dist.py."""
-        seen = set(self.ready_order)
-        order = self.ready_order + [i for i in range(len(self.flat.params) - 1, -1, -1) if i not in seen]
+        hook did not fire go last).  The order is RANK 0's, broadcast to everybody (what DDP does): the order a rank records
+        depends on the shapes of ITS batch -- fused.mix_lora_supported needs B*T >= 4096, linear_add_eligible / cmix_eligible
+        need M % 256 == 0, and the fused nodes hand over the LoRA / x_* gradients in a different order than the plain ones --
+        so two ranks fed differently shaped batches on step 0 would otherwise cut their buckets at different byte boundaries
+        and the collectives would mismatch (hang or silently wrong sums).  One host-synchronous broadcast of n_params int32,
+        once per run.  tests/test_trainer_dist.py drives the two ranks through different orders and asserts the common cut."""
+        n = len(self.flat.params)
+        order = list(self.ready_order)
+        if self.world > 1:
+            dev = self.flat.flat_grad.device if self.backend == "nccl" else torch.device("cpu")
+            t = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            if self.rank == 0:
+                t[:len(order)] = torch.tensor(order, dtype=torch.int32)
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(t, src=src, group=self.group)
+            theirs = [int(i) for i in t.tolist() if i >= 0]
+            self.order_differs_from_rank0 = theirs != order
+            order = theirs
+        self.ready_order = order
+        seen = set(order)
+        order = order + [i for i in range(n - 1, -1, -1) if i not in seen]
         self._cut(order)
         self.rebuilt = True
 
@@ -208,17 +228,22 @@ class BucketedAllReduce:
             self.ready_order.append(i)
         b = self.param_bucket[i]
         self.pending[b] -= 1
-        if self.pending[b] == 0:
-            self._launch(b)
+        # buckets go on the wire strictly in INDEX order (as DDP's reducer does): a bucket that completes early waits for its
+        # predecessors.  The sequence of collectives is then the same on every rank at every step even when the ranks' hooks
+        # fire in different orders (differently shaped batches take different fused paths) -- a mismatched sequence is a hang.
+        while self.next_bucket < len(self.pending) and self.pending[self.next_bucket] == 0:
+            self._launch(self.next_bucket)
+            self.next_bucket += 1
 
     def _launch(self, b):
         from . import fused
         fused.wgrad_side_sync()   # ... including the weight gradients still running on fused's side stream
         self.flat.flush()   # the bucket's slices must hold the final gradients
+        self.launched.append(b)
         for s, e in self.runs[b]:
-            self._exchange(s, e)
+            self._exchange(s, e, b)
 
-    def _exchange(self, s, e):
+    def _exchange(self, s, e, b=-1):
         if self.shard:
             for r in range(self.world):   # the run's intersection with every rank's slab goes to that rank only
                 lo, hi = self.slab(r)
@@ -227,10 +252,10 @@ class BucketedAllReduce:
                     continue
                 piece = self.flat.flat_grad[lo:hi]
                 if self.backend == "nccl":
-                    self.works.append(dist.reduce(piece, dst=dist.get_global_rank(self.group, r) if self.group is not None else r,
-                                                  op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self.works.append((b, dist.reduce(piece, dst=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                                      op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
                     if r == self.rank:
-                        self.summed.append((lo, hi))
+                        self.summed.append((b, lo, hi))
                 else:   # gloo (CPU tests): fp32, synchronous
                     tmp = piece.float()
                     dist.reduce(tmp, dst=r, op=dist.ReduceOp.SUM, group=self.group)
@@ -241,44 +266,64 @@ class BucketedAllReduce:
         if self.backend == "nccl":
             if self.use_avg:
                 try:
-                    self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                    self.works.append((b, dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)))
                     return
                 except RuntimeError:   # a collective library without AVG for this dtype: SUM now, one scale in finish()
                     self.use_avg = False
-            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self.summed.append((s, e))
+            self.works.append((b, dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            self.summed.append((b, s, e))
         else:  # gloo (CPU tests): no AVG, and bf16 support varies -> reduce in fp32
             tmp = view.float()
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
             view.copy_((tmp / self.world).to(view.dtype))
 
-    def finish(self):
+    def finish(self, on_bucket=None):
         """Wait for every bucket (also launches buckets whose hooks never fired, e.g. unused params).  Backward always runs: a
-        NaN step backpropagates like any other and the optimizer kernel substitutes a zero gradient (DataParallelTrainer.step)."""
+        NaN step backpropagates like any other and the optimizer kernel substitutes a zero gradient (DataParallelTrainer.step).
+
+        on_bucket(runs): called once per bucket, in launch order, as soon as THAT bucket's collectives have completed on the
+        compute stream's timeline (work.wait() = the compute stream waits for RCCL's stream up to that collective) -- the
+        optimizer steps bucket b while buckets b+1.. are still on the wire, instead of one replicated pass behind the last
+        all-reduce.  Returns True if it was called for every bucket (False: exchange disabled, caller does one whole pass)."""
         self.flat.finish_backward()
         if not self.enabled:
-            return
-        for b, left in enumerate(self.pending):
-            if left > 0:
-                self._launch(b)
+            return False
+        for b in range(self.next_bucket, len(self.pending)):   # incomplete buckets (unused parameters) and their successors
+            self._launch(b)
         # wait() makes the compute stream wait for RCCL's stream; what the compute stream then stalls is the exposed
-        # (non-overlapped) part of the exchange -- bracketed by two events when `measure` is on (bench.py)
+        # (non-overlapped) part of the exchange -- bracketed by two events when `measure` is on (bench.py); with on_bucket
+        # the bracket also holds the optimizer launches of the earlier buckets (that is the point: they fill the stall)
         if self.measure and self.works:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for w in self.works:
-            w.wait()
+        per_bucket = on_bucket is not None and not self.shard
+        if per_bucket:
+            by_b, scale_b = {}, {}
+            for b, w in self.works:
+                by_b.setdefault(b, []).append(w)
+            for b, s, e in self.summed:
+                scale_b.setdefault(b, []).append((s, e))
+            for b in self.launched:
+                for w in by_b.get(b, ()):
+                    w.wait()
+                for s, e in scale_b.get(b, ()):
+                    self.flat.flat_grad[s:e].mul_(1.0 / self.world)
+                on_bucket(self.runs[b])
+        else:
+            for _, w in self.works:
+                w.wait()
+            for _, s, e in self.summed:
+                self.flat.flat_grad[s:e].mul_(1.0 / self.world)
         if self.measure and self.works:
             e1.record()
             self.wait_events.append((e0, e1))
-        self.works = []
-        for s, e in self.summed:
-            self.flat.flat_grad[s:e].mul_(1.0 / self.world)
-        self.summed = []
-        if not self.rebuilt and self.ready_order:
+        self.works, self.summed, self.launched = [], [], []
+        if not self.rebuilt and (self.ready_order or self.world > 1):
             self.rebuild_from_ready_order()   # once, after the first backward pass (also resets `pending`)
         else:
             self.pending = [b[2] for b in self.buckets]
+            self.next_bucket = 0
+        return per_bucket
 
 
 def linear_warmup_decay(step, total_steps, warmup_steps, lr, lr_final):
@@ -331,7 +376,8 @@ class DataParallelTrainer:
 
     def __init__(self, model: torch.nn.Module, lr=1e-4, lr_final=1e-5, warmup_steps=100, total_steps=100000,
                  weight_decay=0.0, betas=(0.9, 0.95), eps=1e-18, bucket_bytes=32 << 20, nan_guard=True,
-                 master_fp32=True, param_groups=None, schedule="linear", force_allreduce=False, shard_optimizer=False):
+                 master_fp32=True, param_groups=None, schedule="linear", force_allreduce=False, shard_optimizer=False,
+                 bucket_optimizer=True):
         """shard_optimizer: every rank reduces the gradient pieces of ITS 1/N slab only, steps AdamW on that slab and broadcasts
         the slab's new bf16 parameters (reduce-scatter + sharded optimizer + all-gather, ZeRO-1 style: the reference's DeepSpeed
         ZeRO-2 engine does the same exchange, train_spark_rwkv7speech.py:483-516).  Same parameters after every step as the
@@ -339,8 +385,12 @@ class DataParallelTrainer:
         for the case that the 8-GPU scaling run shows an exposed all-reduce tail.
         NOTE for code that reads gradients after step(): in shard mode only the slices of a rank's OWN slab hold the reduced (mean)
         gradient; `p.grad` of parameters in foreign slabs holds this rank's local, unreduced gradient (gradient-norm logging or
-        clipping must all-reduce its own partial over the own slab, `reducer.slab(rank)`)."""
+        clipping must all-reduce its own partial over the own slab, `reducer.slab(rank)`).
+        bucket_optimizer (default, all-reduce mode with > 1 rank): AdamW runs bucket by bucket, each as soon as its own
+        all-reduce has completed, so the optimizer pass (2.1-2.4 ms for the 0.4B model) overlaps the buckets still on the wire
+        instead of sitting behind the last one.  Element-wise the same update: identical parameters to the one-pass mode."""
         self.model = model
+        self.bucket_optimizer = bool(bucket_optimizer)
         self.flat = FlatBuffers(model)
         self.reducer = BucketedAllReduce(self.flat, bucket_bytes, force=force_allreduce, shard=shard_optimizer)
         self.shard_optimizer = bool(shard_optimizer) and self.reducer.enabled
@@ -411,12 +461,13 @@ class DataParallelTrainer:
         base = self.current_lr()
         return {g[0]: base * g[1] for g in self.group_defs}
 
-    def _torch_adamw(self, lr, skip):
+    def _torch_adamw(self, lr, skip, lo_s=None, hi_s=None):
         g_all = self.flat.flat_grad
         b1, b2 = self.betas
         t = self.step_idx + 1
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
-        lo_s, hi_s = self.reducer.slab(self.reducer.rank) if self.shard_optimizer else (0, self.flat.numel)
+        if lo_s is None:
+            lo_s, hi_s = self.reducer.slab(self.reducer.rank) if self.shard_optimizer else (0, self.flat.numel)
         for s, e, gi in self.runs:
             s, e = max(s, lo_s), min(e, hi_s)   # sharded: this rank's slab only
             if s >= e:
@@ -473,27 +524,37 @@ class DataParallelTrainer:
         else:
             self.nan_flag.zero_()
         loss.backward()
-        self.reducer.finish()
-        if flag_work is not None:
-            flag_work.wait()
         lr = self.current_lr()
         self.last_lr = lr
-        if self.hip_adamw:
-            import ctypes
-            from . import _lib
-            P = lambda t: ctypes.c_void_p(t.data_ptr())
-            f = ctypes.c_float
-            lo, hi = self.reducer.slab(self.reducer.rank) if self.shard_optimizer else (0, self.flat.numel)
-            with torch.cuda.device_of(self.master):
-                rc = 0 if hi <= lo else _lib.lib().rwkv7_adamw_groups_bf16(
-                    ctypes.c_long(hi - lo), P(self.master[lo:hi]), P(self.flat.flat_grad[lo:hi]), P(self.exp_avg[lo:hi]),
-                    P(self.exp_avg_sq[lo:hi]), P(self.flat.flat_param[lo:hi]), P(self.slab_group[lo // 128:hi // 128]), P(self.group_tab),
-                    len(self.group_defs), P(self.nan_flag),
-                    f(lr), f(self.betas[0]), f(self.betas[1]), f(self.eps), self.step_idx + 1,
-                    ctypes.c_void_p(torch.cuda.current_stream(self.master.device).cuda_stream))
-            _lib.check(rc, "adamw")
-        else:
-            self._torch_adamw(lr, self.nan_flag)
+        if flag_work is not None:
+            flag_work.wait()   # enqueued before backward: long done; the optimizer launches below read the flag
+
+        def adamw(lo, hi):
+            if hi <= lo:
+                return
+            if self.hip_adamw:
+                import ctypes
+                from . import _lib
+                P = lambda t: ctypes.c_void_p(t.data_ptr())
+                f = ctypes.c_float
+                with torch.cuda.device_of(self.master):
+                    rc = _lib.lib().rwkv7_adamw_groups_bf16(
+                        ctypes.c_long(hi - lo), P(self.master[lo:hi]), P(self.flat.flat_grad[lo:hi]), P(self.exp_avg[lo:hi]),
+                        P(self.exp_avg_sq[lo:hi]), P(self.flat.flat_param[lo:hi]), P(self.slab_group[lo // 128:hi // 128]), P(self.group_tab),
+                        len(self.group_defs), P(self.nan_flag),
+                        f(lr), f(self.betas[0]), f(self.betas[1]), f(self.eps), self.step_idx + 1,
+                        ctypes.c_void_p(torch.cuda.current_stream(self.master.device).cuda_stream))
+                _lib.check(rc, "adamw")
+            else:
+                self._torch_adamw(lr, self.nan_flag, lo, hi)
+
+        def on_bucket(runs):   # the runs of one bucket tile 128-aligned pieces of the flat buffers
+            for s_, e_ in runs:
+                adamw(s_, e_)
+
+        stepped = self.reducer.finish(on_bucket if self.bucket_optimizer and not self.shard_optimizer else None)
+        if not stepped:
+            adamw(*(self.reducer.slab(self.reducer.rank) if self.shard_optimizer else (0, self.flat.numel)))
         if self.shard_optimizer:
             self._broadcast_slabs()
         for m in self._param_caches:

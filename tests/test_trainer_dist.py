@@ -26,9 +26,13 @@ class Toy(torch.nn.Module):
         self.attn.w_lora = torch.nn.Module()
         self.attn.w_lora.lora = torch.nn.Sequential(torch.nn.Linear(64, 8, bias=False), torch.nn.Tanh(), torch.nn.Linear(8, 64))
 
-    def forward(self, x, y, poison=False):
+    def forward(self, x, y, poison=False, lora_first=False):
         h = torch.tanh(self.a(x))
-        h = torch.tanh(self.b(h) + self.attn.w_lora.lora(h))
+        if lora_first:   # same value, but the autograd nodes are created (hence run backwards) in the other order
+            lo = self.attn.w_lora.lora(h)
+            h = torch.tanh(self.b(h) + lo)
+        else:
+            h = torch.tanh(self.b(h) + self.attn.w_lora.lora(h))
         loss = torch.nn.functional.mse_loss(self.c(h), y)
         if poison:
             loss = loss * float("nan")
@@ -48,13 +52,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, shard=False):
+def _worker(rank, world, port, q, shard=False, bucket_opt=True):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     trainer.init_distributed("gloo")
     torch.set_num_threads(1)
     model = Toy()
-    tr = trainer.DataParallelTrainer(model, lr=1e-2, warmup_steps=0, total_steps=100, bucket_bytes=4096, shard_optimizer=shard)
+    tr = trainer.DataParallelTrainer(model, lr=1e-2, warmup_steps=0, total_steps=100, bucket_bytes=4096, shard_optimizer=shard,
+                                     bucket_optimizer=bucket_opt)
     if shard:   # the two slabs tile the flat buffer, and a bucket really is split between the owners
         (a0, a1), (b0, b1) = tr.reducer.slab(0), tr.reducer.slab(1)
         assert a0 == 0 and a1 == b0 and b1 == tr.flat.numel and a1 % 128 == 0
@@ -65,8 +70,17 @@ def _worker(rank, world, port, q, shard=False):
     first_cut = [list(r) for r in tr.reducer.runs]
     for step in range(3):
         x, y = _data(rank, step)
-        losses.append(float(tr.step(x=x, y=y)))
+        # step 0: rank 1 builds its graph in another order (what differently shaped batches do to the fused paths of the real
+        # model), so ITS gradient-ready order differs from rank 0's -- the buckets must still be cut identically (rank 0's order
+        # is broadcast, trainer.BucketedAllReduce.rebuild_from_ready_order)
+        own_order = []
         if step == 0:
+            orig = tr.reducer._ready
+            tr.flat.on_ready = lambda i, o=orig: (own_order.append(i), o(i))
+        losses.append(float(tr.step(x=x, y=y, lora_first=(rank == 1 and step == 0))))
+        if step == 0:
+            tr.flat.on_ready = tr.reducer._ready
+            assert tr.reducer.order_differs_from_rank0 == (rank == 1), (rank, own_order, tr.reducer.ready_order)
             # after the first backward pass the buckets are re-cut along the order the gradient hooks fired in (trainer.BucketedAllReduce.
             # rebuild_from_ready_order): the LoRA is registered AFTER `c` but used BEFORE it, so registration order put its gradients
             # (ready late) into the bucket that should open the exchange.  Now: `c` first, `a` last among the used ones, the never-used
@@ -90,15 +104,16 @@ def _worker(rank, world, port, q, shard=False):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("shard", [False, True])
-def test_two_rank_gloo_matches_single_process_average(shard):
-    """shard=False: bucketed all-reduce + replicated AdamW.  shard=True (DataParallelTrainer(shard_optimizer=True), SURVEY H6's
+@pytest.mark.parametrize("shard,bucket_opt", [(False, True), (False, False), (True, True)])
+def test_two_rank_gloo_matches_single_process_average(shard, bucket_opt):
+    """bucket_opt: AdamW bucket by bucket as each bucket's all-reduce completes (the default) vs one pass after the last one --
+    the same parameters either way.  shard=False: bucketed all-reduce + replicated AdamW.  shard=True (DataParallelTrainer(shard_optimizer=True), SURVEY H6's
     fallback): gradient pieces reduced to the slab owners, AdamW on the own slab only, parameter slabs broadcast -- the replicas
     must come out identical to each other and to the single-process reference in both modes, NaN step included."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, shard)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, shard, bucket_opt)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=150) for _ in range(2)], key=lambda t: t[0])
