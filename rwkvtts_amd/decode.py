@@ -377,12 +377,15 @@ class MultiGroupDecoder:
                     d.steps_run += 1
             # groups whose sequences have all met EOS drop out (one read-back per group every EOS_CHECK_EVERY rounds)
             if (it + 1) % GraphDecoder.EOS_CHECK_EVERY == 0 and live and live[0].eos is not None:
-                flags = []
+                still = []
                 for d, st in zip(self.decoders, self.streams):
                     if d in live:
-                        with torch.cuda.stream(st):   # on the stream that writes the flag: the read-back waits for the replays queued so far
-                            flags.append((d, d.unfinished.any()))
-                live = [d for d, f in flags if bool(f)]
+                        # reduction AND read-back on the stream that writes the flag (the copy to the host is ordered behind the
+                        # replays queued there so far; on the main stream it would race with them)
+                        with torch.cuda.stream(st):
+                            if bool(d.unfinished.any()):
+                                still.append(d)
+                live = still
                 if not live:
                     break
         outs = []

@@ -235,6 +235,47 @@ def test_config3_xy_model_full_depth_24_layers_train_steps_B4_L8192():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# configs[1] -- the headline configuration, whole
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+def test_config1_spark_0p4b_full_model_24_layers_train_steps_B8_L4096():
+    """configs[1] as bench.py times it (spark_llm.py:105-172 on the 0.4B base): 24 layers, D = 1024, H = 16, V = 8193, the Spark
+    batch [TAG2, 255 text, TAG0, 32 global, TAG1, 3806 semantic] built WITH autograd through the four embedding tables, B = 8,
+    L = 4096, bf16, AdamW on fp32 masters.  The loss starts at log 8193 (random head), falls over three steps on one batch,
+    gradients reach the first and the last layer AND the input-side embedding tables, the chunked MFMA WKV7 kernels are what ran
+    (T % 32 == 0, bf16), and the peak stays under 80 GiB (bench: 52.9 GiB)."""
+    import math
+    from rwkvtts_amd import backbone, trainer
+    from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = backbone.config_0p4b()
+    kw = {k: v for k, v in base.to_dict().items() if k in backbone.RWKV7Config.__dataclass_fields__ and k != "extra"}
+    assert kw["num_hidden_layers"] == 24 and kw["hidden_size"] == 1024
+    model = RWKV7ForSpeech(RWKV7SpeechConfig(**kw)).init_weights(seed=0)
+    assert model.config.vocab_size == 8193 and model.config.num_heads == 16
+    model = model.to(DEV).to(torch.bfloat16).train()
+    tr = trainer.DataParallelTrainer(model, lr=1e-3, warmup_steps=0, total_steps=10)
+    mk = lambda: L.synthetic_spark_batch(model, 8, 4096, seed=1234)
+    b0 = mk()
+    assert b0["inputs_embeds"].shape == (8, 4096, 1024) and int((b0["labels"] != -100).sum()) == 8 * 3806
+    l0 = tr.step(**b0).item()
+    assert math.isfinite(l0) and abs(l0 - math.log(8193)) < 0.05 * math.log(8193), (l0, math.log(8193))
+    for li in (0, 23):
+        g = model.model.layers[li].attn.r_proj.weight.grad
+        assert g is not None and torch.isfinite(g.float()).all() and g.float().abs().sum().item() > 0, li
+    for tab in (model.text_embedder, model.global_embedder, model.tts_tag_embedder, model.model.embeddings):
+        assert tab.weight.grad is not None and tab.weight.grad.float().abs().sum().item() > 0
+    l1 = tr.step(**mk()).item()
+    l2 = tr.step(**mk()).item()
+    assert math.isfinite(l2) and l2 < l1 < l0, (l0, l1, l2)
+    peak = torch.cuda.max_memory_allocated()
+    assert peak < 80 * 2**30, peak / 2**30
+    del tr, model
+    torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # configs[4]
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.timeout(1200)
