@@ -15,11 +15,13 @@ SMALL = dict(hidden_size=128, num_hidden_layers=2, decay_low_rank_dim=32, a_low_
              gate_low_rank_dim=32)
 
 
-def _spark_pair(seed=3, vocab=257):
+def _spark_pair(seed=3, vocab=257, head=None):
     cfg = RWKV7SpeechConfig(vocab_size=vocab, text_vocab_size=300, audio_global_vocab_size=64, **SMALL)
     rcfg = R.RefConfig(vocab_size=vocab, **SMALL)
     p = R.init_params(rcfg, seed=seed)
     p["lm_head.weight"] = torch.randn(vocab, 128, generator=torch.Generator().manual_seed(seed)) * 0.05
+    if head is not None:
+        p["lm_head.weight"] = head(p, rcfg)
     model = RWKV7ForSpeech(cfg)
     sd = dict(p)
     for n in ("text_embedder", "global_embedder", "tts_tag_embedder"):
@@ -110,15 +112,33 @@ def test_greedy_generate_ids_bit_exact_vs_oracle():
     assert torch.equal(ids, torch.stack(want, 1))
 
 
+def _wandering_head(p, rcfg):
+    """A random head on a random backbone sends greedy decoding into a fixed point within a step or two (one token for ever: the
+    recurrent state converges and nothing is tested after that).  This head adds, to the 0.05-sigma random rows, 0.1 x the
+    (centred, normalised) hidden state that token perm[i] leaves behind from a zero state to row i: token i is mildly favoured
+    right after perm[i], the walk keeps moving, and -- the weight is small -- where it goes depends on the carried state (it
+    follows the permutation in only ~10 % of the steps; the oracle's top-2 margins have median 0.2 and minimum 4e-4)."""
+    g = torch.Generator().manual_seed(21)
+    emb = p["model.embeddings.weight"]
+    h1, _ = R.backbone(p, rcfg, emb[:256].unsqueeze(1), None, R.zero_states(rcfg, 256))
+    h1 = h1[:, 0] - h1[:, 0].mean(0, keepdim=True)
+    h1 = h1 / h1.norm(dim=1, keepdim=True)
+    perm = torch.randperm(256, generator=g)
+    W = torch.randn(257, 128, generator=g) * 0.05
+    W[:256] += 0.1 * h1[perm]
+    return W
+
+
 @pytest.mark.timeout(600)
 def test_greedy_generate_512_tokens_bit_exact_vs_oracle_left_pad_and_suppressed_ids():
     """north_star: "bit-exact argmax token ids for greedy decode" -- the 24-token case above is thin for a recurrence whose
     errors accumulate in the state, so: B = 4 with three different left paddings, 512 new tokens on the persistent state,
-    two suppressed ids (one of them the EOS id, so no row stops early), fp32, against the CPU oracle stepping its own state
-    list token by token.  Equality of every one of the 2 048 ids; if a position ever differs, the test only accepts it when the
-    ORACLE's own top-2 margin there is a numerical tie (< 1e-5: two fp32 implementations cannot be asked to order those), and
-    nothing after a tie is compared for that row (the histories differ from there on)."""
-    model, p, rcfg = _spark_pair(seed=21)
+    two suppressed ids (one of them the EOS id, so no row stops early), fp32, a head under which the greedy walk keeps visiting
+    new tokens (`_wandering_head`), against the CPU oracle stepping its own state list token by token.  Equality of every one
+    of the 2 048 ids; if a position ever differs, the test only accepts it when the ORACLE's own top-2 margin there is a
+    numerical tie (< 1e-5: two fp32 implementations cannot be asked to order those), and nothing after a tie is compared for
+    that row (the histories differ from there on)."""
+    model, p, rcfg = _spark_pair(seed=21, head=_wandering_head)
     B, P, NEW, SUP = 4, 20, 512, [256, 7]
     g = torch.Generator().manual_seed(4)
     x = torch.randn(B, P, 128, generator=g) * 0.5
@@ -147,8 +167,8 @@ def test_greedy_generate_512_tokens_bit_exact_vs_oracle_left_pad_and_suppressed_
             alive[b] = False
             ties += 1
         h, states = R.backbone(p, rcfg, emb[ids[:, t]].unsqueeze(1), None, states)   # the GPU's history, so the live rows stay comparable
-    assert ties == 0 or alive.sum() >= B - 1, "more than one row ran into an fp32 tie: pick another seed"
-    assert len(set(ids[0].tolist())) > 20   # the sequences are not stuck in a short cycle
+    assert ties == 0, "an fp32 tie in the oracle's own margins: pick another seed"
+    assert all(len(set(row.tolist())) >= 40 for row in ids), [len(set(row.tolist())) for row in ids]   # the walk keeps moving
 
 
 def test_backward_matches_oracle_autograd():
