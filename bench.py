@@ -54,13 +54,44 @@ def _free_port():
 
 
 def _device_info(torch, dev):
-    """Name / CU count / clock of the GPU the line was measured on (boxes of one pool differ by several per cent)."""
+    """Name / CU count of the GPU the line was measured on, plus a FINGERPRINT of the box (boxes of one pool differ by several per
+    cent in kernel time; lines from different boxes can be normalised by these): the shader clock torch reports right after the
+    timed steps, a ~40 ms device-to-device copy probe (1 GiB read + 1 GiB written, GB/s) and a ~40 ms bf16 GEMM probe
+    (8192 x 8192 x 8192 through the library, TFLOP/s).  Run AFTER the timed region (called when the JSON line is assembled)."""
     try:
         p = torch.cuda.get_device_properties(dev)
-        return {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
-                "hbm_gib": round(p.total_memory / 2**30)}
+        out = {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
+               "hbm_gib": round(p.total_memory / 2**30)}
     except Exception as e:
         return {"error": repr(e)}
+    try:
+        out["sclk_mhz_after_steps"] = int(torch.cuda.clock_rate())
+    except Exception:   # amdsmi / rocm-smi bindings absent: the probes below still fingerprint the box
+        out["sclk_mhz_after_steps"] = None
+    try:
+        def timed(fn, n):
+            fn()
+            torch.cuda.synchronize(dev)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(n):
+                fn()
+            e.record()
+            torch.cuda.synchronize(dev)
+            return s.elapsed_time(e) / n
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        ms = timed(lambda: dst.copy_(src), 8)
+        out["copy_probe_gbs"] = round(2 * (1 << 30) / ms / 1e6, 0)
+        del src, dst
+        a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+        b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+        ms = timed(lambda: torch.mm(a, b.t()), 40)
+        out["gemm8192_probe_tflops"] = round(2 * 8192**3 / ms / 1e9, 0)
+        del a, b
+    except Exception as e:   # never let the fingerprint take the line down
+        out["probe_error"] = repr(e)
+    return out
 
 
 def self_launch(n):
@@ -335,7 +366,7 @@ def main():
         th = B * T * H
         chunk_parts = [k for k in ("wkv7c_bseq", "wkv7c_bwd_out") if k in kern]
         if "wkv7c_op_bwd" in kern:   # --via-reference-op: the op's launches are timed as one unit each way
-            bwd_ms, bwd_name = kern["wkv7c_op_bwd"], f"torch.ops.wind_backstepping.backward -> wkv7c_bseq + wkv7c_bwd_out9 ({cfg.num_hidden_layers}x per step)"
+            bwd_ms, bwd_name = kern["wkv7c_op_bwd"], f"torch.ops.wind_backstepping.backward -> wkv7c_bseq + wkv7c_bwd_out10 ({cfg.num_hidden_layers}x per step)"
             fwd_ms, fwd_name = kern["wkv7c_op_fwd"], "torch.ops.wind_backstepping.forward -> wkv7c_prep + wkv7c_fwd9"
             pmc_bwd, pmc_fwd = "wkv7c_bwd", "wkv7c_fwd"
         elif "wkv7c_bwd_out" in kern:

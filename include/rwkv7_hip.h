@@ -352,6 +352,10 @@ int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const voi
                                    const void *a, const void *b, const void *dy, const void *hs, const float *sa,
                                    const float *z, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
                                    void *da, void *db, rwkv7_stream_t stream);
+/*      which per-chunk gradient kernel the entry above (and rwkv7_wkv_bwd_fast_bf16) launches (A/B knob, process-wide): 10 (default) =
+ *      csrc/wkv7_chunk_bwd10.hip (raw rows by LDS-DMA, unpadded XOR-swizzled planes, state prologue and phase A in one barrier interval),
+ *      9 = csrc/wkv7_chunk_bwd9.hip (round 3/4).  Same arithmetic.  Returns the previous value; other arguments leave it unchanged. */
+int rwkv7_set_bwd_out_generation(int generation);
 /* ---- head loss: softmax cross-entropy of a chunk of bf16 logits [rows,V], forward and backward in one pass
  *      (spark_llm.py:146-160, FusedLinearCrossEntropyLoss).  labels int64 [rows]; rows with label == ignore_index give 0.
  *      loss_rows[rows] = logsumexp - logit[label]; logits are REPLACED by (softmax - onehot) * scale. ---- */

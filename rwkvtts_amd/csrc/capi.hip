@@ -56,6 +56,8 @@ int mix_lora_wcat_fwd(const MixLoraDesc &, int, int, void *, hipStream_t);
 int mix_lora_wcat_bwd(const MixLoraDesc &, int, int, const void *, hipStream_t);
 int mix_lora_combine_fwd(const MixLoraDesc &, long, int, int, const void *, const void *, hipStream_t);
 int mix_lora_combine_bwd(const MixLoraDesc &, long, int, int, const void *, void *, hipStream_t);
+int chunk_bwd_out10_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
+                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                         const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
@@ -144,6 +146,18 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
 // the reference-schema pair on the chunked (MFMA) kernels: `s` as an arena [hs | T^-1 | e_vk] (include/rwkv7_hip.h)
 namespace {
 constexpr size_t kArenaRec = (size_t)RWKV7_Q15_REC * 2, kArenaTinv = 32 * 32 * sizeof(float);
+int g_bwd_out_generation = 10;   // 10: csrc/wkv7_chunk_bwd10.hip (LDS-DMA rows, swizzled planes, merged prologue / phase A), 9: csrc/wkv7_chunk_bwd9.hip
+int bwd_out_dispatch(int B, int T, int H, const void *w, const void *q, const void *k, const void *v, const void *a, const void *b,
+                     const void *dy, const void *hs, const float *sa, const float *z, const void *e_vk, void *dw, void *dq, void *dk,
+                     void *dv, void *da, void *db, hipStream_t st) {
+    return g_bwd_out_generation == 9 ? rwkv7::chunk_bwd_out9_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, st)
+                                     : rwkv7::chunk_bwd_out10_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, st);
+}
+}
+int rwkv7_set_bwd_out_generation(int gen) {
+    const int prev = g_bwd_out_generation;
+    if (gen == 9 || gen == 10) g_bwd_out_generation = gen;
+    return prev;
 }
 int rwkv7_wkv_fwd_fast_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                             const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream) {
@@ -168,7 +182,7 @@ int rwkv7_wkv_bwd_fast_bf16(int B, int T, int H, const void *w, const void *q, c
     float *z = reinterpret_cast<float *>(base + n * (2 * kArenaRec + kArenaTinv));   // fp32 [B,T,H,64]: 8192 B per chunk and head
     const int rc = rwkv7::chunk_bseq_bf16(B, T, H, w, q, a, b, dy, tinv, e_vk, z, nullptr, 0, (hipStream_t)stream);
     if (rc != 0) return rc;
-    return rwkv7::chunk_bwd_out9_bf16(B, T, H, w, q, k, v, a, b, dy, base, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
+    return bwd_out_dispatch(B, T, H, w, q, k, v, a, b, dy, base, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
 
 #define BWD2_BODY(IMPL, WIDE)                                                                                 \
@@ -473,7 +487,7 @@ int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const voi
         any_null({w, q, k, v, a, b, dy, hs, (const void *)sa, (const void *)z, e_vk, dw, dq, dk, dv, da, db}))
         return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
-    return rwkv7::chunk_bwd_out9_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
+    return bwd_out_dispatch(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
 static int g_gemm_generation = 4;   // 4: csrc/gemm_nt4.hip (K % 1024 == 0), 1: csrc/gemm_relusq.hip
 int rwkv7_set_gemm_generation(int gen) {

@@ -5,7 +5,7 @@ products as ONE bf16 plane) it prints, per gradient, the worst error in units of
 the floor of _assert_bf16_close): < 1 passes.  Shapes and seeds: the parametrisations of test_chunked_forward_plus_backward_vs_oracle
 plus two more seeds of the largest, and three (batch, head) slices of BASELINE configs[1].
 
-    RWKV7_HIP_SO=tools/ab/lib_b9_<mask>.so python tests/b9_single_probe.py"""
+    RWKV7_HIP_SO=tools/ab/lib_b9_<mask>.so python tools/b9_single_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

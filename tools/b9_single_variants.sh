@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds tools/ab/lib_b9_<mask>.so for the masks given (default: the fourteen single-operand masks): csrc/wkv7_chunk_bwd9.hip compiled with
 # -DWKV7C_B9_SINGLE=<mask>, linked with the objects of the current library build (python -m rwkvtts_amd.build first).  Then, on the GPU box:
-#   for f in tools/ab/lib_b9_*.so; do RWKV7_HIP_SO=$f python tests/b9_single_probe.py; done
+#   for f in tools/ab/lib_b9_*.so; do RWKV7_HIP_SO=$f python tools/b9_single_probe.py; done
 cd "$(dirname "$0")/.."
 FLAGS="-O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -fgpu-flush-denormals-to-zero -Wno-unused-result -Wno-pass-failed"
 OTHERS=$(ls rwkvtts_amd/lib/*.o | grep -v wkv7_chunk_bwd9.o)

@@ -67,8 +67,8 @@ def main():
                        "runs per counter group, no tracing). KiB per launch; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: "
                        "FETCH_SIZE counts half of a wide coalesced read stream, MI355X_MICROARCH.md). wkv7c_* = what bf16 training "
                        "launches; wkv7_* = the scalar reference-schema kernels.",
-           "wkv7c_bwd": group(tab, ["wkv7c_bseq_kernel", "wkv7c_bwd_out9_kernel"], B, T, H, src,
-                              ["wkv7_chunk_bseq.hip", "wkv7_chunk_bwd9.hip", "chunk_bwd_common.h"] + COMMON),
+           "wkv7c_bwd": group(tab, ["wkv7c_bseq_kernel", "wkv7c_bwd_out10_kernel"], B, T, H, src,
+                              ["wkv7_chunk_bseq.hip", "wkv7_chunk_bwd10.hip", "chunk_bwd_common.h"] + COMMON),
            "wkv7c_fwd": group(tab, ["wkv7c_prep_kernel", "wkv7c_fwd9_kernel"], B, T, H, src,
                               ["wkv7_chunk_fwd.hip", "wkv7_chunk_fwd9.hip"] + COMMON),
            "wkv7_bwd": group(tab, ["wkv7_bwd_kernel<rwkv7::bf16_t, 2, 4>"], B, T, H, src, ["wkv7_bwd.hip", "wkv7_common.h"]),
