@@ -368,6 +368,9 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out10_kernel(
         // ---- I1: E' planes + rowsum(E * H_C)  |  the eight single products -- in opposite order on the two waves of a SIMD -------------
         // acc1: waves 0-1 dQ.  acc3: waves 0-1 dA.  acc2: waves 2-3 dK, 4-5 dV, 6-7 dB.
         f32x16 acc1 = zero16(), acc2 = zero16(), acc3 = zero16();
+        // the ten lane-constant fragment offsets of the swizzled planes, once per chunk from an opaque copy of the lane id (hoisted out of
+        // the chunk loop they drag the derived addresses along: 256 registers + 56 spilled)
+        const SwLane s = sw_lane(fresh10(lane));
         auto state_prologue = [&]() {
             float gk[8], ev[8], hv[8], x[8], part[8];
             q15_decode8(curm.e[0], curm.e[1], sh_sE[slot], sh_sE[slot + 32], ev);
@@ -398,7 +401,6 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out10_kernel(
             reinterpret_cast<float *>(sm + L::DT8)[wave * kN + kk] = red;
         };
         auto phase_a = [&]() {
-            const SwLane s = sw_lane(fresh10(lane));
             const int ln = fresh10(lane);
             if (wave <= 1) {   // both products on H0 (its planes are complete since I0): dQ: D[t][k] = sum_v dY[t][v] H0[v][k] ; dA: Z H0^T
                 mma_sw_k64<64, false, false, 64, true, true>(acc1, sm + L::DYp, sm + L::DYp, 0, sm + L::HTh, sm + L::HTl, wave * 32, s);
@@ -461,7 +463,6 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out10_kernel(
         // pieces queue at the texture addresser, 16 cycles each, and every wave stands in that queue: 0.9-1.3k cycles per chunk) ----------
         {
             const long cbn = more ? chunk_base(chunk + 1) : 0;
-            const SwLane s = sw_lane(fresh10(lane));
             const uint16_t *const Pvy = sm + L::P0, *const Pvz = sm + L::P0 + 2 * L::A1, *const Puy = sm + L::P0 + 4 * L::A1, *const Puz = sm + L::P0 + 6 * L::A1;
             dma_pieces(cbn, 0, 2);
             if (wave <= 1) {
