@@ -329,7 +329,7 @@ class _KeyReluSq(torch.autograd.Function):
         dk = torch.empty_like(s)
         _call("relusq_bwd_s", s, ctypes.c_long(s.numel()), _p(s), _p(ds2), _p(dk))
         x2 = _c(x).view(-1, x.shape[-1])
-        dx = torch.mm(dk, weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(dk, weight).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _wgrad(dk, x2, ctx.wparam)
@@ -392,6 +392,32 @@ class _ReluSqValue(torch.autograd.Function):
 # nor rwkv7_relusq_bwd runs, and one [rows, F] activation less is kept per layer.  Same-box A/B (tools/ab_step.py): see DESIGN.md section 4.
 FUSED_CMIX = os.environ.get("RWKV7_FUSED_CMIX", "1") == "1"
 FUSED_CMIX_HITS = [0]
+# Round 5: input gradients dx = dy @ W (W [N_out, K_in] as nn.Linear stores it) are an "NN" product for the library -- the contraction
+# index is the ROW index of W -- and the kernels it picks for that layout are slower than the "NT" ones of the forward product (both
+# operands contraction-contiguous): 76.5 against 63.7 us at 32768 x 1024 x 1024, 246 against 181 us for the channel-mix key's input
+# gradient (profiles/r05m_dgrad_layout_probe.txt), with bit-identical results.  W^T is one small transpose (2-8 MB,
+# rwkv7_transpose_bf16) per weight and step.  RWKV7_DGRAD_NT=0: off.
+# Inside the training step it pays for the long contraction only (N_out = 4096: 24 x 65 us per step); the 1024-wide input gradients run
+# at ~59 us in the step either way (profiles/r05o_step_busy.txt), so they keep the library's layout and save the transpose.
+DGRAD_NT = os.environ.get("RWKV7_DGRAD_NT", "1") == "1"
+DGRAD_NT_MIN_N = int(os.environ.get("RWKV7_DGRAD_NT_MIN_N", "2048"))
+DGRAD_NT_HITS = [0]
+
+
+def _dgrad(dy2, weight):
+    """dy2 [M, N] @ weight [N, K] -> [M, K]."""
+    N, K = weight.shape
+    if (DGRAD_NT and dy2.is_cuda and dy2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and dy2.shape[0] >= WGRAD_MIN_ROWS
+            and N % 64 == 0 and K % 64 == 0 and N >= DGRAD_NT_MIN_N and K >= 256 and weight.is_contiguous() and dy2.is_contiguous()):
+        wt = torch.empty(K, N, dtype=weight.dtype, device=weight.device)
+        with torch.cuda.device_of(dy2):
+            rc = _lib.lib().rwkv7_transpose_bf16(N, K, _p(weight), _p(wt), _stream(dy2))
+        _lib.check(rc, "transpose(dgrad)")
+        DGRAD_NT_HITS[0] += 1
+        return torch.mm(dy2, wt.t())
+    return torch.mm(dy2, weight)
+
+
 TRANSPOSE_KERNEL = True   # W_value^T through rwkv7_transpose_bf16 instead of torch's strided copy (27 -> ~6 us per layer)
 
 
@@ -438,7 +464,7 @@ class _ChannelMix(torch.autograd.Function):
         with torch.cuda.device_of(s):
             rc = _lib.lib().rwkv7_gemm_nt_relusq_bwd_s_bf16(M, F, D, _p(d2), _p(wt), _p(s), _p(dk), _stream(s))
         _lib.check(rc, "gemm_nt_relusq_bwd_s")
-        dx = torch.mm(dk, wk).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(dk, wk).view(ctx.shape) if ctx.needs_input_grad[0] else None
         dwk = _wgrad(dk, x2, ctx.wk) if ctx.needs_input_grad[1] else None
         dwv = _wgrad(d2, s, ctx.wv) if ctx.needs_input_grad[2] else None
         return dx, dwk, dwv
@@ -844,7 +870,7 @@ class _Linear(torch.autograd.Function):
         K = x.shape[-1]
         dy2 = _c(dy).view(-1, dy.shape[-1])
         x2 = _c(x).view(-1, K)
-        dx = torch.mm(dy2, weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(dy2, weight).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:   # (queued before the input-gradient GEMM instead: +0.8 ms per step, same-box A/B)
             dw = _wgrad(dy2, x2, ctx.wparam)
@@ -880,10 +906,10 @@ class _DualLinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if da2 is not None and db2 is not None:
-                dx = torch.mm(da2, wa)
+                dx = _dgrad(da2, wa)
                 dx.addmm_(db2, wb)
             elif da2 is not None:
-                dx = torch.mm(da2, wa)
+                dx = _dgrad(da2, wa)
             elif db2 is not None:
                 dx = torch.mm(db2, wb)
             dx = None if dx is None else dx.view(x.shape)
@@ -965,7 +991,7 @@ class _LinearAdd(torch.autograd.Function):
     def backward(ctx, d1):
         y2, weight = ctx.saved_tensors
         d2 = _c(d1).view(-1, d1.shape[-1])
-        dy = torch.mm(d2, weight).view(ctx.yshape) if ctx.needs_input_grad[0] else None
+        dy = _dgrad(d2, weight).view(ctx.yshape) if ctx.needs_input_grad[0] else None
         dw = _wgrad(d2, y2, ctx.wparam) if ctx.needs_input_grad[1] else None
         return dy, dw, (d1 if ctx.needs_input_grad[2] else None)
 

@@ -49,9 +49,16 @@ def synthetic_spark_batch(llm, B: int, T: int = 4096, seed: int = 1234, n_text: 
     g = torch.Generator().manual_seed(seed)
     n_sem = T - 3 - n_text - n_global
     assert n_sem > 0
-    text = torch.randint(0, cfg.text_vocab_size, (B, n_text), generator=g).to(dev)
-    glob = torch.randint(0, cfg.audio_global_vocab_size, (B, n_global), generator=g).to(dev)
-    sem = torch.randint(0, cfg.vocab_size - 1, (B, n_sem), generator=g).to(dev)
+    # ids leave the host from pinned memory without a synchronising copy (what a DataLoader with pin_memory=True + non_blocking .to()
+    # does): a pageable .to(dev) makes the host wait for everything queued before it, i.e. for the previous step's optimizer, and the
+    # GPU then idles while the host builds the batch (1.75 ms per step in profiles/r05i_step_busy.txt)
+    def up(t):
+        if torch.device(dev).type != "cuda":
+            return t.to(dev)
+        return t.pin_memory().to(dev, non_blocking=True)
+    text = up(torch.randint(0, cfg.text_vocab_size, (B, n_text), generator=g))
+    glob = up(torch.randint(0, cfg.audio_global_vocab_size, (B, n_global), generator=g))
+    sem = up(torch.randint(0, cfg.vocab_size - 1, (B, n_sem), generator=g))
     tag = lambda i: llm.tts_tag_embedder(torch.full((B, 1), i, dtype=torch.long, device=dev))
     embs = torch.cat([tag(2), llm.text_embedder(text), tag(0), llm.global_embedder(glob), tag(1),
                       llm.model.embeddings(sem)], dim=1)

@@ -24,6 +24,9 @@ import torch
 import torch.distributed as dist
 
 
+FLUSH_EVERY = int(os.environ.get("RWKV7_FLUSH_EVERY", "48"))   # adopted gradients per in-backward flush (0: one flush at the end)
+
+
 def init_distributed(backend: Optional[str] = None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run contract).  Returns
     (rank, local_rank, world).  No-op for world size 1."""
@@ -84,6 +87,11 @@ class FlatBuffers:
             g = param.grad
             if g is not None and g.data_ptr() != self.views[i].data_ptr():
                 self.to_copy.append(i)   # moved into its slice by flush(): one multi-tensor copy for many parameters
+                # ... in batches WHILE backward runs: left to the end, the ~500 small gradients of a 24-layer model are one burst of
+                # host work (list building + multi-tensor launches, 1.4 ms) behind the last backward kernel, with the GPU idle
+                # (profiles/r05k_step_busy.txt); a batch flushed from a hook is host work under the layers still queued
+                if len(self.to_copy) >= FLUSH_EVERY > 0:
+                    self.flush()
             self.fired[i] = True
             if self.on_ready is not None:
                 self.on_ready(i)
@@ -119,14 +127,22 @@ class FlatBuffers:
             p._grad_slot_used = False
             self.fired[i] = False
 
-    def finish_backward(self):
-        """After backward: zero the slices that received nothing, re-attach every .grad."""
+    def finish_backward(self, reattach=True):
+        """After backward: zero the slices that received nothing, re-attach every .grad.
+        reattach=False (DataParallelTrainer.step): only what the GPU needs -- the flush and the zeroing -- so that the optimizer can be
+        launched at once; the ~800 attribute writes of `reattach()` (about 1 ms of host time during which the GPU sat idle between
+        the last backward kernel and AdamW, profiles/r05i_step_busy.txt) run behind that launch."""
         from . import fused
         fused.wgrad_side_sync()   # weight gradients queued on the side stream land before anything reads the buffer
         self.flush()
-        for i, p in enumerate(self.params):
+        for i in range(len(self.params)):
             if not self.fired[i]:
                 self.views[i].zero_()
+        if reattach:
+            self.reattach()
+
+    def reattach(self):
+        for i, p in enumerate(self.params):
             p.grad = self.views[i]
             p._grad_slot_used = True
 
@@ -161,6 +177,7 @@ class BucketedAllReduce:
         self.launched = []       # buckets in launch order (the order finish() hands them to `on_bucket`)
         self.use_avg, self.summed = True, []
         self.measure, self.wait_events = False, []
+        self.defer_reattach = False   # DataParallelTrainer sets it: it calls flat.reattach() itself, behind the optimizer launch
         self.enabled = self.world > 1 or (force and dist.is_initialized())
         if self.enabled:
             flat.on_ready = self._ready
@@ -285,7 +302,7 @@ class BucketedAllReduce:
         compute stream's timeline (work.wait() = the compute stream waits for RCCL's stream up to that collective) -- the
         optimizer steps bucket b while buckets b+1.. are still on the wire, instead of one replicated pass behind the last
         all-reduce.  Returns True if it was called for every bucket (False: exchange disabled, caller does one whole pass)."""
-        self.flat.finish_backward()
+        self.flat.finish_backward(reattach=self.defer_reattach is False)
         if not self.enabled:
             return False
         for b in range(self.next_bucket, len(self.pending)):   # incomplete buckets (unused parameters) and their successors
@@ -394,6 +411,7 @@ class DataParallelTrainer:
         self.flat = FlatBuffers(model)
         self.reducer = BucketedAllReduce(self.flat, bucket_bytes, force=force_allreduce, shard=shard_optimizer)
         self.shard_optimizer = bool(shard_optimizer) and self.reducer.enabled
+        self.reducer.defer_reattach = True
         self.world = self.reducer.world
         self.master = self.flat.flat_param.float() if master_fp32 and self.flat.flat_param.dtype != torch.float32 \
             else self.flat.flat_param
@@ -557,6 +575,7 @@ class DataParallelTrainer:
             adamw(*(self.reducer.slab(self.reducer.rank) if self.shard_optimizer else (0, self.flat.numel)))
         if self.shard_optimizer:
             self._broadcast_slabs()
+        self.flat.reattach()   # host-only bookkeeping, behind the optimizer launch (see FlatBuffers.finish_backward)
         for m in self._param_caches:
             m._mix_key = None
         self.step_idx += 1

@@ -60,3 +60,17 @@ for s_, e_, n_ in win:
 print("idle gaps > 20 us by (kernel before -> kernel after): count per step, ms per step")
 for k, (c, v) in sorted(gp.items(), key=lambda kv: -kv[1][1])[:16]:
     print(f"   {c / nsteps:5.1f}  {v:6.3f} ms   {k[0]}  ->  {k[1]}")
+
+# the three largest gaps of the last step, with their neighbourhood (full names, time since the step's first kernel)
+last = [r for r in rows if r[0] >= rows[ad[-2]][1] and r[1] <= hi]
+t0 = last[0][0]
+cand = []
+pe = None
+for j, (s_, e_, n_) in enumerate(last):
+    if pe is not None and s_ - pe > 100000:
+        cand.append((s_ - pe, j))
+    pe = e_ if pe is None else max(pe, e_)
+for g_, j in sorted(cand, reverse=True)[:4]:
+    print(f"gap {g_ / 1e3:.0f} us at +{(last[j][0] - t0) / 1e6:.2f} ms of the last step ({(hi - t0) / 1e6:.1f} ms long), launch index {j} of {len(last)}:")
+    for q in range(max(0, j - 3), min(len(last), j + 3)):
+        print(f"      {'>>' if q == j else '  '} +{(last[q][0] - t0) / 1e6:8.3f} ms  {(last[q][1] - last[q][0]) / 1e3:8.1f} us  {last[q][2][:150]}")
