@@ -458,11 +458,12 @@ def main():
         if world > 1:
             r = tr.reducer
             out["comm"] = {"rccl_ranks": world, "backend": r.backend, "bytes_allreduced_per_step": tr.flat.numel * tr.flat.flat_grad.element_size(),
-                           "buckets": len(r.buckets), "bucket_order": "gradient-ready order (re-cut after the first backward pass)" if r.rebuilt else "reverse registration order",
+                           "buckets": len(r.buckets), "bucket_order": "rank 0's gradient-ready order, broadcast (re-cut after the first backward pass); launched in index order" if r.rebuilt else "reverse registration order",
+                           "optimizer": "AdamW bucket by bucket as each all-reduce completes" if tr.bucket_optimizer and not tr.shard_optimizer else "one pass behind the last bucket",
                            "bucket_mib": [round(sum(e - s for s, e in runs) * tr.flat.flat_grad.element_size() / 2**20, 1) for runs in r.runs],
                            "bucket_runs": [len(runs) for runs in r.runs],
                            "exposed_wait_ms_per_step": round(sum(s_.elapsed_time(e_) for s_, e_ in r.wait_events) / a.steps, 3),
-                           "note": "exposed = time the compute stream stalls on the buckets' wait() after backward has been enqueued (HIP events, rank 0)"}
+                           "note": "exposed = time the compute stream stalls in the buckets' wait() calls (HIP event pairs around each bucket's waits, rank 0; the optimizer launches between them are not counted)"}
         if world == 1 and not a.no_decode and a.layout == "spark":
             try:
                 out["decode"] = decode_rate(model, dev)

@@ -307,12 +307,15 @@ class BucketedAllReduce:
             return False
         for b in range(self.next_bucket, len(self.pending)):   # incomplete buckets (unused parameters) and their successors
             self._launch(b)
-        # wait() makes the compute stream wait for RCCL's stream; what the compute stream then stalls is the exposed
-        # (non-overlapped) part of the exchange -- bracketed by two events when `measure` is on (bench.py); with on_bucket
-        # the bracket also holds the optimizer launches of the earlier buckets (that is the point: they fill the stall)
-        if self.measure and self.works:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        # wait() makes the compute stream wait for RCCL's stream; what the compute stream then stalls is the exposed (non-overlapped)
+        # part of the exchange -- bracketed by event pairs when `measure` is on (bench.py): one pair around ALL waits in the one-pass
+        # mode, one pair around each bucket's waits in the per-bucket mode (the optimizer launches between them are work, not stall)
+        def bracket():
+            if self.measure and self.works:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                return e
+            return None
         per_bucket = on_bucket is not None and not self.shard
         if per_bucket:
             by_b, scale_b = {}, {}
@@ -321,19 +324,24 @@ class BucketedAllReduce:
             for b, s, e in self.summed:
                 scale_b.setdefault(b, []).append((s, e))
             for b in self.launched:
+                e0 = bracket()
                 for w in by_b.get(b, ()):
                     w.wait()
+                e1 = bracket()
+                if e0 is not None:
+                    self.wait_events.append((e0, e1))
                 for s, e in scale_b.get(b, ()):
                     self.flat.flat_grad[s:e].mul_(1.0 / self.world)
                 on_bucket(self.runs[b])
         else:
+            e0 = bracket()
             for _, w in self.works:
                 w.wait()
+            e1 = bracket()
+            if e0 is not None:
+                self.wait_events.append((e0, e1))
             for _, s, e in self.summed:
                 self.flat.flat_grad[s:e].mul_(1.0 / self.world)
-        if self.measure and self.works:
-            e1.record()
-            self.wait_events.append((e0, e1))
         self.works, self.summed, self.launched = [], [], []
         if not self.rebuilt and (self.ready_order or self.world > 1):
             self.rebuild_from_ready_order()   # once, after the first backward pass (also resets `pending`)
