@@ -112,10 +112,25 @@ class _FusedLinearCE(torch.autograd.Function):
                 (db * g).to(ctx.wdtype) if db is not None else None, None, None, None, None)
 
 
-def fused_linear_cross_entropy(hidden, labels, weight, bias=None, ignore_index=-100, chunk=4096,
+LOGITS_CHUNK_BYTES = int(os.environ.get("RWKV7_CE_CHUNK_BYTES", str(1 << 30)))
+
+
+def auto_chunk(rows, V, esize=2):
+    """Rows per chunk of the head GEMMs: as many as keep the chunk's logits under LOGITS_CHUNK_BYTES (1 GiB of the GPU's 288), in
+    multiples of 4096.  The first cut used 4096 rows whatever the vocabulary: eight rounds of three 69-GFLOP GEMMs for the Spark head
+    (V = 8193), each too small to fill the chip (0.69-0.80 PF/s, 2.96 ms per step for the node, profiles/r05q_ce_head_probe.txt); the
+    whole batch as ONE chunk is 0.54 GB of logits.  The 66 661-wide XY head keeps 4096-row chunks (0.55 GB each)."""
+    c = max(4096, (LOGITS_CHUNK_BYTES // (esize * V)) // 4096 * 4096)
+    return rows if c >= rows else c
+
+
+def fused_linear_cross_entropy(hidden, labels, weight, bias=None, ignore_index=-100, chunk=None,
                                label_smoothing=0.0):
-    """hidden [..., D], labels [...] (already shifted by the caller) -> mean CE over labels != ignore_index."""
+    """hidden [..., D], labels [...] (already shifted by the caller) -> mean CE over labels != ignore_index.
+    chunk: rows per round of head GEMMs (None: auto_chunk)."""
     D = hidden.shape[-1]
+    if chunk is None:
+        chunk = auto_chunk(hidden.numel() // D, weight.shape[0], hidden.element_size())
     return _FusedLinearCE.apply(hidden.reshape(-1, D), weight, bias, labels.reshape(-1), ignore_index, chunk,
                                 label_smoothing)
 
