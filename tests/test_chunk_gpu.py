@@ -112,6 +112,41 @@ def test_chunked_forward_plus_backward_vs_oracle(c_oracle, B, T, H, seed):
         _assert_bf16_close(g, go, n, ulps=2.0)
 
 
+@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 96, 3, 4), (3, 2080, 2, 5)])   # one chunk; odd chunk counts; 65 chunks x 6 heads = 390:
+def test_both_gradient_kernel_generations_vs_oracle_and_each_other(c_oracle, B, T, H, seed):       # not a multiple of the chunks per workgroup
+    """rwkv7_set_bwd_out_generation: 10 = wkv7c_bwd_out10 (round 5: raw rows by LDS-DMA, swizzled planes, merged prologue / phase A;
+    the default), 9 = wkv7c_bwd_out9.  Both inside the 2-ulp bar against the C oracle; against each other dq, dk, dv, da, db are the
+    SAME BITS (same products, same MFMA order) and dw within one bf16 ulp (its epilogue sum is contracted differently under
+    -ffast-math in the two kernels).  The landing area of generation 10 is refilled one chunk ahead: a workgroup's last chunk, a
+    launch with one chunk in all, and a chunk count that does not divide by the chunks per workgroup are the edge cases."""
+    from rwkvtts_amd import _lib
+    lib = _lib.lib()
+    ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).bfloat16()
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    g_o = c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)
+    d = [t.to(DEV) for t in ins]
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
+    out = {}
+    prev = lib.rwkv7_set_bwd_out_generation(10)
+    try:
+        assert prev == 10, "generation 10 is the default"
+        for gen in (9, 10):
+            assert lib.rwkv7_set_bwd_out_generation(gen) in (9, 10)
+            out[gen] = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv)
+            torch.cuda.synchronize()
+            for n, g, go in zip(NAMES, out[gen], g_o):
+                _assert_bf16_close(g, go, f"{n} (generation {gen})", ulps=2.0)
+        assert lib.rwkv7_set_bwd_out_generation(7) == 10 and lib.rwkv7_set_bwd_out_generation(10) == 10   # unknown values change nothing
+    finally:
+        lib.rwkv7_set_bwd_out_generation(10)
+    for n, a, b in zip(NAMES, out[9], out[10]):
+        if n == "dw":
+            _assert_bf16_close(a, b.float().cpu(), "dw, generation 9 vs 10", ulps=1.0)
+        else:
+            assert torch.equal(a, b), n
+
+
 def test_full_size_config2_chunked_pair_vs_oracle_slices(c_oracle):
     """BASELINE.json configs[1] (B=8, T=4096, H=16, bf16) through the chunked MFMA forward + backward that the training
     step uses: (i) everything finite; (ii) three (batch, head) slices -- first, middle, last workgroups -- equal the

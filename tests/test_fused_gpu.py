@@ -807,3 +807,22 @@ def test_transpose_kernel(R, C):
     one = ctypes.c_void_p(16)
     assert L.rwkv7_transpose_bf16(R, C, None, one, None) == -1
     assert L.rwkv7_transpose_bf16(100, 64, one, one, None) == -4
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 1024), (8192, 2048, 512), (4096, 1024, 1024)])
+def test_input_gradient_on_the_transposed_weight_is_the_same_product(M, N, K, monkeypatch):
+    """fused._dgrad (round 5): dx = dy @ W through the library's NT kernel on W^T (rwkv7_transpose_bf16) for long contractions
+    (N >= DGRAD_NT_MIN_N) -- the same bits as torch.mm(dy, W), and the plain product below the threshold."""
+    g = torch.Generator().manual_seed(M + N)
+    dy = (torch.randn(M, N, generator=g) * 0.1).bfloat16().to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    want = torch.mm(dy, W)
+    hits = fused.DGRAD_NT_HITS[0]
+    got = fused._dgrad(dy, W)
+    assert torch.equal(got, want)
+    assert fused.DGRAD_NT_HITS[0] == hits + (1 if N >= fused.DGRAD_NT_MIN_N else 0)
+    monkeypatch.setattr(fused, "DGRAD_NT_MIN_N", 256)   # force the transposed route for every shape
+    got = fused._dgrad(dy, W)
+    assert torch.equal(got, want) and fused.DGRAD_NT_HITS[0] == hits + (2 if N >= 2048 else 1)
+    monkeypatch.setattr(fused, "DGRAD_NT", False)
+    assert torch.equal(fused._dgrad(dy, W), want)
