@@ -303,12 +303,20 @@ struct GemvSeg {
     int ncols;
 };
 
+#ifndef DEC_NT_WEIGHTS
+#define DEC_NT_WEIGHTS 0
+#endif
 template <int KSTEPS>
 __device__ __forceinline__ void gemv_steps(f32x16 &acc, gu16 wp, const uint16_t *xp) {
     bf16x8 a[KSTEPS], b[KSTEPS];
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) {
+#if DEC_NT_WEIGHTS
+        // weight rows are read once per step by one workgroup (0.65 GB per step, more than L2 + MALL hold): non-temporal
+        a[i] = __builtin_nontemporal_load((const bf16x8 __attribute__((address_space(1))) *)(wp + 16 * i));
+#else
         a[i] = *(const bf16x8 __attribute__((address_space(1))) *)(wp + 16 * i);
+#endif
         b[i] = *reinterpret_cast<const bf16x8 *>(xp + 16 * i);
     }
     // all loads of the round are issued before the first MFMA: left alone, the scheduler sinks each pair of loads to its MFMA
