@@ -4,7 +4,8 @@
 // (wkv7_chunk_bwd9.hip, whose header has the formulas); three structural changes (round 5):
 //
 //  (a) RAW ROWS BY LDS-DMA.  The nine row streams of a chunk (w q k a b v dy bf16, u = sa and z fp32: 44 KB) land in a dedicated
-//      LDS area by global_load_lds_dwordx4 (44 pieces of 1 KB, 5-6 per wave), issued one chunk ahead at the top of phase B and
+//      LDS area by global_load_lds_dwordx4 (44 pieces of 1 KB, 5-6 per wave; inline asm, see glds16), issued one chunk ahead, two
+//      pieces at a time between the products of phase B (one burst queues at the texture addresser: 0.9-1.3k cycles per wave), and
 //      waited for (vmcnt) in front of the gradient stores: no staging registers (24 VGPRs), no restage stores (44 KB through the
 //      ~80 B/clk VGPR->LDS path), no restage barrier.  The landing image is lane-linear (base + lane * 16), so the swizzle that makes
 //      the compute-mapping reads cheap sits on the SOURCE address (cdna_hip_programming.md rule 21).
