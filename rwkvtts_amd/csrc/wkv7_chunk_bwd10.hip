@@ -46,6 +46,9 @@ __device__ long long g_cbwd10_timing[8 * 16];
 #define B10TIMING 0
 #endif
 
+#ifndef WKV7C_B10_K64_ONE
+#define WKV7C_B10_K64_ONE 0   // experiment: the K = 64 products in one round of 16 + 16 fragments
+#endif
 namespace {
 constexpr int kOut10MinChunksPerWG = 8, kOut10MaxChunksPerWG = 64;
 
@@ -122,8 +125,12 @@ __device__ __forceinline__ void mma_sw(f32x16 &acc, const uint16_t *Xh, const ui
 template <int XW, bool XKM, bool XSPLIT, int YW, bool YKM, bool YSPLIT>
 __device__ __forceinline__ void mma_sw_k64(f32x16 &acc, const uint16_t *Xh, const uint16_t *Xl, int xb, const uint16_t *Yh,
                                            const uint16_t *Yl, int yb, const SwLane &s) {
+#if WKV7C_B10_K64_ONE
+    mma_sw<4, XW, XKM, XSPLIT, YW, YKM, YSPLIT>(acc, Xh, Xl, xb, Yh, Yl, yb, s, 0);
+#else
     mma_sw<2, XW, XKM, XSPLIT, YW, YKM, YSPLIT>(acc, Xh, Xl, xb, Yh, Yl, yb, s, 0);
     mma_sw<2, XW, XKM, XSPLIT, YW, YKM, YSPLIT>(acc, Xh, Xl, xb, Yh, Yl, yb, s, 2);
+#endif
 }
 
 struct Out10Smem {  // offsets in uint16 units
