@@ -41,40 +41,61 @@ __device__ __forceinline__ float ld_scalar<float>(const float *p) { return *p; }
 // --------------------------------------------------------------------------------------------------------------
 // T = (I - A_ab)^-1 per chunk
 // --------------------------------------------------------------------------------------------------------------
+// Round 5: the contraction over the 64 channels runs in TWO passes of 32 (lane = channel 32 p + (lane & 31), time half lane >> 5:
+// every lane walks 16 steps per pass, the upper half starting from its twin's decay sum), so the operand planes are [32][32 + 8]
+// instead of [32][64 + 8]: 10 KB of LDS per wave instead of 18 and 48 instead of 96 prefetched values per lane -- the kernel is a
+// chain of latencies (two serial scans, 0.18 instructions per cycle and SIMD at the two waves per SIMD that 18 KB allowed), and its
+// throughput is the number of chunks in flight per CU: 16 waves instead of 8.  Same instruction count per chunk.
 template <typename T>
-__global__ __launch_bounds__(64) void wkv7c_prep_kernel(int T_, int H, const T *__restrict__ w_, const T *__restrict__ a_,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void wkv7c_prep_kernel(int T_, int H, const T *__restrict__ w_, const T *__restrict__ a_,
                                                         const T *__restrict__ b_, float *__restrict__ tinv_) {
-    constexpr int LD = kN + kPad;
-    __shared__ __attribute__((aligned(16))) uint16_t ATh[kC * LD], ATl[kC * LD], BHh[kC * LD], BHl[kC * LD];
+    constexpr int LD = kC + kPad;   // 32 channels of a pass + padding
+    __shared__ __attribute__((aligned(16))) uint16_t planes[4 * kC * LD];
+    uint16_t *ATh = planes, *ATl = planes + kC * LD, *BHh = planes + 2 * kC * LD, *BHl = planes + 3 * kC * LD;
+    static_assert(2 * kC * LD * 2 >= kC * 2 * 16 * 4, "the back substitution's A^T copy must fit over the a~ planes");
     const int nc = T_ / kC;
     const int bh = blockIdx.x / nc, c = blockIdx.x - bh * nc;
     const int bb = bh / H, hh = bh - bb * H;
     const int lane = threadIdx.x;
-    const long base = (((long)bb * T_ + (long)c * kC) * H + hh) * kN + lane;
+    const int kc = lane & 31, th = lane >> 5;
     const long tstride = (long)H * kN;
-    // all 96 loads of the chunk are requested before the first use: issued four steps at a time (as this loop once was) the
-    // kernel spent most of its 31k cycles waiting for eight rounds of HBM latency
-    float wv[kC], av_[kC], bv_[kC];
+    const long base = (((long)bb * T_ + (long)c * kC + 16 * th) * H + hh) * kN + kc;
+    // both passes' loads are requested before the first use (2 x 48 per lane): the kernel pays one HBM latency
+    float wv[2][16], av_[2][16], bv_[2][16];
 #pragma unroll
-    for (int t = 0; t < kC; t++) {
-        const long idx = base + t * tstride;
-        wv[t] = ld_scalar<T>(w_ + idx);
-        av_[t] = ld_scalar<T>(a_ + idx);
-        bv_[t] = ld_scalar<T>(b_ + idx);
-    }
-    float G = 0.f;
+    for (int p = 0; p < 2; p++)
 #pragma unroll
-    for (int t = 0; t < kC; t++) {
-        const float lw = -fast_exp(wv[t]);
-        const float at = av_[t] * fast_exp(G);  // a * gamma_{t-1}
-        G += lw;
-        const float bh_ = bv_[t] * fast_exp(-G);  // b / gamma_t
-        split2(at, ATh[t * LD + lane], ATl[t * LD + lane]);
-        split2(bh_, BHh[t * LD + lane], BHl[t * LD + lane]);
-    }
-    __syncthreads();
+        for (int j = 0; j < 16; j++) {
+            const long idx = base + 32 * p + j * tstride;
+            wv[p][j] = ld_scalar<T>(w_ + idx);
+            av_[p][j] = ld_scalar<T>(a_ + idx);
+            bv_[p][j] = ld_scalar<T>(b_ + idx);
+        }
     f32x16 acc = zero16();
-    mma_tile3<kN>(acc, BHh, BHl, LD, ATh, ATl, LD, lane);  // D[m = s][n = t] = b^_s . a~_t = A_ab[t][s]
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        float lw[16], tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            lw[j] = -fast_exp(wv[p][j]);
+            tot += lw[j];
+        }
+        // steps 16..31 start from the decay sum of steps 0..15 of the same channel: the twin lane's total
+        const float first = __shfl(tot, kc);
+        float G = th ? first : 0.f;
+        if (p == 1) __syncthreads();   // pass 0's fragments have been read (one wave: LDS is in order; the barrier is for the compiler)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int t = 16 * th + j;
+            const float at = av_[p][j] * fast_exp(G);  // a * gamma_{t-1}
+            G += lw[j];
+            const float bh_ = bv_[p][j] * fast_exp(-G);  // b / gamma_t
+            split2(at, ATh[t * LD + kc], ATl[t * LD + kc]);
+            split2(bh_, BHh[t * LD + kc], BHl[t * LD + kc]);
+        }
+        __syncthreads();
+        mma_tile3<kC>(acc, BHh, BHl, LD, ATh, ATl, LD, lane);  // D[m = s][n = t] += b^_s . a~_t over this pass's 32 channels = A_ab[t][s]
+    }
     mask_lower_T<true>(acc, lane);
     // T = I + T A  =>  T[t][r] = delta(t,r) + sum_{q>r} T[t][q] A[q][r], r = 31..0, row t on lane t AND its twin t + 32: the twins
     // split the sum by the parity of q (round 4; before, both computed the whole row with A[q][r] fetched by v_readlane: 496 readlane
