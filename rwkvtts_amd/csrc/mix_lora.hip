@@ -41,25 +41,47 @@ __global__ void wcat_fwd_kernel(MixLoraDesc d, int R, int D, uint16_t *__restric
     }
 }
 
-// dW1_i[row][c] = dWa (1 - mu) + dWb mu ;  dmu_i[c] = sum_rows W1 (dWb - dWa).  Block = 64 columns x 4 row groups of branch blockIdx.y
-// (first cut: one thread per column walking all rows, 16 blocks in all: 88 us for 0.6 M elements)
-__global__ void wcat_bwd_kernel(MixLoraDesc d, int R, int D, const uint16_t *__restrict__ dwcat) {
-    __shared__ float red[4][64];
-    const int i = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+// dW1_i[row][c] = dWa (1 - mu) + dWb mu ;  dmu_i[c] = sum_rows W1 (dWb - dWa).  Block = 64 columns x 16 row groups of branch blockIdx.y
+// (first cut: one thread per column walking all rows, 16 blocks in all: 88 us for 0.6 M elements; round 4: 4 row groups, a loop of up
+// to 32 dependent load rounds per thread: 25 us; round 5: 16 row groups, the <= 8 rows of a thread unrolled with clamped, unconditional
+// loads -- one memory latency)
+constexpr int kWcatRG = 16, kWcatRows = 8;
+__global__ __launch_bounds__(64 * kWcatRG) void wcat_bwd_kernel(MixLoraDesc d, int R, int D, const uint16_t *__restrict__ dwcat) {
+    __shared__ float red[kWcatRG][64];
+    const int i = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = min(blockIdx.x * 64 + cl, D - 1);
+    const bool live = blockIdx.x * 64 + cl < D;
     const uint16_t *w = reinterpret_cast<const uint16_t *>(d.w1[i]);
     uint16_t *dw = reinterpret_cast<uint16_t *>(d.out[i]);
+    const int ri = d.r[i];
+    const float m = bf2f(reinterpret_cast<const uint16_t *>(d.mu[i])[c]);
     float acc = 0.f;
-    if (c < D) {
-        const float m = bf2f(reinterpret_cast<const uint16_t *>(d.mu[i])[c]);
-        for (int rr = rg; rr < d.r[i]; rr += 4) {
-            const float da = bf2f(dwcat[(long)(d.off[i] + rr) * D + c]), db = bf2f(dwcat[(long)(R + d.off[i] + rr) * D + c]);
-            dw[(long)rr * D + c] = f2bf(da * (1.f - m) + db * m);
-            acc += bf2f(w[(long)rr * D + c]) * (db - da);
+    for (int r0 = 0; r0 < ri; r0 += kWcatRG * kWcatRows) {   // 128 rows per trip (one trip up to rank 128)
+        uint16_t ra[kWcatRows], rb[kWcatRows], rw[kWcatRows];
+#pragma unroll
+        for (int j = 0; j < kWcatRows; j++) {
+            const int rr = min(r0 + rg + kWcatRG * j, ri - 1);
+            ra[j] = dwcat[(long)(d.off[i] + rr) * D + c];
+            rb[j] = dwcat[(long)(R + d.off[i] + rr) * D + c];
+            rw[j] = w[(long)rr * D + c];
+        }
+#pragma unroll
+        for (int j = 0; j < kWcatRows; j++) {
+            const int rr = r0 + rg + kWcatRG * j;
+            const float da = bf2f(ra[j]), db = bf2f(rb[j]);
+            if (rr < ri && live) {
+                dw[(long)rr * D + c] = f2bf(da * (1.f - m) + db * m);
+                acc += bf2f(rw[j]) * (db - da);
+            }
         }
     }
     red[rg][cl] = acc;
     __syncthreads();
-    if (rg == 0 && c < D) reinterpret_cast<uint16_t *>(d.out2[i])[c] = f2bf(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    if (rg == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < kWcatRG; g++) t += red[g][cl];
+        reinterpret_cast<uint16_t *>(d.out2[i])[c] = f2bf(t);
+    }
 }
 
 __device__ __forceinline__ float act_fwd(int a, float x) {
@@ -142,7 +164,7 @@ int mix_lora_wcat_fwd(const MixLoraDesc &d, int R, int D, void *wcat, hipStream_
 }
 int mix_lora_wcat_bwd(const MixLoraDesc &d, int R, int D, const void *dwcat, hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(wcat_bwd_kernel, dim3((D + 63) / 64, d.nb), dim3(256), 0, st, d, R, D, (const uint16_t *)dwcat);
+    hipLaunchKernelGGL(wcat_bwd_kernel, dim3((D + 63) / 64, d.nb), dim3(64 * kWcatRG), 0, st, d, R, D, (const uint16_t *)dwcat);
     return (int)hipGetLastError();
 }
 int mix_lora_combine_fwd(const MixLoraDesc &d, long M, int T, int R, const void *G, const void *mask, hipStream_t st) {
