@@ -84,8 +84,8 @@ int rwkv7_wkv_workspace_bytes(int B, int T, int H, size_t *s_bytes, size_t *sa_b
  * argument of these `_variant` twins, never a hidden switch that changes what the plain entry points above launch.
  *   cols_per_lane : state columns per lane of the scalar forward kernel -- 0 automatic by B*H (what the plain entry does), 4, 8
  *   wide          : row-split backward -- 0 = 256 threads, 2 state rows per lane tile (plain entry); 1 = 512 threads, 1 row
- *   waves         : chunked bf16 forward -- 9 = producer/consumer kernel, two dependent products per chunk (plain entry),
- *                   4 = the 4-wave kernel (the one fp32 tensors run) */
+ *   (The chunked bf16 forward has one shipped kernel, csrc/wkv7_chunk_fwd9.hip; the bf16 instantiation of the 4-wave kernel that fp32
+ *   tensors run is a lab-build entry, include/rwkv7_hip_lab.h.) */
 int rwkv7_wkv_fwd_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                const void *a, const void *b, void *y, float *s, float *sa, int cols_per_lane, rwkv7_stream_t stream);
 int rwkv7_wkv_fwd_variant_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
@@ -97,9 +97,6 @@ int rwkv7_wkv_bwd_split_variant_bf16(int B, int T, int H, const void *w, const v
                                      const void *a, const void *b, const void *dy, const float *s, const float *sa,
                                      void *const *dw, void *const *dq, void *const *dk, void *dv, void *const *da,
                                      void *const *db, int wide, rwkv7_stream_t stream);
-int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                         const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
-                                         const int *seq_chunk_off, int nseq, int waves, rwkv7_stream_t stream);
 
 /* ---- same backward with each head split over two workgroups (32 state rows each) so that 256 CUs are busy at
  *      B*H = 128.  dv is complete; dw,dq,dk,da,db are HOST arrays of 2 device pointers receiving the two partial
@@ -334,7 +331,7 @@ int rwkv7_wkv_chunk_fwd_seq_bf16(int B, int T, int H, const void *w, const void 
 int rwkv7_wkv_chunk_fwd_seq_f32(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                 const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
                                 const int *seq_chunk_off, int nseq, rwkv7_stream_t stream);
-/* ---- chunked backward, bf16 (csrc/wkv7_chunk_bseq.hip, wkv7_chunk_bwd9.hip; reference wkv7_cuda.cu:54-130).  With H = S^T and the
+/* ---- chunked backward, bf16 (csrc/wkv7_chunk_bseq.hip, wkv7_chunk_bwd10.hip; reference wkv7_cuda.cu:54-130).  With H = S^T and the
  *      chunk quantities above, the adjoint state obeys E_c = M_c^T E_{c+1} + N'_c.  T % 32 == 0.
  *   bseq    : sequential over chunks (reverse), one workgroup per (head, half of the value columns): the recurrence in factored
  *             form, E_c = E' + A~^T Z + Q~^T dY with Z = (T^T B^) E' + (T^T A_qb^T) dY, E' = g_C E_{c+1} -- M_c^T and N'_c are
@@ -347,15 +344,14 @@ int rwkv7_wkv_chunk_bseq_bf16(int B, int T, int H, const void *w, const void *q,
 /*             z (may be NULL): fp32 [B,T,H,64], Z_t = dL/du_t (u = sa), which the recurrence forms anyway.  With it the per-chunk
  *             gradient kernel needs neither T^-1 nor an A_qb -> G1 -> Z chain of its own.
  *   bwd_out_z : parallel over chunks: the six gradients (the contract of wind_backstepping::backward) from what the chunked
- *             forward saved (hs, sa) and e_vk, z of `bseq`; two matrix phases per chunk (csrc/wkv7_chunk_bwd9.hip). */
+ *             forward saved (hs, sa) and e_vk, z of `bseq`; two matrix phases per chunk (csrc/wkv7_chunk_bwd10.hip: raw rows by
+ *             LDS-DMA, unpadded XOR-swizzled planes, state prologue and phase A in one barrier interval). */
 int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                                    const void *a, const void *b, const void *dy, const void *hs, const float *sa,
                                    const float *z, const void *e_vk, void *dw, void *dq, void *dk, void *dv,
                                    void *da, void *db, rwkv7_stream_t stream);
-/*      which per-chunk gradient kernel the entry above (and rwkv7_wkv_bwd_fast_bf16) launches (A/B knob, process-wide): 10 (default) =
- *      csrc/wkv7_chunk_bwd10.hip (raw rows by LDS-DMA, unpadded XOR-swizzled planes, state prologue and phase A in one barrier interval),
- *      9 = csrc/wkv7_chunk_bwd9.hip (round 3/4).  Same arithmetic.  Returns the previous value; other arguments leave it unchanged. */
-int rwkv7_set_bwd_out_generation(int generation);
+/*      (The round-3/4 per-chunk gradient kernel, csrc/lab/wkv7_chunk_bwd9.hip, is an A/B twin with its own entry point in the lab build:
+ *      include/rwkv7_hip_lab.h.  There are no process-wide switches in this library.) */
 /* ---- head loss: softmax cross-entropy of a chunk of bf16 logits [rows,V], forward and backward in one pass
  *      (spark_llm.py:146-160, FusedLinearCrossEntropyLoss).  labels int64 [rows]; rows with label == ignore_index give 0.
  *      loss_rows[rows] = logsumexp - logit[label]; logits are REPLACED by (softmax - onehot) * scale. ---- */
@@ -396,9 +392,9 @@ int rwkv7_transpose_bf16(int R, int C, const void *in, void *out, rwkv7_stream_t
 int rwkv7_wgrad_skinny_bf16(long M, int N, int K, int S, const void *dy, const void *x, float *parts, rwkv7_stream_t stream);
 
 /* ---- C[M][N] = epi(A[M][K] . W[N][K]^T), bf16, fp32 accumulation: the channel-mix key projection with its activation as
- *      the epilogue (epilogue 1: relu(.)^2, rwkv_s2s_single_ffn.py:228; 0: none).  Hand-written 256 x 256 x 64 MFMA kernel fed by
- *      LDS-DMA (csrc/gemm_relusq.hip); M, N multiples of 256, K of 64 (RWKV7_ESHAPE otherwise).  A measured experiment against
- *      the library GEMM + rwkv7_relusq_fwd pair (tools/bench_gemm_relusq.py). ---- */
+ *      the epilogue (epilogue 1: relu(.)^2, rwkv_s2s_single_ffn.py:228; 0: none).  Hand-written persistent MFMA kernel fed by
+ *      LDS-DMA (csrc/gemm_nt4.hip); M, N multiples of 256, K of 1024 (RWKV7_ESHAPE otherwise); bit-identical to the library
+ *      GEMM + rwkv7_relusq_fwd pair. ---- */
 int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, rwkv7_stream_t stream);
 /*      the backward of the activation as the epilogue of the value projection's input-gradient GEMM (round 4):
  *      C[M][N] = bf16(A[M][K] . W[N][K]^T) * 2 relu(aux[M][N]) -- A = dy, W = value.weight^T (contiguous [N = F][K = D]), aux = the key
@@ -412,13 +408,9 @@ int rwkv7_gemm_nt_relusq_bwd_s_bf16(int M, int N, int K, const void *A, const vo
  *      x = x + att(...) of rwkv_s2s_single_ffn.py:262-276 for the output projection (fused.linear_add); what nn.Linear followed by the
  *      add of the two bf16 tensors produces, bit for bit.  csrc/gemm_nt4.hip only: K % 1024 == 0.  C must not alias resid. */
 int rwkv7_gemm_nt_add_bf16(int M, int N, int K, const void *A, const void *W, const void *resid, void *C, rwkv7_stream_t stream);
-/*      which own GEMM the two entries above run (A/B knob, process-wide): 4 (default) = csrc/gemm_nt4.hip (four waves, quadrant phases,
- *      ring of eight half-tile slots; K % 1024 == 0, other K fall back to generation 1), 1 = csrc/gemm_relusq.hip.  Returns the
- *      previous value; other arguments leave it unchanged. */
-int rwkv7_set_gemm_generation(int generation);
-/*      variant (A/B) of generation 1: 0 = K tile 64, two LDS buffers (the plain entry); 1 = K tile 32, four buffers, three tiles in flight */
-int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant,
-                               rwkv7_stream_t stream);
+/*      All four entries run csrc/gemm_nt4.hip (four waves, quadrant phases, ring of eight half-tile LDS slots): M, N multiples of 256,
+ *      K a multiple of 1024, RWKV7_ESHAPE otherwise.  The first-generation kernel (csrc/lab/gemm_relusq.hip, K % 64 == 0) lives in the lab
+ *      build under its own entry points (include/rwkv7_hip_lab.h). */
 
 /* ---- the low-rank branches of the time-mix block taken THROUGH the token-shift lerp (fused.mix_lora; rwkv_s2s_single_ffn.py:160-190):
  *      (xm (1 - mu) + shift(xm) mu) W1^T = xm (W1 * (1 - mu))^T + shift(xm) (W1 * mu)^T, so one GEMM G = x [W_a ; W_b]^T on the LayerNorm
@@ -456,10 +448,10 @@ int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const v
  *      workspace: rwkv7_decode_workspace_bytes() bytes, 256-byte aligned, owned by the caller, reused step after step;
  *      its first 8 bytes are the barrier words {arrivals, timeout flag}: flag != 0 after a step means a grid barrier was not
  *      met within ~0.1 s (the kernel then exits instead of hanging; the step's results are invalid).
- *      persistent = 0: 7 L + 2 ordinary launches, one kernel per phase (the default of the Python host: 1.05 ms per step at
- *      BASELINE configs[4], a stream-ordered kernel boundary costs ~1.5 us); 1: ONE launch, the same phase bodies separated by
- *      7 L + 1 device-scope barriers (measured 7.4 us per barrier on MI355X -- 3.9 us of arrivals/polling on one counter plus
- *      1.8 us L2 write-back and 1.6 us invalidate, the XCD L2s not being coherent -- so it is the slower mode: 2.4 ms).
+ *      persistent = 0: ordinary launches, one kernel per phase (a stream-ordered kernel boundary costs ~1.5 us).  persistent = 1
+ *      (ONE launch, the same phase bodies separated by device-scope barriers; measured 7.4 us per barrier on MI355X -- 3.9 us of
+ *      arrivals/polling on one counter plus 1.8 us L2 write-back and 1.6 us invalidate, the XCD L2s not being coherent -- 2.4 ms per
+ *      step) exists in the lab build only (python -m rwkvtts_amd.build --lab): the shipped library answers RWKV7_ESHAPE.
  *      Errors: RWKV7_ESHAPE unless B in [1,32], D = 64 H <= 4096, F % 64 == 0, every rank a multiple of 32 and <= 256, ranks sum <= 512. */
 enum {
     RWKV7_DEC_LN0_W, RWKV7_DEC_LN0_B, RWKV7_DEC_LN1_W, RWKV7_DEC_LN1_B, RWKV7_DEC_LN2_W, RWKV7_DEC_LN2_B,

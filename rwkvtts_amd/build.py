@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "librwkv7_hip.so")
+LAB_SO = os.path.join(LIBDIR, "librwkv7_hip_lab.so")   # --lab: the shipped entries + the superseded A/B twins (include/rwkv7_hip_lab.h)
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only", "-fgpu-flush-denormals-to-zero",
          "-Wno-unused-result", "-Wno-pass-failed"]
@@ -35,8 +36,11 @@ def source_hashes(names):
     return out
 
 
-def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+def sources(lab: bool = False):
+    out = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    if lab:
+        out += sorted(glob.glob(os.path.join(CSRC, "lab", "*.hip")))
+    return out
 
 
 def _stale():
@@ -46,6 +50,25 @@ def _stale():
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
         glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     return any(os.path.getmtime(p) > mt for p in deps)
+
+
+def build_lab(verbose: bool = False) -> str:
+    """The lab library: every source compiled with -DRWKV7_LAB into its own object directory, linked into LAB_SO.  Never touches SO."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objdir = os.path.join(LIBDIR, "lab")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    objs = []
+    for src in sources(lab=True):
+        obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(p) for p in [src] + hdrs):
+            cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-DRWKV7_LAB", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LAB_SO, *objs])
+    return LAB_SO
 
 
 def build(force: bool = False, verbose: bool = False, extra=()) -> str:
@@ -88,9 +111,12 @@ if __name__ == "__main__":
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--resource-usage", action="store_true", help="print VGPR/LDS/occupancy per kernel")
     ap.add_argument("--timing", action="store_true", help="profiling build: per-phase s_memtime counters in the chunked kernels")
+    ap.add_argument("--lab", action="store_true", help="also build lib/librwkv7_hip_lab.so (superseded A/B twins, rwkv7_hip_lab.h)")
     a = ap.parse_args()
     extra = ["-Rpass-analysis=kernel-resource-usage"] if a.resource_usage else []
     if a.timing:
         extra.append("-DWKV7C_TIMING")
     print(build(force=a.force or a.resource_usage or a.timing, verbose=a.verbose, extra=extra))
+    if a.lab:
+        print(build_lab(verbose=a.verbose))
     sys.exit(0)

@@ -27,7 +27,7 @@ int wkv_bwd_split_f32(int, int, int, const void *, const void *, const void *, c
 int chunk_prep_bf16(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_prep_f32(int, int, int, const void *, const void *, const void *, float *, hipStream_t);
 int chunk_fwd_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
-                   const float *, void *, float *, void *, const int *, int, int, hipStream_t);
+                   const float *, void *, float *, void *, const int *, int, hipStream_t);
 int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *,
                   const float *, void *, float *, void *, const int *, int, hipStream_t);
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
@@ -39,9 +39,6 @@ int adamw_step(long, float *, const void *, float *, float *, void *, const uint
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
 int chunk_bseq_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const float *, void *,
                     float *, const int *, int, hipStream_t);
-int gemm_nt_bf16(int, int, int, const void *, const void *, void *, int, hipStream_t);
-int gemm_nt_bf16_variant(int, int, int, const void *, const void *, void *, int, int, hipStream_t);
-int gemm_nt_relusq_bwd_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
 int gemm_nt4_bf16(int, int, int, const void *, const void *, void *, const void *, int, hipStream_t);
 struct MixLoraDesc {
     int nb;
@@ -58,8 +55,6 @@ int mix_lora_combine_fwd(const MixLoraDesc &, long, int, int, const void *, cons
 int mix_lora_combine_bwd(const MixLoraDesc &, long, int, int, const void *, void *, hipStream_t);
 int chunk_bwd_out10_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                          const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
-int chunk_bwd_out9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
-                        const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int transpose_bf16(int, int, const void *, void *, hipStream_t);
 int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
@@ -146,18 +141,6 @@ int rwkv7_wkv_bwd_f32(int B, int T, int H, const void *w, const void *q, const v
 // the reference-schema pair on the chunked (MFMA) kernels: `s` as an arena [hs | T^-1 | e_vk] (include/rwkv7_hip.h)
 namespace {
 constexpr size_t kArenaRec = (size_t)RWKV7_Q15_REC * 2, kArenaTinv = 32 * 32 * sizeof(float);
-int g_bwd_out_generation = 10;   // 10: csrc/wkv7_chunk_bwd10.hip (LDS-DMA rows, swizzled planes, merged prologue / phase A), 9: csrc/wkv7_chunk_bwd9.hip
-int bwd_out_dispatch(int B, int T, int H, const void *w, const void *q, const void *k, const void *v, const void *a, const void *b,
-                     const void *dy, const void *hs, const float *sa, const float *z, const void *e_vk, void *dw, void *dq, void *dk,
-                     void *dv, void *da, void *db, hipStream_t st) {
-    return g_bwd_out_generation == 9 ? rwkv7::chunk_bwd_out9_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, st)
-                                     : rwkv7::chunk_bwd_out10_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, st);
-}
-}
-int rwkv7_set_bwd_out_generation(int gen) {
-    const int prev = g_bwd_out_generation;
-    if (gen == 9 || gen == 10) g_bwd_out_generation = gen;
-    return prev;
 }
 int rwkv7_wkv_fwd_fast_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                             const void *a, const void *b, void *y, float *s, float *sa, rwkv7_stream_t stream) {
@@ -168,7 +151,7 @@ int rwkv7_wkv_fwd_fast_bf16(int B, int T, int H, const void *w, const void *q, c
     float *tinv = reinterpret_cast<float *>(base + n * kArenaRec);
     const int rc = rwkv7::chunk_prep_bf16(B, T, H, w, a, b, tinv, (hipStream_t)stream);
     if (rc != 0) return rc;
-    return rwkv7::chunk_fwd_bf16(B, T, H, w, q, k, v, a, b, tinv, y, sa, base, nullptr, 0, 9, (hipStream_t)stream);
+    return rwkv7::chunk_fwd_bf16(B, T, H, w, q, k, v, a, b, tinv, y, sa, base, nullptr, 0, (hipStream_t)stream);
 }
 int rwkv7_wkv_bwd_fast_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
                             const void *a, const void *b, const void *dy, float *s, const float *sa, void *dw,
@@ -182,7 +165,7 @@ int rwkv7_wkv_bwd_fast_bf16(int B, int T, int H, const void *w, const void *q, c
     float *z = reinterpret_cast<float *>(base + n * (2 * kArenaRec + kArenaTinv));   // fp32 [B,T,H,64]: 8192 B per chunk and head
     const int rc = rwkv7::chunk_bseq_bf16(B, T, H, w, q, a, b, dy, tinv, e_vk, z, nullptr, 0, (hipStream_t)stream);
     if (rc != 0) return rc;
-    return bwd_out_dispatch(B, T, H, w, q, k, v, a, b, dy, base, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
+    return rwkv7::chunk_bwd_out10_bf16(B, T, H, w, q, k, v, a, b, dy, base, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
 
 #define BWD2_BODY(IMPL, WIDE)                                                                                 \
@@ -434,7 +417,7 @@ EW_DEFINE(f32, float)
 
 
 // ---- chunked (MFMA) WKV7 -----------------------------------------------------------------------------------------
-#define CHUNK_DEFINE(SFX, WAVES_ARG)                                                                                          \
+#define CHUNK_DEFINE(SFX)                                                                                          \
     int rwkv7_wkv_chunk_prep_##SFX(int B, int T, int H, const void *w, const void *a, const void *b, float *tinv,   \
                                    rwkv7_stream_t stream) {                                                         \
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, a, b, tinv})) return RWKV7_EINVAL;                           \
@@ -447,7 +430,7 @@ EW_DEFINE(f32, float)
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
         if ((sa == nullptr) != (hs == nullptr)) return RWKV7_EINVAL;                                                \
         if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;                                                            \
-        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, nullptr, 0, WAVES_ARG (hipStream_t)stream); \
+        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, nullptr, 0, (hipStream_t)stream); \
     }                                                                                                               \
     int rwkv7_wkv_chunk_fwd_seq_##SFX(int B, int T, int H, const void *w, const void *q, const void *k, const void *v, \
                                       const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs, \
@@ -455,23 +438,11 @@ EW_DEFINE(f32, float)
         if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;               \
         if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;    \
         if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;                                                            \
-        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, WAVES_ARG (hipStream_t)stream); \
+        return rwkv7::chunk_fwd_##SFX(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, (hipStream_t)stream); \
     }
-#define RWKV7_COMMA ,
-CHUNK_DEFINE(bf16, 9 RWKV7_COMMA)
-CHUNK_DEFINE(f32, )
-// A/B and cross-check: the 4-wave kernel (waves = 4) or the 8-wave producer/consumer kernel (9, what the plain entry launches)
-int rwkv7_wkv_chunk_fwd_seq_variant_bf16(int B, int T, int H, const void *w, const void *q, const void *k, const void *v,
-                                         const void *a, const void *b, const float *tinv, void *y, float *sa, void *hs,
-                                         const int *seq_chunk_off, int nseq, int waves, rwkv7_stream_t stream) {
-    if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, k, v, a, b, tinv, y})) return RWKV7_EINVAL;
-    if ((sa == nullptr) != (hs == nullptr) || (seq_chunk_off != nullptr && nseq <= 0)) return RWKV7_EINVAL;
-    if (T % RWKV7_CHUNK_T != 0) return RWKV7_ECHUNK;
-    if (waves != 4 && waves != 9) return RWKV7_ESHAPE;
-    return rwkv7::chunk_fwd_bf16(B, T, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_chunk_off, nseq, waves, (hipStream_t)stream);
-}
-
-// chunked backward (bf16): csrc/wkv7_chunk_bseq.hip (adjoint recurrence, writes E and Z) + csrc/wkv7_chunk_bwd9.hip (per-chunk gradients)
+CHUNK_DEFINE(bf16)
+CHUNK_DEFINE(f32)
+// chunked backward (bf16): csrc/wkv7_chunk_bseq.hip (adjoint recurrence, writes E and Z) + csrc/wkv7_chunk_bwd10.hip (per-chunk gradients)
 int rwkv7_wkv_chunk_bseq_bf16(int B, int T, int H, const void *w, const void *q, const void *a, const void *b, const void *dy,
                               const float *tinv, void *e_vk, float *z, const int *seq_chunk_off, int nseq, rwkv7_stream_t stream) {
     if (B <= 0 || T <= 0 || H <= 0 || any_null({w, q, a, b, dy, (const void *)tinv, (const void *)e_vk})) return RWKV7_EINVAL;
@@ -487,25 +458,17 @@ int rwkv7_wkv_chunk_bwd_out_z_bf16(int B, int T, int H, const void *w, const voi
         any_null({w, q, k, v, a, b, dy, hs, (const void *)sa, (const void *)z, e_vk, dw, dq, dk, dv, da, db}))
         return RWKV7_EINVAL;
     if (T % 32 != 0) return RWKV7_ECHUNK;
-    return bwd_out_dispatch(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
-}
-static int g_gemm_generation = 4;   // 4: csrc/gemm_nt4.hip (K % 1024 == 0), 1: csrc/gemm_relusq.hip
-int rwkv7_set_gemm_generation(int gen) {
-    const int prev = g_gemm_generation;
-    if (gen == 1 || gen == 4) g_gemm_generation = gen;
-    return prev;
+    return rwkv7::chunk_bwd_out10_bf16(B, T, H, w, q, k, v, a, b, dy, hs, sa, z, e_vk, dw, dq, dk, dv, da, db, (hipStream_t)stream);
 }
 int rwkv7_gemm_nt_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, rwkv7_stream_t stream) {
     if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;
-    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || epilogue < 0 || epilogue > 1) return RWKV7_ESHAPE;
-    if (g_gemm_generation == 4 && K % 1024 == 0) return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, nullptr, epilogue, (hipStream_t)stream);
-    return rwkv7::gemm_nt_bf16(M, N, K, A, W, C, epilogue, (hipStream_t)stream);
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 1024 != 0 || epilogue < 0 || epilogue > 1) return RWKV7_ESHAPE;
+    return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, nullptr, epilogue, (hipStream_t)stream);
 }
 int rwkv7_gemm_nt_relusq_bwd_bf16(int M, int N, int K, const void *A, const void *W, const void *aux, void *C, rwkv7_stream_t stream) {
     if (any_null({A, W, aux, (const void *)C})) return RWKV7_EINVAL;
-    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0) return RWKV7_ESHAPE;
-    if (g_gemm_generation == 4 && K % 1024 == 0) return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, aux, 2, (hipStream_t)stream);
-    return rwkv7::gemm_nt_relusq_bwd_bf16(M, N, K, A, W, aux, C, (hipStream_t)stream);
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 1024 != 0) return RWKV7_ESHAPE;
+    return rwkv7::gemm_nt4_bf16(M, N, K, A, W, C, aux, 2, (hipStream_t)stream);
 }
 int rwkv7_gemm_nt_relusq_bwd_s_bf16(int M, int N, int K, const void *A, const void *W, const void *s, void *C, rwkv7_stream_t stream) {
     if (any_null({A, W, s, (const void *)C})) return RWKV7_EINVAL;
@@ -594,12 +557,6 @@ int rwkv7_mix_lora_combine_bwd_bf16(int nb, const int *ranks, const int *acts, l
         d.out2[i] = const_cast<void *>(dy[i]);
     }
     return rwkv7::mix_lora_combine_bwd(d, M, T, R, mask, dG, (hipStream_t)stream);
-}
-int rwkv7_gemm_nt_variant_bf16(int M, int N, int K, const void *A, const void *W, void *C, int epilogue, int variant, rwkv7_stream_t stream) {
-    if (any_null({A, W, (const void *)C})) return RWKV7_EINVAL;
-    if (M <= 0 || N <= 0 || K <= 0 || M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || epilogue < 0 || epilogue > 1 || variant < 0 || variant > 1)
-        return RWKV7_ESHAPE;
-    return rwkv7::gemm_nt_bf16_variant(M, N, K, A, W, C, epilogue, variant, (hipStream_t)stream);
 }
 int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const void *bias, void *y, rwkv7_stream_t stream) {
     if (any_null({x, w, y})) return RWKV7_EINVAL;

@@ -764,6 +764,7 @@ template <> struct Variant<0> { static constexpr int NG = 1, NF1 = 4, NF2 = 8; }
 template <> struct Variant<1> { static constexpr int NG = 2, NF1 = 8, NF2 = 16; };
 template <> struct Variant<2> { static constexpr int NG = kMaxE / 4, NF1 = kUpFrags, NF2 = kUpFrags; };
 
+#ifdef RWKV7_LAB   // the one-launch variant lost (2.4 ms against 0.93 ms per step): lab build only (python -m rwkvtts_amd.build --lab)
 // mode 1: the step; mode 2 (debug): the barriers alone
 template <int V>
 __global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDesc d, int mode) {
@@ -790,6 +791,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDe
         if (idx + 1 < nphase) grid_barrier(d.bar, target, gridDim.x, mode);
     }
 }
+#endif
 
 // One kernel per phase (round 3; until then one kernel with a switch over the phase: every phase paid for the registers and
 // the SGPR spills of the largest one).  (Reading the descriptor from device memory through a 16-byte kernel argument instead was
@@ -938,6 +940,7 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
     d.bar = (unsigned *)(ws + w.bar);
     (void)hipGetLastError();
     const int variant = pick_variant(D, Rw, Ra, Rv, Rg);
+#ifdef RWKV7_LAB
     if (persistent) {
         int dev = 0, cus = 0;
         hipError_t e = hipGetDevice(&dev);
@@ -950,7 +953,11 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
         if (variant == 0) decode_persistent_kernel<0><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
         else if (variant == 1) decode_persistent_kernel<1><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
         else decode_persistent_kernel<2><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
-    } else {
+    } else
+#else
+    if (persistent) return -4;   // RWKV7_ESHAPE: the persistent variant exists in the lab build only
+#endif
+    {
         // one launch per phase, each sized to its own item count
         const int N2 = 3 * D + Rw + Ra + Rv + Rg;
         const int g_phase[7] = {B, (N2 / 32) * w.ks_qkv, H * ((B + 1) / 2), (D / 32) * w.ks_o, B, F / 16, (D / 32) * w.ks_val};

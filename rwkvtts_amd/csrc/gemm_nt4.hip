@@ -35,6 +35,7 @@
 // moves 64 KB through the LDS, as long as the MFMAs beside it, plus latency and a barrier); the DMA in its scalar-base form
 // (inline asm, no 64-bit VALU add per instruction): +-0.
 #include "chunk_common.h"
+#include "launch_attr.h"
 #ifndef GEMM4_EXP
 #define GEMM4_EXP 0
 #endif
@@ -343,13 +344,9 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(int M, int N, int K, cons
 namespace {
 template <int EPI>
 int launch_gemm4(int M, int N, int K, const void *A, const void *W, void *C, const void *aux, hipStream_t st) {
-    static bool attr = false;
+    static DynLdsOnce lds_once;
     auto kern = &gemm_nt4_kernel<EPI>;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds4);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(kern), (int)kLds4); e != hipSuccess) return (int)e;
     (void)hipGetLastError();
     const int ntiles = (M / TM4) * (N / TN4);
     kern<<<dim3(ntiles < 256 ? ntiles : 256), dim3(256), kLds4, st>>>(M, N, K, (const uint16_t *)A, (const uint16_t *)W, (uint16_t *)C,

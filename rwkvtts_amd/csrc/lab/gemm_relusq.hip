@@ -15,7 +15,8 @@
 // the same box (0.856 before).  K tile 32 with four buffers (three tiles in flight, counted vmcnt, raw barrier): slower (0.83) --
 // it is not the DMA latency that limits the loop.  PMC: same HBM traffic and L2 misses as the library's kernel, 1.6x its L2
 // requests.  Outcome of the experiment: fused.py (FUSED_KEY_RELUSQ) -- ties the library pair inside the training step, not adopted.
-#include "chunk_common.h"
+#include "../chunk_common.h"
+#include "../launch_attr.h"
 
 namespace rwkv7 {
 namespace {
@@ -208,14 +209,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(int M, int N, int K, 
 namespace {
 template <int EPI, int BK, int NBUF>
 int launch_gemm(int M, int N, int K, const void *A, const void *W, void *C, hipStream_t st, const void *aux = nullptr) {
-    static bool attr = false;
+    static DynLdsOnce lds_once;
     auto kern = &gemm_nt_bf16_kernel<EPI, BK, NBUF>;
     constexpr size_t lds_bytes = GemmCfg<BK, NBUF>::lds;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(kern), (int)lds_bytes); e != hipSuccess) return (int)e;
     (void)hipGetLastError();
     const int ntiles = (M / GBM) * (N / GBN);
     kern<<<dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds_bytes, st>>>(M, N, K, (const uint16_t *)A, (const uint16_t *)W, (uint16_t *)C,

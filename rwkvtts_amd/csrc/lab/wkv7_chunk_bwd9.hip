@@ -20,7 +20,8 @@
 // the wave that had nothing in phase A)
 // then the ten accumulator tiles are staged (fp32, over the dead operand planes) and the epilogue runs as before.  T^-1, A_qb and
 // G1 are not needed at all: 28 (rows) + 8 (u) + 8 (z) + 8.5 (E) + 8.5 (H_C) KB in, 24 KB out per chunk; LDS 133 KB.
-#include "chunk_bwd_common.h"
+#include "../chunk_bwd_common.h"
+#include "../launch_attr.h"
 
 // experiment ("measure operand by operand"): bit i set = the lo plane of operand i is written as zeros, i.e. that
 // operand enters its products as ONE bf16 plane.  0 Q~  1 A~  2 K^  3 B^  4 U  5 Z  6 E'  7 H0  8 P_vy  9 P_vz  10 P_uy  11 P_uz  12 A_qk  13 A_ak
@@ -527,13 +528,8 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out9_kernel(
 int chunk_bwd_out9_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a, const void *b,
                         const void *dy, const void *hs, const float *sa, const float *z, const void *e_vk, void *dw, void *dq, void *dk,
                         void *dv, void *da, void *db, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_bwd_out9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)Out9Smem::bytes);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static DynLdsOnce lds_once;
+    if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(&wkv7c_bwd_out9_kernel), (int)Out9Smem::bytes); e != hipSuccess) return (int)e;
     (void)hipGetLastError();
     const int total = B * H * (T_ / kC);
     int cpw = kOut9MinChunksPerWG;

@@ -23,6 +23,7 @@
 //   * the 8 input streams are prefetched one 16-step stage ahead into registers, converted once, and read
 //     back from LDS as float4 per lane (its 4 columns / 4 rows).
 #include "wkv7_common.h"
+#include "launch_attr.h"
 
 namespace rwkv7 {
 
@@ -314,13 +315,8 @@ static int launch_bwd(int B, int T_, int H, const void *w, const void *q, const 
                       const void *a, const void *b, const void *dy, const float *s, const float *sa,
                       const BwdOuts<T> &outs, hipStream_t stream) {
     constexpr size_t smem = bwd_smem_bytes<NW>();
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7_bwd_kernel<T, RT, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static DynLdsOnce lds_once;
+    if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(&wkv7_bwd_kernel<T, RT, NW>), (int)smem); e != hipSuccess) return (int)e;
     (void)hipGetLastError();  // drop any stale error left by an earlier runtime call of the host program
     hipLaunchKernelGGL((wkv7_bwd_kernel<T, RT, NW>), dim3(B * H * (kN / (NW * 4 * RT))), dim3(64 * NW), smem, stream,
                        T_, H, (const T *)w, (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b,

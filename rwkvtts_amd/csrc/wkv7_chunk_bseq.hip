@@ -31,6 +31,7 @@
 // 3.9k cycles per chunk; B" on the waves that compute E_c instead of wave 0: no change; an LDS flag instead of the barrier for the
 // X" hand-off inside interval b: +4.2 % (profiles/experiments_r04/bseq_xpp_relocation.patch).
 #include "chunk_common.h"
+#include "launch_attr.h"
 
 namespace rwkv7 {
 
@@ -336,13 +337,8 @@ __global__ __launch_bounds__(512) void wkv7c_bseq_kernel(int T_, int H, const bf
 
 int chunk_bseq_bf16(int B, int T_, int H, const void *w, const void *q, const void *a, const void *b, const void *dy, const float *tinv,
                     void *e_vk, float *z, const int *seq_off, int nseq, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_bseq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)BSSmem::bytes);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static DynLdsOnce lds_once;
+    if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(&wkv7c_bseq_kernel), (int)BSSmem::bytes); e != hipSuccess) return (int)e;
     (void)hipGetLastError();
     hipLaunchKernelGGL(wkv7c_bseq_kernel, dim3((seq_off ? nseq : B) * H * 2), dim3(512), BSSmem::bytes, st, T_, H, (const bf16_t *)w,
                        (const bf16_t *)q, (const bf16_t *)a, (const bf16_t *)b, (const bf16_t *)dy, tinv, (uint16_t *)e_vk, z, seq_off);

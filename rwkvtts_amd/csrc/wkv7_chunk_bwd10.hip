@@ -27,6 +27,7 @@
 //             MFMAs per SIMD (waves w, w + 4): I1 32 / 28 / 20 / 20, I2 46 / 46 / 44 / 44 (bwd_out9: phase A 20 / 20 / 20 / 16, B 54 / 54 / 48 / 48)
 //     I3      accumulators -> fp32 staging ; I4 epilogue ; I5 gradient rows out
 #include "chunk_bwd_common.h"
+#include "launch_attr.h"
 
 namespace rwkv7 {
 
@@ -578,13 +579,8 @@ __global__ __launch_bounds__(512) void wkv7c_bwd_out10_kernel(
 int chunk_bwd_out10_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a, const void *b,
                          const void *dy, const void *hs, const float *sa, const float *z, const void *e_vk, void *dw, void *dq, void *dk,
                          void *dv, void *da, void *db, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_bwd_out10_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)Out10Smem::bytes);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static DynLdsOnce lds_once;
+    if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(&wkv7c_bwd_out10_kernel), (int)Out10Smem::bytes); e != hipSuccess) return (int)e;
     (void)hipGetLastError();
     const int total = B * H * (T_ / kC);
     int cpw = kOut10MinChunksPerWG;

@@ -15,6 +15,7 @@
 // Saved for backward: U (= the scalar kernel's `sa`, fp32 [B,T,H,64]) and the state at the START of every chunk,
 // hs fp32 [B,H,T/32,64(k),64(v)].
 #include "chunk_common.h"
+#include "launch_attr.h"
 
 namespace rwkv7 {
 
@@ -520,13 +521,8 @@ template <typename T, bool SAVE>
 static int launch_fwd_t(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                         const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq,
                         hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_fwd_kernel<T, SAVE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FwdSmem::total<T>());
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static DynLdsOnce lds_once;
+    if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(&wkv7c_fwd_kernel<T, SAVE>), (int)FwdSmem::total<T>()); e != hipSuccess) return (int)e;
     (void)hipGetLastError();
     hipLaunchKernelGGL((wkv7c_fwd_kernel<T, SAVE>), dim3((seq_off ? nseq : B) * H * 2), dim3(256), FwdSmem::total<T>(), st, T_, H,
                        (const T *)w, (const T *)q, (const T *)k, (const T *)v, (const T *)a, (const T *)b, tinv, (T *)y, sa, (uint16_t *)hs, seq_off);
@@ -540,16 +536,22 @@ int chunk_prep_f32(int B, int T_, int H, const void *w, const void *a, const voi
     return launch_prep<float>(B, T_, H, w, a, b, tinv, st);
 }
 // bf16 tensors run the 8-wave producer / consumer kernel (wkv7_chunk_fwd9.hip: 278 us against 495 us for this 4-wave kernel at
-// B=8, T=4096, H=16); waves == 4 (rwkv7_wkv_chunk_fwd_seq_variant_bf16) selects this one (A/B, cross-check).  fp32 tensors always run here.
+// B=8, T=4096, H=16).  fp32 tensors always run here.  The bf16 instantiation of this 4-wave kernel is an A/B twin and a cross-check:
+// it is compiled into the lab build only (python -m rwkvtts_amd.build --lab, include/rwkv7_hip_lab.h).
 int chunk_fwd9_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const float *,
                     void *, float *, void *, const int *, int, hipStream_t);
 
 int chunk_fwd_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
-                   const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, int waves, hipStream_t st) {
-    if (waves == 9) return chunk_fwd9_bf16(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st);
+                   const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, hipStream_t st) {
+    return chunk_fwd9_bf16(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st);
+}
+#ifdef RWKV7_LAB
+int chunk_fwd4_bf16(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
+                    const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, hipStream_t st) {
     return (sa && hs) ? launch_fwd_t<bf16_t, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st)
                       : launch_fwd_t<bf16_t, false>(B, T_, H, w, q, k, v, a, b, tinv, y, nullptr, nullptr, seq_off, nseq, st);
 }
+#endif
 int chunk_fwd_f32(int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                   const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, hipStream_t st) {
     return (sa && hs) ? launch_fwd_t<float, true>(B, T_, H, w, q, k, v, a, b, tinv, y, sa, hs, seq_off, nseq, st)

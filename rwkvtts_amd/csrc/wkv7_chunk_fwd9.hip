@@ -25,6 +25,7 @@
 // go through a ~80 B/clk path (MI355X_MICROARCH.md, LDS table) and are half of the interval.  Producer waves at s_setprio 1:
 // 5.3k cycles per chunk (the consumer waves lose the VALU slots) -- off.
 #include "chunk_common.h"
+#include "launch_attr.h"
 
 #ifndef WKV7C_F9_PRODUCER_PRIO
 #define WKV7C_F9_PRODUCER_PRIO 0
@@ -373,16 +374,9 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
 
 static int launch_fwd9(bool save, int B, int T_, int H, const void *w, const void *q, const void *k, const void *v, const void *a,
                        const void *b, const float *tinv, void *y, float *sa, void *hs, const int *seq_off, int nseq, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_fwd9_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)F9Smem::bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wkv7c_fwd9_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)F9Smem::bytes);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static DynLdsOnce lds_once, lds_once2;
+    if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(&wkv7c_fwd9_kernel<true>), (int)F9Smem::bytes); e != hipSuccess) return (int)e;
+    if (hipError_t e = lds_once2.ensure(reinterpret_cast<const void *>(&wkv7c_fwd9_kernel<false>), (int)F9Smem::bytes); e != hipSuccess) return (int)e;
     (void)hipGetLastError();
     const dim3 grid((seq_off ? nseq : B) * H * 2), block(512);
     if (save)

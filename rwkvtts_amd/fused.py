@@ -286,7 +286,7 @@ def relu_sq(x):
     return _ReluSq.apply(x)
 
 
-# The channel-mix key projection with relu(.)^2 as the GEMM's epilogue (csrc/gemm_relusq.hip: hand-written 256 x 256 x 64 MFMA kernel
+# The channel-mix key projection with relu(.)^2 as the GEMM's epilogue (round 2: csrc/lab/gemm_relusq.hip, hand-written 256 x 256 x 64 MFMA kernel
 # fed by LDS-DMA, persistent over the output tiles; bit-identical output; the pre-activation is never written and the backward takes
 # 2 relu(x) = 2 sqrt(s) from the output, rwkv7_relusq_bwd_s).  A measured experiment, OFF by default:
 # isolated (tools/bench_gemm_relusq.py, 32768 x 4096 x 1024) 297-302 us against 254-274 + 87 us for the library GEMM + rwkv7_relusq_fwd
@@ -295,7 +295,7 @@ def relu_sq(x):
 # (tools/ab_step.py) -- no gain, so the pair stays.  The bar was the library's rate on this shape in the same process.
 # Round 4: the entry now runs the second-generation kernel (csrc/gemm_nt4.hip) for K % 1024 == 0 and the pair of fusions lives in
 # channel_mix below (on by default); this stand-alone node stays as the A/B switch of the forward half (-1.02 ms on its own).
-# bf16, M and N multiples of 256, K of 64; RWKV7_FUSED_KEY_RELUSQ=1 (or the attribute) switches it on.
+# bf16, M and N multiples of 256, K of 1024 (csrc/gemm_nt4.hip); RWKV7_FUSED_KEY_RELUSQ=1 (or the attribute) switches it on.
 FUSED_KEY_RELUSQ = os.environ.get("RWKV7_FUSED_KEY_RELUSQ", "0") == "1"
 FUSED_KEY_RELUSQ_HITS = [0]
 
@@ -303,7 +303,7 @@ FUSED_KEY_RELUSQ_HITS = [0]
 def key_relusq_eligible(x, weight):
     M = x.numel() // x.shape[-1]
     return (FUSED_KEY_RELUSQ and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and M % 256 == 0
-            and weight.shape[0] % 256 == 0 and weight.shape[1] % 64 == 0)
+            and weight.shape[0] % 256 == 0 and weight.shape[1] % 1024 == 0)
 
 
 class _KeyReluSq(torch.autograd.Function):
@@ -350,7 +350,7 @@ FUSED_RELUSQ_VALUE_BWD = os.environ.get("RWKV7_FUSED_RELUSQ_VALUE_BWD", "0") == 
 def relusq_value_eligible(h, weight):
     M = h.numel() // h.shape[-1]
     return (FUSED_RELUSQ_VALUE_BWD and h.is_cuda and h.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and M % 256 == 0
-            and weight.shape[1] % 256 == 0 and weight.shape[0] % 64 == 0 and torch.is_grad_enabled())
+            and weight.shape[1] % 256 == 0 and weight.shape[0] % 1024 == 0 and torch.is_grad_enabled())
 
 
 class _ReluSqValue(torch.autograd.Function):

@@ -312,7 +312,7 @@ def wkv7_chunk_prep(w, a, b):
     return tinv
 
 
-def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None, waves=None):
+def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None):
     """Chunked forward.  Returns y, and (tinv, sa, hs) when save (what the chunked backward consumes; hs = the state at the
     start of every chunk as q15 records, see q15_decode).
     seq_off: packed rows -- int32 [nseq + 1] device tensor of cumulative 32-step chunk counts over the [B][T/32] chunk
@@ -328,10 +328,7 @@ def wkv7_chunk_forward(w, q, k, v, a, b, save=True, seq_off=None, waves=None):
     with torch.cuda.device_of(w), _timed("wkv7c_fwd", w):
         args = (B, T, H, _p(w), _p(q), _p(k), _p(v), _p(a), _p(b), _p(tinv), _p(y),
                 None if sa is None else _p(sa), None if hs is None else _p(hs), *_seq_args(seq_off))
-        if waves is None:
-            rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_seq_" + sfx)(*args, _stream(w))
-        else:   # measurements / cross-checks: the 4-wave or the 8-wave bf16 kernel, chosen explicitly
-            rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_seq_variant_" + sfx)(*args, int(waves), _stream(w))
+        rc = getattr(_lib.lib(), "rwkv7_wkv_chunk_fwd_seq_" + sfx)(*args, _stream(w))
     _lib.check(rc, "wkv7_chunk_forward")
     return (y, tinv, sa, hs) if save else y
 
@@ -367,7 +364,7 @@ def wkv7_chunk_bwd_seq(w, q, a, b, dy, tinv, seq_off=None, want_z=False):
 def wkv7_chunk_backward(w, q, k, v, a, b, dy, hs, sa, tinv, seq_off=None):
     """Chunked (MFMA) WKV7 backward, bf16: same gradients as torch.ops.wind_backstepping.backward, T % 32 == 0, from what
     wkv7_chunk_forward saved (hs, sa, tinv).  Two launches: the adjoint-state recurrence (csrc/wkv7_chunk_bseq.hip, which also
-    writes Z = dL/du) and the per-chunk gradients from Z (csrc/wkv7_chunk_bwd9.hip, two matrix phases).
+    writes Z = dL/du) and the per-chunk gradients from Z (csrc/wkv7_chunk_bwd10.hip, two matrix phases).
     Returns (dw, dq, dk, dv, da, db)."""
     B, T, H, C = w.shape
     if hs.dtype != torch.int16 or hs.shape[-1] != Q15_REC or sa.dtype != torch.float32 or tinv.dtype != torch.float32:

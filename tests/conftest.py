@@ -52,3 +52,15 @@ def c_oracle():
     from oracle import c_oracle as co
     co.build()
     return co
+
+
+@pytest.fixture(scope="session")
+def lab():
+    """tools/lab.py over rwkvtts_amd/lib/librwkv7_hip_lab.so (python -m rwkvtts_amd.build --lab): the superseded A/B twins of the shipped
+    kernels.  Cases that cross-check against them are skipped when the lab library has not been built."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lab as _lab
+    if not _lab.available():
+        pytest.skip("lab library not built (python -m rwkvtts_amd.build --lab)")
+    _lab.lib()
+    return _lab

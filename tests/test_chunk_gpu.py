@@ -113,36 +113,36 @@ def test_chunked_forward_plus_backward_vs_oracle(c_oracle, B, T, H, seed):
 
 
 @pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 96, 3, 4), (3, 2080, 2, 5)])   # one chunk; odd chunk counts; 65 chunks x 6 heads = 390:
-def test_both_gradient_kernel_generations_vs_oracle_and_each_other(c_oracle, B, T, H, seed):       # not a multiple of the chunks per workgroup
-    """rwkv7_set_bwd_out_generation: 10 = wkv7c_bwd_out10 (round 5: raw rows by LDS-DMA, swizzled planes, merged prologue / phase A;
-    the default), 9 = wkv7c_bwd_out9.  Both inside the 2-ulp bar against the C oracle; against each other dq, dk, dv, da, db are the
-    SAME BITS (same products, same MFMA order) and dw within one bf16 ulp (its epilogue sum is contracted differently under
-    -ffast-math in the two kernels).  The landing area of generation 10 is refilled one chunk ahead: a workgroup's last chunk, a
-    launch with one chunk in all, and a chunk count that does not divide by the chunks per workgroup are the edge cases."""
-    from rwkvtts_amd import _lib
-    lib = _lib.lib()
+def test_gradient_kernel_edge_chunk_counts_vs_oracle(c_oracle, B, T, H, seed):                 # not a multiple of the chunks per workgroup
+    """wkv7c_bwd_out10 (raw rows by LDS-DMA, swizzled planes, merged prologue / phase A) inside the 2-ulp bar against the C oracle.  Its
+    landing area is refilled one chunk ahead: a workgroup's last chunk, a launch with one chunk in all, and a chunk count that does
+    not divide by the chunks per workgroup are the edge cases."""
     ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
     dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).bfloat16()
     y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
     g_o = c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)
     d = [t.to(DEV) for t in ins]
     y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
-    out = {}
-    prev = lib.rwkv7_set_bwd_out_generation(10)
-    try:
-        assert prev == 10, "generation 10 is the default"
-        for gen in (9, 10):
-            assert lib.rwkv7_set_bwd_out_generation(gen) in (9, 10)
-            out[gen] = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv)
-            torch.cuda.synchronize()
-            for n, g, go in zip(NAMES, out[gen], g_o):
-                _assert_bf16_close(g, go, f"{n} (generation {gen})", ulps=2.0)
-        assert lib.rwkv7_set_bwd_out_generation(7) == 10 and lib.rwkv7_set_bwd_out_generation(10) == 10   # unknown values change nothing
-    finally:
-        lib.rwkv7_set_bwd_out_generation(10)
-    for n, a, b in zip(NAMES, out[9], out[10]):
+    out = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv)
+    torch.cuda.synchronize()
+    for n, g, go in zip(NAMES, out, g_o):
+        _assert_bf16_close(g, go, n, ulps=2.0)
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 96, 3, 4), (3, 2080, 2, 5)])
+def test_gradient_kernel_vs_round4_twin_lab(lab, B, T, H, seed):
+    """Lab cross-check (skipped without the lab library): against csrc/lab/wkv7_chunk_bwd9.hip dq, dk, dv, da, db are the SAME BITS (same
+    products, same MFMA order) and dw within one bf16 ulp (its epilogue sum is contracted differently under -ffast-math)."""
+    d = [t.to(DEV) for t in make_wkv_inputs(B, T, H, seed, torch.bfloat16)]
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).bfloat16().to(DEV)
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
+    e_vk, z = ops.wkv7_chunk_bwd_seq(d[0], d[1], d[4], d[5], dy, tinv, want_z=True)
+    new = ops.wkv7_chunk_backward(*d, dy, hs, sa, tinv)
+    old = lab.bwd_out9(*d, dy, hs, sa, z, e_vk)
+    torch.cuda.synchronize()
+    for n, a, b in zip(NAMES, old, new):
         if n == "dw":
-            _assert_bf16_close(a, b.float().cpu(), "dw, generation 9 vs 10", ulps=1.0)
+            _assert_bf16_close(a, b.float().cpu(), "dw, bwd_out9 vs bwd_out10", ulps=1.0)
         else:
             assert torch.equal(a, b), n
 
@@ -211,40 +211,30 @@ def test_packed_sequences_equal_separate_sequences_vs_oracle(c_oracle):
                 _assert_bf16_close(g[b:b + 1, lo:hi], go, f"{n}[{b},{lo}:{hi}]", ulps=2.0)
 
 
-DEFAULT_FWD_WAVES = 9   # what the plain entry point rwkv7_wkv_chunk_fwd_seq_bf16 launches
-
-
-@pytest.mark.parametrize("waves", [9])
-@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
-def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T, H, seed, waves):
-    """wkv7_chunk_fwd9.hip (producer / consumer split; W = T A~ and X' = T A_ak made beside the chain, two dependent products per
-    chunk; `waves` = 9 of rwkv7_wkv_chunk_fwd_seq_variant_bf16):
-    the same bars against the C oracle as the 4-wave kernel, feeding the chunked backward; and against the 4-wave kernel itself the
-    fp32 outputs agree to rounding (hipcc contracts the split prologue differently: last-ulp differences of the scaled operands;
-    the two-product form associates U = T(A~ S + A_ak V) as (T A~) S + (T A_ak) V), also on packed rows."""
-    from rwkvtts_amd import _lib
-    lib = _lib.lib()
-    ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
-    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).bfloat16()
-    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
-    g_o = c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)
-    d = [t.to(DEV) for t in ins]
+def _fwd_cuts(B, T):
     nc = T // 32
     cuts = {0, B * nc}
     for b in range(B):   # every row ends a sequence; rows with more than one chunk are cut once more
         cuts.add(b * nc + nc)
         if nc > 1:
             cuts.add(b * nc + (nc + b) // 2)
-    seq_off = torch.tensor(sorted(cuts), dtype=torch.int32, device=DEV)
-    ref = ops.wkv7_chunk_forward(*d, waves=4)
-    ref_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off, waves=4)
-    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d, waves=waves)
-    got_p = ops.wkv7_chunk_forward(*d, seq_off=seq_off, waves=waves)
-    plain = ops.wkv7_chunk_forward(*d)
+    return torch.tensor(sorted(cuts), dtype=torch.int32, device=DEV)
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
+def test_eight_wave_forward_kernel_vs_oracle(c_oracle, B, T, H, seed):
+    """wkv7_chunk_fwd9.hip (producer / consumer split; W = T A~ and X' = T A_ak made beside the chain, two dependent products per
+    chunk; what rwkv7_wkv_chunk_fwd_seq_bf16 launches): y, sa and the chunk states against the C oracle, feeding the chunked backward
+    (2-ulp bar on the six gradients)."""
+    ins = make_wkv_inputs(B, T, H, seed, torch.bfloat16)
+    dy = (torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))).bfloat16()
+    y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
+    g_o = c_oracle.wkv7_bwd(*ins, dy, s_o, sa_o)
+    d = [t.to(DEV) for t in ins]
+    nc = T // 32
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
     grads = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv)
     torch.cuda.synchronize()
-    if waves == DEFAULT_FWD_WAVES:
-        assert all(torch.equal(a_, b_) for a_, b_ in zip(plain, (y, tinv, sa, hs)))
     _assert_bf16_close(y, y_o, "y")
     _assert_f32_close(sa, sa_o, "sa", 2e-3)
     hsf = ops.q15_decode(hs).transpose(-1, -2)
@@ -252,10 +242,21 @@ def test_eight_wave_forward_kernel_vs_oracle_and_four_wave_kernel(c_oracle, B, T
         _assert_f32_close(hsf[:, :, c], s_o[:, :, 2 * c - 1], f"hs[{c}]", 2e-3)
     for n, g, go in zip(NAMES, grads, g_o):
         _assert_bf16_close(g, go, n, ulps=2.0)
-    for a, b in ((ref, (y, tinv, sa, hs)), (ref_p, got_p)):
-        assert torch.equal(a[1], b[1])                                   # T^-1: same kernel
-        _assert_bf16_close(b[0], a[0].cpu(), "y 8 vs 4", ulps=1.0)
-        _assert_f32_close(b[2], a[2].cpu(), "sa 8 vs 4", 1e-4)
-        _assert_f32_close(ops.q15_decode(b[3]), ops.q15_decode(a[3]).cpu(), "hs 8 vs 4", 1e-4)
+
+
+@pytest.mark.parametrize("B,T,H,seed", [(1, 32, 1, 0), (2, 64, 3, 1), (2, 512, 12, 2), (1, 1024, 2, 3)])
+def test_eight_wave_forward_kernel_vs_four_wave_kernel_lab(lab, B, T, H, seed):
+    """Lab cross-check (tools/lab.py, skipped without the lab library): against the bf16 instantiation of the 4-wave kernel the fp32
+    outputs agree to rounding (hipcc contracts the split prologue differently: last-ulp differences of the scaled operands; the
+    two-product form associates U = T(A~ S + A_ak V) as (T A~) S + (T A_ak) V), also on packed rows."""
+    d = [t.to(DEV) for t in make_wkv_inputs(B, T, H, seed, torch.bfloat16)]
+    seq_off = _fwd_cuts(B, T)
+    for so in (None, seq_off):
+        got = ops.wkv7_chunk_forward(*d, seq_off=so)
+        ref = lab.chunk_forward4(*d, got[1], seq_off=so)
+        torch.cuda.synchronize()
+        _assert_bf16_close(got[0], ref[0].cpu(), "y 8 vs 4", ulps=1.0)
+        _assert_f32_close(got[2], ref[2].cpu(), "sa 8 vs 4", 1e-4)
+        _assert_f32_close(ops.q15_decode(got[3]), ops.q15_decode(ref[3]).cpu(), "hs 8 vs 4", 1e-4)
 
 

@@ -61,10 +61,8 @@ def test_step_kernel_vs_module_path_and_fp32(D, L, V, ranks, B, bias):
     prompt = torch.randint(0, V, (B, 6), generator=g).to(DEV)
     c16, lg = _prefill(m16, prompt, B, torch.bfloat16)
     c32, lg32 = _prefill(m32, prompt, B, torch.float32)
-    ck = _clone_cache(c16)   # step kernel, persistent
     cp = _clone_cache(c16)   # step kernel, one launch per phase
     ct = _clone_cache(c16)   # one launch per phase through the device-table entry (rwkv7_decode_step_bf16)
-    step_k = DecodeStep(m16.model, m16.lm_head, ck, persistent=True)
     step_p = DecodeStep(m16.model, m16.lm_head, cp, persistent=False)
     step_t = DecodeStep(m16.model, m16.lm_head, ct, persistent=False, host_table=False)
     emb = m16.model.embeddings.weight
@@ -75,22 +73,17 @@ def test_step_kernel_vs_module_path_and_fp32(D, L, V, ranks, B, bias):
             lg32 = m32(input_ids=ids[:, None], past_key_values=c32, use_cache=True).logits[:, -1].float()
             lmod = m16(input_ids=ids[:, None], past_key_values=c16, use_cache=True).logits[:, -1].float()
             x = torch.nn.functional.embedding(ids, emb)
-            lk = step_k(x).clone()
             lp = step_p(x).clone()
             assert torch.equal(step_t(x), lp)   # pointers as kernel arguments or fetched from the table: the same kernels otherwise
-        assert not step_k.barrier_timed_out()
-        assert torch.isfinite(lk).all()
-        # same arithmetic in both launch modes
-        assert torch.equal(lk, lp), (lk - lp).abs().max().item()
+        assert torch.isfinite(lp).all()
         scale = lg32.abs().max().item()
         worst_mod = max(worst_mod, (lmod - lg32).abs().max().item() / scale)
-        worst_ker = max(worst_ker, (lk - lg32).abs().max().item() / scale)
+        worst_ker = max(worst_ker, (lp - lg32).abs().max().item() / scale)
     assert worst_ker < 3e-2, (worst_ker, worst_mod)
     assert worst_ker < 1.5 * worst_mod + 2e-3, (worst_ker, worst_mod)
     for st_, sp in zip(ct.states, cp.states):
         assert torch.equal(st_.att_kv, sp.att_kv) and torch.equal(st_.att_x_prev, sp.att_x_prev) and torch.equal(st_.ffn_x_prev, sp.ffn_x_prev)
-    for sk, sp, s32 in zip(ck.states, cp.states, c32.states):
-        assert torch.equal(sk.att_kv, sp.att_kv) and torch.equal(sk.att_x_prev, sp.att_x_prev) and torch.equal(sk.ffn_x_prev, sp.ffn_x_prev)
+    for sk, s32 in zip(cp.states, c32.states):
         ref = s32.att_kv
         assert (sk.att_kv - ref).abs().max().item() < 3e-2 * ref.abs().max().item() + 1e-3
         assert (sk.att_x_prev.float() - s32.att_x_prev).abs().max().item() < 5e-2 * s32.att_x_prev.abs().max().item() + 1e-2

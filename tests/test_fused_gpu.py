@@ -488,9 +488,9 @@ def test_hip_adamw_groups_and_device_skip_flag_match_torch_adamw():
                                        f(0.9), f(0.95), f(1e-8), 1, None) == -4  # n % 128 != 0 with groups
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (2048, 4096, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (512, 768, 2048), (2048, 4096, 1024)])
 def test_key_projection_with_relu_squared_epilogue_equals_the_gemm_plus_kernel_pair(M, N, K):
-    """csrc/gemm_relusq.hip (rwkv7_gemm_nt_bf16: 256 x 256 x 64 MFMA tiles fed by LDS-DMA, relu(.)^2 as the epilogue;
+    """csrc/gemm_nt4.hip (rwkv7_gemm_nt_bf16: persistent MFMA kernel fed by LDS-DMA, relu(.)^2 as the epilogue;
     rwkv_s2s_single_ffn.py:228) behind fused.key_relu_sq: the forward is BIT-identical to the library GEMM followed by
     rwkv7_relusq_fwd (fp32 accumulation over K in the same 16-wide steps is not guaranteed, so equality is asserted only where it was
     observed -- 2 bf16 ulp otherwise); the backward (2 relu(x) taken as 2 sqrt(s) from the output) gives the pair's gradients to
@@ -529,7 +529,7 @@ def _key_relusq_case(fused, M, N, K):
     assert fused.key_relu_sq(x[:100], w) is None and fused.key_relu_sq(x.float(), w.float()) is None
 
 
-@pytest.mark.parametrize("M,F,D", [(256, 256, 64), (512, 768, 128), (2048, 4096, 1024)])
+@pytest.mark.parametrize("M,F,D", [(256, 256, 1024), (512, 768, 2048), (2048, 4096, 1024)])
 def test_relu_squared_backward_inside_the_value_dgrad_gemm(M, F, D, monkeypatch):
     """fused.relu_sq_value (round 4): value(relu(h)^2) whose backward forms dh = bf16(dy W_value) * 2 relu(h) in ONE launch
     (rwkv7_gemm_nt_relusq_bwd_bf16: the own MFMA GEMM with h as an auxiliary epilogue operand) against the separate nodes (library
@@ -566,10 +566,10 @@ def test_relu_squared_backward_inside_the_value_dgrad_gemm(M, F, D, monkeypatch)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (512, 1024, 1024), (2048, 4096, 1024), (1024, 1024, 4096), (256 * 9, 256 * 5, 2048), (256 * 33, 256 * 8, 1024)])
 def test_second_generation_gemm_all_epilogues_against_the_library_compositions(M, N, K):
     """csrc/gemm_nt4.hip (four waves, quadrant phases over a ring of eight half-tile slots, counted vmcnt, deferred-drain epilogue
-    through LDS) behind the same C entries as csrc/gemm_relusq.hip: epilogue 0 against the library GEMM, 1 against GEMM +
+    through LDS): epilogue 0 against the library GEMM, 1 against GEMM +
     rwkv7_relusq_fwd, 2 against GEMM + rwkv7_relusq_bwd (aux = h), 3 against GEMM + rwkv7_relusq_bwd_s (aux = s) -- each bit for
     bit where the library accumulates K in the same order, within one bf16 ulp of the GEMM result otherwise; several tiles per
-    workgroup and tile counts that are not a multiple of the grid included (ragged persistence); generation 1 gives the same bits."""
+    workgroup and tile counts that are not a multiple of the grid included (ragged persistence)."""
     import ctypes
     from rwkvtts_amd import _lib, fused
     lib = _lib.lib()
@@ -587,39 +587,54 @@ def test_second_generation_gemm_all_epilogues_against_the_library_compositions(M
         d = (got.float() - want.float()).abs()
         assert (d <= tol).all(), d.max().item()
 
-    prev = lib.rwkv7_set_gemm_generation(4)
-    try:
-        outs = {}
-        for gen in (4, 1):
-            lib.rwkv7_set_gemm_generation(gen)
-            C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
-            assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C), 0, st) == 0
-            close(C, ref)
-            outs[gen] = C.clone()
-            C1 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
-            assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C1), 1, st) == 0
-            assert torch.equal(C1, fused.relu_sq(C))                       # the activation of the kernel's own product, bit for bit
-            C2 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
-            assert lib.rwkv7_gemm_nt_relusq_bwd_bf16(M, N, K, P(A), P(W), P(aux), P(C2), st) == 0
-            want2 = torch.empty_like(C)
-            fused._call("relusq_bwd", aux, ctypes.c_long(aux.numel()), P(aux), P(C), P(want2))
-            assert torch.equal(C2, want2)
-        assert torch.equal(outs[4], outs[1])
-        lib.rwkv7_set_gemm_generation(4)
-        s_act = fused.relu_sq(aux)
-        C3 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
-        assert lib.rwkv7_gemm_nt_relusq_bwd_s_bf16(M, N, K, P(A), P(W), P(s_act), P(C3), st) == 0
-        want3 = torch.empty_like(C3)
-        fused._call("relusq_bwd_s", s_act, ctypes.c_long(s_act.numel()), P(s_act), P(outs[4]), P(want3))
-        assert torch.equal(C3, want3)
-        # repeated launches give the same bits (a race in the slot ring would come and go)
-        for _ in range(5):
-            C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-            assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C), 0, st) == 0
-            assert torch.equal(C, outs[4])
-        assert lib.rwkv7_gemm_nt_relusq_bwd_s_bf16(M, N, 960, P(A), P(W), P(s_act), P(C3), st) == -4      # K % 1024: RWKV7_ESHAPE
-    finally:
-        lib.rwkv7_set_gemm_generation(prev)
+    C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C), 0, st) == 0
+    close(C, ref)
+    C1 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C1), 1, st) == 0
+    assert torch.equal(C1, fused.relu_sq(C))                       # the activation of the kernel's own product, bit for bit
+    C2 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    assert lib.rwkv7_gemm_nt_relusq_bwd_bf16(M, N, K, P(A), P(W), P(aux), P(C2), st) == 0
+    want2 = torch.empty_like(C)
+    fused._call("relusq_bwd", aux, ctypes.c_long(aux.numel()), P(aux), P(C), P(want2))
+    assert torch.equal(C2, want2)
+    s_act = fused.relu_sq(aux)
+    C3 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    assert lib.rwkv7_gemm_nt_relusq_bwd_s_bf16(M, N, K, P(A), P(W), P(s_act), P(C3), st) == 0
+    want3 = torch.empty_like(C3)
+    fused._call("relusq_bwd_s", s_act, ctypes.c_long(s_act.numel()), P(s_act), P(C), P(want3))
+    assert torch.equal(C3, want3)
+    # repeated launches give the same bits (a race in the slot ring would come and go)
+    for _ in range(5):
+        Cr = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(Cr), 0, st) == 0
+        assert torch.equal(Cr, C)
+    for fn_args in ((lib.rwkv7_gemm_nt_relusq_bwd_s_bf16, (P(s_act), P(C3))), (lib.rwkv7_gemm_nt_relusq_bwd_bf16, (P(aux), P(C3)))):
+        assert fn_args[0](M, N, 960, P(A), P(W), *fn_args[1], st) == -4                                   # K % 1024: RWKV7_ESHAPE
+    assert lib.rwkv7_gemm_nt_bf16(M, N, 960, P(A), P(W), P(C3), 0, st) == -4
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 1024), (256 * 9, 256 * 5, 2048)])
+def test_second_generation_gemm_vs_first_generation_lab(lab, M, N, K):
+    """Lab cross-check (skipped without the lab library): csrc/lab/gemm_relusq.hip, the first-generation kernel, gives the same bits
+    for the plain product, the relu^2 epilogue and the 2 relu(aux) epilogue."""
+    import ctypes
+    from rwkvtts_amd import _lib
+    lib = _lib.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * (K ** -0.5)).to(DEV, torch.bfloat16)
+    aux = (torch.randn(M, N, generator=g) * 0.7).to(DEV, torch.bfloat16)
+    for epi in (0, 1):
+        C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        assert lib.rwkv7_gemm_nt_bf16(M, N, K, P(A), P(W), P(C), epi, st) == 0
+        for variant in (0, 1):
+            assert torch.equal(C, lab.gemm_nt_gen1(A, W, epi, variant))
+    C2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    assert lib.rwkv7_gemm_nt_relusq_bwd_bf16(M, N, K, P(A), P(W), P(aux), P(C2), st) == 0
+    assert torch.equal(C2, lab.gemm_nt_relusq_bwd_gen1(A, W, aux))
 
 
 @pytest.mark.parametrize("M,F,D", [(512, 1024, 1024), (2048, 4096, 1024)])

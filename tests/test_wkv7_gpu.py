@@ -263,7 +263,7 @@ def test_forward_both_lane_shapes_vs_oracle(c_oracle, cw, dtype):
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     sfx = "bf16" if dtype == torch.bfloat16 else "f32"
     lib = _lib.lib()
-    # explicit shape argument of the *_variant entry points (the library has no global switches)
+    # explicit shape argument of the *_variant entry points (each variant has its own entry point; the library has no global switches)
     rc = getattr(lib, "rwkv7_wkv_fwd_variant_" + sfx)(B, T, H, *[P(t) for t in d], P(y), P(s), P(sa), cw, None)
     assert rc == 0
     if dtype == torch.bfloat16:

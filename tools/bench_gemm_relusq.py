@@ -1,4 +1,4 @@
-"""The channel-mix key projection with relu(.)^2 as the GEMM epilogue (csrc/gemm_relusq.hip) against what the step runs today: the
+"""The channel-mix key projection with relu(.)^2 as the GEMM epilogue (first generation, csrc/lab/gemm_relusq.hip: needs `python -m rwkvtts_amd.build --lab`) against what the step runs today: the
 library GEMM (hipBLASLt through torch) followed by rwkv7_relusq_fwd.  Same process, same tensors, HIP events.
 
     python tools/bench_gemm_relusq.py [M N K]      default 32768 4096 1024 (0.4B, B=8, L=4096)"""
@@ -6,6 +6,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rwkvtts_amd import _lib, fused
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lab
 
 M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (32768, 4096, 1024)
 dev = "cuda:0"
@@ -19,9 +21,7 @@ st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def own(epi, variant=1):
-    rc = lib.rwkv7_gemm_nt_variant_bf16(M, N, K, P(A), P(W), P(C), epi, variant, st())
-    assert rc == 0, rc
-    return C
+    return lab.gemm_nt_gen1(A, W, epi, variant)
 
 
 def lib_pair():

@@ -7,7 +7,7 @@ from rwkvtts_amd.synthetic import make_wkv_inputs
 B, T, H = 8, 4096, 16
 ins = make_wkv_inputs(B, T, H, 1, torch.bfloat16, "cuda:0")
 lib = _lib.lib()
-run = lambda: ops.wkv7_chunk_forward(*ins, waves=9)
+run = lambda: ops.wkv7_chunk_forward(*ins)
 run(); torch.cuda.synchronize()
 lib.rwkv7_debug_cfwd9_timing(None, 1)
 N = 5
