@@ -94,10 +94,185 @@ def _device_info(torch, dev):
     return out
 
 
+
+class Watchdog:
+    """`with Watchdog(seconds, what, state)`: if the block has not finished after `seconds`, print WHICH rank is stuck WHERE (and
+    `state()`, e.g. the gradient buckets on the wire) to stderr and end the process with exit code 3 -- so that a hung first
+    multi-GPU run leaves a diagnosis instead of a bare timeout.  One daemon timer thread per block; no cost when it does not fire."""
+
+    def __init__(self, seconds, what, state=None):
+        self.seconds, self.what, self.state = seconds, what, state
+
+    def _fire(self):
+        rank = os.environ.get("RANK", "0")
+        lines = [f"[bench watchdog] rank {rank} (pid {os.getpid()}, LOCAL_RANK {os.environ.get('LOCAL_RANK', '0')}) still in "
+                 f"'{self.what}' after {self.seconds:.0f} s"]
+        try:
+            if self.state is not None:
+                lines.append(f"[bench watchdog] rank {rank} state: {self.state()}")
+        except Exception as e:
+            lines.append(f"[bench watchdog] rank {rank} state unavailable: {e!r}")
+        print("\n".join(lines), file=sys.stderr, flush=True)
+        try:
+            import faulthandler
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        except Exception:
+            pass
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        self.t = threading.Timer(self.seconds, self._fire)
+        self.t.daemon = True
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def _checkin(store, stage, rank):
+    if store is not None:
+        try:
+            store.set(f"bench/{stage}/{rank}", "1")
+        except Exception:
+            pass
+
+
+def _missing(store, stage, world):
+    """Ranks that have NOT passed `stage` yet (read from the rendezvous TCP store, which does not need the collective backend)."""
+    if store is None:
+        return "unknown (no store)"
+    out = []
+    for r in range(world):
+        try:
+            if not store.check([f"bench/{stage}/{r}"]):
+                out.append(r)
+        except Exception:
+            out.append(r)
+    return f"ranks not past '{stage}': {out or 'none'}"
+
+
+def preflight(torch, rank, local_rank, world, dev, one_device, timeout_s=60.0, log=print):
+    """First contact with the collective backend, BEFORE the model is built: who sits where, which RCCL, and one all-reduce of each
+    kind the step uses (64 MiB bf16 AVG -- two 32 MiB buckets' worth -- and the 1-element MAX of the NaN flag;
+    train_spark_rwkv7speech.py:566-572, 664-670), each under a watchdog that names the ranks that did not arrive.  Returns a dict for
+    the JSON line's `comm.preflight`."""
+    import torch.distributed as dist
+    info = {}
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        store = None
+    backend = dist.get_backend()
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception as e:
+        ver = repr(e)
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": int(dev.index), "name": props.name,
+                "pci": getattr(props, "pci_bus_id", None), "pid": os.getpid()}
+    except Exception as e:
+        mine = {"rank": rank, "local_rank": local_rank, "error": repr(e)}
+    _checkin(store, "start", rank)
+    with Watchdog(timeout_s, "preflight: all_gather_object of the rank <-> device map", lambda: _missing(store, "start", world)):
+        table = [None] * world
+        dist.all_gather_object(table, mine)
+    _checkin(store, "map", rank)
+    info.update({"backend": backend, "rccl_version": ver, "ranks": table,
+                 "env": {k: os.environ.get(k) for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_P2P_DISABLE", "NCCL_SOCKET_IFNAME",
+                                                        "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES") if os.environ.get(k) is not None}})
+    devs = [t.get("device") for t in table if isinstance(t, dict)]
+    if not one_device and len(set(devs)) != world:
+        raise SystemExit(f"preflight: {world} ranks on devices {devs}: every rank needs its own GPU (LOCAL_RANK not set by the launcher?)")
+    if rank == 0:
+        log(f"preflight: backend {backend}, RCCL {ver}, ranks -> devices {[(t.get('rank'), t.get('device'), t.get('pci')) for t in table]}")
+    # the two collectives of the step
+    n = (64 << 20) // 2
+    buf = torch.full((n,), float(rank + 1), dtype=torch.bfloat16, device=dev)
+    flag = torch.tensor([float(rank)], device=dev)
+    avg = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM    # gloo (the one-device rehearsal) has no AVG
+    with Watchdog(timeout_s, "preflight: first 64 MiB bf16 all-reduce (communicator set-up)", lambda: _missing(store, "map", world)):
+        dist.all_reduce(buf, op=avg)
+        torch.cuda.synchronize(dev)
+    _checkin(store, "allreduce1", rank)
+    want = (world + 1) / 2.0 if backend == "nccl" else world * (world + 1) / 2.0
+    got = float(buf[:8].float().mean().item())
+    if abs(got - want) > 1e-2 * want:
+        raise SystemExit(f"preflight: all-reduce gave {got}, expected {want} (rank {rank})")
+    reps = 5
+    with Watchdog(timeout_s, f"preflight: {reps} timed 64 MiB all-reduces + MAX", lambda: _missing(store, "allreduce1", world)):
+        buf.fill_(1.0)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf, op=avg)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize(dev)
+    _checkin(store, "done", rank)
+    if float(flag.item()) != float(world - 1):
+        raise SystemExit(f"preflight: MAX all-reduce gave {float(flag.item())}, expected {world - 1}")
+    nbytes = n * 2
+    info["allreduce_64mib"] = {"ms": round(dt * 1e3, 3), "algbw_gbs": round(nbytes / dt / 1e9, 1),
+                               "busbw_gbs": round(nbytes / dt / 1e9 * 2 * (world - 1) / world, 1), "op": "AVG" if backend == "nccl" else "SUM"}
+    if rank == 0:
+        log(f"preflight: 64 MiB bf16 all-reduce {dt * 1e3:.3f} ms = {nbytes / dt / 1e9:.1f} GB/s algorithmic "
+            f"({info['allreduce_64mib']['busbw_gbs']} GB/s bus), MAX ok")
+    del buf
+    return info
+
+
+def wkv7_probe(torch, dev, reps=12):
+    """Box fingerprint that DOES separate the box classes of the pool: the WKV7 chunked group itself, isolated --
+    prep + fwd9 + bseq + bwd_out10 at configs[1]'s shape (8, 4096, 16) on fixed synthetic inputs, median of `reps` back-to-back rounds
+    timed with HIP events, after the timed region.  `ms_per_step / wkv7_group_probe_ms` is the box-normalised step."""
+    from rwkvtts_amd import ops
+    from rwkvtts_amd.synthetic import make_wkv_inputs
+    ins = make_wkv_inputs(8, 4096, 16, 1234, torch.bfloat16, dev)
+    dy = torch.randn(8, 4096, 16, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(5)).bfloat16()
+
+    def once():
+        y, tinv, sa, hs = ops.wkv7_chunk_forward(*ins)
+        ops.wkv7_chunk_backward(*ins, dy, hs, sa, tinv)
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        once()
+        e.record()
+        ts.append((s, e))
+    torch.cuda.synchronize(dev)
+    ms = sorted(s.elapsed_time(e) for s, e in ts)
+    return round(ms[len(ms) // 2], 4)
+
+
+PACKED_FRACTIONS = (0.125, 0.11, 0.1, 0.095, 0.09, 0.085, 0.08, 0.07, 0.06, 0.05, 0.04, 0.035, 0.03, 0.02, 0.01)
+
+
+def packed_lengths(total):
+    """A fixed spread of sequence lengths (3 % ... 12.5 % of the row, none a multiple of 32) that sum to `total`: the packed
+    variable-length workload of --packed (data/utils/spark_dataset.py:111-162 packs real utterances the same way)."""
+    lens = [max(300, int(total * f) // 2 * 2 + 1) for f in PACKED_FRACTIONS]
+    lens[-1] += total - sum(lens)
+    assert lens[-1] > 290 and sum(lens) == total, lens
+    return lens
+
+
 def self_launch(n):
     """`python bench.py --gpus N` (the form the driver uses) -> N ranks under torch.distributed.run on this node."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("NCCL_DEBUG", "WARN")                # RCCL's own warnings (transport fall-backs, failed IPC) reach stderr
+    env.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     os.execvpe(sys.executable, cmd, env)
@@ -257,6 +432,11 @@ def main():
     ap.add_argument("--via-reference-op", action="store_true",
                     help="A/B: the scan through torch.ops.wind_backstepping.forward/backward (the reference's plug-in point, wkv7_op.cpp:21-29; "
                          "for bf16 and T % 32 == 0 it launches the same chunked MFMA kernels, with `s` as their arena) instead of the direct calls")
+    ap.add_argument("--packed", action="store_true",
+                    help="SURVEY 8f N1: the same B x L positions as ONE packed variable-length row [1, B L, D] + cu_seqlens on the device "
+                         "(15 sequences of 300 ... 4096 positions; spark layout only): the packed training path of train_spark_rwkv7speech.py:238-239")
+    ap.add_argument("--preflight-timeout", type=float, default=60.0, help="N > 1: seconds each preflight collective may take before the watchdog reports")
+    ap.add_argument("--step-timeout", type=float, default=300.0, help="N > 1: seconds a training step may take before the watchdog reports")
     ap.add_argument("--scalar-wkv", action="store_true", help="A/B: scalar WKV7 kernels (reference schema fwd, row-split bwd) instead of the chunked MFMA pair")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -287,7 +467,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or let bench.py launch itself)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pre = None
     if world > 1:
+        pre = preflight(torch, rank, local_rank, world, dev, a.one_device, a.preflight_timeout,
+                        log=lambda m: print(f"[bench {time.strftime('%H:%M:%S')}] {m}", file=sys.stderr, flush=True))
         torch.distributed.barrier()
 
     base = {"0.1b": backbone.config_0p1b, "0.4b": backbone.config_0p4b, "1.5b": backbone.config_1p5b}[a.model]()
@@ -309,7 +492,17 @@ def main():
     tr = trainer.DataParallelTrainer(model, lr=1e-4, warmup_steps=10, total_steps=1000, shard_optimizer=a.shard_optimizer)
     H = cfg.num_heads
 
-    if a.layout == "spark":
+    if a.layout == "spark" and a.packed:
+        lens = packed_lengths(B * T)
+        cu_dev = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+
+        def make_batch(i):
+            # one packed row: every sequence its own Spark sample (tags, text, global, semantic ids), embedded WITH autograd and
+            # concatenated, cu_seqlens a DEVICE tensor (no host read-back in the step: backbone._forward_packed_device)
+            parts = [synthetic_spark_batch(model, 1, n, seed=1234 + rank + 1000 * i + 17 * j, n_text=min(255, n // 4)) for j, n in enumerate(lens)]
+            return dict(inputs_embeds=torch.cat([p_["inputs_embeds"] for p_ in parts], 1), labels=torch.cat([p_["labels"] for p_ in parts], 1),
+                        cu_seqlens=cu_dev)
+    elif a.layout == "spark":
         def make_batch(i):
             # built inside the step WITH autograd, as data/utils/spark_dataset.py:163-239 does under the reference's training
             # loop (train_spark_rwkv7speech.py:630-634): the four embedding tables get gradients, their backward is timed
@@ -327,8 +520,19 @@ def main():
                 xy_cache[k] = b
             return dict(xy_cache[k], use_cache=False)
 
+    def reducer_state():
+        r = tr.reducer
+        return (f"{len(r.buckets)} gradient buckets; on the wire (launch order) {list(r.launched)}; next bucket to launch {r.next_bucket}; "
+                f"gradients still missing per bucket {list(getattr(r, 'pending', []))}; collectives not yet waited for {len(r.works)}")
+
     def one_step(i):
-        return tr.step(**make_batch(i))
+        if world == 1:
+            return tr.step(**make_batch(i))
+        with Watchdog(a.step_timeout, f"training step {i} (forward / backward / bucketed gradient exchange / AdamW)", reducer_state):
+            out_ = tr.step(**make_batch(i))
+            if i < a.warmup:
+                torch.cuda.synchronize()    # warm-up steps complete inside their watchdog; timed steps stay asynchronous
+            return out_
 
     def sync():
         if world > 1:
@@ -449,6 +653,14 @@ def main():
             "device": _device_info(torch, dev),
             "roofline": roof,
         }
+        try:   # the box-class indicator: the isolated WKV7 group, and the step expressed in units of it
+            out["device"]["wkv7_group_probe_ms"] = wkv7_probe(torch, dev)
+            out["device"]["step_over_wkv7_probe"] = round(ms / out["device"]["wkv7_group_probe_ms"], 2)
+        except Exception as e:
+            out["device"]["wkv7_probe_error"] = repr(e)
+        if a.packed and a.layout == "spark":
+            out["config"]["workload"] += f"; PACKED: one row [1, {B * T}, D] of {len(lens)} sequences ({min(lens)}..{max(lens)} positions), cu_seqlens on the device (SURVEY 8f N1)"
+            out["config"]["packed_lengths"] = lens
         if a.wgrad_side_stream:
             out["config"]["wgrad"] = "weight gradients on a side stream (fused.WGRAD_SIDE_STREAM)"
         if a.via_reference_op:
@@ -457,7 +669,8 @@ def main():
             out["rehearsal"] = f"{world} ranks sharing GPU 0, exchange over gloo: exercises the launch path, not a measurement"
         if world > 1:
             r = tr.reducer
-            out["comm"] = {"rccl_ranks": world, "backend": r.backend, "bytes_allreduced_per_step": tr.flat.numel * tr.flat.flat_grad.element_size(),
+            ev_ms = sum(s_.elapsed_time(e_) for s_, e_ in r.wait_events) / a.steps
+            out["comm"] = {"preflight": pre, "rccl_ranks": world, "backend": r.backend, "bytes_allreduced_per_step": tr.flat.numel * tr.flat.flat_grad.element_size(),
                            "buckets": len(r.buckets), "bucket_order": "rank 0's gradient-ready order, broadcast (re-cut after the first backward pass); launched in index order" if r.rebuilt else "reverse registration order",
                            "optimizer": "AdamW bucket by bucket as each all-reduce completes" if tr.bucket_optimizer and not tr.shard_optimizer else "one pass behind the last bucket",
                            "bucket_mib": [round(sum(e - s for s, e in runs) * tr.flat.flat_grad.element_size() / 2**20, 1) for runs in r.runs],

@@ -519,6 +519,34 @@ class RWKV7Model(nn.Module):
                 x, delta, v_first = layer(x, delta, mask, v_first, st, seq_start)
         return fused.add_layer_norm(x, delta, self.norm)[1] if delta is not None else fused.layer_norm(x, self.norm)
 
+    def _forward_packed_device(self, x, cu_seqlens):
+        """The packed path for a `cu_seqlens` that lives on the DEVICE (as fla consumes it; train_spark_rwkv7speech.py:238-239): no
+        host read-back.  The 32-aligned layout of `_forward_packed` is computed with tensor ops from the cumulative lengths; only its
+        SIZE must be known on the host, and that is bounded by shapes alone: every non-empty sequence grows by at most 32 positions, so
+        the aligned row has at most total + 32 nseq positions (rounded up to a chunk).  Chunks between the last sequence and that bound
+        form one extra all-masked pseudo-sequence, so no chunk is left to uninitialised memory.  Empty sequences own empty chunk ranges
+        (the kernels return at once); positions outside [cu[0], cu[-1]) come back as zeros."""
+        C = ops.CHUNK_T
+        total, D = x.shape[1], x.shape[-1]
+        nseq = cu_seqlens.numel() - 1
+        t_max = (total + C * nseq + C - 1) // C * C
+        cu = cu_seqlens.to(torch.int64)
+        lens = cu[1:] - cu[:-1]
+        alen = torch.where(lens > 0, (torch.div(lens, C, rounding_mode="floor") + 1) * C, torch.zeros_like(lens))
+        ends = torch.cumsum(alen, 0)
+        starts = ends - alen
+        j = torch.arange(total, device=x.device)
+        sq = torch.searchsorted(cu[1:].contiguous(), j, right=True).clamp_(max=nseq - 1)
+        valid = (j >= cu[0]) & (j < cu[-1])
+        dest = torch.where(valid, starts[sq] + (j - cu[sq]), torch.full_like(j, t_max))     # invalid positions -> the dump row
+        seq_off = torch.cat([starts.new_zeros(1), ends, ends.new_full((1,), t_max)])
+        seq_off = torch.div(seq_off, C, rounding_mode="floor").to(torch.int32)                 # [nseq + 2]: the sequences + the masked tail
+        x_al = x.new_zeros(t_max + 1, D).index_copy(0, dest, x[0])[:t_max]
+        mask = x.new_zeros(t_max + 1, 1).index_fill_(0, dest, 1.0)[:t_max]
+        out = self._run_layers(x_al.unsqueeze(0), mask.unsqueeze(0), None, seq_off)
+        packed = out[0].index_select(0, dest.clamp(max=t_max - 1)) * valid.unsqueeze(-1).to(out.dtype)
+        return ModelOutput(last_hidden_state=packed.unsqueeze(0), past_key_values=None)
+
     def _forward_packed(self, x, cu_seqlens):
         """Packed variable-length batch (data/utils/spark_dataset.py:111-162,
         train_spark_rwkv7speech.py:238-239; fla's `cu_seqlens`): x is ONE row [1, sum T, D], sequence i occupies
@@ -533,10 +561,12 @@ class RWKV7Model(nn.Module):
         parallel.  Everything else is position-wise.  Other dtypes: unpack into a right-padded masked
         batch, run, pack again."""
         assert x.shape[0] == 1, "cu_seqlens expects a packed [1, total, D] row"
-        cu = cu_seqlens.tolist()
+        native = (PACKED_NATIVE and x.is_cuda and x.dtype == torch.bfloat16 and fused.CHUNKED_WKV_FWD and fused.CHUNKED_WKV_BWD)
+        if native and cu_seqlens.is_cuda:
+            return self._forward_packed_device(x, cu_seqlens)
+        cu = cu_seqlens.tolist()      # a HOST tensor (what the reference's collators build: spark_dataset.py:150-160): no device sync
         lens = [b - a for a, b in zip(cu[:-1], cu[1:])]
-        if (PACKED_NATIVE and x.is_cuda and x.dtype == torch.bfloat16 and fused.CHUNKED_WKV_FWD and fused.CHUNKED_WKV_BWD
-                and sum(lens) > 0):
+        if native and sum(lens) > 0:
             C = ops.CHUNK_T
             D = x.shape[-1]
             starts, t_al = [], 0
@@ -544,12 +574,12 @@ class RWKV7Model(nn.Module):
                 starts.append(t_al)
                 if n > 0:
                     t_al += (n // C + 1) * C      # >= n + 1, multiple of 32
-            dest = torch.cat([torch.arange(s_, s_ + n) for s_, n in zip(starts, lens) if n > 0]).to(x.device)
+            dest = torch.cat([torch.arange(s_, s_ + n) for s_, n in zip(starts, lens) if n > 0]).to(x.device, non_blocking=True)
             seq_off = torch.tensor([s_ // C for s_, n in zip(starts, lens) if n > 0] + [t_al // C], dtype=torch.int32)
             src = x[0, cu[0]:cu[-1]]
             x_al = x.new_zeros(t_al, D).index_copy(0, dest, src)
             mask = x.new_zeros(t_al, 1).index_fill_(0, dest, 1.0)
-            out = self._run_layers(x_al.unsqueeze(0), mask.unsqueeze(0), None, seq_off.to(x.device))
+            out = self._run_layers(x_al.unsqueeze(0), mask.unsqueeze(0), None, seq_off.to(x.device, non_blocking=True))
             packed = out[0].index_select(0, dest)
             if cu[0] > 0 or packed.shape[0] < x.shape[1]:
                 packed = torch.cat([packed.new_zeros(cu[0], D), packed, packed.new_zeros(x.shape[1] - cu[-1], D)], 0)

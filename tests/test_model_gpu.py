@@ -532,7 +532,7 @@ def test_trainer_fast_gradient_path_equals_accumulate_path():
     assert fb.flat_grad[o:o + 8].abs().sum() == 0
 
 
-@pytest.mark.parametrize("lens", [[70, 33, 128, 5], [32, 64], [1, 1, 200]])
+@pytest.mark.parametrize("lens", [[70, 33, 128, 5], [32, 64], [1, 1, 200], [40, 0, 7, 0]])
 def test_packed_rows_native_sequence_ranges(lens):
     """cu_seqlens batches in bf16 run on the chunked WKV7 kernels' per-sequence chunk ranges (32-aligned re-layout; forward
     recurrence in rwkv7_wkv_chunk_fwd_seq_bf16 and adjoint recurrence in rwkv7_wkv_chunk_bseq_bf16 per sequence) instead
@@ -552,7 +552,7 @@ def test_packed_rows_native_sequence_ranges(lens):
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
     wgt = torch.randn(1, total + 3, 128, generator=g).to(DEV)
 
-    def run(native):
+    def run(native, cu=cu):
         backbone.PACKED_NATIVE = native
         try:
             model.zero_grad(set_to_none=True)
@@ -563,7 +563,11 @@ def test_packed_rows_native_sequence_ranges(lens):
         finally:
             backbone.PACKED_NATIVE = True
 
-    h1, dx1, g1 = run(True)
+    h1, dx1, g1 = run(True)              # cu_seqlens on the device: layout computed with tensor ops, no host read-back (backbone._forward_packed_device)
+    hh, dxh, gh = run(True, cu.cpu())    # cu_seqlens on the host (what the reference's collators build): the exact layout
+    assert torch.equal(h1, hh) and torch.equal(dx1, dxh)     # same positions, same kernels: the all-masked tail changes nothing
+    for n in gh:
+        assert (g1[n] - gh[n]).abs().max().item() <= 2e-2 * gh[n].abs().max().item() + 1e-4, n    # row sums over a longer (zero-padded) row
     h0, dx0, g0 = run(False)
     assert h1.shape == h0.shape and torch.isfinite(h1).all()
     assert (h1[0, total:] == 0).all() and (dx1[0, total:] == 0).all()

@@ -135,10 +135,13 @@ def _two_ranks(backend, one_device, shard=False):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_rccl_real_model_replicas_identical_and_equal_single_process_mean():
+@pytest.mark.parametrize("shard", [False, True])
+def test_two_ranks_rccl_real_model_replicas_identical_and_equal_single_process_mean(shard):
+    """Runs whenever the box has two GPUs (bf16 AVG buckets from the backward hooks, MAX NaN flag; shard=True: the --shard-optimizer
+    fall-back, reduce to slab owners + sharded AdamW + broadcast)."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the GPU test box has one; the same run over gloo on one GPU is the next test)")
-    _two_ranks("nccl", False)
+    _two_ranks("nccl", False, shard)
 
 
 @pytest.mark.timeout(600)
