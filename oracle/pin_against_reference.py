@@ -13,6 +13,8 @@ fixtures are OUTPUTS OF THE REFERENCE'S FUNCTIONS run here:
                        with RWKV7_BATCH_OP routed to the C oracle
   wkv7_scan.npz        C-oracle outputs on seeded inputs (regression vectors; the scan itself is pinned
                        through tmix_one_chain, and its backward through torch.autograd of the scan)
+  wkv7_scan_g1.npz     the same at SURVEY 8(c) G1's (2,512,12,64): three heads of bf16 oracle outputs + fp32 autograd
+                       gradients, fp64 digests of every tensor
 
 Usage:  python oracle/pin_against_reference.py [--write]
 """
@@ -311,6 +313,36 @@ def pin_scan_and_backward(write):
         for nm, t in zip(("dw", "dq", "dk", "dv", "da", "db"), g16):
             gold[f"{tag}.{nm}"] = t
     save("wkv7_scan.npz", write, **gold)
+    # SURVEY 8(c) G1's third shape, (B,T,H,N) = (2,512,12,64): the analytic backward of the C oracle against torch.autograd through the
+    # fp32 torch scan on EVERY head (a transcription error in the oracle's backward that only shows at depth -- 32 checkpoints of 16
+    # steps, the backward walking them in reverse -- would be caught here), and committed vectors: bf16 oracle outputs for three heads
+    # (heads are independent in WKV7) plus fp64 digests of every input and output tensor, inputs regenerated by make_wkv_inputs.
+    B, T, H, seed = 2, 512, 12, 2
+    w, q, k, v, a, b = make_wkv_inputs(B, T, H, seed)
+    y_c, s_c, sa_c = c_oracle.wkv7_fwd(w, q, k, v, a, b)
+    leaves = [t.clone().requires_grad_(True) for t in (w, q, k, v, a, b)]
+    y_t, S_t = R.wkv7_scan(leaves[1], leaves[0], leaves[2], leaves[3], leaves[4], leaves[5])
+    report(f"fwd y (B{B} T{T} H{H})", y_c, y_t.detach(), 1e-5)
+    report("fwd final state vs checkpoint", s_c[:, :, -1].transpose(-1, -2), S_t.detach(), 1e-5)
+    dy = torch.randn(B, T, H, 64, generator=torch.Generator().manual_seed(seed + 100))
+    y_t.backward(dy)
+    grads_c = c_oracle.wkv7_bwd(w, q, k, v, a, b, dy, s_c, sa_c)
+    for nm, gc, lf in zip(("dw", "dq", "dk", "dv", "da", "db"), grads_c, leaves):
+        report(f"bwd {nm} (B{B} T{T} H{H})", gc, lf.grad, 2e-4)
+    ins16 = [t.bfloat16() for t in (w, q, k, v, a, b)]
+    y16, s16, sa16 = c_oracle.wkv7_fwd(*ins16)
+    g16 = c_oracle.wkv7_bwd(*ins16, dy.bfloat16(), s16, sa16)
+    heads = [0, 7, 11]
+    dig = lambda t: torch.tensor([t.double().sum().item(), t.double().square().sum().item()], dtype=torch.float64)
+    g1 = {"shape": torch.tensor([B, T, H, 64, seed]), "heads": torch.tensor(heads)}
+    for nm, t in zip(("w", "q", "k", "v", "a", "b", "dy"), ins16 + [dy.bfloat16()]):
+        g1[f"digest.{nm}"] = dig(t)
+    for nm, t in zip(("y", "dw", "dq", "dk", "dv", "da", "db"), [y16] + list(g16)):
+        g1[f"digest.{nm}"] = dig(t)
+        g1[nm] = t[:, :, heads].contiguous()
+    for nm, lf in zip(("dw", "dq", "dk", "dv", "da", "db"), leaves):     # fp32 autograd gradients of the same heads (fp32 inputs)
+        g1[f"autograd.{nm}"] = lf.grad[:, :, heads].contiguous()
+    save("wkv7_scan_g1.npz", write, **g1)
 
 
 def main():

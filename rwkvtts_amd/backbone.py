@@ -202,6 +202,13 @@ FUSED_ADD_LN_MIX6 = False
 # kernels).  Measured in the same-box A/B (tools/ab_step.py): +0.15 ms per step -- the extra 64 MiB store eats the 30 us the one-pass
 # forward is ahead; off.
 FUSED_ADD_LN_MIX6_FWD = False
+def _row_align(n):
+    """Rows of the re-laid-out packed row: a multiple of the 32-step chunk, and of 256 once the row is long enough for the own GEMMs'
+    256-row tiles to matter (fused.cmix_eligible / linear_add need M % 256 == 0: a 33 248-position row fell off those paths and ran
+    50 % slower than the same tokens as [8, 4096])."""
+    return (n + 255) // 256 * 256 if n >= 2048 else (n + 31) // 32 * 32
+
+
 # cu_seqlens batches run on the chunked kernels' sequence flags (bf16); False: always unpack into a padded masked batch
 PACKED_NATIVE = True
 
@@ -519,7 +526,7 @@ class RWKV7Model(nn.Module):
                 x, delta, v_first = layer(x, delta, mask, v_first, st, seq_start)
         return fused.add_layer_norm(x, delta, self.norm)[1] if delta is not None else fused.layer_norm(x, self.norm)
 
-    def _forward_packed_device(self, x, cu_seqlens):
+    def _forward_packed_device(self, x, cu_seqlens):   # noqa: D401
         """The packed path for a `cu_seqlens` that lives on the DEVICE (as fla consumes it; train_spark_rwkv7speech.py:238-239): no
         host read-back.  The 32-aligned layout of `_forward_packed` is computed with tensor ops from the cumulative lengths; only its
         SIZE must be known on the host, and that is bounded by shapes alone: every non-empty sequence grows by at most 32 positions, so
@@ -529,7 +536,7 @@ class RWKV7Model(nn.Module):
         C = ops.CHUNK_T
         total, D = x.shape[1], x.shape[-1]
         nseq = cu_seqlens.numel() - 1
-        t_max = (total + C * nseq + C - 1) // C * C
+        t_max = _row_align(total + C * nseq)
         cu = cu_seqlens.to(torch.int64)
         lens = cu[1:] - cu[:-1]
         alen = torch.where(lens > 0, (torch.div(lens, C, rounding_mode="floor") + 1) * C, torch.zeros_like(lens))
@@ -575,7 +582,11 @@ class RWKV7Model(nn.Module):
                 if n > 0:
                     t_al += (n // C + 1) * C      # >= n + 1, multiple of 32
             dest = torch.cat([torch.arange(s_, s_ + n) for s_, n in zip(starts, lens) if n > 0]).to(x.device, non_blocking=True)
-            seq_off = torch.tensor([s_ // C for s_, n in zip(starts, lens) if n > 0] + [t_al // C], dtype=torch.int32)
+            seq_chunks = [s_ // C for s_, n in zip(starts, lens) if n > 0] + [t_al // C]
+            if _row_align(t_al) > t_al:      # an all-masked pseudo-sequence up to the next multiple of 256 rows (the fused GEMM paths' tile grid)
+                t_al = _row_align(t_al)
+                seq_chunks.append(t_al // C)
+            seq_off = torch.tensor(seq_chunks, dtype=torch.int32)
             src = x[0, cu[0]:cu[-1]]
             x_al = x.new_zeros(t_al, D).index_copy(0, dest, src)
             mask = x.new_zeros(t_al, 1).index_fill_(0, dest, 1.0)

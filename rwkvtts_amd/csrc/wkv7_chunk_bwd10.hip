@@ -583,8 +583,19 @@ int chunk_bwd_out10_bf16(int B, int T_, int H, const void *w, const void *q, con
     if (hipError_t e = lds_once.ensure(reinterpret_cast<const void *>(&wkv7c_bwd_out10_kernel), (int)Out10Smem::bytes); e != hipSuccess) return (int)e;
     (void)hipGetLastError();
     const int total = B * H * (T_ / kC);
+    // chunks per workgroup: one workgroup per CU is resident (159.5 KB of LDS), so the launch runs in ceil(grid / CUs) rounds of cpw chunks
+    // each.  More chunks per workgroup amortise its prologue (and the landing area is refilled one chunk ahead), but a grid just above a
+    // multiple of the CU count pays a whole extra round for a few workgroups: 16 640 chunks (a packed row of 33 280 positions, H = 16) at
+    // cpw = 64 are 260 workgroups = two rounds, 0.70 ms against 0.39 ms for 16 384 chunks.  Take the cpw with the fewest chunk-rounds
+    // (+2 chunks' worth of prologue per round), the larger one on a tie.
     int cpw = kOut10MinChunksPerWG;
-    while (cpw < kOut10MaxChunksPerWG && total / (2 * cpw) >= 256) cpw *= 2;
+    {
+        long best = -1;
+        for (int c = kOut10MinChunksPerWG; c <= kOut10MaxChunksPerWG; c *= 2) {
+            const long grid = (total + c - 1) / c, rounds = (grid + 255) / 256, cost = rounds * (c + 2);
+            if (best < 0 || cost <= best) best = cost, cpw = c;
+        }
+    }
     Out10Rows rows;
     rows.p[0] = w; rows.p[1] = q; rows.p[2] = k; rows.p[3] = a; rows.p[4] = b; rows.p[5] = v; rows.p[6] = dy; rows.p[7] = sa; rows.p[8] = z;
     hipLaunchKernelGGL(wkv7c_bwd_out10_kernel, dim3((total + cpw - 1) / cpw), dim3(512), Out10Smem::bytes, st, rows, T_, H, total, cpw,

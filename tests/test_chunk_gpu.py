@@ -147,6 +147,27 @@ def test_gradient_kernel_vs_round4_twin_lab(lab, B, T, H, seed):
             assert torch.equal(a, b), n
 
 
+def test_chunked_pair_against_committed_g1_vectors_2_512_12_64():
+    """SURVEY 8(c) G1 (2,512,12,64) from the COMMITTED vectors (tests/golden/wkv7_scan_g1.npz, written by
+    oracle/pin_against_reference.py [4] next to the check of the oracle's backward against torch.autograd on every head): y within
+    1 bf16 ulp, the six gradients within 2 ulp of the oracle's vectors on three heads, and every gradient tensor within bf16 noise of
+    the committed fp32 autograd gradients -- no oracle code runs in this test."""
+    from conftest import load_golden
+    from test_oracle_golden import _g1_inputs
+    g = load_golden("wkv7_scan_g1.npz")
+    ins, dy, heads = _g1_inputs(g)
+    d = [t.to(DEV) for t in ins]
+    y, tinv, sa, hs = ops.wkv7_chunk_forward(*d)
+    grads = ops.wkv7_chunk_backward(*d, dy.to(DEV), hs, sa, tinv)
+    torch.cuda.synchronize()
+    _assert_bf16_close(y[:, :, heads], g["y"], "y")
+    for n, gr in zip(NAMES, grads):
+        _assert_bf16_close(gr[:, :, heads], g[n], n, ulps=2.0)
+        ref = g[f"autograd.{n}"]
+        rel = ((gr[:, :, heads].float().cpu() - ref).norm() / ref.norm()).item()
+        assert rel < 2e-2, (n, rel)
+
+
 def test_full_size_config2_chunked_pair_vs_oracle_slices(c_oracle):
     """BASELINE.json configs[1] (B=8, T=4096, H=16, bf16) through the chunked MFMA forward + backward that the training
     step uses: (i) everything finite; (ii) three (batch, head) slices -- first, middle, last workgroups -- equal the

@@ -580,6 +580,8 @@ def test_packed_rows_native_sequence_ranges(lens):
     with torch.no_grad():
         o = 0
         for n in lens:
+            if n == 0:
+                continue
             alone = model(inputs_embeds=x0[:, o:o + n]).last_hidden_state.float()
             assert (h1[:, o:o + n] - alone).abs().max().item() < 3e-2 * alone.abs().max().item(), (o, n)
             o += n
