@@ -307,7 +307,9 @@ def cosy_forward(p, cfg: RefConfig, batch, speech_token_size, lsm_weight=0.0, le
 
 def xy_forward(p, cfg: RefConfig, input_ids, attention_mask, labels, num_channels, lsm_weight=0.0, wkv=None):
     """model/llm/xy_llm.py:203-240: sum of channel embeddings, 8 biased heads, sum of per-channel CE, no shift."""
-    x = sum(p[f"embs.{i}.weight"][input_ids[:, :, i]] for i in range(num_channels))
+    # nn.Embedding(..., padding_idx = vocab - 1) per channel (xy_llm.py:162,168): the pad row receives NO gradient
+    x = sum(F.embedding(input_ids[:, :, i], p[f"embs.{i}.weight"], padding_idx=p[f"embs.{i}.weight"].shape[0] - 1)
+            for i in range(num_channels))
     h, _ = backbone(p, cfg, x, attention_mask, None, wkv)
     logits = [_lin(h, p[f"heads.{i}.weight"]) + p[f"heads.{i}.bias"] for i in range(num_channels)]
     loss = None

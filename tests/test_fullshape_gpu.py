@@ -93,19 +93,23 @@ def test_spark_0p4b_full_depth_B2_L256_left_padded_logits_argmax_loss_and_gradie
     assert abs(out.loss.item() - loss_o.item()) < 1e-4
     # (ii) one bf16 training step: chunked MFMA WKV7 pair, fused stages, fused linear + CE
     m16 = m32.to(torch.bfloat16).train()
+    m16.dropout.p = 0.0       # spark_llm.py:123-124 drops 2 % of the input embeddings in training: off, the oracle has no RNG twin
     x16 = x.to(DEV, torch.bfloat16).requires_grad_(True)
     out16 = m16(inputs_embeds=x16, attention_mask=mask.to(DEV), labels=labels.to(DEV))
     out16.loss.backward()
     assert abs(out16.loss.item() - loss_o.item()) < 2e-2 * abs(loss_o.item())
     rels = _rel_errors(dict(m16.named_parameters()), pr, skip)
-    dx, dxo = x16.grad.float().cpu()[valid], xr.grad[valid]
+    # (the last padded position predicts the first valid label -- labels are shifted by one, spark_llm.py:154-156 -- so padded
+    # positions do carry gradient: compare all of them)
+    dx, dxo = x16.grad.float().cpu(), xr.grad
     rels["inputs_embeds"] = ((dx - dxo).norm() / dxo.norm()).item()
-    assert (x16.grad.float().cpu()[~valid] == 0).all(), "gradient on padded positions"
+    assert (dx[1, :PAD - 1] == 0).all() and (dxo[1, :PAD - 1] == 0).all(), "gradient on padded positions that predict nothing"
     median, top = _summary(rels)
     print(f"0.4B x 24 layers: fp32 logits max|d| {err:.2e}; bf16 gradient rel. L2 error median {median:.2e}, worst five {top} over {len(rels)} tensors")
     assert len(rels) > 24 * 30
-    assert median < 5e-2, f"median relative L2 gradient error {median:.3e}; worst five: {top}"
-    assert top[0][1] < 0.2, f"relative L2 gradient errors, worst five: {top}"
+    # measured: median 2.2e-2, worst 8.7e-2 (layer 21 a_lora bias); a wrong kernel gives O(1)
+    assert median < 4e-2, f"median relative L2 gradient error {median:.3e}; worst five: {top}"
+    assert top[0][1] < 0.15, f"relative L2 gradient errors, worst five: {top}"
 
 
 @pytest.mark.timeout(1500)
@@ -152,8 +156,9 @@ def test_xy_1p5b_full_depth_128_steps_logits_loss_and_gradients_vs_oracle():
     median, top = _summary(rels)
     print(f"1.5B XY x 24 layers: fp32 logits max|d| {max(errs):.2e}; bf16 gradient rel. L2 error median {median:.2e}, worst five {top} over {len(rels)} tensors")
     assert len(rels) > 24 * 30 + 16
-    assert median < 5e-2, f"median relative L2 gradient error {median:.3e}; worst five: {top}"
-    assert top[0][1] < 0.2, f"relative L2 gradient errors, worst five: {top}"
+    # measured: median 2.35e-2, worst 3.7e-2 (layer 23 x_w)
+    assert median < 4e-2, f"median relative L2 gradient error {median:.3e}; worst five: {top}"
+    assert top[0][1] < 0.08, f"relative L2 gradient errors, worst five: {top}"
 
 
 @pytest.mark.timeout(900)
@@ -190,6 +195,7 @@ def test_packed_row_non_aligned_lengths_loss_and_gradients_vs_oracle_per_sequenc
     loss_o = torch.nn.functional.cross_entropy(logits_o.view(total, -1), lab.view(-1), ignore_index=-100)
     loss_o.backward()
     m16 = model.to(DEV).to(torch.bfloat16).train()
+    m16.dropout.p = 0.0       # (the 2 % input dropout of spark_llm.py:123-124 has no twin in the oracle)
     for cu_t in (cu.to(DEV), cu):                         # device cu_seqlens (no host read-back) and host cu_seqlens (exact layout)
         m16.zero_grad(set_to_none=True)
         out = m16(inputs_embeds=x.to(DEV, torch.bfloat16), labels=labels.to(DEV), cu_seqlens=cu_t)
@@ -199,4 +205,4 @@ def test_packed_row_non_aligned_lengths_loss_and_gradients_vs_oracle_per_sequenc
         median, top = _summary(rels)
         print(f"packed {lens} ({'device' if cu_t.is_cuda else 'host'} cu_seqlens): bf16 gradient rel. L2 error median {median:.2e}, worst five {top}")
         assert len(rels) > NL * 30
-        assert median < 4e-2 and top[0][1] < 0.15, f"median {median:.3e}; worst five: {top}"
+        assert median < 3e-2 and top[0][1] < 0.06, f"median {median:.3e}; worst five: {top}"     # measured 1.4e-2 / 2.5e-2
