@@ -7,28 +7,33 @@
 // hipGraph that is 430 launches and 4.0 ms for a step whose HBM traffic (0.65 GB of weights + 0.4 GB of state) would take
 // 0.13 ms.
 //
-// The step is a chain of grid-wide dependencies, and a dependent launch costs ~4-5 us whatever it does (rounds 3-5: 7 phases per
-// layer, 0.93 ms per step, p10-p90 of every phase within +-3 % of its median: profiles/r05k_decode_gap_trace.txt).  Round 6 cuts the
-// chain from 7 to FIVE phases per layer (and 2 -> 1 for the tail) by removing the three kinds of phase that only existed to form rows:
-//   * the residual add is the EPILOGUE of the projection that produces the branch: the output projection and the channel-mix value
-//     projection run with the whole K range inside one workgroup (TW = 4 ... 16 columns per workgroup, no K split, no partial sums)
-//     and write x <- x + W y in place (fp32 residual stream);
-//   * LayerNorm and the token-shift lerp are the PROLOGUE of the sweep that consumes them: every workgroup of the r/k/v/low-rank sweep
-//     and of the channel-mix key sweep reads the 32 residual rows (128 KB from L2), forms the row statistics itself (8 lanes per row,
-//     the row's elements in registers, DPP sums -- no LDS, the same order in every workgroup, so all of them compute the same bits)
-//     and builds its own bf16 B operand [32][K range] in LDS, lerp of its segment included;
-//   * the new h rows (this step's token-shift state) go to a scratch row block and are copied into att_x_prev / ffn_x_prev by the
-//     NEXT phase's epilogue (the sweep itself still reads the old rows in every workgroup).
-//   A  sweep   [LN0 (layer 0)] LN1 + lerp -> r, k, v and the four low-rank down projections on MFMA -> fp32 partials [KS][32][N2]
-//   B  head    per (head, 2 sequences): up projections, decay, value residual, kk normalisation, the 64x64 fp32 state update in
-//              place, y, GroupNorm, bonus, gate -> bf16 rows                                                         (:493-505)
-//   C  o_proj  x <- x + yg W_o^T (full K, residual epilogue); att_x_prev <- h                                        (:506)
-//   D  key     LN2 + lerp -> key projection, relu(.)^2 -> bf16 rows                                                  (:546-548)
-//   E  value   x <- x + kact W_v^T (full K, residual epilogue); ffn_x_prev <- h                                      (:548-549)
-// and ONE tail launch: model norm as the prologue of the head projection -> fp32 logits.  5 L + 1 launches (121 for the 0.4B model,
-// 170 before).  The previous 7-phase form is kept as profiles/experiments_r06/decode_step_7phase.hip.txt.
+// Here the step is 7 grid-wide phases per layer:
+//   P0 row    x += previous channel-mix output (K-split partials); h = LayerNorm1(x); six token-shift lerps -> bf16 rows;
+//             att_x_prev <- h                                                      (rwkv_s2s_single_ffn.py:486-487)
+//   P1 gemv   r, k, v projections and the four low-rank down projections in one sweep: [32 x K] . W^T on MFMA, the batch
+//             rows are the 32-wide B operand, K split over waves and workgroups -> fp32 partials   (:489-491,497-500)
+//   P2 head   per (head, 2 sequences): low-rank up projections (+ tanh / sigmoid), decay, value residual, kk
+//             normalisation, the 64x64 fp32 state update in place, y, GroupNorm, bonus, gate -> bf16 rows   (:493-505)
+//   P3 gemv   output projection -> partials                                                                  (:506)
+//   P4 row    x += attention output; h = LayerNorm2(x); channel-mix lerp; ffn_x_prev <- h                    (:546-547)
+//   P5 gemv   key projection, relu(.)^2 -> bf16 rows (no K split: the activation needs the whole sum)        (:548)
+//   P6 gemv   value projection -> partials                                                                   (:548-549)
+// and a final row phase (last residual add + model norm) and the head projection -> fp32 logits.  GEMV phases write fp32
+// K-split partials [KS][32][N] that the consumer sums when it loads them, so no phase waits for a reduction.  A phase is a
+// chain of load latencies, so every phase requests whatever does not depend on the previous phase (state rows, parameter
+// vectors, up-projection rows) before it reads the activations, and sums partials with all loads of a round in flight.
+//
+// Two ways to run the phases (same bodies, bit-identical results, tests/test_decode_step_gpu.py):
+//   persistent = 0  one launch per phase (7 L + 2), one kernel per phase, each sized to its item count.  Measured at configs[4]
+//                   (0.4B, B = 32, tools/decode_phase_profile.py): row phases 3.1-3.6 us at best, GEMV phases 3.5-6.6 us, head
+//                   phase 7.4-8.5 us (round 2: 13 us -- see head_phase), 1.05 ms per step in the replayed graph = 30.5 k
+//                   tokens/s (module path: 4.0 ms, 8 k tokens/s).
+//   persistent = 1  ONE launch of 256 resident workgroups that meet at a device-scope barrier between phases.  Measured:
+//                   7.4 us per barrier -- 3.9 us for 256 arrivals + polling on one counter, 1.8 us for the agent-scope
+//                   release (L2 write-back) and 1.6 us for the acquire (invalidate); the XCDs' L2s are not coherent with
+//                   each other, so both are needed -- against ~1.5 us for a stream-ordered kernel boundary: 2.4 ms per step.
+//                   Kept as an option (and as a cross-check of the phase bodies); the Python host uses persistent = 0.
 #include "chunk_common.h"
-#include "launch_attr.h"
 
 namespace rwkv7 {
 
@@ -47,16 +52,16 @@ enum DecPtr {
 struct DecodeDesc {
     int B, D, H, L, F, V;
     int Rw, Ra, Rv, Rg;
-    int ks_qkv;
+    int ks_qkv, ks_o, ks_val;
     float ln_eps, gn_eps;
     const void *const *tbl;   // [L][DP_COUNT] device pointers
     const uint16_t *x_in;     // [B][D] bf16 embeddings of the current tokens
     const uint16_t *norm_w, *norm_b, *head_w, *head_b;
     float *logits;            // [B][V]
     // workspace
-    float *x, *vfirst, *p_qkv;      // residual stream fp32 [32][D]; layer 0's v; K-split partials of the sweep
-    uint16_t *yg, *kact, *h_att, *h_ffn;   // head-phase output rows, relu(key)^2 rows, this step's h rows (att / ffn token shift)
-    unsigned *bar;            // [1] stays 0 (the step has no in-kernel barrier any more; the host still reads the word)
+    float *xa, *xb, *vfirst, *p_qkv, *p_att, *p_val;
+    uint16_t *mixed, *yg, *kx, *kact, *hfin;
+    unsigned *bar;            // [0] arrival counter, [1] timeout flag
 };
 
 #ifdef WKV7C_TIMING
@@ -77,10 +82,10 @@ struct DecodeDesc {
 namespace {
 
 constexpr int kDecThreads = 256;
-constexpr int kProThreads = 512;             // phases with a row prologue (A, D, tail)
 constexpr int kRows = 32;                  // row capacity of every scratch matrix (the MFMA B operand is 32 wide)
-constexpr int kMaxD = 2048;                // hidden size covered by the register-resident row prologue (64 float4 per thread)
+constexpr int kMaxE = 16;                  // D <= 4096: elements per thread in the row phases
 constexpr int kMaxR = 512;                 // Rw + Ra + Rv + Rg
+constexpr unsigned kSpinLimit = 1u << 21;  // ~0.1 s: a barrier that is not met by then raises the flag instead of hanging the GPU
 
 constexpr int kHidLD = kMaxR + 8;          // bf16 hidden rows, padded
 constexpr int kUpFrags = 16;               // 16-wide k-steps of one up-projection job (a rank of 256)
@@ -92,20 +97,10 @@ struct HeadSm {
     float y[2][64];
     float dot[2];
 };
-union DecSmem {   // the head phase's static LDS
-    HeadSm h;
-};
-// LDS of a GEMV phase (dynamic): the waves' partial accumulators; with a row prologue also the bf16 B operand of the current K chunk
-// and the chunk's LayerNorm / lerp vectors
-constexpr int kChunk = 1024;               // K columns of one prologue chunk
-constexpr int kBsLD = kChunk + 8;
-struct GemvSm {
+union DecSmem {
     float part[3][64][17];
-};
-struct ProSm {
-    float part[7][64][17];
-    __attribute__((aligned(16))) uint16_t par[3][kChunk];   // lnw, lnb, mix of the chunk (bf16)
-    __attribute__((aligned(16))) uint16_t Bs[kRows][kBsLD];
+    HeadSm h;
+    float red[32];
 };
 
 // Pointers read from the layer table are generic: loads through them are flat_load, which counts on BOTH memory counters and
@@ -115,7 +110,6 @@ typedef const uint16_t __attribute__((address_space(1))) *gu16;
 typedef float __attribute__((address_space(1))) *gf32;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 typedef uint16_t __attribute__((address_space(1))) *gu16m;   // written through (the token-shift rows)
 #define G_U16M(p) ((gu16m)(p))
 #define G_U16(p) ((gu16)(p))
@@ -125,6 +119,15 @@ __device__ __forceinline__ float wave_sum(float x) {
     x += __shfl_xor(x, 16);
     x += __shfl_xor(x, 32);
     return x;
+}
+
+__device__ __forceinline__ float block_sum256(float v, float *red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // red may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -139,98 +142,203 @@ __device__ __forceinline__ int fresh_s(int x) {
 // error below 6e-8 in the decay exponent w (libm's log1pf is ~40 instructions with branches on the phase's critical path)
 __device__ __forceinline__ float softplus_d(float u) { return u > 20.f ? u : __logf(1.f + __expf(u)); }
 
+// One agent-scope release (L2 write-back) on arrival, a relaxed spin, one agent-scope acquire (cache invalidate) on exit: an
+// acquire inside the spin loop would invalidate this XCD's L2 under the workgroups that are still computing.
+// mode (debug): 1, 2 = full barrier; 3 = no fences; 4 = release only; 5 = acquire only
+__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned &target, unsigned nwg, int mode = 1) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        target += nwg;
+        if (mode <= 2 || mode == 4) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0u) {
+                if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (spins > kSpinLimit) {
+                    __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        if (mode <= 2 || mode == 5) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ float4 bf4(uint2 r) {
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
                        __uint_as_float(r.y & 0xffff0000u));
 }
-__device__ __forceinline__ float4 bf4v(uint2v r) { return bf4(make_uint2(r.x, r.y)); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// Every thread owns float4 column groups g = tid + 256 i, i < NG (NG = ceil(D / 1024): the host picks the instantiation).  All
+// loads of the row (residual, the partial sums eight at a time, norm and lerp parameters, the shifted row) are unconditional --
+// lanes beyond the row repeat its last group, partial sums beyond `nparts` repeat the last one and are dropped -- and are issued
+// before the first reduction: the phase pays one memory latency.  (Round 2's form guarded each load by `g < D / 4` and
+// `p < nparts`: every guarded load is waited for behind its issue, and the parameter rows came through generic pointers, i.e.
+// flat_load -- four serialised latencies per phase.)
+template <int NMIX, int NG>
+__device__ __forceinline__ void row_phase(const DecodeDesc &d, int b, float *red, const float *x_old, const float *parts, int nparts,
+                                          const uint16_t *x_in, gu16 ln0w, gu16 ln0b, float *x_out, gu16 lnw, gu16 lnb, gu16m x_prev,
+                                          const gu16 *mixp, uint16_t *out) {
+// the NG instantiations (per-phase kernels: the model's; persistent kernel: the widest) must round alike: no reassociation of the
+// row sums under -ffast-math, no contraction left to the optimiser (it differs between the instantiations)
+#pragma clang fp reassociate(off) contract(off)
+    typedef const uint2v __attribute__((address_space(1))) *gq;
+    const int D = d.D, tid = threadIdx.x, D4 = D >> 2;
+    const float invD = 1.f / (float)D;
+    const long rb = (long)b * D;
+    float4 x[NG];
+    uint2v wln[NG], bln[NG], xp[NG], mx[NMIX > 0 ? NMIX : 1][NG];
+    bool live[NG];
+    int col[NG];
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+        const int g = tid + kDecThreads * i;
+        live[i] = g < D4;
+        col[i] = 4 * min(g, D4 - 1);
+        wln[i] = *(gq)(lnw + col[i]);
+        bln[i] = *(gq)(lnb + col[i]);
+        if (NMIX > 0) {
+            xp[i] = *(gq)(x_prev + rb + col[i]);
+#pragma unroll
+            for (int j = 0; j < NMIX; j++) mx[j][i] = *(gq)(mixp[j] + col[i]);
+        }
+    }
+    float s = 0.f;
+    if (x_in) {   // layer 0: the embeddings (scalar branch)
+#pragma unroll
+        for (int i = 0; i < NG; i++) x[i] = bf4(*reinterpret_cast<const uint2 *>(x_in + rb + col[i]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < NG; i++) x[i] = *reinterpret_cast<const float4 *>(x_old + rb + col[i]);
+        for (int p0 = 0; p0 < nparts; p0 += 8) {
+            float4 t[NG][8];
+#pragma unroll
+            for (int i = 0; i < NG; i++)
+#pragma unroll
+                for (int p = 0; p < 8; p++)
+                    t[i][p] = *reinterpret_cast<const float4 *>(parts + ((long)min(p0 + p, nparts - 1) * kRows + b) * D + col[i]);
+#pragma unroll
+            for (int i = 0; i < NG; i++)
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    const float m = p0 + p < nparts ? 1.f : 0.f;
+                    x[i].x = fmaf(t[i][p].x, m, x[i].x); x[i].y = fmaf(t[i][p].y, m, x[i].y);
+                    x[i].z = fmaf(t[i][p].z, m, x[i].z); x[i].w = fmaf(t[i][p].w, m, x[i].w);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NG; i++) s += live[i] ? (x[i].x + x[i].y) + (x[i].z + x[i].w) : 0.f;
+    auto sqdev = [&](float mean) {
+#pragma clang fp reassociate(off) contract(off)
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, e = x[i].w - mean;
+            q += live[i] ? (a * a + bb * bb) + (c * c + e * e) : 0.f;
+        }
+        return q;
+    };
+    if (x_in) {  // pre_norm of the first block (rwkv_s2s_single_ffn.py:253-254); its output is a bf16 tensor
+        uint2v w0[NG], b0[NG];
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            w0[i] = *(gq)(ln0w + col[i]);
+            b0[i] = *(gq)(ln0b + col[i]);
+        }
+        const float mean = block_sum256(s, red) * invD;
+        const float rstd = rsqrtf(block_sum256(sqdev(mean), red) * invD + d.ln_eps);
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const float4 w = bf4(make_uint2(w0[i].x, w0[i].y)), bi = bf4(make_uint2(b0[i].x, b0[i].y));
+            const uint32_t lo = cvt_pk((x[i].x - mean) * rstd * w.x + bi.x, (x[i].y - mean) * rstd * w.y + bi.y);
+            const uint32_t hi = cvt_pk((x[i].z - mean) * rstd * w.z + bi.z, (x[i].w - mean) * rstd * w.w + bi.w);
+            x[i] = bf4(make_uint2(lo, hi));
+            s += live[i] ? (x[i].x + x[i].y) + (x[i].z + x[i].w) : 0.f;
+        }
+    }
+    const float mean = block_sum256(s, red) * invD;
+    const float rstd = rsqrtf(block_sum256(sqdev(mean), red) * invD + d.ln_eps);
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+        if (live[i]) {
+            const int c = col[i];
+            if (x_out) *reinterpret_cast<float4 *>(x_out + rb + c) = x[i];
+            const float4 w = bf4(make_uint2(wln[i].x, wln[i].y)), bi = bf4(make_uint2(bln[i].x, bln[i].y));
+            const uint2 hb = make_uint2(cvt_pk((x[i].x - mean) * rstd * w.x + bi.x, (x[i].y - mean) * rstd * w.y + bi.y),
+                                        cvt_pk((x[i].z - mean) * rstd * w.z + bi.z, (x[i].w - mean) * rstd * w.w + bi.w));
+            if (NMIX == 0) {
+                *reinterpret_cast<uint2 *>(out + rb + c) = hb;
+            } else {
+                const float4 h = bf4(hb), pv = bf4(make_uint2(xp[i].x, xp[i].y));
+                const float4 xx = make_float4(pv.x - h.x, pv.y - h.y, pv.z - h.z, pv.w - h.w);
+#pragma unroll
+                for (int j = 0; j < NMIX; j++) {
+                    const float4 m = bf4(make_uint2(mx[j][i].x, mx[j][i].y));
+                    *reinterpret_cast<uint2 *>(out + ((long)j * kRows + b) * D + c) =
+                        make_uint2(cvt_pk(fmaf(xx.x, m.x, h.x), fmaf(xx.y, m.y, h.y)), cvt_pk(fmaf(xx.z, m.z, h.z), fmaf(xx.w, m.w, h.w)));
+                }
+                uint2v hv;
+                hv.x = hb.x; hv.y = hb.y;
+                *(uint2v __attribute__((address_space(1))) *)(x_prev + rb + c) = hv;
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
-// GEMV phases: out[n][col] = sum_k X[n][k] W[col][k]; one item = TW columns x one K split.
+// GEMV phases: out[ks][n][col] = sum_{k in split ks} X[n][k] W[col][k]; one item = 32 columns x one K split.
 // D[m][n]: m = output column inside the tile (A operand = W rows), n = sequence (B operand = X rows).
 // ---------------------------------------------------------------------------------------------------------------------
 struct GemvSeg {
     gu16 W;              // [ncols][K]; global address space: through a generic pointer the weight rows are flat_load, which the
                          // compiler drains with vmcnt(0) every two k-steps (four serialised latencies per sweep, round 2)
-    const uint16_t *X;   // PRO = 0: bf16 [32][K] B operand rows in global memory
-    gu16 mix;            // PRO = 1: the segment's token-shift lerp vector [K]
-    int ntiles;          // TW-column tiles (the last one may be partial: ncols)
+    const uint16_t *X;   // bf16 [32][K]
+    int ntiles;          // 32-column tiles (the last one may be partial: ncols)
     int ncols;
 };
 
-// the row prologue's inputs (PRO >= 1)
-struct RowPro {
-    const float *x;            // residual stream fp32 [32][D] (layer > 0, tail)
-    const uint16_t *x_in;      // layer 0: bf16 [B][D] embeddings, else nullptr
-    gu16 ln0w, ln0b;           // layer 0: pre_norm (rwkv_s2s_single_ffn.py:253-254; its output is a bf16 tensor = the residual stream)
-    float *x_out;              // layer 0: the residual stream is born here (written by the items of column tile 0)
-    gu16 lnw, lnb;             // the LayerNorm in front of the sweep
-    gu16 prev;                 // PRO = 1: previous step's h rows bf16 [B][D] (token shift, :486-487 / :546-547)
-    uint16_t *hnext;           // PRO = 1: this step's h rows (scratch [B][D]); copied over `prev` by the next phase
-};
-// the epilogue's row copy: dst[B*D] <- src[B*D] (bf16), split over the launch's workgroups
-struct RowCopy {
-    gu16m dst;
-    const uint16_t *src;
-};
-
-template <int KSTEPS>
-__device__ __forceinline__ void load_a(bf16x8 (&a)[KSTEPS], gu16 wp) {
-#pragma unroll
-    for (int i = 0; i < KSTEPS; i++) a[i] = *(const bf16x8 __attribute__((address_space(1))) *)(wp + 16 * i);
-}
+#ifndef DEC_NT_WEIGHTS
+#define DEC_NT_WEIGHTS 0
+#endif
 template <int KSTEPS>
 __device__ __forceinline__ void gemv_steps(f32x16 &acc, gu16 wp, const uint16_t *xp) {
     bf16x8 a[KSTEPS], b[KSTEPS];
-    load_a<KSTEPS>(a, wp);
 #pragma unroll
-    for (int i = 0; i < KSTEPS; i++) b[i] = *reinterpret_cast<const bf16x8 *>(xp + 16 * i);
+    for (int i = 0; i < KSTEPS; i++) {
+#if DEC_NT_WEIGHTS
+        // weight rows are read once per step by one workgroup (0.65 GB per step, more than L2 + MALL hold): non-temporal
+        a[i] = __builtin_nontemporal_load((const bf16x8 __attribute__((address_space(1))) *)(wp + 16 * i));
+#else
+        a[i] = *(const bf16x8 __attribute__((address_space(1))) *)(wp + 16 * i);
+#endif
+        b[i] = *reinterpret_cast<const bf16x8 *>(xp + 16 * i);
+    }
     // all loads of the round are issued before the first MFMA: left alone, the scheduler sinks each pair of loads to its MFMA
     // (shorter live ranges) and the sweep walks through its K range with 2.5 k-steps in flight
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
 }
-// the same with the weight fragments already in registers and the B operand in LDS
-template <int KSTEPS>
-__device__ __forceinline__ void mfma_lds(f32x16 &acc, const bf16x8 (&a)[KSTEPS], const uint16_t *bp, int n) {
-    bf16x8 b[KSTEPS];
-#pragma unroll
-    for (int i = 0; i < KSTEPS; i++) b[i] = *reinterpret_cast<const bf16x8 *>(bp + 16 * (i < n ? i : 0));
-#pragma unroll
-    for (int i = 0; i < KSTEPS; i++)
-        if (i < n) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
-}
 
-// PRO     0: B operand rows from global memory (segs[].X).  1: LayerNorm + token-shift lerp of the residual rows as the prologue.
-//         2: LayerNorm only (the tail: model norm in front of the head projection).
-// OUTMODE 0: fp32 out[ks][n][col] (+ bias): K-split partials / logits.  1: KS = 1, out is bf16 [n][col] = relu(.)^2 (the channel-mix
-//         key).  2: KS = 1, out is the fp32 residual stream, out[n][col] += sum (in place: a workgroup owns its columns).
-// TW:     columns per tile.  16 / 8 / 4: the MFMA's 32 A rows repeat the tile's weight rows (the upper results are ignored) -- for the
-//         sweeps that cannot split K, where 32-column tiles would leave most of the CUs idle.
-// NQ:     float4 column groups per thread in the row prologue (16: D <= 1024, 32: D <= 2048; the host picks the instantiation).
-//         Thread t of 512 owns row r = t >> 4 and the groups c = (t & 15) + 16 i: sixteen lanes per row, the row sums are four DPP steps.
-template <int PRO, int OUTMODE, int NSEG, int TW, int NQ, bool LAYER0 = false>
-__device__ __forceinline__ void gemv_phase(const DecodeDesc &d, void *smem_, const GemvSeg (&segs)[NSEG], const RowPro &rp, int K, int KS,
-                                           void *out_, int ldo, const uint16_t *bias, const RowCopy &cp) {
-    constexpr bool layer0 = LAYER0;
-    using Sm = typename std::conditional<PRO != 0, ProSm, GemvSm>::type;
-    Sm &sm = *reinterpret_cast<Sm *>(smem_);
+// OUTMODE 0: fp32 partials out[ks][n][col] (+ bias);  1: KS = 1 and out is bf16 [n][col] = relu(.)^2 (the channel-mix key)
+// TW: columns per tile.  16: the MFMA's 32 A rows hold each of the 16 weight rows twice (the upper half of the result is
+// ignored) -- for the sweep that cannot split K (OUTMODE 1: F / 32 = 128 items would leave half of the CUs idle).
+template <int OUTMODE, int NSEG, int TW = 32>
+__device__ __forceinline__ void gemv_phase(const DecodeDesc &d, DecSmem &sm, const GemvSeg (&segs)[NSEG], int K, int KS, void *out_,
+                                           int ldo, const uint16_t *bias) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int ntiles = 0;
 #pragma unroll
     for (int s = 0; s < NSEG; s++) ntiles += segs[s].ntiles;
     const int nitems = ntiles * KS;
-    const int krange = K / KS;
+    const int kw = K / KS / 4;  // K range of one wave (multiple of 16)
     const int nrow = min(lane & 31, d.B - 1);
-    // the epilogue's row copy (this step's h rows -> the token-shift state): a few hundred bytes per workgroup, requested first
-    if (cp.src) {
-        const int n8 = d.B * d.D / 8;   // 16-byte pieces
-        for (int i = blockIdx.x * kDecThreads + tid; i < n8; i += gridDim.x * kDecThreads) {
-            const u32x4v v = *reinterpret_cast<const u32x4v *>(cp.src + 8 * (long)i);
-            *(u32x4v __attribute__((address_space(1))) *)(cp.dst + 8 * (long)i) = v;
-        }
-    }
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int tile = item / KS, ks = item - tile * KS;
         // segment of this tile (unrolled with constant indices: the table stays in registers)
@@ -243,7 +351,6 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, void *smem_, con
             const bool here = tile >= first_tile;   // segments are in ascending tile order: the last match wins
             sg.W = here ? segs[s].W : sg.W;
             sg.X = here ? segs[s].X : sg.X;
-            sg.mix = here ? segs[s].mix : sg.mix;
             sg.ntiles = here ? segs[s].ntiles : sg.ntiles;
             sg.ncols = here ? segs[s].ncols : sg.ncols;
             t = here ? tile - first_tile : t;
@@ -251,174 +358,33 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, void *smem_, con
         }
         const int c0 = t * TW;                                  // first column of the tile inside its segment
         const int mrow = min(c0 + (lane & (TW - 1)), sg.ncols - 1);
-        const int kb = ks * krange;                             // first K column of the item
+        const int kbeg = ks * (K / KS) + wave * kw + (lane >> 5) * 8;
+        gu16 wp = sg.W + (long)mrow * K + kbeg;
+        const uint16_t *xp = sg.X + (long)nrow * K + kbeg;
         f32x16 acc = zero16();
-        if constexpr (PRO == 0) {
-            const int kw = krange / 4;  // K range of one wave (multiple of 16)
-            const int kbeg = kb + wave * kw + (lane >> 5) * 8;
-            gu16 wp = sg.W + (long)mrow * K + kbeg;
-            const uint16_t *xp = sg.X + (long)nrow * K + kbeg;
-            int k = 0;
-            for (; k + 256 <= kw; k += 256) gemv_steps<16>(acc, wp + k, xp + k);   // un-split sweeps: one round of loads per 256 k
-            for (; k + 128 <= kw; k += 128) gemv_steps<8>(acc, wp + k, xp + k);
-            for (; k + 32 <= kw; k += 32) gemv_steps<2>(acc, wp + k, xp + k);
-            for (; k + 16 <= kw; k += 16) gemv_steps<1>(acc, wp + k, xp + k);
-            __syncthreads();  // part[] of the previous item has been consumed
-        } else {
-// every workgroup must round alike (they all recompute the same rows), and like the instantiation of the other width: no
-// reassociation of the row sums under -ffast-math, no contraction left to the optimiser
-#pragma clang fp reassociate(off) contract(off)
-            // 512 threads: 16 lanes per row (thread t: row t >> 4, float4 groups (t & 15) + 16 i), eight waves that split the chunk's K
-            // range.  (With 256 threads the row's 128 values per thread, the previous-h values and the prefetched weight fragments are
-            // 256 VALU registers before any temporary: 250-570 spilled registers per phase.)
-            typedef const uint2v __attribute__((address_space(1))) *gq;
-            constexpr int NW = kProThreads / 64;
-            const int D = d.D, D4 = D >> 2;
-            const float invD = 1.f / (float)D;
-            const int r = tid >> 4, j = tid & 15;
-            const int rr = min(r, d.B - 1);
-            const long rb = (long)rr * D;
-            const int nlive = D4 >> 4;                          // groups per thread that exist (D % 64 == 0): a SCALAR bound, i < nlive
-            const bool first_tile_item = tile == 0;             // the items of column tile 0 cover every K column once: they publish rows
-            // ---- loads, all unconditional (clamped), in the order of use: the first chunk's weight fragments, the rows, the chunk's vectors
-            const int len0 = min(krange, kChunk), kw0 = len0 / NW, ns0 = kw0 / 16;   // chunk 0: columns, per wave, k-steps per wave (<= 8)
-            bf16x8 a0[8];
-            {
-                gu16 wp = sg.W + (long)mrow * K + kb + wave * kw0 + (lane >> 5) * 8;
-#pragma unroll
-                for (int i = 0; i < 8; i++) a0[i] = *(const bf16x8 __attribute__((address_space(1))) *)(wp + 16 * (i < ns0 ? i : 0));
-            }
-            float4 x[NQ];
-            auto colof = [&](int i) { return 4 * j + 64 * min(i, nlive - 1); };
-            if (layer0) {
-#pragma unroll
-                for (int i = 0; i < NQ; i++) x[i] = bf4(*reinterpret_cast<const uint2 *>(rp.x_in + rb + colof(i)));
-            } else {
-#pragma unroll
-                for (int i = 0; i < NQ; i++) x[i] = *reinterpret_cast<const float4 *>(rp.x + rb + colof(i));
-            }
-            uint2v pv[16];             // PRO = 1: the previous h of this thread's groups inside the current chunk (slot i & 15)
-            auto load_prev = [&](int kc, int len) {
-                if (PRO == 1) {
-                    const int i0 = kc >> 6, i1 = (kc + len) >> 6;   // the chunk's groups: i0 <= i < i1 (<= 16 of them)
-#pragma unroll
-                    for (int i = 0; i < NQ; i++) {
-                        const uint2v v = *(gq)(rp.prev + rb + colof(i));
-                        if (NQ <= 16) pv[i & 15] = v;
-                        else pv[i & 15] = (i >= i0 && i < i1) ? v : pv[i & 15];
-                    }
-                }
-            };
-            auto load_par = [&](int kc, int len, uint2v (&pp)[3]) {
-                const int c = kc + min(4 * tid, len - 4);
-                pp[0] = *(gq)(rp.lnw + c);
-                pp[1] = *(gq)(rp.lnb + c);
-                pp[2] = PRO == 1 ? *(gq)(sg.mix + c) : pp[1];
-            };
-            if (NQ > 16) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) pv[i] = uint2v{0u, 0u};
-            }
-            load_prev(kb, len0);
-            uint2v par0[3];
-            load_par(kb, len0, par0);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- row statistics: 16 lanes per row, the row in registers, two passes (mean, then squared deviations), DPP sums
-            auto stats = [&](float &mean, float &rstd, float eps) {
-#pragma clang fp reassociate(off) contract(off)
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < NQ; i++) s += i < nlive ? (x[i].x + x[i].y) + (x[i].z + x[i].w) : 0.f;
-                mean = sum16(s) * invD;
-                float q = 0.f;
-#pragma unroll
-                for (int i = 0; i < NQ; i++) {
-                    const float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, e = x[i].w - mean;
-                    q += i < nlive ? (a * a + bb * bb) + (c * c + e * e) : 0.f;
-                }
-                rstd = rsqrtf(sum16(q) * invD + eps);
-            };
-            float mean, rstd;
-            if (layer0) {   // pre_norm of the first block: its bf16 output IS the residual stream
-                float m0, r0;
-                stats(m0, r0, d.ln_eps);
-#pragma unroll
-                for (int i = 0; i < NQ; i++) {   // (the pre_norm vectors are fetched here, behind the statistics: one layer of L pays this latency)
-                    const float4 w = bf4v(*(gq)(rp.ln0w + colof(i))), bi = bf4v(*(gq)(rp.ln0b + colof(i)));
-                    const uint32_t lo = cvt_pk((x[i].x - m0) * r0 * w.x + bi.x, (x[i].y - m0) * r0 * w.y + bi.y);
-                    const uint32_t hi = cvt_pk((x[i].z - m0) * r0 * w.z + bi.z, (x[i].w - m0) * r0 * w.w + bi.w);
-                    x[i] = bf4(make_uint2(lo, hi));
-                }
-            }
-            stats(mean, rstd, d.ln_eps);
-            // ---- chunks of <= 1024 K columns: vectors -> LDS, B operand rows -> LDS, MFMA sweep.  D <= 1024 (NQ = 16): always ONE chunk,
-            // and the loop with its second set of loads is not compiled.
-            constexpr bool SINGLE = NQ <= 16;
-            auto build_b = [&](int kc, int len, const uint2v (&par)[3]) {
-                const int i0 = kc >> 6, i1 = min((kc + len) >> 6, nlive);
-                __syncthreads();   // the previous chunk's / item's LDS has been consumed
-                if (4 * tid < len) {
-#pragma unroll
-                    for (int a = 0; a < 3; a++) *reinterpret_cast<uint2v *>(&sm.par[a][4 * tid]) = par[a];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < NQ; i++) {
-                    if (i >= i0 && i < i1) {    // scalar: the chunk's groups
-                        const int cg = 4 * j + 64 * i, c = cg - kc;
-                        const float4 w = bf4(*reinterpret_cast<const uint2 *>(&sm.par[0][c])), bi = bf4(*reinterpret_cast<const uint2 *>(&sm.par[1][c]));
-                        const uint2 hb = make_uint2(cvt_pk((x[i].x - mean) * rstd * w.x + bi.x, (x[i].y - mean) * rstd * w.y + bi.y),
-                                                    cvt_pk((x[i].z - mean) * rstd * w.z + bi.z, (x[i].w - mean) * rstd * w.w + bi.w));
-                        uint2 ob = hb;
-                        if (PRO == 1) {
-                            const float4 h = bf4(hb), pvv = bf4v(pv[i & 15]), m = bf4(*reinterpret_cast<const uint2 *>(&sm.par[2][c]));
-                            const float4 xx = make_float4(pvv.x - h.x, pvv.y - h.y, pvv.z - h.z, pvv.w - h.w);
-                            ob = make_uint2(cvt_pk(fmaf(xx.x, m.x, h.x), fmaf(xx.y, m.y, h.y)), cvt_pk(fmaf(xx.z, m.z, h.z), fmaf(xx.w, m.w, h.w)));
-                        }
-                        *reinterpret_cast<uint2 *>(&sm.Bs[r][c]) = ob;
-                        if (first_tile_item && r < d.B) {
-                            if (PRO == 1) *reinterpret_cast<uint2 *>(rp.hnext + (long)r * D + cg) = hb;
-                            if (layer0) *reinterpret_cast<float4 *>(rp.x_out + (long)r * D + cg) = x[i];
-                        }
-                    }
-                }
-                __syncthreads();
-            };
-            build_b(kb, len0, par0);
-            mfma_lds<8>(acc, a0, &sm.Bs[lane & 31][wave * kw0 + (lane >> 5) * 8], ns0);
-            if constexpr (!SINGLE) {
-                for (int kc = kb + kChunk; kc < kb + krange; kc += kChunk) {
-                    const int len = min(kb + krange - kc, kChunk), kw = len / NW, ns = kw / 16;
-                    uint2v par[3];
-                    load_prev(kc, len);
-                    load_par(kc, len, par);
-                    bf16x8 a1[8];
-                    gu16 wp = sg.W + (long)mrow * K + kc + wave * kw + (lane >> 5) * 8;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) a1[i] = *(const bf16x8 __attribute__((address_space(1))) *)(wp + 16 * (i < ns ? i : 0));
-                    build_b(kc, len, par);
-                    mfma_lds<8>(acc, a1, &sm.Bs[lane & 31][wave * kw + (lane >> 5) * 8], ns);
-                }
-            }
-        }
+        int k = 0;
+        for (; k + 256 <= kw; k += 256) gemv_steps<16>(acc, wp + k, xp + k);   // un-split sweeps (key, head): one round of loads
+        for (; k + 128 <= kw; k += 128) gemv_steps<8>(acc, wp + k, xp + k);
+        for (; k + 32 <= kw; k += 32) gemv_steps<2>(acc, wp + k, xp + k);
+        for (; k + 16 <= kw; k += 16) gemv_steps<1>(acc, wp + k, xp + k);
+        __syncthreads();  // part[] of the previous item has been consumed
         if (wave > 0) {
 #pragma unroll
-            for (int r_ = 0; r_ < 16; r_++) sm.part[wave - 1][lane][r_] = acc[r_];
+            for (int r = 0; r < 16; r++) sm.part[wave - 1][lane][r] = acc[r];
         }
         __syncthreads();
-        if (wave == 0 && (TW >= 8 || lane < 32)) {
+        if (wave == 0) {
             const int n = lane & 31;
             float *op = (float *)out_ + ((long)ks * kRows + n) * ldo + col_base + c0;
             uint16_t *ob = (uint16_t *)out_ + (long)n * ldo + col_base + c0;
             const bool vec = (ldo & 3) == 0 && ((col_base + c0) & 3) == 0;
 #pragma unroll
-            for (int j_ = 0; j_ < (TW >= 8 ? TW / 8 : 1); j_++) {
-                const int c = 8 * j_ + 4 * (lane >> 5);  // 4 consecutive columns of the tile
+            for (int j = 0; j < TW / 8; j++) {
+                const int c = 8 * j + 4 * (lane >> 5);  // 4 consecutive columns of the tile
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    v[i] = acc[4 * j_ + i] + sm.part[0][lane][4 * j_ + i] + sm.part[1][lane][4 * j_ + i] + sm.part[2][lane][4 * j_ + i];
-                    if (PRO != 0) v[i] += (sm.part[3][lane][4 * j_ + i] + sm.part[4][lane][4 * j_ + i]) + (sm.part[5][lane][4 * j_ + i] + sm.part[6][lane][4 * j_ + i]);
+                    v[i] = acc[4 * j + i] + sm.part[0][lane][4 * j + i] + sm.part[1][lane][4 * j + i] + sm.part[2][lane][4 * j + i];
                     if (bias && c0 + c + i < sg.ncols) v[i] += bf2f(bias[col_base + c0 + c + i]);
                 }
                 if (OUTMODE == 1) {
@@ -429,10 +395,6 @@ __device__ __forceinline__ void gemv_phase(const DecodeDesc &d, void *smem_, con
                     }
                     if (n < d.B) *reinterpret_cast<uint2 *>(ob + c) = make_uint2(cvt_pk(v[0], v[1]), cvt_pk(v[2], v[3]));  // F % 64 == 0
                 } else if (n < d.B) {
-                    if (OUTMODE == 2) {   // residual epilogue: D % 64 == 0, so the four columns are always inside and 16-byte aligned
-                        const float4 xo = *reinterpret_cast<const float4 *>(op + c);
-                        v[0] += xo.x; v[1] += xo.y; v[2] += xo.z; v[3] += xo.w;
-                    }
                     if (vec && c0 + c + 3 < sg.ncols) {   // write-through, like the state rows: read next by workgroups on other XCDs
                         f32x4v t4;
                         t4.x = v[0]; t4.y = v[1]; t4.z = v[2]; t4.w = v[3];
@@ -693,41 +655,40 @@ __device__ __forceinline__ void head_phase(const DecodeDesc &d, DecSmem &smu, in
     }
 }
 
-// the layer's pointers: a row of the device table ...
+// the layer's pointers: a row of the device table (persistent kernel) ...
 struct TblRow {
     const void *const *base;
     __device__ __forceinline__ const void *operator[](int i) const { return base[i]; }
 };
-// ... or the phase's own pointers as kernel arguments: no dependent table load between the kernel arguments and the first data
-// (0.3-0.4 us per launch, measured in round 3).
+// ... or, in the one-kernel-per-phase mode, the phase's own pointers as kernel arguments: no dependent table load between the
+// kernel arguments and the first data.  (Round 2 measured all 38 pointers as arguments of the all-phases kernel SLOWER by 0.5-1.5 us
+// per phase -- 300 bytes of kernarg and 76 more live SGPRs in a kernel that already spilled them; a phase needs 1 to 13.)
 __host__ __device__ constexpr int dp_slot(int ph, int dp) {
     switch (ph) {
     case 0:
         switch (dp) {
         case DP_LN0_W: return 0; case DP_LN0_B: return 1; case DP_LN1_W: return 2; case DP_LN1_B: return 3; case DP_XR: return 4;
         case DP_XW: return 5; case DP_XK: return 6; case DP_XV: return 7; case DP_XA: return 8; case DP_XG: return 9;
-        case DP_ATT_XPREV: return 10; case DP_WR: return 11; case DP_WK: return 12; case DP_WV: return 13; case DP_W1: return 14;
-        case DP_A1: return 15; case DP_V1: return 16; case DP_G1: return 17; default: return -1;
+        case DP_ATT_XPREV: return 10; default: return -1;
         }
     case 1:
+        switch (dp) {
+        case DP_WR: return 0; case DP_WK: return 1; case DP_WV: return 2; case DP_W1: return 3; case DP_A1: return 4; case DP_V1: return 5;
+        case DP_G1: return 6; default: return -1;
+        }
+    case 2:
         switch (dp) {
         case DP_W2: return 0; case DP_A2: return 1; case DP_V2: return 2; case DP_G2: return 3; case DP_KK: return 4; case DP_KA: return 5;
         case DP_RK: return 6; case DP_GNW: return 7; case DP_GNB: return 8; case DP_W0: return 9; case DP_A0: return 10;
         case DP_V0: return 11; case DP_ATT_KV: return 12; default: return -1;
         }
-    case 2:
-        switch (dp) {
-        case DP_WO: return 0; case DP_ATT_XPREV: return 1; default: return -1;
-        }
-    case 3:
-        switch (dp) {
-        case DP_LN2_W: return 0; case DP_LN2_B: return 1; case DP_FXK: return 2; case DP_FFN_XPREV: return 3; case DP_WKEY: return 4;
-        default: return -1;
-        }
+    case 3: return dp == DP_WO ? 0 : -1;
     case 4:
         switch (dp) {
-        case DP_WVAL: return 0; case DP_FFN_XPREV: return 1; default: return -1;
+        case DP_LN2_W: return 0; case DP_LN2_B: return 1; case DP_FXK: return 2; case DP_FFN_XPREV: return 3; default: return -1;
         }
+    case 5: return dp == DP_WKEY ? 0 : -1;
+    case 6: return dp == DP_WVAL ? 0 : -1;
     default: return -1;
     }
 }
@@ -742,131 +703,162 @@ struct ArgRow {
     __device__ __forceinline__ const void *operator[](int dp) const { return p[dp_slot(PH, dp) >= 0 ? dp_slot(PH, dp) : 0]; }
 };
 
-// PH 0-4: the phases A-E of layer l; PH 5: the tail (model norm + head projection).
-// P1: row prologue phases (0, 3, 5): NQ; head phase: NF1.  P2: head phase: NF2; residual phases (2, 4) and the key phase (3): TW.
-template <int PH, int P1, int P2, bool LAYER0, class LP>
-__device__ __forceinline__ void run_phase(const DecodeDesc &d, void *sm, int l, const LP &lp) {
+// PH 0-6: the phases of layer l; PH 7, 8: the tail (last residual add + model norm; head projection).  P1, P2: row phases:
+// P1 = NG (float4 groups per thread); head phase: fragment slots NF1, NF2.
+template <int PH, int P1, int P2, class LP>
+__device__ __forceinline__ void run_phase(const DecodeDesc &d, DecSmem &sm, int l, const LP &lp) {
     const int D = d.D;
-    const RowCopy nocopy{nullptr, nullptr};
-    if constexpr (PH == 0) {
-        RowPro rp;
-        rp.x = d.x; rp.x_in = LAYER0 ? d.x_in : nullptr; rp.ln0w = G_U16(lp[DP_LN0_W]); rp.ln0b = G_U16(lp[DP_LN0_B]); rp.x_out = d.x;
-        rp.lnw = G_U16(lp[DP_LN1_W]); rp.lnb = G_U16(lp[DP_LN1_B]); rp.prev = G_U16(lp[DP_ATT_XPREV]); rp.hnext = d.h_att;
-        // layer 0 has no value-residual branch: its columns stay unwritten and unread
-        const GemvSeg segs[7] = {{G_U16(lp[DP_WR]), nullptr, G_U16(lp[DP_XR]), D / 32, D},
-                                 {G_U16(lp[DP_WK]), nullptr, G_U16(lp[DP_XK]), D / 32, D},
-                                 {G_U16(lp[DP_WV]), nullptr, G_U16(lp[DP_XV]), D / 32, D},
-                                 {G_U16(lp[DP_W1]), nullptr, G_U16(lp[DP_XW]), d.Rw / 32, d.Rw},
-                                 {G_U16(lp[DP_A1]), nullptr, G_U16(lp[DP_XA]), d.Ra / 32, d.Ra},
-                                 {G_U16(LAYER0 ? lp[DP_A1] : lp[DP_V1]), nullptr, G_U16(lp[DP_XV]), LAYER0 ? 0 : d.Rv / 32, d.Rv},
-                                 {G_U16(lp[DP_G1]), nullptr, G_U16(lp[DP_XG]), d.Rg / 32, d.Rg}};
-        gemv_phase<1, 0, 7, 32, P1, LAYER0>(d, sm, segs, rp, D, d.ks_qkv, d.p_qkv, 3 * D + d.Rw + d.Ra + d.Rv + d.Rg, nullptr, nocopy);
+    if constexpr (PH == 7) {
+        for (int b = blockIdx.x; b < d.B; b += gridDim.x)
+            row_phase<0, P1>(d, b, sm.red, d.xa, d.p_val, d.ks_val, nullptr, nullptr, nullptr, nullptr, G_U16(d.norm_w), G_U16(d.norm_b),
+                             nullptr, nullptr, d.hfin);
+    } else if constexpr (PH == 8) {
+        const GemvSeg seg[1] = {{G_U16(d.head_w), d.hfin, (d.V + 31) / 32, d.V}};
+        gemv_phase<0, 1>(d, sm, seg, D, 1, d.logits, d.V, d.head_b);
+    } else if constexpr (PH == 0) {
+        const gu16 mixp[6] = {G_U16(lp[DP_XR]), G_U16(lp[DP_XW]), G_U16(lp[DP_XK]), G_U16(lp[DP_XV]), G_U16(lp[DP_XA]), G_U16(lp[DP_XG])};
+        const gu16 ln0w = G_U16(lp[DP_LN0_W]), ln0b = G_U16(lp[DP_LN0_B]), ln1w = G_U16(lp[DP_LN1_W]), ln1b = G_U16(lp[DP_LN1_B]);
+        const gu16m xprev = G_U16M(lp[DP_ATT_XPREV]);
+        for (int b = blockIdx.x; b < d.B; b += gridDim.x)
+            row_phase<6, P1>(d, b, sm.red, d.xa, d.p_val, d.ks_val, l == 0 ? d.x_in : nullptr, ln0w, ln0b, d.xb, ln1w, ln1b, xprev, mixp,
+                             d.mixed);
     } else if constexpr (PH == 1) {
-        head_phase<P1, P2>(d, *reinterpret_cast<DecSmem *>(sm), l, lp);
+        const long RS = (long)kRows * D;  // one mixed plane: order r, w, k, v, a, g
+        // layer 0 has no value-residual branch: its columns stay unwritten and unread
+        const GemvSeg segs[7] = {{G_U16(lp[DP_WR]), d.mixed + 0 * RS, D / 32, D},
+                                 {G_U16(lp[DP_WK]), d.mixed + 2 * RS, D / 32, D},
+                                 {G_U16(lp[DP_WV]), d.mixed + 3 * RS, D / 32, D},
+                                 {G_U16(lp[DP_W1]), d.mixed + 1 * RS, d.Rw / 32, d.Rw},
+                                 {G_U16(lp[DP_A1]), d.mixed + 4 * RS, d.Ra / 32, d.Ra},
+                                 {G_U16(l == 0 ? lp[DP_A1] : lp[DP_V1]), d.mixed + 3 * RS, l == 0 ? 0 : d.Rv / 32, d.Rv},
+                                 {G_U16(lp[DP_G1]), d.mixed + 5 * RS, d.Rg / 32, d.Rg}};
+        gemv_phase<0, 7>(d, sm, segs, D, d.ks_qkv, d.p_qkv, 3 * D + d.Rw + d.Ra + d.Rv + d.Rg, nullptr);
     } else if constexpr (PH == 2) {
-        const GemvSeg seg[1] = {{G_U16(lp[DP_WO]), d.yg, nullptr, D / P2, D}};
-        const RowCopy cp{G_U16M(lp[DP_ATT_XPREV]), d.h_att};
-        gemv_phase<0, 2, 1, P2, 0>(d, sm, seg, RowPro{}, D, 1, d.x, D, nullptr, cp);
-    } else if constexpr (PH == 3) {   // P2 = columns per tile: 16 while F / 32 tiles would leave CUs idle (0.4B: 128), else 32
-        RowPro rp;
-        rp.x = d.x; rp.x_in = nullptr; rp.ln0w = rp.ln0b = nullptr; rp.x_out = nullptr;
-        rp.lnw = G_U16(lp[DP_LN2_W]); rp.lnb = G_U16(lp[DP_LN2_B]); rp.prev = G_U16(lp[DP_FFN_XPREV]); rp.hnext = d.h_ffn;
-        const GemvSeg seg[1] = {{G_U16(lp[DP_WKEY]), nullptr, G_U16(lp[DP_FXK]), d.F / P2, d.F}};
-        gemv_phase<1, 1, 1, P2, P1>(d, sm, seg, rp, D, 1, d.kact, d.F, nullptr, nocopy);
+        head_phase<P1, P2>(d, sm, l, lp);
+    } else if constexpr (PH == 3) {
+        const GemvSeg seg[1] = {{G_U16(lp[DP_WO]), d.yg, D / 32, D}};
+        gemv_phase<0, 1>(d, sm, seg, D, d.ks_o, d.p_att, D, nullptr);
     } else if constexpr (PH == 4) {
-        const GemvSeg seg[1] = {{G_U16(lp[DP_WVAL]), d.kact, nullptr, D / P2, D}};
-        const RowCopy cp{G_U16M(lp[DP_FFN_XPREV]), d.h_ffn};
-        gemv_phase<0, 2, 1, P2, 0>(d, sm, seg, RowPro{}, d.F, 1, d.x, D, nullptr, cp);
+        const gu16 mixp[1] = {G_U16(lp[DP_FXK])};
+        const gu16 ln2w = G_U16(lp[DP_LN2_W]), ln2b = G_U16(lp[DP_LN2_B]);
+        const gu16m xprev = G_U16M(lp[DP_FFN_XPREV]);
+        for (int b = blockIdx.x; b < d.B; b += gridDim.x)
+            row_phase<1, P1>(d, b, sm.red, d.xb, d.p_att, d.ks_o, nullptr, nullptr, nullptr, d.xa, ln2w, ln2b, xprev, mixp, d.kx);
+    } else if constexpr (PH == 5) {   // P1 = columns per tile: 16 while F / 32 tiles would leave CUs idle (0.4B: 128), else 32
+        const GemvSeg seg[1] = {{G_U16(lp[DP_WKEY]), d.kx, d.F / P1, d.F}};
+        gemv_phase<1, 1, P1>(d, sm, seg, D, 1, d.kact, d.F, nullptr);
     } else {
-        RowPro rp;
-        rp.x = d.x; rp.x_in = nullptr; rp.ln0w = rp.ln0b = nullptr; rp.x_out = nullptr;
-        rp.lnw = G_U16(d.norm_w); rp.lnb = G_U16(d.norm_b); rp.prev = nullptr; rp.hnext = nullptr;
-        const GemvSeg seg[1] = {{G_U16(d.head_w), nullptr, nullptr, (d.V + 31) / 32, d.V}};
-        gemv_phase<2, 0, 1, 32, P1>(d, sm, seg, rp, D, 1, d.logits, d.V, d.head_b, nocopy);
+        const GemvSeg seg[1] = {{G_U16(lp[DP_WVAL]), d.kact, D / 32, D}};
+        gemv_phase<0, 1>(d, sm, seg, d.F, d.ks_val, d.p_val, D, nullptr);
     }
 }
 
+constexpr int kGrid = 256;
 constexpr int kSplitCap = 256;   // workgroups a GEMV phase counts on (512 -- two per CU, finer K splits -- measured 15 % slower)
 
-// Two instantiations of the width-dependent phases: NQ float4 groups per thread in the row prologues, NF1 / NF2 fragment slots in the
-// head phase.  0: D <= 1024, ranks <= 64 / 128 (0.4B); 1: D <= 2048, ranks <= 256 (1.5B).
+// Three instantiations of the width-dependent phases, shared by both launch modes so that they round alike (-ffast-math contracts
+// and reassociates differently in different instantiations): NG float4 groups per thread in the row phases, NF1 / NF2 fragment
+// slots in the head phase.  0: D <= 1024, ranks <= 64 / 128 (0.4B); 1: D <= 2048, ranks <= 128 / 256 (1.5B); 2: D <= 4096, ranks <= 256.
 template <int V> struct Variant;
-template <> struct Variant<0> { static constexpr int NQ = 16, NF1 = 4, NF2 = 8; };
-template <> struct Variant<1> { static constexpr int NQ = 32, NF1 = kUpFrags, NF2 = kUpFrags; };
+template <> struct Variant<0> { static constexpr int NG = 1, NF1 = 4, NF2 = 8; };
+template <> struct Variant<1> { static constexpr int NG = 2, NF1 = 8, NF2 = 16; };
+template <> struct Variant<2> { static constexpr int NG = kMaxE / 4, NF1 = kUpFrags, NF2 = kUpFrags; };
 
-template <int PH> constexpr int phase_threads() { return (PH == 0 || PH == 3 || PH == 5) ? kProThreads : kDecThreads; }
-template <int PH> constexpr size_t phase_lds() { return (PH == 0 || PH == 3 || PH == 5) ? sizeof(ProSm) : (PH == 1 ? sizeof(DecSmem) : sizeof(GemvSm)); }
+#ifdef RWKV7_LAB   // the one-launch variant lost (2.4 ms against 0.93 ms per step): lab build only (python -m rwkvtts_amd.build --lab)
+// mode 1: the step; mode 2 (debug): the barriers alone
+template <int V>
+__global__ __launch_bounds__(kDecThreads) void decode_persistent_kernel(DecodeDesc d, int mode) {
+    using W = Variant<V>;
+    __shared__ DecSmem sm;
+    unsigned target = 0;
+    const int nphase = 7 * d.L + 2;
+    for (int idx = 0; idx < nphase; idx++) {   // one call site per phase body
+        const int l = idx / 7, ph = idx - 7 * l + (l == d.L ? 7 : 0);
+        if (mode == 1) {
+            const TblRow lp{d.tbl + (long)(l < d.L ? l : 0) * DP_COUNT};
+            switch (ph) {
+            case 0: run_phase<0, W::NG, 0>(d, sm, l, lp); break;
+            case 1: run_phase<1, 0, 0>(d, sm, l, lp); break;
+            case 2: run_phase<2, W::NF1, W::NF2>(d, sm, l, lp); break;
+            case 3: run_phase<3, 0, 0>(d, sm, l, lp); break;
+            case 4: run_phase<4, W::NG, 0>(d, sm, l, lp); break;
+            case 5: run_phase<5, 16, 0>(d, sm, l, lp); break;
+            case 6: run_phase<6, 0, 0>(d, sm, l, lp); break;
+            case 7: run_phase<7, W::NG, 0>(d, sm, l, lp); break;
+            default: run_phase<8, 0, 0>(d, sm, l, lp); break;
+            }
+        }
+        if (idx + 1 < nphase) grid_barrier(d.bar, target, gridDim.x, mode);
+    }
+}
+#endif
 
 // One kernel per phase (round 3; until then one kernel with a switch over the phase: every phase paid for the registers and
-// the SGPR spills of the largest one).
-template <int PH, int P1, int P2, bool LAYER0>
-__global__ __launch_bounds__(phase_threads<PH>()) void decode_phase_kernel(DecodeDesc d, int l, ArgRow<PH> row) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_sm[];
-    run_phase<PH, P1, P2, LAYER0>(d, dyn_sm, l, row);
+// the SGPR spills of the largest one).  (Reading the descriptor from device memory through a 16-byte kernel argument instead was
+// measured 3 % slower in the replayed graph: one more dependent load at the head of every phase.)
+template <int PH, int P1, int P2>
+__global__ __launch_bounds__(kDecThreads) void decode_phase_kernel(DecodeDesc d, int l, ArgRow<PH> row) {
+    __shared__ DecSmem sm;
+    run_phase<PH, P1, P2>(d, sm, l, row);
 }
 // the same phase reading its pointers from the device table (callers that have no host copy of it)
-template <int PH, int P1, int P2, bool LAYER0>
-__global__ __launch_bounds__(phase_threads<PH>()) void decode_phase_tbl_kernel(DecodeDesc d, int l) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_sm[];
-    run_phase<PH, P1, P2, LAYER0>(d, dyn_sm, l, TblRow{d.tbl + (long)(PH < 5 ? l : 0) * DP_COUNT});
+template <int PH, int P1, int P2>
+__global__ __launch_bounds__(kDecThreads) void decode_phase_tbl_kernel(DecodeDesc d, int l) {
+    __shared__ DecSmem sm;
+    run_phase<PH, P1, P2>(d, sm, l, TblRow{d.tbl + (long)(PH < 7 ? l : 0) * DP_COUNT});
 }
 
-// host_tbl: the layer table in host memory, or nullptr.  Returns a hipError_t (the dynamic-LDS attribute of a prologue kernel).
-template <int PH, int P1 = 0, int P2 = 0, bool LAYER0 = false>
-inline hipError_t launch_phase(int items, hipStream_t st, const DecodeDesc &d, int l, const void *const *host_tbl) {
-    constexpr size_t lds = phase_lds<PH>();
-    static DynLdsOnce once_tbl, once_arg;
+// host_tbl: the layer table in host memory, or nullptr
+template <int PH, int P1 = 0, int P2 = 0>
+inline void launch_phase(int items, hipStream_t st, const DecodeDesc &d, int l, const void *const *host_tbl) {
     if (!host_tbl) {
-        auto kern = &decode_phase_tbl_kernel<PH, P1, P2, LAYER0>;
-        if (lds > 48 * 1024)
-            if (hipError_t e = once_tbl.ensure(reinterpret_cast<const void *>(kern), (int)lds); e != hipSuccess) return e;
-        kern<<<dim3(items), dim3(phase_threads<PH>()), lds, st>>>(d, l);
-        return hipSuccess;
+        decode_phase_tbl_kernel<PH, P1, P2><<<dim3(items), dim3(kDecThreads), 0, st>>>(d, l);
+        return;
     }
     ArgRow<PH> row;
     row.p[0] = nullptr;
-    if (PH < 5)
+    if (PH < 7)
         for (int dp = 0; dp < DP_COUNT; dp++)
             if (dp_slot(PH, dp) >= 0) row.p[dp_slot(PH, dp)] = host_tbl[(long)l * DP_COUNT + dp];
-    auto kern = &decode_phase_kernel<PH, P1, P2, LAYER0>;
-    if (lds > 48 * 1024)
-        if (hipError_t e = once_arg.ensure(reinterpret_cast<const void *>(kern), (int)lds); e != hipSuccess) return e;
-    kern<<<dim3(items), dim3(phase_threads<PH>()), lds, st>>>(d, l, row);
-    return hipSuccess;
+    decode_phase_kernel<PH, P1, P2><<<dim3(items), dim3(kDecThreads), 0, st>>>(d, l, row);
 }
 
-// TWR: columns per workgroup of the two residual sweeps (full K): D / TWR workgroups
-template <int V, int TWR>
-hipError_t launch_phases(int items_a, int items_a_l0, int items_head, int L, int V_, hipStream_t st, const DecodeDesc &d, const void *const *ht) {
+template <int V>
+void launch_phases(const int (&g_phase)[7], int items_l0_p1, int B, int L, int V_, hipStream_t st, const DecodeDesc &d,
+                   const void *const *ht) {
     using W = Variant<V>;
-    hipError_t e = hipSuccess;
-    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     for (int l = 0; l < L; l++) {
-        if (l == 0) ok(launch_phase<0, W::NQ, 0, true>(items_a_l0, st, d, l, ht));
-        else ok(launch_phase<0, W::NQ, 0, false>(items_a, st, d, l, ht));
-        ok(launch_phase<1, W::NF1, W::NF2>(items_head, st, d, l, ht));
-        ok(launch_phase<2, 0, TWR>(d.D / TWR, st, d, l, ht));
-        if (d.F / 32 >= kSplitCap) ok(launch_phase<3, W::NQ, 32>(d.F / 32, st, d, l, ht));
-        else ok(launch_phase<3, W::NQ, 16>(d.F / 16, st, d, l, ht));
-        ok(launch_phase<4, 0, TWR>(d.D / TWR, st, d, l, ht));
+        launch_phase<0, W::NG>(g_phase[0], st, d, l, ht);
+        launch_phase<1>(l == 0 ? items_l0_p1 : g_phase[1], st, d, l, ht);
+        launch_phase<2, W::NF1, W::NF2>(g_phase[2], st, d, l, ht);
+        launch_phase<3>(g_phase[3], st, d, l, ht);
+        launch_phase<4, W::NG>(g_phase[4], st, d, l, ht);
+        if (d.F / 32 >= kSplitCap) launch_phase<5, 32>(d.F / 32, st, d, l, ht);
+        else launch_phase<5, 16>(g_phase[5], st, d, l, ht);
+        launch_phase<6>(g_phase[6], st, d, l, ht);
     }
-    ok(launch_phase<5, W::NQ>((V_ + 31) / 32, st, d, L, ht));
-    return e;
+    launch_phase<7, W::NG>(B, st, d, L, ht);
+    launch_phase<8>((V_ + 31) / 32, st, d, L, ht);
 }
 
 inline int pick_variant(int D, int Rw, int Ra, int Rv, int Rg) {
-    const int nf1 = max(Rw, Ra) / 16, nf2 = max(Rv, Rg) / 16;
-    return (D <= 1024 && nf1 <= Variant<0>::NF1 && nf2 <= Variant<0>::NF2) ? 0 : 1;
+    const int ng = (D / 4 + kDecThreads - 1) / kDecThreads, nf1 = max(Rw, Ra) / 16, nf2 = max(Rv, Rg) / 16;
+    for (int v = 0; v < 2; v++) {
+        const int NG = v == 0 ? Variant<0>::NG : Variant<1>::NG, NF1 = v == 0 ? Variant<0>::NF1 : Variant<1>::NF1,
+                  NF2 = v == 0 ? Variant<0>::NF2 : Variant<1>::NF2;
+        if (ng <= NG && nf1 <= NF1 && nf2 <= NF2) return v;
+    }
+    return 2;
 }
 
-// K split of the r/k/v/low-rank sweep: minimise the work of the busiest workgroup, where an item costs its K range plus a fixed
+// K split of a GEMV phase: minimise the work of the busiest workgroup, where an item costs its K range plus a fixed
 // latency worth ~256 k (measured: a 16-way split of the r/k/v sweep -- 7 short items per workgroup -- took 13 us, the 2-way
 // split 5 us); ties go to the smaller split (fewer partials to sum)
 int pick_ks(int ntiles, int K, int grid) {
     int best = 0;
     long best_cost = -1;
     for (int ks = 1; ks <= 16; ks *= 2) {
-        if (K % (ks * 8 * 16) != 0) continue;   // eight waves x 16-wide k-steps
+        if (K % (ks * 4 * 16) != 0) continue;
         const long cost = (long)((ntiles * ks + grid - 1) / grid) * (K / ks + 256);
         if (best_cost < 0 || cost < best_cost) {
             best = ks;
@@ -879,31 +871,37 @@ int pick_ks(int ntiles, int K, int grid) {
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t x, vfirst, p_qkv, kact, yg, h_att, h_ffn, bar, total;
-    int ks_qkv;
+    size_t xa, xb, vfirst, p_qkv, p_att, kact, p_val, mixed, yg, kx, hfin, bar, total;
+    int ks_qkv, ks_o, ks_val;
 };
 
 bool ws_layout(int D, int F, int Rw, int Ra, int Rv, int Rg, WsLayout &w) {
     const int N2 = 3 * D + Rw + Ra + Rv + Rg;
     w.ks_qkv = pick_ks(N2 / 32, D, kSplitCap);
-    if (!w.ks_qkv || D % 64 != 0) return false;
+    w.ks_o = pick_ks(D / 32, D, kSplitCap);
+    w.ks_val = pick_ks(D / 32, F, kSplitCap);
+    if (!w.ks_qkv || !w.ks_o || !w.ks_val || D % 64 != 0) return false;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
-    w.bar = take(256);   // first: [1] timeout flag of the retired in-kernel barrier (the host reads byte offset 4: always 0)
-    w.x = take((size_t)kRows * D * 4);
+    w.bar = take(256);   // first: [0] arrival counter, [1] timeout flag (the host reads byte offset 4)
+    w.xa = take((size_t)kRows * D * 4);
+    w.xb = take((size_t)kRows * D * 4);
     w.vfirst = take((size_t)kRows * D * 4);
     w.p_qkv = take((size_t)w.ks_qkv * kRows * N2 * 4);
+    w.p_att = take((size_t)w.ks_o * kRows * D * 4);
     w.kact = take((size_t)kRows * F * 2);
+    w.p_val = take((size_t)w.ks_val * kRows * D * 4);
+    w.mixed = take((size_t)6 * kRows * D * 2);
     w.yg = take((size_t)kRows * D * 2);
-    w.h_att = take((size_t)kRows * D * 2);
-    w.h_ffn = take((size_t)kRows * D * 2);
+    w.kx = take((size_t)kRows * D * 2);
+    w.hfin = take((size_t)kRows * D * 2);
     w.total = o;
     return true;
 }
 
 bool shape_ok(int B, int D, int H, int F, int V, int Rw, int Ra, int Rv, int Rg) {
     auto r_ok = [](int r) { return r >= 32 && r % 32 == 0 && r <= 16 * kUpFrags; };
-    return B >= 1 && B <= kRows && D == H * 64 && D % 128 == 0 && D <= kMaxD && F % 64 == 0 && V >= 1 && r_ok(Rw) &&
+    return B >= 1 && B <= kRows && D == H * 64 && D % 64 == 0 && D <= kDecThreads * kMaxE && F % 64 == 0 && V >= 1 && r_ok(Rw) &&
            r_ok(Ra) && r_ok(Rv) && r_ok(Rg) && Rw + Ra + Rv + Rg <= kMaxR;
 }
 
@@ -923,40 +921,51 @@ int decode_step_bf16(int B, int D, int H, int L, int F, int V, int Rw, int Ra, i
                      hipStream_t st) {
     WsLayout w;
     if (!shape_ok(B, D, H, F, V, Rw, Ra, Rv, Rg) || L < 1 || !ws_layout(D, F, Rw, Ra, Rv, Rg, w)) return -4;  // RWKV7_ESHAPE
-    if (persistent) return -4;   // the one-launch variant (device-scope barriers: 2.4 ms per step) was retired in round 6
     char *ws = (char *)workspace;
     DecodeDesc d;
     d.B = B; d.D = D; d.H = H; d.L = L; d.F = F; d.V = V;
     d.Rw = Rw; d.Ra = Ra; d.Rv = Rv; d.Rg = Rg;
-    d.ks_qkv = w.ks_qkv;
+    d.ks_qkv = w.ks_qkv; d.ks_o = w.ks_o; d.ks_val = w.ks_val;
     d.ln_eps = ln_eps; d.gn_eps = gn_eps;
     d.tbl = layer_tbl;
     d.x_in = (const uint16_t *)x_in;
     d.norm_w = (const uint16_t *)norm_w; d.norm_b = (const uint16_t *)norm_b;
     d.head_w = (const uint16_t *)head_w; d.head_b = (const uint16_t *)head_b;
     d.logits = logits;
-    d.x = (float *)(ws + w.x); d.vfirst = (float *)(ws + w.vfirst);
-    d.p_qkv = (float *)(ws + w.p_qkv); d.kact = (uint16_t *)(ws + w.kact);
-    d.yg = (uint16_t *)(ws + w.yg); d.h_att = (uint16_t *)(ws + w.h_att); d.h_ffn = (uint16_t *)(ws + w.h_ffn);
+    d.xa = (float *)(ws + w.xa); d.xb = (float *)(ws + w.xb); d.vfirst = (float *)(ws + w.vfirst);
+    d.p_qkv = (float *)(ws + w.p_qkv); d.p_att = (float *)(ws + w.p_att); d.kact = (uint16_t *)(ws + w.kact);
+    d.p_val = (float *)(ws + w.p_val);
+    d.mixed = (uint16_t *)(ws + w.mixed); d.yg = (uint16_t *)(ws + w.yg); d.kx = (uint16_t *)(ws + w.kx);
+    d.hfin = (uint16_t *)(ws + w.hfin);
     d.bar = (unsigned *)(ws + w.bar);
     (void)hipGetLastError();
     const int variant = pick_variant(D, Rw, Ra, Rv, Rg);
-    const int N2 = 3 * D + Rw + Ra + Rv + Rg;
-    const int items_a = (N2 / 32) * w.ks_qkv, items_a_l0 = items_a - (Rv / 32) * w.ks_qkv;   // layer 0 has no value-residual columns
-    const int items_head = H * ((B + 1) / 2);
-    // columns per workgroup of the residual sweeps: as many workgroups as fit one round of the chip
-    const int twr = D / 4 <= kSplitCap ? 4 : (D / 8 <= kSplitCap ? 8 : 16);
-    hipError_t e;
-    if (variant == 0) {
-        e = twr == 4 ? launch_phases<0, 4>(items_a, items_a_l0, items_head, L, V, st, d, layer_tbl_host)
-          : twr == 8 ? launch_phases<0, 8>(items_a, items_a_l0, items_head, L, V, st, d, layer_tbl_host)
-                     : launch_phases<0, 16>(items_a, items_a_l0, items_head, L, V, st, d, layer_tbl_host);
-    } else {
-        e = twr == 4 ? launch_phases<1, 4>(items_a, items_a_l0, items_head, L, V, st, d, layer_tbl_host)
-          : twr == 8 ? launch_phases<1, 8>(items_a, items_a_l0, items_head, L, V, st, d, layer_tbl_host)
-                     : launch_phases<1, 16>(items_a, items_a_l0, items_head, L, V, st, d, layer_tbl_host);
+#ifdef RWKV7_LAB
+    if (persistent) {
+        int dev = 0, cus = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return (int)e;
+        // every workgroup must be resident at once: one per CU (14 KB of LDS; 4 waves of <= 512 VGPRs fit any CU)
+        const int grid = cus < kGrid ? cus : kGrid;
+        e = hipMemsetAsync(d.bar, 0, 8, st);
+        if (e != hipSuccess) return (int)e;
+        if (variant == 0) decode_persistent_kernel<0><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
+        else if (variant == 1) decode_persistent_kernel<1><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
+        else decode_persistent_kernel<2><<<dim3(grid), dim3(kDecThreads), 0, st>>>(d, persistent);
+    } else
+#else
+    if (persistent) return -4;   // RWKV7_ESHAPE: the persistent variant exists in the lab build only
+#endif
+    {
+        // one launch per phase, each sized to its own item count
+        const int N2 = 3 * D + Rw + Ra + Rv + Rg;
+        const int g_phase[7] = {B, (N2 / 32) * w.ks_qkv, H * ((B + 1) / 2), (D / 32) * w.ks_o, B, F / 16, (D / 32) * w.ks_val};
+        const int p1_l0 = g_phase[1] - (Rv / 32) * w.ks_qkv;   // layer 0 has no value-residual columns
+        if (variant == 0) launch_phases<0>(g_phase, p1_l0, B, L, V, st, d, layer_tbl_host);
+        else if (variant == 1) launch_phases<1>(g_phase, p1_l0, B, L, V, st, d, layer_tbl_host);
+        else launch_phases<2>(g_phase, p1_l0, B, L, V, st, d, layer_tbl_host);
     }
-    if (e != hipSuccess) return (int)e;
     return (int)hipGetLastError();
 }
 

@@ -3,9 +3,9 @@ rwkv_s2s_single_ffn.py:417-445, HF generate via inference/rwkv7speech_inference.
 
 Two levels:
   * DecodeStep -- the whole T = 1 step of the stack (all layers on the in-place recurrent state, final norm, head
-    projection) through rwkv7_decode_step_bf16 (csrc/decode_step.hip): 5 grid-wide phases per layer (round 6: LayerNorm + token
-    shift as the prologue of the sweep that consumes them, the residual adds as epilogues of the output / value projections)
-    instead of ~18 module-level launches, one launch per phase.
+    projection) through rwkv7_decode_step_bf16 (csrc/decode_step.hip): 7 grid-wide phases per layer instead of ~18
+    module-level launches, either as one launch per phase (default) or as ONE persistent kernel with device-scope barriers
+    between the phases (persistent=1; slower on MI355X, the barrier costs 7.4 us against ~1.5 us for a kernel boundary).
   * GraphDecoder -- greedy or sampled (temperature / top-k / top-p, device RNG) loop around it: embedding lookup of the
     previous ids, the step, suppress + argmax/sampling and the bookkeeping are recorded once into a hipGraph on static buffers
     and replayed per token; the ids never leave the device until the end.  Models the step kernel does not cover (fp32 weights, B > 32, odd low-rank sizes) run the module-by-module
@@ -86,7 +86,7 @@ class DecodeStep:
         self.table = self.table_host.to(dev)
         self.norm, self.head = backbone.norm, lm_head
         self.logits = torch.empty(self.B, self.dims.V, dtype=torch.float32, device=dev)
-        self.persistent = int(persistent)   # must be 0: the one-launch variant was retired in round 6 (the library answers RWKV7_ESHAPE)
+        self.persistent = int(persistent)   # 2 (debug): the barriers of the persistent kernel without the phases
 
     @staticmethod
     def supported(backbone, lm_head, cache: Cache) -> Optional[str]:
@@ -97,8 +97,8 @@ class DecodeStep:
         B = cache[0].att_x_prev.shape[0]
         if not 1 <= B <= 32:
             return f"B = {B} (1..32)"
-        if cfg.hidden_size > 2048 or cfg.hidden_size % 128:
-            return "hidden size (the step kernel's row prologue covers D <= 2048, D % 128 == 0)"
+        if cfg.hidden_size > 4096 or cfg.hidden_size % 64:
+            return "hidden size"
         if not getattr(cfg, "norm_bias", True):
             return "LayerNorm without bias"
         tensors = [lm_head.weight] + [p for p in backbone.layers.parameters()] + list(backbone.norm.parameters())
