@@ -154,14 +154,17 @@ class _MixLora(torch.autograd.Function):
 
 
 def mix_lora_supported(x, state, seq_start, w1s=None):
-    """w1s: the down-projection weights of the low-rank branches that would ride on the fused path; what the C entry points
+    """w1s: the down-projection weights of the low-rank branches that would ride on the fused path (a list, or a callable that builds
+    it -- called only when everything else already holds, so eager decode / packed rows do not pay for the lists); what the C entry points
     require of them (rwkv7_mix_lora_wcat_*: at most 4 branches, every rank a multiple of 8, bf16, contiguous) is checked HERE so
     that an unusual config (rank 20, fp32 LoRA) falls back to token_shift_mix6 instead of raising RWKV7_ESHAPE mid-training."""
-    if w1s is not None and not (0 < len(w1s) <= 4 and all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2
-                                                         and w.shape[0] % 8 == 0 for w in w1s)):
-        return False
-    return (FUSED_MIX_LORA and state is None and seq_start is None and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
-            and x.requires_grad and x.dim() == 3 and x.shape[0] * x.shape[1] >= WGRAD_MIN_ROWS and x.shape[-1] % 8 == 0)
+    if not (FUSED_MIX_LORA and state is None and seq_start is None and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
+            and x.requires_grad and x.dim() == 3 and x.shape[0] * x.shape[1] >= WGRAD_MIN_ROWS and x.shape[-1] % 8 == 0):
+        return False     # the cheap rejections first (decode, packed rows, no grad): the weights are looked at only on the training path
+    if w1s is not None:
+        w1s = w1s() if callable(w1s) else w1s
+        return 0 < len(w1s) <= 4 and all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2 and w.shape[0] % 8 == 0 for w in w1s)
+    return True
 
 
 def _ptr_array(ts):

@@ -130,7 +130,11 @@ def fused_linear_cross_entropy(hidden, labels, weight, bias=None, ignore_index=-
     chunk: rows per round of head GEMMs (None: auto_chunk)."""
     D = hidden.shape[-1]
     if chunk is None:
-        chunk = auto_chunk(hidden.numel() // D, weight.shape[0], hidden.element_size())
+        # the HIP kernel path keeps ONE bf16 logits tensor per chunk; the torch chain (RWKV7_HIP_CE=0, fp32 models, int32 labels, a
+        # non-bf16 bias) keeps fp32 logits, an fp32 softmax and a copy in the hidden dtype: budget 3 x 4 bytes per logit there
+        hip = (HIP_CE and hidden.is_cuda and hidden.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+               and (bias is None or bias.dtype == torch.bfloat16) and labels.dtype == torch.int64)
+        chunk = auto_chunk(hidden.numel() // D, weight.shape[0], hidden.element_size() if hip else 12)
     return _FusedLinearCE.apply(hidden.reshape(-1, D), weight, bias, labels.reshape(-1), ignore_index, chunk,
                                 label_smoothing)
 

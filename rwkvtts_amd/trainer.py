@@ -100,6 +100,9 @@ class FlatBuffers:
     def flush(self):
         """Copy the adopted gradients collected so far into their slices (one multi-tensor launch) and attach the slices."""
         if self.to_copy:
+            # INVARIANT: every gradient in to_copy was produced on the CURRENT stream.  Weight gradients computed on the side stream
+            # (fused.WGRAD_SIDE_STREAM) are written straight into their slice (param._grad_slot) and never come through here; a future
+            # fused node that hands a side-stream tensor back as .grad must call fused.wgrad_side_sync() before this copy.
             src = [self.params[i].grad for i in self.to_copy]
             dst = [self.views[i] for i in self.to_copy]
             if src[0].is_cuda and all(s.dtype == d.dtype for s, d in zip(src, dst)):
@@ -210,7 +213,11 @@ class BucketedAllReduce:
 
     def rebuild_from_ready_order(self):
         """Re-cut the buckets along the order in which the gradient hooks fired in the pass just finished (once; parameters whose
-        hook did not fire go last).  The order is RANK 0's, broadcast to everybody (what DDP does): the order a rank records
+        hook did not fire go last).  STEP 0 IS NOT REPRESENTATIVE: until this re-cut the buckets follow reverse registration order and
+        go on the wire in index order, and bucket 0 then holds the input-side embedding tables whose gradients arrive LAST -- no
+        all-reduce starts before backward ends (no overlap), and the re-cut itself is a host-synchronous broadcast + tolist().  Warm-up
+        steps absorb it: bench.py times from step W on (W >= 1) and reports `comm.bucket_order` so a line measured on the initial cut
+        is recognisable.  The order is RANK 0's, broadcast to everybody (what DDP does): the order a rank records
         depends on the shapes of ITS batch -- fused.mix_lora_supported needs B*T >= 4096, linear_add_eligible / cmix_eligible
         need M % 256 == 0, and the fused nodes hand over the LoRA / x_* gradients in a different order than the plain ones --
         so two ranks fed differently shaped batches on step 0 would otherwise cut their buckets at different byte boundaries
