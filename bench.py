@@ -258,12 +258,19 @@ def wkv7_probe(torch, dev, reps=12):
 PACKED_FRACTIONS = (0.125, 0.11, 0.1, 0.095, 0.09, 0.085, 0.08, 0.07, 0.06, 0.05, 0.04, 0.035, 0.03, 0.02, 0.01)
 
 
-def packed_lengths(total):
-    """A fixed spread of sequence lengths (3 % ... 12.5 % of the row, none a multiple of 32) that sum to `total`: the packed
-    variable-length workload of --packed (data/utils/spark_dataset.py:111-162 packs real utterances the same way)."""
-    lens = [max(300, int(total * f) // 2 * 2 + 1) for f in PACKED_FRACTIONS]
-    lens[-1] += total - sum(lens)
-    assert lens[-1] > 290 and sum(lens) == total, lens
+def packed_lengths(budget):
+    """A fixed spread of sequence lengths (1 % ... 12.5 % of the row, none a multiple of 32) whose 32-ALIGNED layout fills exactly
+    `budget` = B x L positions (every sequence is followed by >= 1 masked position up to the next chunk boundary: backbone
+    ._forward_packed): the packed variable-length workload of --packed (data/utils/spark_dataset.py:111-162 packs real
+    utterances into a token budget, max_cu_seqlens, the same way).  The row then has the shape the GEMMs of the [B, L] step have."""
+    n = len(PACKED_FRACTIONS)
+    tokens = budget - 32 * n
+    lens = [max(300, int(tokens * f) // 2 * 2 + 1) for f in PACKED_FRACTIONS]
+    lens[-1] += tokens - sum(lens)
+    if lens[-1] % 32 == 0:
+        lens[-1] -= 1
+    # device-side cu_seqlens: the aligned row is sized from shapes alone, round-up-256(tokens + 32 n) = budget
+    assert lens[-1] > 200 and (sum(lens) + 32 * n + 255) // 256 * 256 == budget, (lens, budget)
     return lens
 
 
@@ -494,14 +501,42 @@ def main():
 
     if a.layout == "spark" and a.packed:
         lens = packed_lengths(B * T)
+        ntok = sum(lens)
         cu_dev = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+        # the row's layout is fixed across steps (the ids are not): per table, where its lookups go in the row -- one lookup per table
+        # and one index_copy each per step, as a collator that batches its embedding launches would do (the reference launches them per
+        # sample, spark_dataset.py:111-162)
+        pos = {"tag": [], "text": [], "glob": [], "sem": []}
+        tag_ids, o = [], 0
+        for n in lens:
+            n_text = min(255, n // 4)
+            n_sem = n - 3 - n_text - 32
+            pos["tag"] += [o, o + 1 + n_text, o + 2 + n_text + 32]
+            tag_ids += [2, 0, 1]
+            pos["text"] += range(o + 1, o + 1 + n_text)
+            pos["glob"] += range(o + 2 + n_text, o + 2 + n_text + 32)
+            pos["sem"] += range(o + 3 + n_text + 32, o + n)
+            assert o + 3 + n_text + 32 + n_sem == o + n
+            o += n
+        pos = {k_: torch.tensor(v_, dtype=torch.long, device=dev) for k_, v_ in pos.items()}
+        tag_ids = torch.tensor(tag_ids, dtype=torch.long, device=dev)
 
         def make_batch(i):
-            # one packed row: every sequence its own Spark sample (tags, text, global, semantic ids), embedded WITH autograd and
-            # concatenated, cu_seqlens a DEVICE tensor (no host read-back in the step: backbone._forward_packed_device)
-            parts = [synthetic_spark_batch(model, 1, n, seed=1234 + rank + 1000 * i + 17 * j, n_text=min(255, n // 4)) for j, n in enumerate(lens)]
-            return dict(inputs_embeds=torch.cat([p_["inputs_embeds"] for p_ in parts], 1), labels=torch.cat([p_["labels"] for p_ in parts], 1),
-                        cu_seqlens=cu_dev)
+            # one packed row [1, sum T, D], embedded WITH autograd (the four tables get gradients), cu_seqlens a DEVICE tensor: no host
+            # read-back in the step (backbone._forward_packed_device)
+            g = torch.Generator().manual_seed(1234 + rank + 1000 * i)
+            up = lambda t: t.pin_memory().to(dev, non_blocking=True)
+            text = up(torch.randint(0, cfg.text_vocab_size, (pos["text"].numel(),), generator=g))
+            glob = up(torch.randint(0, cfg.audio_global_vocab_size, (pos["glob"].numel(),), generator=g))
+            sem = up(torch.randint(0, cfg.vocab_size - 1, (pos["sem"].numel(),), generator=g))
+            row = torch.zeros(ntok, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
+            row = row.index_copy(0, pos["tag"], model.tts_tag_embedder(tag_ids))
+            row = row.index_copy(0, pos["text"], model.text_embedder(text))
+            row = row.index_copy(0, pos["glob"], model.global_embedder(glob))
+            row = row.index_copy(0, pos["sem"], model.model.embeddings(sem))
+            labels = torch.full((ntok,), -100, dtype=torch.long, device=dev)
+            labels[pos["sem"]] = sem
+            return dict(inputs_embeds=row.unsqueeze(0), labels=labels.unsqueeze(0), cu_seqlens=cu_dev)
     elif a.layout == "spark":
         def make_batch(i):
             # built inside the step WITH autograd, as data/utils/spark_dataset.py:163-239 does under the reference's training
@@ -565,7 +600,8 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        value = world * B * T * a.steps / dt
+        tokens_per_rank = sum(lens) if (a.packed and a.layout == "spark") else B * T    # packed: the real tokens, not the aligned buffer
+        value = world * tokens_per_rank * a.steps / dt
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items() if v}
         th = B * T * H
         chunk_parts = [k for k in ("wkv7c_bseq", "wkv7c_bwd_out") if k in kern]
@@ -659,7 +695,8 @@ def main():
         except Exception as e:
             out["device"]["wkv7_probe_error"] = repr(e)
         if a.packed and a.layout == "spark":
-            out["config"]["workload"] += f"; PACKED: one row [1, {B * T}, D] of {len(lens)} sequences ({min(lens)}..{max(lens)} positions), cu_seqlens on the device (SURVEY 8f N1)"
+            out["config"]["workload"] += (f"; PACKED: one row [1, {sum(lens)}, D] of {len(lens)} sequences ({min(lens)}..{max(lens)} positions; "
+                                          f"32-aligned layout = {B * T} positions), cu_seqlens on the device (SURVEY 8f N1); value counts the {sum(lens)} real tokens")
             out["config"]["packed_lengths"] = lens
         if a.wgrad_side_stream:
             out["config"]["wgrad"] = "weight gradients on a side stream (fused.WGRAD_SIDE_STREAM)"

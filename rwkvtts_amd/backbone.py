@@ -266,7 +266,7 @@ class RWKV7Attention(nn.Module):
         With `state`, token shift and the WKV state are carried (and updated in place).
         seq_start (int32 [nseq+1] chunk offsets): packed rows, see RWKV7Model._forward_packed."""
         x_prev = None if state is None else state.att_x_prev
-        if FUSED_TMIX_CORE and fused.mix_lora_supported(x, state, seq_start, lambda: self.lora_branches()[1]):
+        if FUSED_TMIX_CORE and fused.mix_lora_supported(x, state, seq_start, lambda: self.lora_branches()[1], mask):
             # training: the four low-rank branches' down projections taken THROUGH the lerp (fused.mix_lora): x_w, x_a, x_g and the
             # branch copy of x_v are never formed
             mus, w1s, acts, names = self.lora_branches()

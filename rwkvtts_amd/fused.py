@@ -153,12 +153,15 @@ class _MixLora(torch.autograd.Function):
         return dx, None, _colsum(part, params.dtype), dwcat
 
 
-def mix_lora_supported(x, state, seq_start, w1s=None):
+def mix_lora_supported(x, state, seq_start, w1s=None, mask=None):
     """w1s: the down-projection weights of the low-rank branches that would ride on the fused path (a list, or a callable that builds
     it -- called only when everything else already holds, so eager decode / packed rows do not pay for the lists); what the C entry points
     require of them (rwkv7_mix_lora_wcat_*: at most 4 branches, every rank a multiple of 8, bf16, contiguous) is checked HERE so
     that an unusual config (rank 20, fp32 LoRA) falls back to token_shift_mix6 instead of raising RWKV7_ESHAPE mid-training."""
-    if not (FUSED_MIX_LORA and state is None and seq_start is None and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
+    # packed rows (seq_start): the 32-aligned layout of RWKV7Model._forward_packed puts at least one MASKED position in front of every
+    # sequence, so "nothing from t - 1 at a sequence start" is the ordinary mask handling of the combine kernels (m_{t-1} = 0) -- the
+    # fused path applies as long as the mask is there (round 6: the packed step had been running the six-lerp path, +8 ms per step)
+    if not (FUSED_MIX_LORA and state is None and (seq_start is None or mask is not None) and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
             and x.requires_grad and x.dim() == 3 and x.shape[0] * x.shape[1] >= WGRAD_MIN_ROWS and x.shape[-1] % 8 == 0):
         return False     # the cheap rejections first (decode, packed rows, no grad): the weights are looked at only on the training path
     if w1s is not None:

@@ -587,6 +587,53 @@ def test_packed_rows_native_sequence_ranges(lens):
             o += n
 
 
+def test_packed_rows_above_4096_positions_take_the_fused_low_rank_path():
+    """Packed rows long enough for fused.mix_lora (B*T >= 4096): the low-rank branches' down projections taken through the lerp ALSO on
+    cu_seqlens batches (the masked position in front of every sequence is what resets the token shift) -- hidden states and every
+    gradient against the padded-batch fallback and against each sequence run alone."""
+    from rwkvtts_amd import backbone, fused
+    cfg = RWKV7Config(hidden_size=128, num_hidden_layers=2, vocab_size=64, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=32, gate_low_rank_dim=32)
+    torch.manual_seed(3)
+    model = RWKV7Model(cfg)
+    backbone.init_weights(model, cfg, seed=5)
+    model = model.to(DEV).to(torch.bfloat16).train()
+    lens = [1500, 1001, 777, 900, 33]
+    total = sum(lens)
+    g = torch.Generator().manual_seed(total)
+    x0 = (torch.randn(1, total, 128, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    wgt = torch.randn(1, total, 128, generator=g).to(DEV)
+
+    def run(native):
+        backbone.PACKED_NATIVE = native
+        try:
+            model.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            hits = fused.FUSED_MIX_LORA_HITS[0]
+            h = model(inputs_embeds=x, cu_seqlens=cu).last_hidden_state
+            (h.float() * wgt).sum().backward()
+            return h.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}, \
+                fused.FUSED_MIX_LORA_HITS[0] - hits
+        finally:
+            backbone.PACKED_NATIVE = True
+
+    h1, dx1, g1, hits1 = run(True)
+    h0, dx0, g0, _ = run(False)
+    assert hits1 >= 2, "the packed row did not take fused.mix_lora"
+    assert (h1 - h0).abs().max().item() < 3e-2 * h0.abs().max().item()
+    assert (dx1 - dx0).abs().max().item() < 4e-2 * dx0.abs().max().item()
+    for n in g0:
+        rel = ((g1[n] - g0[n]).norm() / g0[n].norm().clamp(min=1e-9)).item()
+        assert rel < 3e-2, (n, rel)
+    with torch.no_grad():
+        o = 0
+        for n in lens:
+            alone = model(inputs_embeds=x0[:, o:o + n]).last_hidden_state.float()
+            assert (h1[:, o:o + n] - alone).abs().max().item() < 3e-2 * alone.abs().max().item(), (o, n)
+            o += n
+
+
 def test_lora_bias_gradients_come_from_the_prepare_backward():
     """The bias gradients of the w / a / v low-rank branches are the column sums the prepare backward leaves in its partials
     (no reduction over B*T rows per bias): the hand-over must actually happen (COLSUM_HITS) and give the gradients that the
