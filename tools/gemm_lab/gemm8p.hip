@@ -43,17 +43,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(int M, int N, int K, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;          // wave tile: rows wr * 128 .., columns wc * 64 ..
     const int nbn = N / BN, nbm = M / BM, ntiles = nbn * nbm, nk = K / BK;
-    // XCD-aware tile order: ids b, b + 8, ... share an L2; give each XCD a contiguous band of row panels, 8 column tiles wide at most
+    // XCD-aware tile order: ids b, b + 8, ... share an L2; give each XCD a contiguous run of tiles (row panels: the A rows are re-used)
     auto tile_origin = [&](int id, int &row0, int &col0) {
-        const int nx = 8, per = ntiles / nx;
         int t = id;
-        if (ntiles % nx == 0) t = (id % nx) * per + id / nx;
-        const int pc = nbn < 8 ? nbn : 8;              // patch of pc column tiles
-        const int patch = t / (pc * (nbn / pc) ), dummy = 0;
-        (void)patch; (void)dummy;
-        const int bm = t / nbn, bn = t % nbn;
-        row0 = bm * BM;
-        col0 = bn * BN;
+        if (ntiles % 8 == 0) t = (id % 8) * (ntiles / 8) + id / 8;
+        row0 = (t / nbn) * BM;
+        col0 = (t % nbn) * BN;
     };
     // LDS-DMA of a half tile: 128 rows x 128 B = 16 pieces of 1 KB (8 rows); wave w issues pieces w and w + 8: slot rows 8 p + lane / 8,
     // 16-byte segment lane & 7 (swizzled on the source side).  Slot row q of an A half mh: tile row (q < 64 ? q : q + 64) + 64 mh
