@@ -265,12 +265,12 @@ def packed_lengths(budget):
     utterances into a token budget, max_cu_seqlens, the same way).  The row then has the shape the GEMMs of the [B, L] step have."""
     n = len(PACKED_FRACTIONS)
     tokens = budget - 32 * n
-    lens = [max(300, int(tokens * f) // 2 * 2 + 1) for f in PACKED_FRACTIONS]
+    lens = [max(65, int(tokens * f) // 2 * 2 + 1) for f in PACKED_FRACTIONS]
     lens[-1] += tokens - sum(lens)
     if lens[-1] % 32 == 0:
         lens[-1] -= 1
     # device-side cu_seqlens: the aligned row is sized from shapes alone, round-up-256(tokens + 32 n) = budget
-    assert lens[-1] > 200 and (sum(lens) + 32 * n + 255) // 256 * 256 == budget, (lens, budget)
+    assert lens[-1] > 32 and (sum(lens) + 32 * n + 255) // 256 * 256 == budget, (lens, budget)
     return lens
 
 

@@ -1,0 +1,49 @@
+"""CPU: the pieces of bench.py that only matter when something goes wrong on a multi-GPU node, or that define a workload."""
+import importlib.util
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_packed_lengths_fill_exactly_the_budget_after_alignment():
+    b = _bench()
+    for budget in (32768, 16384, 65536):
+        lens = b.packed_lengths(budget)
+        n = len(lens)
+        assert all(x > 32 and x % 32 != 0 for x in lens)
+        assert sum(lens) == budget - 32 * n                               # what `value` counts: the real tokens
+        assert sum((x // 32 + 1) * 32 for x in lens) <= budget            # every sequence + >= 1 masked position, 32-aligned, fits
+        assert (sum(lens) + 32 * n + 255) // 256 * 256 == budget          # the device path's shape-only bound is the budget itself
+
+
+def test_watchdog_reports_the_stuck_stage_and_exits_3():
+    code = textwrap.dedent(f"""
+        import sys, time
+        sys.path.insert(0, {ROOT!r})
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_mod", {os.path.join(ROOT, 'bench.py')!r})
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        with b.Watchdog(0.3, "preflight: first all-reduce", lambda: "ranks not past 'map': [1]"):
+            time.sleep(5)
+        print("NOT REACHED")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=dict(os.environ, RANK="1", LOCAL_RANK="1"))
+    assert r.returncode == 3, (r.returncode, r.stderr[-400:])
+    assert "rank 1" in r.stderr and "preflight: first all-reduce" in r.stderr and "ranks not past 'map': [1]" in r.stderr
+    assert "NOT REACHED" not in r.stdout
+
+
+def test_watchdog_is_silent_when_the_stage_finishes():
+    b = _bench()
+    with b.Watchdog(5.0, "quick stage"):
+        pass
