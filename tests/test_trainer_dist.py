@@ -1,4 +1,4 @@
-"""CPU, world size 2 over gloo: the data-parallel machinery of rwkvtts_amd/trainer.py (flat buffers, bucketed
+"""CPU, world sizes 2 and 8 over gloo: the data-parallel machinery of rwkvtts_amd/trainer.py (flat buffers, bucketed
 all-reduce from backward hooks, NaN flag, fp32 master AdamW) on a model-agnostic toy network.  The HIP model
 itself cannot run on CPU (by design), the exchange logic can."""
 import os
@@ -60,10 +60,11 @@ def _worker(rank, world, port, q, shard=False, bucket_opt=True):
     model = Toy()
     tr = trainer.DataParallelTrainer(model, lr=1e-2, warmup_steps=0, total_steps=100, bucket_bytes=4096, shard_optimizer=shard,
                                      bucket_optimizer=bucket_opt)
-    if shard:   # the two slabs tile the flat buffer, and a bucket really is split between the owners
-        (a0, a1), (b0, b1) = tr.reducer.slab(0), tr.reducer.slab(1)
-        assert a0 == 0 and a1 == b0 and b1 == tr.flat.numel and a1 % 128 == 0
-        assert any(s < a1 < e for s, e, _ in tr.reducer.buckets)
+    if shard:   # the slabs tile the flat buffer, and a bucket really is split between owners
+        slabs = [tr.reducer.slab(r) for r in range(world)]
+        assert slabs[0][0] == 0 and slabs[-1][1] == tr.flat.numel and all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]))
+        assert all(a[1] % 128 == 0 for a in slabs[:-1])
+        assert any(s < slabs[0][1] < e for s, e, _ in tr.reducer.buckets)
     assert len(tr.reducer.buckets) > 2  # several buckets -> hooks fire in backward order
     losses = []
     names = [n for n, p_ in model.named_parameters() if p_.requires_grad]
@@ -103,33 +104,29 @@ def _worker(rank, world, port, q, shard=False, bucket_opt=True):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-@pytest.mark.parametrize("shard,bucket_opt", [(False, True), (False, False), (True, True)])
-def test_two_rank_gloo_matches_single_process_average(shard, bucket_opt):
-    """bucket_opt: AdamW bucket by bucket as each bucket's all-reduce completes (the default) vs one pass after the last one --
-    the same parameters either way.  shard=False: bucketed all-reduce + replicated AdamW.  shard=True (DataParallelTrainer(shard_optimizer=True), SURVEY H6's
-    fallback): gradient pieces reduced to the slab owners, AdamW on the own slab only, parameter slabs broadcast -- the replicas
-    must come out identical to each other and to the single-process reference in both modes, NaN step included."""
+def _run_world(world, shard, bucket_opt):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, shard, bucket_opt)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, shard, bucket_opt)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=150) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(30)
+        p.join(60)
         assert p.exitcode == 0
-    (_, p0, b0, _), (_, p1, b1, _) = [(r, torch.from_numpy(a), torch.from_numpy(b), l) for r, a, b, l, _ in res]
-    assert torch.equal(p0, p1) and torch.equal(b0, b1), "replicas diverged"
-    assert res[0][4] == res[1][4], "the ranks re-cut their buckets differently"
-    # single-process reference: torch.optim.AdamW on an untouched copy of the model, fed the gradient of the mean of the two
-    # ranks' losses (= the average of the two ranks' gradients)
+    reps = [(torch.from_numpy(a), torch.from_numpy(b)) for _, a, b, _, _ in res]
+    for pr, br in reps[1:]:
+        assert torch.equal(reps[0][0], pr) and torch.equal(reps[0][1], br), "replicas diverged"
+    assert all(r[4] == res[0][4] for r in res), "the ranks re-cut their buckets differently"
+    p0, b0 = reps[0]
+    # single-process reference: torch.optim.AdamW on an untouched copy of the model, fed the gradient of the mean of the ranks'
+    # losses (= the average of the ranks' gradients)
     model = Toy()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-18, weight_decay=0.0)
     for step in range(3):
         opt.zero_grad()
-        loss = sum(model(*_data(r, step)).loss for r in range(2)) / 2
+        loss = sum(model(*_data(r, step)).loss for r in range(world)) / world
         loss.backward()
         model.unused.grad = torch.zeros_like(model.unused)
         for g_ in opt.param_groups:
@@ -138,6 +135,25 @@ def test_two_rank_gloo_matches_single_process_average(shard, bucket_opt):
     ref = torch.cat([torch.nn.functional.pad(p.detach().reshape(-1), (0, (-p.numel()) % 128)) for p in model.parameters()])
     assert torch.allclose(ref, b0, atol=1e-6), (ref - b0).abs().max()
     assert torch.isfinite(p0).all()  # the poisoned step did not write NaNs into the weights
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("shard,bucket_opt", [(False, True), (False, False), (True, True)])
+def test_two_rank_gloo_matches_single_process_average(shard, bucket_opt):
+    """bucket_opt: AdamW bucket by bucket as each bucket's all-reduce completes (the default) vs one pass after the last one --
+    the same parameters either way.  shard=False: bucketed all-reduce + replicated AdamW.  shard=True (DataParallelTrainer(shard_optimizer=True), SURVEY H6's
+    fallback): gradient pieces reduced to the slab owners, AdamW on the own slab only, parameter slabs broadcast -- the replicas
+    must come out identical to each other and to the single-process reference in both modes, NaN step included."""
+    _run_world(2, shard, bucket_opt)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("shard", [False, True])
+def test_eight_rank_gloo_matches_single_process_average(shard):
+    """BASELINE configs[2]'s world size (8 ranks) over gloo: eight replicas identical to each other and to single-process AdamW on the
+    mean of the eight gradients; rank 1 records another gradient-ready order on step 0, one rank poisons a step with NaN; with
+    shard=True eight slab owners tile the flat buffer."""
+    _run_world(8, shard, True)
 
 
 def test_reference_param_groups_and_cosine_schedule_match_torch_adamw():
