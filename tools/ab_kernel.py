@@ -45,6 +45,13 @@ for name, fn in kernels.items():
     med = [sorted(s.elapsed_time(e) for s, e in t)[len(t) // 2] * 1e3 for t in ts]
     print(f"{name:16s} A {med[0]:7.1f} us   B {med[1]:7.1f} us   ({med[1] - med[0]:+.1f} us, {100 * (med[1] / med[0] - 1):+.1f} %)", flush=True)
 # results of the two libraries agree bit for bit?
+res = []
+for L in libs:
+    y2.zero_(); sa2.zero_(); hs2.zero_(); e_vk.zero_(); z.zero_()
+    kernels["wkv7c_fwd9"](L); kernels["wkv7c_bseq"](L)
+    torch.cuda.synchronize()
+    res.append([t.clone() for t in (y2, sa2, hs2, e_vk, z)])
+print("fwd9 (y, sa, hs) and bseq (e_vk, z) identical:", [torch.equal(x, y_) for x, y_ in zip(*res)])
 outs = []
 for L in libs:
     kernels["wkv7c_bwd_out9"](L)
