@@ -1,6 +1,6 @@
 """Test infrastructure (not collected): the operand-by-operand precision probe of wkv7c_bwd_out9.
 
-For the library named by RWKV7_HIP_SO (a build of csrc/wkv7_chunk_bwd9.hip with -DWKV7C_B9_SINGLE=<mask>: the masked operands enter their
+For the library named by RWKV7_HIP_SO (a build of csrc/lab/wkv7_chunk_bwd9.hip (lab build) with -DWKV7C_B9_SINGLE=<mask>: the masked operands enter their
 products as ONE bf16 plane) it prints, per gradient, the worst error in units of the parity bar of tests/test_chunk_gpu.py (2 bf16 ulp with
 the floor of _assert_bf16_close): < 1 passes.  Shapes and seeds: the parametrisations of test_chunked_forward_plus_backward_vs_oracle
 plus two more seeds of the largest, and three (batch, head) slices of BASELINE configs[1].

@@ -1,4 +1,4 @@
-"""Library GEMM (hipBLASLt through torch) against the own MFMA GEMM (csrc/gemm_relusq.hip, rwkv7_gemm_nt_bf16), HOT (same operands every
+"""Library GEMM (hipBLASLt through torch) against the own MFMA GEMM (rwkv7_gemm_nt_bf16: csrc/gemm_nt4.hip since round 4; the first generation is csrc/lab/gemm_relusq.hip), HOT (same operands every
 call: they sit in the 256 MB infinity cache) and COLD (operands rotate through R buffer sets larger than the cache together -- what the
 training step sees).  HIP events, same process.
 
