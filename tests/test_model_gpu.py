@@ -587,6 +587,37 @@ def test_packed_rows_native_sequence_ranges(lens):
             o += n
 
 
+def test_packed_row_with_leading_and_trailing_unowned_positions_device_vs_host_cu_seqlens():
+    """cu_seqlens[0] > 0 and positions behind cu_seqlens[-1]: both belong to no sequence and come back as zeros with zero gradient; the
+    device-side layout (dump row for unowned positions, shape-only row size) must agree with the host-side one bit for bit."""
+    cfg = RWKV7Config(hidden_size=128, num_hidden_layers=2, vocab_size=64, decay_low_rank_dim=32, a_low_rank_dim=32,
+                      v_low_rank_dim=32, gate_low_rank_dim=32)
+    torch.manual_seed(4)
+    model = RWKV7Model(cfg)
+    from rwkvtts_amd import backbone
+    backbone.init_weights(model, cfg, seed=6)
+    model = model.to(DEV).to(torch.bfloat16).train()
+    g = torch.Generator().manual_seed(7)
+    x0 = (torch.randn(1, 140, 128, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    wgt = torch.randn(1, 140, 128, generator=g).to(DEV)
+    cu = torch.tensor([5, 75, 108, 108, 131], dtype=torch.int32)      # 5 leading, 9 trailing unowned positions; one empty sequence
+    outs = []
+    for c in (cu.to(DEV), cu):
+        model.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        h = model(inputs_embeds=x, cu_seqlens=c).last_hidden_state
+        (h.float() * wgt).sum().backward()
+        outs.append((h.detach().float(), x.grad.float()))
+    (hd, dxd), (hh, dxh) = outs
+    assert torch.equal(hd, hh) and torch.equal(dxd, dxh)
+    for t in (hd, dxd):
+        assert (t[0, :5] == 0).all() and (t[0, 131:] == 0).all() and t[0, 5:131].abs().sum() > 0
+    with torch.no_grad():
+        for lo, hi in ((5, 75), (75, 108), (108, 131)):
+            alone = model(inputs_embeds=x0[:, lo:hi]).last_hidden_state.float()
+            assert (hd[:, lo:hi] - alone).abs().max().item() < 3e-2 * alone.abs().max().item(), (lo, hi)
+
+
 def test_packed_rows_above_4096_positions_take_the_fused_low_rank_path():
     """Packed rows long enough for fused.mix_lora (B*T >= 4096): the low-rank branches' down projections taken through the lerp ALSO on
     cu_seqlens batches (the masked position in front of every sequence is what resets the token shift) -- hidden states and every
