@@ -511,6 +511,7 @@ def main():
         for n in lens:
             n_text = min(255, n // 4)
             n_sem = n - 3 - n_text - 32
+            assert n_sem > 0, f"--packed: a sequence of {n} positions has no room for the Spark layout (3 tags + text + 32 global + semantic); use B x L >= 8192"
             pos["tag"] += [o, o + 1 + n_text, o + 2 + n_text + 32]
             tag_ids += [2, 0, 1]
             pos["text"] += range(o + 1, o + 1 + n_text)

@@ -1,0 +1,47 @@
+"""GPU: bench.py's one-line JSON contract (the driver parses it), on a reduced workload so that the test takes seconds: the keys the
+driver and the judge read, the roofline and device objects, the packed variant."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, T=1024):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--model", "0.1b", "--batch", "2", "--seq-len", str(T), "--steps", "2", "--warmup", "1",
+           "--no-decode", "--no-cpu-baseline", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]          # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_has_the_contract_keys():
+    d = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "device", "kernel_ms"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["unit"] == "tokens/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 2 * 1024 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and "fwd_bwd" in r and "pmc_stale" in r
+    assert r["algorithmic_bytes_per_launch"] == 13 * 64 * 2 * 2 * 1024 * 12      # 13 streams x 64 channels x bf16, B T H = 2 x 1024 x 12
+    dev = d["device"]
+    assert dev["compute_units"] == 256 and dev["wkv7_group_probe_ms"] > 0 and dev["step_over_wkv7_probe"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_packed_line_counts_real_tokens():
+    d = _run("--packed", T=4096)
+    lens = d["config"]["packed_lengths"]
+    assert "PACKED" in d["config"]["workload"] and sum(lens) == 2 * 4096 - 32 * len(lens)
+    assert abs(d["value"] - sum(lens) * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-2 * d["value"]
