@@ -385,6 +385,10 @@ int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accum
 /*   out[C][R] = in[R][C]^T, 16-bit elements, R % 64 == 0 and C % 64 == 0: the NT operand W_value^T of the channel-mix backward's
  *   input-gradient GEMM (rwkv7_gemm_nt_relusq_bwd_s_bf16; autograd of rwkv_s2s_single_ffn.py:229). */
 int rwkv7_transpose_bf16(int R, int C, const void *in, void *out, rwkv7_stream_t stream);
+/*   out[r][0..D) = idx[r] >= 0 ? src[idx[r]][0..D) : 0 for r < n_out -- 16-bit rows, D % 8 == 0, idx int32 on the device.  The re-layout
+ *   of a packed `cu_seqlens` row (train_spark_rwkv7speech.py:238-239, data/utils/spark_dataset.py:111-162) into the 32-aligned row the
+ *   chunked WKV7 kernels walk, and back: the maps are injective, so forward and backward of both directions are this one gather. */
+int rwkv7_gather_rows_bf16(long n_out, int D, const void *src, const int *idx, void *out, rwkv7_stream_t stream);
 /*   Weight gradient of a low-rank projection (rwkv_s2s_single_ffn.py:172-184, autograd of x @ w1 / h @ w2): for y = x W^T,
  *   parts[s][N][K] (fp32) = dy[slab s][N]^T x[slab s][K], slab = M / S consecutive rows (a multiple of 128); one of N, K is the
  *   rank (32, 64 or 128), the other a multiple of 256.  bf16 operands, fp32 accumulation on MFMA; finish with

@@ -545,13 +545,23 @@ class RWKV7Model(nn.Module):
         j = torch.arange(total, device=x.device)
         sq = torch.searchsorted(cu[1:].contiguous(), j, right=True).clamp_(max=nseq - 1)
         valid = (j >= cu[0]) & (j < cu[-1])
-        dest = torch.where(valid, starts[sq] + (j - cu[sq]), torch.full_like(j, t_max))     # invalid positions -> the dump row
+        dest = torch.where(valid, starts[sq] + (j - cu[sq]), torch.full_like(j, -1))        # aligned row of every packed position; -1: unowned
         seq_off = torch.cat([starts.new_zeros(1), ends, ends.new_full((1,), t_max)])
         seq_off = torch.div(seq_off, C, rounding_mode="floor").to(torch.int32)                 # [nseq + 2]: the sequences + the masked tail
-        x_al = x.new_zeros(t_max + 1, D).index_copy(0, dest, x[0])[:t_max]
-        mask = x.new_zeros(t_max + 1, 1).index_fill_(0, dest, 1.0)[:t_max]
+        return self._run_packed_aligned(x, dest.to(torch.int32), t_max, seq_off)
+
+    def _run_packed_aligned(self, x, dest, t_al, seq_off):
+        """x [1, total, D] -> the 32-aligned row of t_al positions (dest int32 [total]: the aligned row of every packed position, -1 for
+        positions that belong to no sequence), the layers, and back.  Both re-layouts and both of their gradients are row gathers
+        (fused.gather_rows: the maps are injective)."""
+        total = x.shape[1]
+        j = torch.arange(total, device=x.device, dtype=torch.int32)
+        src_of = torch.full((t_al + 1,), -1, dtype=torch.int32, device=x.device)       # packed position held by every aligned row (-1: masked)
+        src_of = src_of.scatter(0, torch.where(dest >= 0, dest, torch.full_like(dest, t_al)).long(), j)[:t_al].contiguous()
+        x_al = fused.gather_rows(x[0], src_of, dest)
+        mask = (src_of >= 0).to(x.dtype).unsqueeze(-1)
         out = self._run_layers(x_al.unsqueeze(0), mask.unsqueeze(0), None, seq_off)
-        packed = out[0].index_select(0, dest.clamp(max=t_max - 1)) * valid.unsqueeze(-1).to(out.dtype)
+        packed = fused.gather_rows(out[0], dest, src_of)
         return ModelOutput(last_hidden_state=packed.unsqueeze(0), past_key_values=None)
 
     def _forward_packed(self, x, cu_seqlens):
@@ -581,20 +591,16 @@ class RWKV7Model(nn.Module):
                 starts.append(t_al)
                 if n > 0:
                     t_al += (n // C + 1) * C      # >= n + 1, multiple of 32
-            dest = torch.cat([torch.arange(s_, s_ + n) for s_, n in zip(starts, lens) if n > 0]).to(x.device, non_blocking=True)
+            dest = torch.full((x.shape[1],), -1, dtype=torch.int32)
+            for s_, n, lo in zip(starts, lens, cu[:-1]):
+                if n > 0:
+                    dest[lo:lo + n] = torch.arange(s_, s_ + n, dtype=torch.int32)
             seq_chunks = [s_ // C for s_, n in zip(starts, lens) if n > 0] + [t_al // C]
             if _row_align(t_al) > t_al:      # an all-masked pseudo-sequence up to the next multiple of 256 rows (the fused GEMM paths' tile grid)
                 t_al = _row_align(t_al)
                 seq_chunks.append(t_al // C)
             seq_off = torch.tensor(seq_chunks, dtype=torch.int32)
-            src = x[0, cu[0]:cu[-1]]
-            x_al = x.new_zeros(t_al, D).index_copy(0, dest, src)
-            mask = x.new_zeros(t_al, 1).index_fill_(0, dest, 1.0)
-            out = self._run_layers(x_al.unsqueeze(0), mask.unsqueeze(0), None, seq_off.to(x.device, non_blocking=True))
-            packed = out[0].index_select(0, dest)
-            if cu[0] > 0 or packed.shape[0] < x.shape[1]:
-                packed = torch.cat([packed.new_zeros(cu[0], D), packed, packed.new_zeros(x.shape[1] - cu[-1], D)], 0)
-            return ModelOutput(last_hidden_state=packed.unsqueeze(0), past_key_values=None)
+            return self._run_packed_aligned(x, dest.to(x.device, non_blocking=True), t_al, seq_off.to(x.device, non_blocking=True))
         seqs = list(x[0, :cu[-1]].split(lens))
         xb = torch.nn.utils.rnn.pad_sequence(seqs, batch_first=True)
         mask = torch.zeros(len(lens), xb.shape[1], dtype=torch.long, device=x.device)

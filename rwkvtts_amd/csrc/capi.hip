@@ -57,6 +57,7 @@ int chunk_bwd_out10_bf16(int, int, int, const void *, const void *, const void *
                          const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int transpose_bf16(int, int, const void *, void *, hipStream_t);
+int gather_rows16(long, int, const void *, const int *, void *, hipStream_t);
 int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
 int sample_rows_f32(int, int, const float *, long, const int *, const int *, const int *, const int *, const int *, int, int, int, int, float,
                     float, unsigned long long, const long *, long *, const void *, int, long, hipStream_t);
@@ -611,6 +612,11 @@ int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accum
     if (n <= 0 || S <= 0 || any_null({(const void *)parts, (const void *)out})) return RWKV7_EINVAL;
     if (n % 4 != 0) return RWKV7_ESHAPE;
     return rwkv7::sum_slabs_bf16(n, S, parts, out, accumulate, (hipStream_t)stream);
+}
+int rwkv7_gather_rows_bf16(long n_out, int D, const void *src, const int *idx, void *out, rwkv7_stream_t stream) {
+    if (n_out <= 0 || D <= 0 || any_null({src, (const void *)idx, (const void *)out})) return RWKV7_EINVAL;
+    if (D % 8 != 0) return RWKV7_ESHAPE;
+    return rwkv7::gather_rows16(n_out, D, src, idx, out, (hipStream_t)stream);
 }
 int rwkv7_transpose_bf16(int R, int C, const void *in, void *out, rwkv7_stream_t stream) {
     if (R <= 0 || C <= 0 || any_null({in, (const void *)out})) return RWKV7_EINVAL;

@@ -1545,6 +1545,27 @@ int transpose_bf16(int R, int C, const void *in, void *out, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// out[r][0..D) = idx[r] >= 0 ? src[idx[r]][0..D) : 0 -- 16-bit elements, D % 8 == 0.  The re-layout of a packed cu_seqlens row into the
+// 32-aligned row of RWKV7Model._forward_packed and back (train_spark_rwkv7speech.py:238-239): both directions and both gradients are
+// GATHERS (the position maps are injective), one pass each instead of zero-fill + index_copy / index_select + mask multiply.
+__global__ __launch_bounds__(256) void gather_rows16_kernel(long n_out, int D8, const uint4 *__restrict__ src, const int *__restrict__ idx,
+                                                            uint4 *__restrict__ out) {
+    const long total = n_out * D8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / D8;
+        const int c = (int)(i - r * D8);
+        const int s_ = idx[r];
+        out[i] = s_ >= 0 ? src[(long)s_ * D8 + c] : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+int gather_rows16(long n_out, int D, const void *src, const int *idx, void *out, hipStream_t st) {
+    (void)hipGetLastError();
+    const long total = n_out * (D / 8);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid), dim3(256), 0, st, n_out, D / 8, (const uint4 *)src, idx, (uint4 *)out);
+    return (int)hipGetLastError();
+}
+
 static inline int finish() { return (int)hipGetLastError(); }
 
 template <typename T>

@@ -789,6 +789,44 @@ def wgrad_splitk(dy2, x2, out=None, slabs=None):
     return out
 
 
+GATHER_ROWS_KERNEL = os.environ.get("RWKV7_GATHER_ROWS_KERNEL", "1") == "1"   # A/B switch: 0 = torch index_select + mask multiply
+
+
+class _GatherRows(torch.autograd.Function):
+    """out[r] = src[idx[r]] (zeros where idx[r] < 0); inv[j] = the output row that took source row j, or -1: the gradient is the same
+    gather the other way (rwkv7_gather_rows_bf16).  src [n_in, D] bf16, idx int32 [n_out], inv int32 [n_in]."""
+
+    @staticmethod
+    def forward(ctx, src, idx, inv):
+        src = _c(src)
+        out = torch.empty(idx.numel(), src.shape[1], dtype=src.dtype, device=src.device)
+        with torch.cuda.device_of(src):
+            rc = _lib.lib().rwkv7_gather_rows_bf16(ctypes.c_long(idx.numel()), src.shape[1], _p(src), _p(idx), _p(out), _stream(src))
+        _lib.check(rc, "gather_rows")
+        ctx.save_for_backward(idx, inv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, inv = ctx.saved_tensors
+        g = _c(g)
+        dsrc = torch.empty(inv.numel(), g.shape[1], dtype=g.dtype, device=g.device)
+        with torch.cuda.device_of(g):
+            rc = _lib.lib().rwkv7_gather_rows_bf16(ctypes.c_long(inv.numel()), g.shape[1], _p(g), _p(inv), _p(dsrc), _stream(g))
+        _lib.check(rc, "gather_rows(bwd)")
+        return dsrc, None, None
+
+
+def gather_rows(src, idx, inv):
+    """Rows of `src` [n_in, D] re-ordered by the injective map idx (int32 [n_out], -1 = a zero row), with its inverse `inv` (int32 [n_in],
+    -1 = the row is dropped) for the backward.  bf16 on the HIP device, D % 8 == 0; anything else takes torch's index ops."""
+    if (GATHER_ROWS_KERNEL and src.is_cuda and src.dtype == torch.bfloat16 and src.shape[1] % 8 == 0 and idx.dtype == torch.int32
+            and inv.dtype == torch.int32):
+        return _GatherRows.apply(src, idx, inv)
+    out = src.index_select(0, idx.clamp(min=0).long())
+    return out * (idx >= 0).unsqueeze(-1).to(out.dtype)
+
+
 # Weight gradients on a second stream.  A layer's dW = dy^T x is needed by nobody until the optimizer (or the bucket's collective):
 # queued on the stream that runs backward it sits between the input-gradient GEMM and the next fused stage and both wait for it.
 # On a side stream it runs beside the stages that follow -- HBM-bound kernels that leave the matrix cores idle and co-reside with

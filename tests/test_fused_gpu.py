@@ -841,3 +841,34 @@ def test_input_gradient_on_the_transposed_weight_is_the_same_product(M, N, K, mo
     assert torch.equal(got, want) and fused.DGRAD_NT_HITS[0] == hits + (2 if N >= 2048 else 1)
     monkeypatch.setattr(fused, "DGRAD_NT", False)
     assert torch.equal(fused._dgrad(dy, W), want)
+
+
+def test_gather_rows_forward_and_backward_are_the_two_gathers():
+    """fused.gather_rows (rwkv7_gather_rows_bf16): the packed <-> aligned re-layout of cu_seqlens rows.  out[r] = src[idx[r]] with zero
+    rows where idx < 0; the gradient w.r.t. src is the gather by the inverse map, zero for dropped rows -- bit for bit what
+    index_select + mask and their autograd give."""
+    from rwkvtts_amd import fused
+    g = torch.Generator().manual_seed(3)
+    n_in, n_out, D = 1000, 1312, 256
+    src = torch.randn(n_in, D, generator=g).to(DEV, torch.bfloat16)
+    keep = torch.randperm(n_in, generator=g)[:900]                 # 100 source rows are dropped
+    slots = torch.randperm(n_out, generator=g)[:900]               # 412 output rows stay zero
+    idx = torch.full((n_out,), -1, dtype=torch.int32)
+    inv = torch.full((n_in,), -1, dtype=torch.int32)
+    idx[slots] = keep.to(torch.int32)
+    inv[keep] = slots.to(torch.int32)
+    idx, inv = idx.to(DEV), inv.to(DEV)
+    w = torch.randn(n_out, D, generator=g).to(DEV, torch.bfloat16)
+    res = []
+    for kern in (True, False):
+        fused.GATHER_ROWS_KERNEL = kern
+        try:
+            s_ = src.clone().requires_grad_(True)
+            out = fused.gather_rows(s_, idx, inv)
+            out.backward(w)
+            res.append((out.detach(), s_.grad))
+        finally:
+            fused.GATHER_ROWS_KERNEL = True
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert (res[0][0][idx < 0] == 0).all() and (res[0][1][inv < 0] == 0).all()
+    assert torch.equal(res[0][0][slots.to(DEV)], src[keep.to(DEV)])
