@@ -439,6 +439,7 @@ def main():
     ap.add_argument("--via-reference-op", action="store_true",
                     help="A/B: the scan through torch.ops.wind_backstepping.forward/backward (the reference's plug-in point, wkv7_op.cpp:21-29; "
                          "for bf16 and T % 32 == 0 it launches the same chunked MFMA kernels, with `s` as their arena) instead of the direct calls")
+    ap.add_argument("--no-packed", action="store_true", help="skip the secondary packed-row measurement after the timed region (N = 1)")
     ap.add_argument("--packed", action="store_true",
                     help="SURVEY 8f N1: the same B x L positions as ONE packed variable-length row [1, B L, D] + cu_seqlens on the device "
                          "(15 sequences of 300 ... 4096 positions; spark layout only): the packed training path of train_spark_rwkv7speech.py:238-239")
@@ -499,7 +500,8 @@ def main():
     tr = trainer.DataParallelTrainer(model, lr=1e-4, warmup_steps=10, total_steps=1000, shard_optimizer=a.shard_optimizer)
     H = cfg.num_heads
 
-    if a.layout == "spark" and a.packed:
+    def packed_builder():
+        """(lens, make_packed_batch): the packed variable-length workload of --packed for this model and B x T."""
         lens = packed_lengths(B * T)
         ntok = sum(lens)
         cu_dev = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
@@ -522,7 +524,7 @@ def main():
         pos = {k_: torch.tensor(v_, dtype=torch.long, device=dev) for k_, v_ in pos.items()}
         tag_ids = torch.tensor(tag_ids, dtype=torch.long, device=dev)
 
-        def make_batch(i):
+        def make_packed(i):
             # one packed row [1, sum T, D], embedded WITH autograd (the four tables get gradients), cu_seqlens a DEVICE tensor: no host
             # read-back in the step (backbone._forward_packed_device)
             g = torch.Generator().manual_seed(1234 + rank + 1000 * i)
@@ -538,6 +540,10 @@ def main():
             labels = torch.full((ntok,), -100, dtype=torch.long, device=dev)
             labels[pos["sem"]] = sem
             return dict(inputs_embeds=row.unsqueeze(0), labels=labels.unsqueeze(0), cu_seqlens=cu_dev)
+        return lens, make_packed
+
+    if a.layout == "spark" and a.packed:
+        lens, make_batch = packed_builder()
     elif a.layout == "spark":
         def make_batch(i):
             # built inside the step WITH autograd, as data/utils/spark_dataset.py:163-239 does under the reference's training
@@ -715,6 +721,24 @@ def main():
                            "bucket_runs": [len(runs) for runs in r.runs],
                            "exposed_wait_ms_per_step": round(sum(s_.elapsed_time(e_) for s_, e_ in r.wait_events) / a.steps, 3),
                            "note": "exposed = time the compute stream stalls in the buckets' wait() calls (HIP event pairs around each bucket's waits, rank 0; the optimizer launches between them are not counted)"}
+        if world == 1 and not a.no_packed and not a.packed and a.layout == "spark" and B * T >= 8192:
+            # SURVEY 8f N1, after the timed region and not part of `value`: the same model and trainer on the PACKED variable-length
+            # workload of --packed (one row of 15 sequences, cu_seqlens on the device), 1 warm-up + 3 timed steps
+            try:
+                plens, make_packed = packed_builder()
+                tr.step(**make_packed(10_000))
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for i_ in range(3):
+                    tr.step(**make_packed(10_001 + i_))
+                torch.cuda.synchronize()
+                pdt = (time.perf_counter() - tp) / 3
+                out["packed"] = {"metric": "packed variable-length training step (cu_seqlens), same model, tokens/s counted on real tokens",
+                                 "ms_per_step": round(pdt * 1e3, 3), "value": round(sum(plens) / pdt, 1), "unit": "tokens/s", "sequences": len(plens),
+                                 "tokens": sum(plens), "aligned_positions": B * T, "steps": 3,
+                                 "vs_plain_step": round(pdt * 1e3 / ms, 4)}
+            except Exception as e:
+                out["packed"] = {"error": repr(e)}
         if world == 1 and not a.no_decode and a.layout == "spark":
             try:
                 out["decode"] = decode_rate(model, dev)

@@ -45,3 +45,15 @@ def test_bench_packed_line_counts_real_tokens():
     lens = d["config"]["packed_lengths"]
     assert "PACKED" in d["config"]["workload"] and sum(lens) == 2 * 4096 - 32 * len(lens)
     assert abs(d["value"] - sum(lens) * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-2 * d["value"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_default_line_carries_the_packed_object():
+    """The default N = 1 line measures the packed row too (after the timed region, outside `value`); --no-packed drops it."""
+    d = _run(T=4096)
+    p = d["packed"]
+    assert "error" not in p, p
+    assert p["aligned_positions"] == 2 * 4096 and p["tokens"] == 2 * 4096 - 32 * p["sequences"] and p["unit"] == "tokens/s"
+    assert abs(p["value"] - p["tokens"] / (p["ms_per_step"] * 1e-3)) < 1e-2 * p["value"]
+    assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-2 * d["value"]     # the headline is untouched by it
+    assert "packed" not in _run("--no-packed", T=4096)
