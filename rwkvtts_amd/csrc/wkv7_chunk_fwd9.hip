@@ -34,17 +34,22 @@
 namespace rwkv7 {
 
 #ifdef WKV7C_TIMING
-// profiling build only (python -m rwkvtts_amd.build --timing): cycle totals per interval (work a, barrier a, work b, barrier b),
-// workgroup 0, per wave; tools/cfwd9_timing.py
-__device__ long long g_cfwd9_timing[8 * 4];
+// profiling build only (python -m rwkvtts_amd.build --timing): cycle totals per wave of workgroup 0, seven slots per chunk --
+// interval a: products | epilogue + LDS drain | barrier wait; interval b: products | update + state planes | the rest | barrier wait
+// (tools/cfwd9_timing.py; profiles/r06z_cfwd9_timing_fine.txt)
+__device__ long long g_cfwd9_timing[8 * 8];
 #define F9STAMP(i)                                              \
     do {                                                        \
         const long long now_ = __builtin_readcyclecounter();    \
         tacc_[i] += now_ - tprev_;                              \
         tprev_ = now_;                                          \
     } while (0)
+#define F9FORCE(x) asm volatile("v_mov_b32 %0, %0" : "+v"(x))          // stamps behind a product: wait for the accumulator
+#define F9DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")   // ... behind LDS stores: wait for them
 #else
 #define F9STAMP(i) do { } while (0)
+#define F9FORCE(x) do { } while (0)
+#define F9DRAIN() do { } while (0)
 #endif
 
 namespace {
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
     for (int i = tid; i < 2 * VH * LDK; i += 512) sm[L::Sh + i] = 0;  // chunk c0 starts from S = 0
     using RawVec = decltype(Raw4<bf16_t>::r);
 #ifdef WKV7C_TIMING
-    long long tacc_[4] = {0, 0, 0, 0};
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev_ = __builtin_readcyclecounter();
 #endif
 
@@ -160,24 +165,29 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
                 if (wave == 0) {         // U = W S + X' V : D[t][v] -> U[v][t]
                     mma_tile3<kN>(accA, sm + L::Wh, sm + L::Wl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
                     mma_gen<kC, false, true, true, false>(accA, sm + L::XPh, sm + L::XPl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
+                    F9FORCE(accA[0]); F9STAMP(0);
                     store_T_split(accA, sm + L::Uh, sm + L::Ul, LDC, lane);
                 } else if (wave == 1) {  // D[m = s][n = t] = b^_s . q~_t = A_qb[t][s], s <= t
                     f32x16 acc = zero16();
                     mma_tile3<kN>(acc, bufc + L::BHh, bufc + L::BHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
+                    F9FORCE(acc[0]); F9STAMP(0);
                     mask_lower_T<false>(acc, lane);
                     store_T_split(acc, sm + L::QBh, sm + L::QBl, LDC, lane);
                 } else if (wave == 2) {  // k^_s . q~_t = A_qk[t][s], s <= t
                     f32x16 acc = zero16();
                     mma_tile3<kN>(acc, bufc + L::KHh, bufc + L::KHl, LDK, bufc + L::QTh, bufc + L::QTl, LDK, lane);
+                    F9FORCE(acc[0]); F9STAMP(0);
                     mask_lower_T<false>(acc, lane);
                     store_T_split(acc, sm + L::QKh, sm + L::QKl, LDC, lane);
                 } else {                 // the part of Y that needs neither U nor the A matrices
                     mma_tile3<kN>(accA, bufc + L::QTh, bufc + L::QTl, LDK, sm + L::Sh, sm + L::Sl, LDK, lane);
+                    F9FORCE(accA[0]); F9STAMP(0);
                 }
             }
-            F9STAMP(0);
-            lds_barrier();
+            F9DRAIN();
             F9STAMP(1);
+            lds_barrier();
+            F9STAMP(2);
             // ----------------------------------------------------------------------------------------------- interval b
             if (cc >= c0) {
                 if (wave == 1 || wave == 2) {
@@ -185,10 +195,12 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
                     f32x16 acc = zero16();  // D[m = k][n = v] = sum_t b^[t][k] U[t][v] + k^[t][k] V[t][v]
                     mma_gen<kC, true, true, false, true>(acc, bufc + L::BHh, bufc + L::BHl, LDK, kt * 32, sm + L::Uh, sm + L::Ul, LDC, 0, lane);
                     mma_gen<kC, true, true, true, false>(acc, bufc + L::KHh, bufc + L::KHl, LDK, kt * 32, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
+                    F9FORCE(acc[0]); F9STAMP(3);
 #pragma unroll
                     for (int r = 0; r < 16; r++) Smaster[r] = gCc[kt * 32 + d_row(r, lane)] * (Smaster[r] + acc[r]);
                     // new state planes S[v][k]: read by waves 0 and 3 in the next interval a (one barrier away)
                     store_T_split(Smaster, sm + L::Sh + kt * 32, sm + L::Sl + kt * 32, LDK, lane);
+                    F9DRAIN(); F9STAMP(4);
                     // the state at the START of chunk cc + 1 = the backward's checkpoint: q15 record straight from the accumulator
                     // tile.  Here, behind the state planes (round 4; round 3 wrote it at the top of the next interval a): the interval
                     // stamps put waves 1, 2 at 2.1k of interval a's 2.26k cycles (the A_qb / A_qk products + this record, sharing their
@@ -197,6 +209,7 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
                 } else if (wave == 3) {
                     mma_gen<kC, false, true, true, false>(accA, sm + L::QKh, sm + L::QKl, LDC, 0, bufc + L::Vt, bufc + L::Vt, LDC, 0, lane);
                     mma_tile3<kC>(accA, sm + L::QBh, sm + L::QBl, LDC, sm + L::Uh, sm + L::Ul, LDC, lane);
+                    F9FORCE(accA[0]); F9STAMP(3);
 #pragma unroll
                     for (int r = 0; r < 16; r++) sh_Y[d_row(r, lane) * kStageLD + (lane & 31)] = accA[r];
                 } else if (wave == 0 && SAVE) {
@@ -224,9 +237,10 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
                 mma_gen<kC, true, true, false, true>(acx, sm + L::AKh, sm + L::AKl, LDC, 0, sm + L::TMh, sm + L::TMl, LDC, 0, lane);
                 store_T_split(acx, sm + L::XPh, sm + L::XPl, LDC, lane);
             }
-            F9STAMP(2);
+            F9DRAIN();
+            F9STAMP(5);
             lds_barrier();
-            F9STAMP(3);
+            F9STAMP(6);
         }
         store_out(c1 - 1);
     } else {
@@ -356,19 +370,20 @@ __global__ __launch_bounds__(512) void wkv7c_fwd9_kernel(int T_, int H, const bf
             tmreg = load_tm(pc + 1);
             issue(clampc(pc + 2));
             __builtin_amdgcn_sched_barrier(0);
-            F9STAMP(0);
-            lds_barrier();
+            F9DRAIN();
             F9STAMP(1);
+            lds_barrier();
+            F9STAMP(2);
             // ----------------------------------------------------------------------------------------------- interval b
             if (pc + 1 < c1) first_half();   // chunk pc + 1
-            F9STAMP(2);
+            F9STAMP(5);
             lds_barrier();
-            F9STAMP(3);
+            F9STAMP(6);
         }
     }
 #ifdef WKV7C_TIMING
     if (blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 4; i++) g_cfwd9_timing[(tid >> 6) * 4 + i] += tacc_[i];
+        for (int i = 0; i < 8; i++) g_cfwd9_timing[(tid >> 6) * 8 + i] += tacc_[i];
 #endif
 }
 
@@ -399,9 +414,9 @@ int chunk_fwd9_bf16(int B, int T_, int H, const void *w, const void *q, const vo
 #ifdef WKV7C_TIMING
 extern "C" int rwkv7_debug_cfwd9_timing(long long *out, int reset) {
     if (reset) {
-        long long z[32] = {0};
+        long long z[64] = {0};
         return (int)hipMemcpyToSymbol(HIP_SYMBOL(rwkv7::g_cfwd9_timing), z, sizeof(z));
     }
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rwkv7::g_cfwd9_timing), sizeof(long long) * 32);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rwkv7::g_cfwd9_timing), sizeof(long long) * 64);
 }
 #endif

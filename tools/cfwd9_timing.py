@@ -14,10 +14,10 @@ N = 5
 for _ in range(N):
     run()
 torch.cuda.synchronize()
-buf = (ctypes.c_longlong * 32)()
+buf = (ctypes.c_longlong * 64)()
 lib.rwkv7_debug_cfwd9_timing(buf, 0)
 chunks = T // 32 + 1
-print("cycles per chunk (workgroup 0): interval a work / barrier wait, interval b work / barrier wait")
+print("cycles per chunk (workgroup 0): interval a = products | epilogue + LDS drain | barrier wait;  interval b = products | update + state planes | rest (record, next chunk's matrices) | barrier wait")
 for wv in range(8):
-    vals = [buf[wv * 4 + i] / N / chunks for i in range(4)]
-    print(f"wave {wv} ({'consumer' if wv < 4 else 'producer'}): total {sum(vals):6.0f} | a {vals[0]:5.0f} / {vals[1]:5.0f}   b {vals[2]:5.0f} / {vals[3]:5.0f}")
+    v = [buf[wv * 8 + i] / N / chunks for i in range(8)]
+    print(f"wave {wv} ({'consumer' if wv < 4 else 'producer'}): total {sum(v):6.0f} | a {v[0]:5.0f} | {v[1]:5.0f} | {v[2]:5.0f}    b {v[3]:5.0f} | {v[4]:5.0f} | {v[5]:5.0f} | {v[6]:5.0f}")
