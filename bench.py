@@ -468,7 +468,18 @@ def main():
     from rwkvtts_amd import backbone, ops, trainer
     from rwkvtts_amd.layouts import synthetic_spark_batch, synthetic_xy_batch
 
-    rank, local_rank, world = trainer.init_distributed("gloo" if a.one_device else None)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # ranks started by torchrun directly (the driver's form) get the same defaults self_launch() gives its children
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        # rendezvous + (with device_id) eager creation of the RCCL communicator: the first place a multi-GPU run can hang
+        with Watchdog(max(a.preflight_timeout, 120.0), "init_process_group: TCP rendezvous at MASTER_ADDR:MASTER_PORT, then RCCL communicator creation "
+                      "(ncclCommInitRank)", lambda: f"MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+                      f"WORLD_SIZE={os.environ.get('WORLD_SIZE')} HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}"):
+            rank, local_rank, world = trainer.init_distributed("gloo" if a.one_device else None)
+    else:
+        rank, local_rank, world = trainer.init_distributed("gloo" if a.one_device else None)
     if a.one_device:
         local_rank = 0
     if world != a.gpus:

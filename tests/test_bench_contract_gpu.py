@@ -57,3 +57,26 @@ def test_bench_default_line_carries_the_packed_object():
     assert abs(p["value"] - p["tokens"] / (p["ms_per_step"] * 1e-3)) < 1e-2 * p["value"]
     assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-2 * d["value"]     # the headline is untouched by it
     assert "packed" not in _run("--no-packed", T=4096)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_in_the_drivers_launch_form():
+    """REHEARSAL of the N > 1 path on a one-GPU box: the driver's own command line (torch.distributed.run ... bench.py --gpus 2), two
+    ranks sharing GPU 0 over gloo (--one-device): process-group creation under its watchdog, preflight, steps, ONE JSON line from rank 0
+    with `comm.preflight`.  Not a measurement."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--model", "0.1b", "--batch", "2", "--seq-len", "1024", "--steps", "2",
+           "--warmup", "1", "--no-decode", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "packed" not in d and "decode" not in d
+    assert abs(d["value"] - 2 * 2 * 1024 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-2 * d["value"]      # whole-job tokens of both ranks
+    pf = d["comm"]["preflight"]
+    assert len(pf["ranks"]) == 2 and pf["allreduce_64mib"]["ms"] > 0 and "exposed_wait_ms_per_step" in d["comm"]
