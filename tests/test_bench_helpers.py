@@ -47,3 +47,17 @@ def test_watchdog_is_silent_when_the_stage_finishes():
     b = _bench()
     with b.Watchdog(5.0, "quick stage"):
         pass
+
+
+def test_committed_pmc_record_matches_the_shipped_kernel_sources():
+    """profiles/pmc_wkv7.json (the `traffic` / `mfma_util` of bench.py's roofline object) is pinned to the kernel sources it was
+    collected on; a source edit without new PMC passes (tools/pmc_wkv.sh + tools/pmc_distill.py) would make the driver's line report
+    `pmc_stale` and a null `traffic` -- caught here instead."""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = json.load(open(os.path.join(root, "profiles", "pmc_wkv7.json")))
+    for key in ("wkv7c_fwd", "wkv7c_bwd"):
+        for name, h in rec[key]["sources"].items():
+            got = hashlib.sha256(open(os.path.join(root, "rwkvtts_amd", "csrc", name), "rb").read()).hexdigest()[:len(h)]
+            assert got == h, f"{name} changed since the PMC passes of {rec[key]['source']}: re-run tools/pmc_wkv.sh and tools/pmc_distill.py"
