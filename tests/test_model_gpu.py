@@ -500,6 +500,46 @@ def test_fused_linear_ce_hip_kernel_bias_and_label_smoothing(V, ls, with_bias):
     assert h.grad[::7].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("scale,ls", [(30.0, 0.0), (300.0, 0.0), (300.0, 0.1), (0.0, 0.05)])
+def test_fused_linear_ce_hip_kernel_extreme_logits(scale, ls):
+    """rwkv7_ce_fwd_bwd_ls_bf16 where a softmax written carelessly breaks: logits of magnitude ~scale x 3 (bf16 logits up to +-1e3: exp
+    overflows without the row maximum), rows whose label is the LAST column of an odd-length row (V = 8193) or column 0, rows whose label
+    carries the dominating logit (p -> 1, loss -> 0) and rows where it carries the smallest (loss ~ the logit range), all-equal logits
+    (scale 0: loss = log V exactly), and a batch with EVERY row ignored (loss 0, gradients 0, no NaN from the 0 / 0 of the mean)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    N, D, V = 256, 64, 8193
+    h = (torch.randn(N, D, generator=g) * scale / 8).bfloat16().to(DEV).requires_grad_(True)
+    w = (torch.randn(V, D, generator=g) * 0.4).bfloat16().to(DEV).requires_grad_(True)
+    logits0 = (h.detach() @ w.detach().t()).float()
+    lab = torch.randint(0, V, (N,), generator=g).to(DEV)
+    lab[0::8] = V - 1
+    lab[1::8] = 0
+    lab[2::8] = logits0[2::8].argmax(-1)
+    lab[3::8] = logits0[3::8].argmin(-1)
+    lab[4::8] = -100
+    l1 = fused_linear_cross_entropy(h, lab, w, None, -100, chunk=128, label_smoothing=ls)
+    l1.backward()
+    logits = logits0.clone().requires_grad_(True)
+    l2 = F.cross_entropy(logits, lab, ignore_index=-100, label_smoothing=ls)
+    l2.backward()
+    assert torch.isfinite(l1).item() and abs(l1.item() - l2.item()) <= 2e-4 * max(abs(l2.item()), 1e-3), (l1.item(), l2.item())
+    if scale == 0.0:
+        assert abs(l1.item() - float(torch.log(torch.tensor(float(V))))) < 1e-4
+    dh_ref = logits.grad @ w.detach().float()
+    dw_ref = logits.grad.t() @ h.detach().float()
+    assert torch.isfinite(h.grad).all() and torch.isfinite(w.grad).all()
+    assert (h.grad.float() - dh_ref).abs().max().item() <= 2e-2 * max(dh_ref.abs().max().item(), 1e-6)
+    assert (w.grad.float() - dw_ref).abs().max().item() <= 2e-2 * max(dw_ref.abs().max().item(), 1e-6)
+    assert h.grad[4::8].abs().max().item() == 0
+    # every row ignored
+    h2 = h.detach().clone().requires_grad_(True)
+    w2 = w.detach().clone().requires_grad_(True)
+    l3 = fused_linear_cross_entropy(h2, torch.full_like(lab, -100), w2, None, -100, chunk=128, label_smoothing=ls)
+    l3.backward()
+    assert l3.item() == 0.0 and h2.grad.abs().max().item() == 0 and w2.grad.abs().max().item() == 0
+
+
 def test_trainer_fast_gradient_path_equals_accumulate_path():
     """DataParallelTrainer.step arms the flat gradient buffer (no zero fill, .grad = None, the split weight gradients are
     written into their slices by rwkv7_sum_slabs_bf16, everything else is adopted and copied by the hook); the result must be
