@@ -175,6 +175,11 @@ __global__ __launch_bounds__(2048 / CW) void wkv7_fwd_kernel(int T_, int H, cons
 #pragma unroll
         for (int i = 0; i < NSLOT; i++) ykeep[i] = sakeep[i] = 0.f;
         auto step = [&](const StepOps &o, const int tt) {
+            // This body is instantiated twice (unrolled full stage, looped ragged tail).  Under -ffast-math the two copies were
+            // contracted differently: y of a step differed in the last fp32 bit (one bf16 ulp on ~1e-4 of the outputs) depending on
+            // whether the step fell into a full stage -- i.e. on where a caller splits a sequence between two state-carrying calls,
+            // which the reference's single loop cannot do (rwkv7_state_fwd_fp16.cu:23-52).  The arithmetic is pinned as written.
+#pragma clang fp reassociate(off) contract(off)
             float wv[CW], qv[CW], kv[CW], av[CW], bv[CW];
 #pragma unroll
             for (int i = 0; i < CW / 4; i++) {

@@ -5,7 +5,7 @@ six gradients within 2 -- and where an element is NOT, an fp64 scan of the same 
 must then be within 1 bf16 ulp of that truth (or 1e-4 of the tensor's maximum, the fp32-accumulation bar).  (It is the oracle that leaves the bar in the strong-decay regimes, and faithfully so: the
 reference's backward rebuilds S_{t-1} from S_t by dividing by the decay, wkv7_cuda.cu:97-104, which amplifies fp32 rounding by up to
 1.83x per step between its checkpoints; the chunked kernels never divide.  soak_debug.py prints the three-way comparison of a case.)
-12 cases by default (seconds); RWKV7_SOAK_CASES=N for a long run (profiles/r06z_chunk_soak.txt: 400 cases)."""
+8 cases by default (all eight regimes once); RWKV7_SOAK_CASES=N for a long run (profiles/r06z_chunk_soak.txt: 400 cases)."""
 import os
 
 import pytest
@@ -75,7 +75,7 @@ def _close_to_oracle_or_truth(got, oracle, truth, what, ulps):
     return int(bad.sum())
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("RWKV7_SOAK_CASES", "12"))))
+@pytest.mark.parametrize("case", range(int(os.environ.get("RWKV7_SOAK_CASES", "8"))))
 def test_chunked_pair_soak_vs_oracle(c_oracle, case):
     mode, shape, ins, dy = soak_inputs(case)
     y_o, s_o, sa_o = c_oracle.wkv7_fwd(*ins)
@@ -100,7 +100,7 @@ def test_chunked_pair_soak_vs_oracle(c_oracle, case):
               f"1 ulp of the fp64 scan: {({k_: v_ for k_, v_ in outl.items() if v_})}")
 
 
-@pytest.mark.parametrize("case", range(max(6, int(os.environ.get("RWKV7_SOAK_CASES", "12")) // 4)))
+@pytest.mark.parametrize("case", range(max(4, int(os.environ.get("RWKV7_SOAK_CASES", "8")) // 4)))
 def test_packed_rows_soak_vs_oracle(c_oracle, case):
     """The same regimes on PACKED rows (seq_off: fla chunk_rwkv7's cu_seqlens at chunk granularity): random cut points, every segment
     against the oracle (or the fp64 scan) run on that segment alone from the zero state."""
@@ -135,7 +135,7 @@ def test_packed_rows_soak_vs_oracle(c_oracle, case):
                 _close_to_oracle_or_truth(gr[b:b + 1, lo:hi], go, lambda i=i: truth(i + 1), f"{n} {tag}", 2.0)
 
 
-@pytest.mark.parametrize("case", range(max(8, int(os.environ.get("RWKV7_SOAK_CASES", "12")) // 4)))
+@pytest.mark.parametrize("case", range(max(8, int(os.environ.get("RWKV7_SOAK_CASES", "8")) // 4)))
 def test_reference_op_soak_vs_oracle(c_oracle, case):
     """The drop-in boundary itself in the same regimes: torch.ops.wind_backstepping.forward / backward through ops.WindBackstepping
     (rwkv_s2s_single_ffn.py:15-35) with T any multiple of 16 -- multiples of 32 in bf16 take the chunked pair, the others and fp32 the scalar
@@ -179,3 +179,34 @@ def test_reference_op_soak_vs_oracle(c_oracle, case):
                 print(f"\n[soak] case {case} {n} {tag}: |HIP - fp64| = {e_h:.3e}, |oracle - fp64| = {e_o:.3e}, max|fp64| = {t.abs().max().item():.3e}")
                 assert e_h <= max(ftol * max(t.abs().max().item(), 1e-3), 2.0 * e_o), \
                     f"{n} {tag}: beyond {ftol} of the oracle, and {e_h:.3e} from the fp64 scan where the oracle is {e_o:.3e}"
+
+
+@pytest.mark.parametrize("case", range(max(8, int(os.environ.get("RWKV7_SOAK_CASES", "8")) // 4)))
+def test_state_forward_soak_vs_oracle(c_oracle, case):
+    """rwkv7_state_fwd_fp16.forward (rwkv7_state_fwd_fp16.cu:9-57: prefill and decode on an external fp32 state, updated in place) in the
+    same regimes: ragged T (1 ... 70, no multiple required), initial states from zero to 10x the typical magnitude, bf16 and fp32; then the
+    SAME rows again in two calls (split at a random step): the carried state must give the same result as the single call, bit for bit."""
+    mode, (B, _, H), ins, _ = soak_inputs(13000 + case)
+    g = torch.Generator().manual_seed(55 + case)
+    T = int(torch.randint(1, min(71, ins[0].shape[1] + 1), (1,), generator=g))
+    dtype = torch.float32 if case % 2 else torch.bfloat16
+    w, q, k, v, a, b = [t[:, :T].contiguous().to(dtype).view(B, T, H * 64) for t in ins]
+    st0 = torch.randn(B, H, 64, 64, generator=g) * (0.0, 0.1, 1.0, 10.0)[case % 4]
+    st_o = st0.clone()
+    y_o = c_oracle.wkv7_state_fwd(st_o, q, w, k, v, a, b)
+    d = [t.to(DEV) for t in (q, w, k, v, a, b)]
+    st = st0.to(DEV)
+    y = ops.RWKV7_BATCH_OP(st, *d)
+    torch.cuda.synchronize()
+    tag = f"[{mode} {(B, T, H)} {str(dtype)[6:]} state x{(0.0, 0.1, 1.0, 10.0)[case % 4]}]"
+    if dtype == torch.bfloat16:
+        _close_to_oracle_or_truth(y, y_o, lambda: y_o, "y " + tag, 1.0)     # no backward, no division: the oracle IS the reference here
+    else:
+        assert (y.cpu() - y_o).abs().max().item() <= 2e-5 * max(y_o.abs().max().item(), 1e-3), "y " + tag
+    assert (st.cpu() - st_o).abs().max().item() <= 2e-5 * max(st_o.abs().max().item(), 1e-3), "state " + tag
+    if T > 1:
+        cut = int(torch.randint(1, T, (1,), generator=g))
+        st2 = st0.to(DEV)
+        y1 = ops.RWKV7_BATCH_OP(st2, *[t[:, :cut].contiguous() for t in d])
+        y2 = ops.RWKV7_BATCH_OP(st2, *[t[:, cut:].contiguous() for t in d])
+        assert torch.equal(torch.cat([y1, y2], 1), y) and torch.equal(st2, st), "split at step %d differs from the single call %s" % (cut, tag)
