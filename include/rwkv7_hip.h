@@ -434,6 +434,18 @@ int rwkv7_mix_lora_combine_fwd_bf16(int nb, const int *ranks, const int *acts, l
 int rwkv7_mix_lora_combine_bwd_bf16(int nb, const int *ranks, const int *acts, long M, int T, const void *mask, const void *const *y,
                                     const void *const *dy, void *dG, rwkv7_stream_t stream);
 
+/* ---- the same low-rank branches' down projections with the lerp as the GEMM's A prologue (csrc/lora_down.hip; rwkv_s2s_single_ffn.py:160-190):
+ *      out_i[t] = act_i(bf16( bf16(xm[t] + (xm[t - 1] - xm[t]) mu_i) W1_i^T )), xm = x * mask, nothing from t - 1 at the first step of a
+ *      sequence (rows are [B][T]) -- the reference's own rounding points; one kernel streams x [M][D] once and writes every branch's
+ *      [M][r_i].  nb <= 4 branches, ranks multiples of 32 with sum <= 512, D a multiple of 128 (<= 4096), M a multiple of 128 and of T.
+ *   pack:  W1_i [r_i][D] -> packed [sum r_i][D] in MFMA fragment order (same bytes, one coalesced 1 KB wave load per fragment); once
+ *          per weight update
+ *   fwd:   acts: 0 none, 1 tanh, 2 sigmoid; mask [M] or NULL; mu / out: HOST arrays of device pointers (mu_i [D], out_i [M][r_i]).
+ *      The gradient is the one of the through-the-lerp form above (combine_bwd, wcat_*). ---- */
+int rwkv7_lora_down_pack_bf16(int nb, const int *ranks, const void *const *w1, int D, void *packed, rwkv7_stream_t stream);
+int rwkv7_lora_down_fwd_bf16(int nb, const int *ranks, const int *acts, long M, int T, int D, const void *x, const void *mask,
+                             const void *const *mu, const void *packed, void *const *out, rwkv7_stream_t stream);
+
 /* ---- decode-step linear layers: y[M,N] = x[M,K] @ w[N,K]^T (+ bias[N]), bf16, M <= 32 rows (one token per sequence and
  *      step), K % 64 == 0.  Replaces the nn.Linear calls of the per-token path (rwkv_s2s_single_ffn.py:482-506,545-549)
  *      for the decode batch; weight-streaming on MFMA, see csrc/gemv32.hip.  bias may be NULL. ---- */

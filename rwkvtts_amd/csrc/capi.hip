@@ -53,6 +53,17 @@ int mix_lora_wcat_fwd(const MixLoraDesc &, int, int, void *, hipStream_t);
 int mix_lora_wcat_bwd(const MixLoraDesc &, int, int, const void *, hipStream_t);
 int mix_lora_combine_fwd(const MixLoraDesc &, long, int, int, const void *, const void *, hipStream_t);
 int mix_lora_combine_bwd(const MixLoraDesc &, long, int, int, const void *, void *, hipStream_t);
+struct LoraDownDesc {
+    int nb;
+    int r[4], off[4];
+    int act[4];
+    const void *w1[4];
+    const void *mu[4];
+    void *out[4];
+    int tile0[5];
+};
+int lora_down_pack(const LoraDownDesc &, int, int, void *, hipStream_t);
+int lora_down_fwd(LoraDownDesc &, int, long, int, int, const void *, const void *, const void *, hipStream_t);
 int chunk_bwd_out10_bf16(int, int, int, const void *, const void *, const void *, const void *, const void *, const void *, const void *,
                          const void *, const float *, const float *, const void *, void *, void *, void *, void *, void *, void *, hipStream_t);
 int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
@@ -558,6 +569,55 @@ int rwkv7_mix_lora_combine_bwd_bf16(int nb, const int *ranks, const int *acts, l
         d.out2[i] = const_cast<void *>(dy[i]);
     }
     return rwkv7::mix_lora_combine_bwd(d, M, T, R, mask, dG, (hipStream_t)stream);
+}
+namespace {
+// ranks: multiples of 32, 1 <= nb <= 4, at most 16 column tiles; fills nb, r, off; returns R or a negative error
+int lora_down_desc(rwkv7::LoraDownDesc &d, int nb, const int *ranks) {
+    if (nb < 1 || nb > 4 || ranks == nullptr) return RWKV7_EINVAL;
+    d.nb = nb;
+    int R = 0;
+    for (int i = 0; i < 4; i++) {
+        d.r[i] = i < nb ? ranks[i] : 0;
+        d.off[i] = R;
+        d.act[i] = 0;
+        d.w1[i] = d.mu[i] = nullptr;
+        d.out[i] = nullptr;
+        if (i < nb) {
+            if (ranks[i] <= 0 || ranks[i] % 32 != 0) return RWKV7_ESHAPE;
+            R += ranks[i];
+        }
+    }
+    for (int i = 0; i < 5; i++) d.tile0[i] = 0;
+    return R <= 512 ? R : RWKV7_ESHAPE;
+}
+}  // namespace
+int rwkv7_lora_down_pack_bf16(int nb, const int *ranks, const void *const *w1, int D, void *packed, rwkv7_stream_t stream) {
+    rwkv7::LoraDownDesc d;
+    const int R = lora_down_desc(d, nb, ranks);
+    if (R < 0) return R;
+    if (w1 == nullptr || packed == nullptr) return RWKV7_EINVAL;
+    if (D <= 0 || D % 128 != 0) return RWKV7_ESHAPE;
+    for (int i = 0; i < nb; i++) {
+        if (w1[i] == nullptr) return RWKV7_EINVAL;
+        d.w1[i] = w1[i];
+    }
+    return rwkv7::lora_down_pack(d, R, D, packed, (hipStream_t)stream);
+}
+int rwkv7_lora_down_fwd_bf16(int nb, const int *ranks, const int *acts, long M, int T, int D, const void *x, const void *mask,
+                             const void *const *mu, const void *packed, void *const *out, rwkv7_stream_t stream) {
+    rwkv7::LoraDownDesc d;
+    const int R = lora_down_desc(d, nb, ranks);
+    if (R < 0) return R;
+    if (acts == nullptr || x == nullptr || mu == nullptr || packed == nullptr || out == nullptr) return RWKV7_EINVAL;
+    if (M <= 0 || T <= 0 || M % T != 0 || M % 128 != 0 || D <= 0 || D % 128 != 0 || D > 4096) return RWKV7_ESHAPE;
+    for (int i = 0; i < nb; i++) {
+        if (mu[i] == nullptr || out[i] == nullptr || acts[i] < 0 || acts[i] > 2) return RWKV7_EINVAL;
+        d.act[i] = acts[i];
+        d.mu[i] = mu[i];
+        d.out[i] = out[i];
+    }
+    const int rc = rwkv7::lora_down_fwd(d, R, M, T, D, x, mask, packed, (hipStream_t)stream);
+    return rc == -4 ? RWKV7_ESHAPE : rc;
 }
 int rwkv7_gemv32_bf16(int M, int N, int K, const void *x, const void *w, const void *bias, void *y, rwkv7_stream_t stream) {
     if (any_null({x, w, y})) return RWKV7_EINVAL;

@@ -245,14 +245,102 @@ class _CombineAct(torch.autograd.Function):
         return dG, None, None, None
 
 
+# Round 6 (late): the branches' down projections with the lerp as the A PROLOGUE of one own MFMA kernel (csrc/lora_down.hip) instead of the
+# library GEMM on [W_a ; W_b] + the combine kernel: the N = 2 R = 576 GEMM runs at 0.63 PF/s in the library (61 us per layer, the time of
+# N = 1024) and the combine kernel adds 20 us; the own kernel streams x once, rounds the mixed inputs to bf16 where the reference does
+# (one rounding the through-the-lerp form skipped) and writes the activated [M, r_i] directly.  Forward only: the backward below is the
+# through-the-lerp gradient unchanged (combine_bwd -> dG; dx += dG wcat; d wcat = dG^T x; wcat_bwd), with wcat rebuilt there.
+# RWKV7_LORA_DOWN_DIRECT=0: the round-4 pair.
+LORA_DOWN_DIRECT = os.environ.get("RWKV7_LORA_DOWN_DIRECT", "1") == "1"
+LORA_DOWN_DIRECT_HITS = [0]
+
+
+def lora_down_direct_supported(x, w1s):
+    """What rwkv7_lora_down_fwd_bf16 takes (csrc/lora_down.hip): rows a multiple of 128, D of 128, ranks multiples of 32, 2..10 column tiles of
+    32 that cut into two contiguous halves of at most five tiles and two branches each (lora_down_cut) -- else the round-4 pair runs."""
+    B, T, D = x.shape
+    ranks = [w.shape[0] for w in w1s]
+    if not (LORA_DOWN_DIRECT and (B * T) % 128 == 0 and D % 128 == 0 and D <= 4096 and all(r % 32 == 0 for r in ranks)):
+        return False
+    tiles = [b for b, r in enumerate(ranks) for _ in range(r // 32)]     # branch of every 32-column tile
+    ok = lambda h: 1 <= len(h) <= 5 and len(set(h)) <= 2
+    return 2 <= len(tiles) <= 10 and any(ok(tiles[:c]) and ok(tiles[c:]) for c in range(1, len(tiles)))
+
+
+class _MixLoraDirect(torch.autograd.Function):
+    """(x_r, x_k, x_v, a_1 .. a_nb) = the three lerps that feed full projections and the branches' activated hidden states."""
+
+    @staticmethod
+    def forward(ctx, x, mask, params, nb, acts, *ts):
+        B, T, D = x.shape
+        x, params = _c(x), _c(params)
+        w1s, mus = [_c(t) for t in ts[:nb]], [_c(t.reshape(-1)) for t in ts[nb:]]
+        nmix = params.shape[0]
+        out = torch.empty(nmix, B, T, D, dtype=x.dtype, device=x.device)
+        _call("mix_fwd", x, B, T, D, nmix, _p(x), _p(None), _p(mask), _p(params), _p(out), min(B * T, _MIX_FWD_BLOCKS))
+        ranks = [w.shape[0] for w in w1s]
+        cr, ca = (ctypes.c_int * nb)(*ranks), (ctypes.c_int * nb)(*acts)
+        packed = torch.empty(sum(ranks), D, dtype=x.dtype, device=x.device)
+        hs = [torch.empty(B, T, r, dtype=x.dtype, device=x.device) for r in ranks]
+        with torch.cuda.device_of(x):
+            rc = _lib.lib().rwkv7_lora_down_pack_bf16(nb, cr, _ptr_array(w1s), D, _p(packed), _stream(x))
+            _lib.check(rc, "lora_down_pack")
+            rc = _lib.lib().rwkv7_lora_down_fwd_bf16(nb, cr, ca, ctypes.c_long(B * T), T, D, _p(x), _p(mask), _ptr_array(mus), _p(packed),
+                                                     _ptr_array(hs), _stream(x))
+            _lib.check(rc, "lora_down_fwd")
+        ctx.save_for_backward(x, mask, params, *w1s, *mus, *hs)
+        ctx.nb, ctx.acts, ctx.mu_shapes = nb, acts, [t.shape for t in ts[nb:]]
+        LORA_DOWN_DIRECT_HITS[0] += 1
+        FUSED_MIX_LORA_HITS[0] += 1
+        return (*[out[i] for i in range(nmix)], *hs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        nb = ctx.nb
+        x, mask, params, *rest = ctx.saved_tensors
+        w1s, mus, hs = rest[:nb], rest[nb:2 * nb], rest[2 * nb:]
+        B, T, D = x.shape
+        nmix = params.shape[0]
+        ranks = [w.shape[0] for w in w1s]
+        R = sum(ranks)
+        cr, ca = (ctypes.c_int * nb)(*ranks), (ctypes.c_int * nb)(*ctx.acts)
+        das = [torch.zeros_like(h) if g is None else _c(g) for g, h in zip(gs[nmix:], hs)]
+        dG = torch.empty(B * T, 2 * R, dtype=x.dtype, device=x.device)
+        wcat = torch.empty(2 * R, D, dtype=x.dtype, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = _lib.lib().rwkv7_mix_lora_combine_bwd_bf16(nb, cr, ca, ctypes.c_long(B * T), T, _p(mask), _ptr_array(hs), _ptr_array(das),
+                                                            _p(dG), _stream(x))
+            _lib.check(rc, "mix_lora_combine_bwd")
+            rc = _lib.lib().rwkv7_mix_lora_wcat_fwd_bf16(nb, cr, _ptr_array(w1s), _ptr_array(mus), D, _p(wcat), _stream(x))
+            _lib.check(rc, "mix_lora_wcat_fwd")
+        g3 = [torch.zeros_like(x) if g is None else _c(g) for g in gs[:nmix]]
+        nblk = max(1, min(-(-B * T // _MIX_BWD_ROWS), _MIX_BWD_BLOCKS))
+        dx = torch.empty_like(x)
+        part = torch.empty(nblk, nmix, D, dtype=torch.float32, device=x.device)
+        ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in g3])
+        _call("mix_bwd", x, B, T, D, nmix, ptrs, _p(x), _p(None), _p(mask), _p(params), _p(dx), _p(part), nblk, _MIX_BWD_ROWS)
+        dx.view(-1, D).addmm_(dG, wcat)
+        dwcat = _c(wgrad_splitk(dG, x.view(-1, D), slabs=WGRAD_SLABS_WCAT))
+        dw1 = [torch.empty_like(w) for w in w1s]
+        dmu = [torch.empty(D, dtype=x.dtype, device=x.device) for _ in range(nb)]
+        with torch.cuda.device_of(x):
+            rc = _lib.lib().rwkv7_mix_lora_wcat_bwd_bf16(nb, cr, _ptr_array(w1s), _ptr_array(mus), D, _p(dwcat), _ptr_array(dw1),
+                                                         _ptr_array(dmu), _stream(x))
+            _lib.check(rc, "mix_lora_wcat_bwd")
+        return (dx, None, _colsum(part, params.dtype), None, None, *dw1, *[g.view(sh) for g, sh in zip(dmu, ctx.mu_shapes)])
+
+
 def mix_lora(x, mask, x_r, x_k, x_v, mus, w1s, acts):
     """x [B,T,D] (LayerNorm output); mus / w1s / acts: the lerp coefficient, Linear(D, r_i) weight and activation name of each low-rank
     branch.  Returns (x_r, x_k, x_v, [a_i]): the three lerps that feed full projections and the branches' ACTIVATED hidden states
     [B,T,r_i] (the inputs of their Linear(r_i, D))."""
     B, T, D = x.shape
     params = torch.cat([p.reshape(1, D) for p in (x_r, x_k, x_v)], 0).to(x.dtype)
-    wcat = _WcatBuild.apply(len(w1s), *w1s, *mus)
     mr = _mask_rows(mask, x)
+    if lora_down_direct_supported(x, w1s):
+        outs = _MixLoraDirect.apply(x, mr, params, len(w1s), tuple(_ACT_CODE[a] for a in acts), *w1s, *mus)
+        return outs[0], outs[1], outs[2], list(outs[3:])
+    wcat = _WcatBuild.apply(len(w1s), *w1s, *mus)
     xr, xk, xv, G = _MixLora.apply(x, mr, params, wcat)
     hs = _CombineAct.apply(G, mr, tuple(w.shape[0] for w in w1s), tuple(_ACT_CODE[a] for a in acts))
     return xr, xk, xv, list(hs)

@@ -872,3 +872,80 @@ def test_gather_rows_forward_and_backward_are_the_two_gathers():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert (res[0][0][idx < 0] == 0).all() and (res[0][1][inv < 0] == 0).all()
     assert torch.equal(res[0][0][slots.to(DEV)], src[keep.to(DEV)])
+
+
+@pytest.mark.parametrize("B,T,D,ranks,masked", [
+    (2, 2048, 1024, (64, 64, 32, 128), False),      # 0.4B, the fast path (no mask, T % 128 == 0)
+    (4, 1024, 1024, (64, 64, 128), True),           # layer 0 (no v branch), masked rows
+    (4, 1056, 1024, (64, 64, 32, 128), False),      # sequence starts inside a tile (T % 128 != 0): per-row multipliers
+    (2, 2048, 2048, (64, 64, 32, 128), True),       # D = 2048
+    (2, 2048, 2048, (96, 96, 64, 256), True),       # 1.5B ranks: 16 column tiles -- not taken by the direct kernel, the round-4 pair runs
+    (2, 2048, 768, (64, 64, 32, 128), False),       # 0.1B width
+])
+def test_lora_down_with_the_lerp_as_gemm_prologue(B, T, D, ranks, masked, monkeypatch):
+    """csrc/lora_down.hip through fused.mix_lora (rwkv_s2s_single_ffn.py:160-190): the branches' activated hidden states against the
+    SEPARATE nodes (six lerps rounded to bf16, four Linear(D, r), activations) -- the kernel rounds where they round, so what is left
+    is the summation order of the fp32 accumulation: a few values one bf16 ulp apart; the three full lerps bit for bit; every
+    gradient to the bars of the through-the-lerp form (its backward is the one that runs)."""
+    from rwkvtts_amd import fused
+    monkeypatch.setattr(fused, "FUSED_MIX_LORA", True)
+    monkeypatch.setattr(fused, "LORA_DOWN_DIRECT", True)
+    nb = len(ranks)
+    g = torch.Generator().manual_seed(B + T + D + nb)
+    x = torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16)
+    mask = None
+    if masked:
+        mask = (torch.rand(B, T, 1, generator=g) > 0.2).to(DEV, torch.bfloat16)
+        mask[:, :3] = 1
+    acts = ["tanh", None, None, "sigmoid"] if nb == 4 else ["tanh", None, "sigmoid"]
+    mus6 = [(torch.rand(1, 1, D, generator=g)).to(DEV, torch.bfloat16) for _ in range(6)]          # r w k v a g
+    w1s = [(torch.randn(r, D, generator=g) * D ** -0.5).to(DEV, torch.bfloat16) for r in ranks]
+    douts = [torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16) for _ in range(3)]
+    dhs = [torch.randn(B, T, r, generator=g).to(DEV, torch.bfloat16) for r in ranks]
+    act_fn = {None: lambda t: t, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+    res = []
+    for mode in ("direct", "through", "separate"):
+        fused.LORA_DOWN_DIRECT = mode == "direct"
+        xi = x.clone().requires_grad_(True)
+        mi = [m.clone().requires_grad_(True) for m in mus6]
+        wi = [w.clone().requires_grad_(True) for w in w1s]
+        x_r, x_w, x_k, x_v, x_a, x_g = mi
+        bm = [x_w, x_a, x_v, x_g] if nb == 4 else [x_w, x_a, x_g]
+        if mode != "separate":
+            assert fused.mix_lora_supported(xi, None, None)
+            hits = fused.LORA_DOWN_DIRECT_HITS[0]
+            xr, xk, xv, hs = fused.mix_lora(xi, mask, x_r, x_k, x_v, bm, wi, acts)
+            direct_ok = sum(ranks) <= 320
+            assert fused.LORA_DOWN_DIRECT_HITS[0] - hits == (1 if mode == "direct" and direct_ok else 0)
+        else:
+            xr, xw, xk, xv, xa, xg = fused.token_shift_mix6(xi, None, x_r, x_w, x_k, x_v, x_a, x_g, mask)
+            ins = [xw, xa, xv, xg] if nb == 4 else [xw, xa, xg]
+            hs = [act_fn[a](torch.nn.functional.linear(t, w)) for t, w, a in zip(ins, wi, acts)]
+        loss_terms = [(o.float() * d.float()).sum() for o, d in zip((xr, xk, xv), douts)] + [(h.float() * d.float()).sum() for h, d in zip(hs, dhs)]
+        sum(loss_terms).backward()
+        torch.cuda.synchronize()
+        used = [0, 2, 3] + ([1, 4, 3, 5] if nb == 4 else [1, 4, 5])
+        res.append(dict(outs=[t.detach().clone() for t in (xr, xk, xv)], hs=[h.detach().clone() for h in hs], dx=xi.grad.clone(),
+                        dmu=[mi[j].grad.clone() for j in sorted(set(used))], dw=[w.grad.clone() for w in wi]))
+    d_, t_, s_ = res
+
+    def rel(u, v):
+        return (u.float() - v.float()).norm().item() / max(v.float().norm().item(), 1e-9)
+
+    for o1, o0 in zip(d_["outs"], s_["outs"]):
+        assert torch.equal(o1, o0)
+    for h1, h0, ht in zip(d_["hs"], s_["hs"], t_["hs"]):
+        if sum(ranks) > 320:
+            assert torch.equal(h1, ht)
+            continue
+        # against the separate nodes: same rounding points -> an order of magnitude inside the through-the-lerp form's distance
+        assert rel(h1, h0) < 1.5e-3, rel(h1, h0)
+        assert rel(h1, h0) < 0.5 * max(rel(ht, h0), 1e-4) + 1e-3, (rel(h1, h0), rel(ht, h0))
+        frac = (h1 != h0).float().mean().item()
+        assert frac < 0.08, frac
+        assert (h1.float() - h0.float()).abs().max().item() <= 2 ** -6 * max(1.0, h0.float().abs().max().item())
+    assert rel(d_["dx"], s_["dx"]) < 8e-3, rel(d_["dx"], s_["dx"])
+    for u, v in zip(d_["dw"], s_["dw"]):
+        assert rel(u, v) < 1.5e-2, rel(u, v)
+    for u, v in zip(d_["dmu"], s_["dmu"]):
+        assert rel(u, v) < 2e-2, rel(u, v)

@@ -25,7 +25,8 @@ def steps(n):
     return ts
 
 
-switches = [("channel-mix backward: W_value^T through the own transpose kernel", fused, "TRANSPOSE_KERNEL", False, True),
+switches = [("low-rank down projections: lerp as the A prologue of the own MFMA kernel (csrc/lora_down.hip)", fused, "LORA_DOWN_DIRECT", False, True),
+            ("channel-mix backward: W_value^T through the own transpose kernel", fused, "TRANSPOSE_KERNEL", False, True),
             ("time-mix side: add + LayerNorm + three lerps one-pass forward (with mix_lora)", fused, "FUSED_ADD_LN_MIX_LORA_FWD", False, True),
             ("parameter-gradient partials: column sums as one launch (sum_slabs tall shape)", fused, "COLSUM_KERNEL", False, True),
             ("round 4 knobs: one-pass backward partials 2048 -> 4096 workgroups", fused, "_ADD_LN_MIX_BWD_BLOCKS", 2048, 4096),
