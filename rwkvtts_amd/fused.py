@@ -306,19 +306,21 @@ class _MixLoraDirect(torch.autograd.Function):
         cr, ca = (ctypes.c_int * nb)(*ranks), (ctypes.c_int * nb)(*ctx.acts)
         das = [torch.zeros_like(h) if g is None else _c(g) for g, h in zip(gs[nmix:], hs)]
         dG = torch.empty(B * T, 2 * R, dtype=x.dtype, device=x.device)
-        wcat = torch.empty(2 * R, D, dtype=x.dtype, device=x.device)
         with torch.cuda.device_of(x):
             rc = _lib.lib().rwkv7_mix_lora_combine_bwd_bf16(nb, cr, ca, ctypes.c_long(B * T), T, _p(mask), _ptr_array(hs), _ptr_array(das),
                                                             _p(dG), _stream(x))
             _lib.check(rc, "mix_lora_combine_bwd")
-            rc = _lib.lib().rwkv7_mix_lora_wcat_fwd_bf16(nb, cr, _ptr_array(w1s), _ptr_array(mus), D, _p(wcat), _stream(x))
-            _lib.check(rc, "mix_lora_wcat_fwd")
         g3 = [torch.zeros_like(x) if g is None else _c(g) for g in gs[:nmix]]
         nblk = max(1, min(-(-B * T // _MIX_BWD_ROWS), _MIX_BWD_BLOCKS))
         dx = torch.empty_like(x)
         part = torch.empty(nblk, nmix, D, dtype=torch.float32, device=x.device)
         ptrs = (ctypes.c_void_p * nmix)(*[g.data_ptr() for g in g3])
         _call("mix_bwd", x, B, T, D, nmix, ptrs, _p(x), _p(None), _p(mask), _p(params), _p(dx), _p(part), nblk, _MIX_BWD_ROWS)
+        wcat = torch.empty(2 * R, D, dtype=x.dtype, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = _lib.lib().rwkv7_mix_lora_wcat_fwd_bf16(nb, cr, _ptr_array(w1s), _ptr_array(mus), D, _p(wcat), _stream(x))
+            _lib.check(rc, "mix_lora_wcat_fwd")
+        # the library's addmm_ stays: an own kernel of this family did the shape in 69 us against 51.5 (profiles/r06zz_lora_dx_ab.txt)
         dx.view(-1, D).addmm_(dG, wcat)
         dwcat = _c(wgrad_splitk(dG, x.view(-1, D), slabs=WGRAD_SLABS_WCAT))
         dw1 = [torch.empty_like(w) for w in w1s]

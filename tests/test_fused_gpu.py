@@ -752,10 +752,14 @@ def test_low_rank_branches_through_the_lerp(B, T, nb, masked, monkeypatch):
 
 
 @pytest.mark.parametrize("B,T,with_branch,masked,layer0", [(2, 2048, True, False, False), (4, 1024, True, True, False), (8, 512, False, False, True)])
-def test_add_layer_norm_mix_lora_one_pass_forward(B, T, with_branch, masked, layer0):
+def test_add_layer_norm_mix_lora_one_pass_forward(B, T, with_branch, masked, layer0, monkeypatch):
     """fused.add_layer_norm_mix_lora (rwkv_s2s_single_ffn.py:158-190, 251-259): residual add + LayerNorm + the three remaining lerps as
     ONE forward kernel (rwkv7_add_ln_mix_fwd_h, nmix = 3) with the branches' GEMM on the stored LayerNorm output, against
-    fused.add_layer_norm followed by fused.mix_lora -- the same arithmetic in the same order, so outputs and every gradient bit for bit."""
+    fused.add_layer_norm followed by fused.mix_lora in its through-the-lerp form (the one-pass experiment keeps the round-4 pair; the
+    direct kernel of csrc/lora_down.hip is pinned off here) -- the same arithmetic in the same order, so outputs and every gradient bit
+    for bit."""
+    from rwkvtts_amd import fused as _fused
+    monkeypatch.setattr(_fused, "LORA_DOWN_DIRECT", False)
     D = 1024
     g = torch.Generator().manual_seed(B * T + with_branch)
     x = torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16)
@@ -949,3 +953,4 @@ def test_lora_down_with_the_lerp_as_gemm_prologue(B, T, D, ranks, masked, monkey
         assert rel(u, v) < 1.5e-2, rel(u, v)
     for u, v in zip(d_["dmu"], s_["dmu"]):
         assert rel(u, v) < 2e-2, rel(u, v)
+
