@@ -394,6 +394,9 @@ int rwkv7_gather_rows_bf16(long n_out, int D, const void *src, const int *idx, v
  *   rank (32, 64 or 128), the other a multiple of 256.  bf16 operands, fp32 accumulation on MFMA; finish with
  *   rwkv7_sum_slabs_bf16(N * K, S, parts, dW, 0). */
 int rwkv7_wgrad_skinny_bf16(long M, int N, int K, int S, const void *dy, const void *x, float *parts, rwkv7_stream_t stream);
+/*   wgrad_mid: the same partials for the [W_a ; W_b] gradient of the through-the-lerp projections (dy = dG [M][N], N = 2 R in {512, 576};
+ *   K a multiple of 256; rows per slab a multiple of 64): neither side is skinny, a workgroup holds a [N / 2][256] fp32 tile. */
+int rwkv7_wgrad_mid_bf16(long M, int N, int K, int S, const void *dy, const void *x, float *parts, rwkv7_stream_t stream);
 
 /* ---- C[M][N] = epi(A[M][K] . W[N][K]^T), bf16, fp32 accumulation: the channel-mix key projection with its activation as
  *      the epilogue (epilogue 1: relu(.)^2, rwkv_s2s_single_ffn.py:228; 0: none).  Hand-written persistent MFMA kernel fed by

@@ -70,6 +70,7 @@ int sum_slabs_bf16(long, int, const float *, void *, int, hipStream_t);
 int transpose_bf16(int, int, const void *, void *, hipStream_t);
 int gather_rows16(long, int, const void *, const int *, void *, hipStream_t);
 int wgrad_skinny_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
+int wgrad_mid_bf16(long, int, int, int, const void *, const void *, float *, hipStream_t);
 int sample_rows_f32(int, int, const float *, long, const int *, const int *, const int *, const int *, const int *, int, int, int, int, float,
                     float, unsigned long long, const long *, long *, const void *, int, long, hipStream_t);
 int ras_step_f32(int, const float *, long *, long *, long *, long *, long, int, float, int, int, float, unsigned long long, hipStream_t);
@@ -667,6 +668,11 @@ int rwkv7_wgrad_skinny_bf16(long M, int N, int K, int S, const void *dy, const v
     if (M <= 0 || S <= 0 || M % S != 0 || (M / S) % 128 != 0 || wide % 256 != 0 || (rank != 32 && rank != 64 && rank != 128))
         return RWKV7_ESHAPE;
     return rwkv7::wgrad_skinny_bf16(M, N, K, S, dy, x, parts, (hipStream_t)stream);
+}
+int rwkv7_wgrad_mid_bf16(long M, int N, int K, int S, const void *dy, const void *x, float *parts, rwkv7_stream_t stream) {
+    if (any_null({dy, x, parts})) return RWKV7_EINVAL;
+    if (M <= 0 || S <= 0 || M % S != 0 || (M / S) % 64 != 0 || K <= 0 || K % 256 != 0 || (N != 512 && N != 576)) return RWKV7_ESHAPE;
+    return rwkv7::wgrad_mid_bf16(M, N, K, S, dy, x, parts, (hipStream_t)stream);
 }
 int rwkv7_sum_slabs_bf16(long n, int S, const float *parts, void *out, int accumulate, rwkv7_stream_t stream) {
     if (n <= 0 || S <= 0 || any_null({(const void *)parts, (const void *)out})) return RWKV7_EINVAL;

@@ -835,6 +835,13 @@ COMPACT_POST_BWD = True   # tmix_post's backward hands dt + (dot, ds) per head t
 SKINNY_WGRAD = True   # low-rank weight gradients through rwkv7_wgrad_skinny_bf16 (A/B switch for tools/ab_step.py)
 
 
+# Round 6 (late): the weight gradient of [W_a ; W_b] (N = 2 R = 576 / 512) on an own kernel instead of 32 library slabs (75 us per layer on a
+# 256 x 192 tile kernel).  RWKV7_MID_WGRAD=0: the library slabs.
+MID_WGRAD = os.environ.get("RWKV7_MID_WGRAD", "1") == "1"
+MID_WGRAD_SLABS = 32
+MID_WGRAD_HITS = [0]
+
+
 def wgrad_splitk(dy2, x2, out=None, slabs=None):
     """dy2[M,N]^T @ x2[M,K] -> [N,K].  The reduction runs over M = B*T rows (32768 at BASELINE configs[1]) while the
     result is at most a few 256x256 tiles, so one BLAS call leaves most CUs idle (measured on MI355X, tools/
@@ -856,6 +863,20 @@ def wgrad_splitk(dy2, x2, out=None, slabs=None):
             _lib.check(rc, "wgrad_skinny")
             rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(N * K), S, _p(part), _p(out), 0, _stream(part))
         _lib.check(rc, "sum_slabs")
+        return out
+    if (MID_WGRAD and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and N in (512, 576) and K % 256 == 0 and M >= WGRAD_MIN_ROWS
+            and M % (MID_WGRAD_SLABS * 64) == 0 and dy2.is_contiguous() and x2.is_contiguous()):
+        # the [W_a ; W_b] gradient of fused.mix_lora: rwkv7_wgrad_mid_bf16 (csrc/wgrad_skinny.hip) + one reduction
+        S = MID_WGRAD_SLABS
+        part = torch.empty(S, N, K, dtype=torch.float32, device=dy2.device)
+        if out is None:
+            out = torch.empty(N, K, dtype=torch.bfloat16, device=dy2.device)
+        with torch.cuda.device_of(part):
+            rc = _lib.lib().rwkv7_wgrad_mid_bf16(ctypes.c_long(M), N, K, S, _p(dy2), _p(x2), _p(part), _stream(part))
+            _lib.check(rc, "wgrad_mid")
+            rc = _lib.lib().rwkv7_sum_slabs_bf16(ctypes.c_long(N * K), S, _p(part), _p(out), 0, _stream(part))
+        _lib.check(rc, "sum_slabs")
+        MID_WGRAD_HITS[0] += 1
         return out
     S = slabs if slabs else (WGRAD_SLABS_SMALL if N * K <= 1024 * 1024 else WGRAD_SLABS_BIG)
     if M < WGRAD_MIN_ROWS or M % (S * 8) != 0:

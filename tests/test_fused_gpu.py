@@ -954,3 +954,26 @@ def test_lora_down_with_the_lerp_as_gemm_prologue(B, T, D, ranks, masked, monkey
     for u, v in zip(d_["dmu"], s_["dmu"]):
         assert rel(u, v) < 2e-2, rel(u, v)
 
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 576, 1024), (4096, 512, 1024), (8192, 576, 2048), (6144, 576, 768)])
+def test_weight_gradient_of_the_lerp_matrices(M, N, K, monkeypatch):
+    """rwkv7_wgrad_mid_bf16 through fused.wgrad_splitk (the [W_a ; W_b] gradient of fused.mix_lora: dG^T x with N = 2 R = 576 / 512,
+    autograd of rwkv_s2s_single_ffn.py:160-190) against the fp32 product: half a bf16 ulp + accumulation noise; and against the library
+    slabs it replaces."""
+    from rwkvtts_amd import fused
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    monkeypatch.setattr(fused, "MID_WGRAD", True)
+    hits = fused.MID_WGRAD_HITS[0]
+    own = fused.wgrad_splitk(dy, x, slabs=32)
+    assert fused.MID_WGRAD_HITS[0] - hits == (1 if K % 256 == 0 and M % 2048 == 0 else 0)
+    monkeypatch.setattr(fused, "MID_WGRAD", False)
+    lib = fused.wgrad_splitk(dy, x, slabs=32)
+    ref = dy.float().t() @ x.float()
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (own.float() - ref).abs().max().item() <= 2 ** -8 * scale
+    assert (own.float() - ref).norm().item() <= 3e-3 * ref.norm().item()
+    assert (own.float() - lib.float()).norm().item() <= 3e-3 * lib.float().norm().item()

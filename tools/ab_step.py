@@ -25,7 +25,8 @@ def steps(n):
     return ts
 
 
-switches = [("low-rank down projections: lerp as the A prologue of the own MFMA kernel (csrc/lora_down.hip)", fused, "LORA_DOWN_DIRECT", False, True),
+switches = [("weight gradient of [W_a ; W_b] (N = 576) on the own kernel rwkv7_wgrad_mid_bf16", fused, "MID_WGRAD", False, True),
+            ("low-rank down projections: lerp as the A prologue of the own MFMA kernel (csrc/lora_down.hip)", fused, "LORA_DOWN_DIRECT", False, True),
             ("channel-mix backward: W_value^T through the own transpose kernel", fused, "TRANSPOSE_KERNEL", False, True),
             ("time-mix side: add + LayerNorm + three lerps one-pass forward (with mix_lora)", fused, "FUSED_ADD_LN_MIX_LORA_FWD", False, True),
             ("parameter-gradient partials: column sums as one launch (sum_slabs tall shape)", fused, "COLSUM_KERNEL", False, True),
