@@ -362,6 +362,10 @@ int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, lo
  *      (softmax - ls / V - (1 - ls) onehot) * scale.  0 <= ls < 1; ls = 0 is the entry above. */
 int rwkv7_ce_fwd_bwd_ls_bf16(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
                              float label_smoothing, rwkv7_stream_t stream);
+/*      The same on logits with a leading dimension ld >= V elements (rows of a buffer padded to aligned rows; columns V .. ld - 1 are
+ *      neither read nor written). */
+int rwkv7_ce_fwd_bwd_ld_bf16(long rows, int V, long ld, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
+                             float label_smoothing, rwkv7_stream_t stream);
 
 /* ---- optimizer step (train_spark_rwkv7speech.py:178-197; torch.optim.AdamW update rule, decoupled weight decay) on a
  *      flat parameter buffer: fp32 master weights p32 and moments m, v updated in place from bf16 gradients g16; the

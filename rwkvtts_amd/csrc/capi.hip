@@ -33,7 +33,7 @@ int chunk_fwd_f32(int, int, int, const void *, const void *, const void *, const
 int chunk_debug_mma(const float *, const float *, float *, float *, hipStream_t);
 int chunk_debug_tr16(const uint16_t *, const int *, uint16_t *, hipStream_t);
 int gemv32_bf16(int, int, int, const void *, const void *, const void *, void *, hipStream_t);
-int ce_fwd_bwd(long, int, void *, const long *, long, float, float *, float, hipStream_t);
+int ce_fwd_bwd(long, int, long, void *, const long *, long, float, float *, float, hipStream_t);
 int adamw_step(long, float *, const void *, float *, float *, void *, const uint8_t *, const float *, const float *, float, float, float, float,
                float, float, float, hipStream_t);
 int lora32_bf16(int, int, int, int, int, const void *, const void *, const void *, const void *, void *, hipStream_t);
@@ -653,14 +653,20 @@ int rwkv7_adamw_bf16(long n, float *p32, const void *g16, float *m, float *v, vo
 int rwkv7_ce_fwd_bwd_bf16(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
                           rwkv7_stream_t stream) {
     if (rows <= 0 || V <= 0 || any_null({(const void *)logits, (const void *)labels, (const void *)loss_rows})) return RWKV7_EINVAL;
-    return rwkv7::ce_fwd_bwd(rows, V, logits, labels, ignore_index, scale, loss_rows, 0.f, (hipStream_t)stream);
+    return rwkv7::ce_fwd_bwd(rows, V, V, logits, labels, ignore_index, scale, loss_rows, 0.f, (hipStream_t)stream);
 }
 int rwkv7_ce_fwd_bwd_ls_bf16(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
                              float label_smoothing,
                           rwkv7_stream_t stream) {
     if (rows <= 0 || V <= 0 || any_null({(const void *)logits, (const void *)labels, (const void *)loss_rows})) return RWKV7_EINVAL;
     if (!(label_smoothing >= 0.f && label_smoothing < 1.f)) return RWKV7_EINVAL;
-    return rwkv7::ce_fwd_bwd(rows, V, logits, labels, ignore_index, scale, loss_rows, label_smoothing, (hipStream_t)stream);
+    return rwkv7::ce_fwd_bwd(rows, V, V, logits, labels, ignore_index, scale, loss_rows, label_smoothing, (hipStream_t)stream);
+}
+int rwkv7_ce_fwd_bwd_ld_bf16(long rows, int V, long ld, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
+                             float label_smoothing, rwkv7_stream_t stream) {
+    if (rows <= 0 || V <= 0 || ld < V || any_null({(const void *)logits, (const void *)labels, (const void *)loss_rows})) return RWKV7_EINVAL;
+    if (!(label_smoothing >= 0.f && label_smoothing < 1.f)) return RWKV7_EINVAL;
+    return rwkv7::ce_fwd_bwd(rows, V, ld, logits, labels, ignore_index, scale, loss_rows, label_smoothing, (hipStream_t)stream);
 }
 int rwkv7_wgrad_skinny_bf16(long M, int N, int K, int S, const void *dy, const void *x, float *parts, rwkv7_stream_t stream) {
     if (any_null({dy, x, parts})) return RWKV7_EINVAL;

@@ -1308,12 +1308,14 @@ int adamw_step(long n, float *p32, const void *g16, float *m, float *v, void *p1
 // v_cvt_pk_bf16_f32.  The first form read and wrote 2 bytes per lane and instruction: 98 us per 4 096 x 8 193 chunk.
 // label smoothing ls (torch.nn.CrossEntropyLoss(label_smoothing), xy_llm.py:233-240): loss = (1 - ls)(lse - x[label]) + ls (lse - mean x),
 // d loss / d x_j = softmax_j - ls / V - (1 - ls) [j == label]; ls = 0 is the plain form, bit for bit what it was.
-__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_t *__restrict__ logits, const long *__restrict__ labels,
+// ld: elements between rows (>= V; round 6: the Spark head's logits live in a buffer padded to a multiple of 256 columns, so rows are 16-byte
+// aligned and the head GEMMs see aligned leading dimensions; the padding columns are neither read nor written here)
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, long ld, bf16_t *__restrict__ logits, const long *__restrict__ labels,
                                                          long ignore_index, float scale, float *__restrict__ loss_rows, float ls) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    uint16_t *x = reinterpret_cast<uint16_t *>(logits) + row * V;
+    uint16_t *x = reinterpret_cast<uint16_t *>(logits) + row * ld;
     const long lab = labels[row];
     const bool valid = lab != ignore_index;
     // [0, head) singles, [head, head + 8 nv) aligned pieces, [head + 8 nv, V) singles
@@ -1384,10 +1386,10 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(long rows, int V, bf16_
     }
 }
 
-int ce_fwd_bwd(long rows, int V, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows, float label_smoothing,
-               hipStream_t st) {
+int ce_fwd_bwd(long rows, int V, long ld, void *logits, const long *labels, long ignore_index, float scale, float *loss_rows,
+               float label_smoothing, hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rows, V, (bf16_t *)logits, labels,
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rows, V, ld, (bf16_t *)logits, labels,
                        ignore_index, scale, loss_rows, label_smoothing);
     return (int)hipGetLastError();
 }

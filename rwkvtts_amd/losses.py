@@ -14,6 +14,8 @@ import torch.nn.functional as F
 
 HIP_CE = os.environ.get("RWKV7_HIP_CE", "1") == "1"   # A/B switch: 0 = the torch chain for every head
 CHECK_LABELS = os.environ.get("RWKV7_CHECK_LABELS", "0") == "1"
+PADDED_HEAD = os.environ.get("RWKV7_PADDED_HEAD", "1") == "1"   # A/B switch (see _FusedLinearCE.forward)
+PADDED_HEAD_HITS = [0]
 
 
 class _FusedLinearCE(torch.autograd.Function):
@@ -26,7 +28,7 @@ class _FusedLinearCE(torch.autograd.Function):
         loss = torch.zeros((), dtype=torch.float32, device=hidden.device)
         need = ctx.needs_input_grad
         dh = torch.empty_like(hidden) if need[0] else None
-        dw = torch.zeros_like(weight, dtype=torch.float32) if need[1] else None
+        dw = None   # allocated below (the padded head accumulates into its own [Vp, D] buffer)
         db = torch.zeros_like(bias, dtype=torch.float32) if (bias is not None and need[2]) else None
         # bias and label smoothing (the XY heads, xy_llm.py:233-240) ride on the same kernel since round 4: at configs[3] the torch
         # chain behind them (fp32 logits, logsumexp, softmax, scatter, casts) was ~40 ms of a 417 ms step
@@ -40,6 +42,22 @@ class _FusedLinearCE(torch.autograd.Function):
             assert not bool(bad.any()), f"labels outside [0, {weight.shape[0]}) that are not ignore_index={ignore_index}"
         hip_ce = (HIP_CE and hidden.is_cuda and hidden.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
                   and (bias is None or bias.dtype == torch.bfloat16) and 0 <= label_smoothing < 1 and labels.dtype == torch.int64)
+        # Round 6 (late): a vocabulary that is not a multiple of 256 (the Spark head: 8 193) makes every row of the logits start on a 2-byte
+        # boundary and gives the three head GEMMs an odd leading dimension (0.75 PF/s in the library).  With PADDED_HEAD the logits live in
+        # a [rows, Vp] buffer, Vp = V rounded up to 256, the weight in a zero-padded [Vp, D] copy: the logits GEMM runs on the own kernel
+        # (rwkv7_gemm_nt_bf16: Vp % 256 == 0), the padding columns are exactly 0 before and after the loss kernel (which never touches them),
+        # so the two gradient GEMMs run over Vp with aligned operands and give the same sums.
+        V = weight.shape[0]
+        Vp = -(-V // 256) * 256
+        padded = (hip_ce and PADDED_HEAD and bias is None and Vp != V and D % 1024 == 0 and N % 256 == 0 and chunk % 256 == 0
+                  and hidden.is_contiguous())
+        if need[1] and not padded:
+            dw = torch.zeros_like(weight, dtype=torch.float32)
+        if padded:
+            w_pad = torch.zeros(Vp, D, dtype=weight.dtype, device=weight.device)
+            w_pad[:V].copy_(weight)
+            dw_pad = torch.zeros(Vp, D, dtype=torch.float32, device=weight.device) if need[1] else None
+            PADDED_HEAD_HITS[0] += 1
         for s in range(0, N, chunk):
             h = hidden[s:s + chunk]
             lab = labels[s:s + chunk]
@@ -47,21 +65,32 @@ class _FusedLinearCE(torch.autograd.Function):
                 # bf16 logits straight from the GEMM; one kernel turns them into per-row losses and d loss / d logits
                 import ctypes
                 from . import _lib
-                pd = F.linear(h, weight, bias)   # bf16 logits as nn.Linear gives them (the bias inside the GEMM's fp32 epilogue)
-                rows = pd.shape[0]
+                rows = h.shape[0]
+                stream = ctypes.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+                if padded:
+                    pd = torch.empty(rows, Vp, dtype=h.dtype, device=h.device)
+                    with torch.cuda.device_of(h):
+                        rc = _lib.lib().rwkv7_gemm_nt_bf16(rows, Vp, D, ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(w_pad.data_ptr()),
+                                                           ctypes.c_void_p(pd.data_ptr()), 0, stream)
+                    _lib.check(rc, "gemm_nt (head logits)")
+                else:
+                    pd = F.linear(h, weight, bias)   # bf16 logits as nn.Linear gives them (the bias inside the GEMM's fp32 epilogue)
                 loss_rows = torch.empty(rows, dtype=torch.float32, device=pd.device)
                 lab_c = lab.contiguous()
                 with torch.cuda.device_of(pd):
-                    rc = _lib.lib().rwkv7_ce_fwd_bwd_ls_bf16(
-                        ctypes.c_long(rows), pd.shape[1], ctypes.c_void_p(pd.data_ptr()), ctypes.c_void_p(lab_c.data_ptr()),
+                    rc = _lib.lib().rwkv7_ce_fwd_bwd_ld_bf16(
+                        ctypes.c_long(rows), V, ctypes.c_long(pd.shape[1]), ctypes.c_void_p(pd.data_ptr()), ctypes.c_void_p(lab_c.data_ptr()),
                         ctypes.c_long(ignore_index), ctypes.c_float(1.0), ctypes.c_void_p(loss_rows.data_ptr()),
-                        ctypes.c_float(float(label_smoothing)), ctypes.c_void_p(torch.cuda.current_stream(pd.device).cuda_stream))
+                        ctypes.c_float(float(label_smoothing)), stream)
                 _lib.check(rc, "ce_fwd_bwd")
                 loss += loss_rows.sum()
                 if need[0]:
-                    dh[s:s + chunk] = pd @ weight
+                    dh[s:s + chunk] = pd @ (w_pad if padded else weight)
                 if need[1]:
-                    dw += (pd.t() @ h).float()
+                    if padded:
+                        dw_pad += (pd.t() @ h).float()
+                    else:
+                        dw += (pd.t() @ h).float()
                 if db is not None:
                     db += pd.sum(0, dtype=torch.float32)
                 continue
@@ -96,6 +125,8 @@ class _FusedLinearCE(torch.autograd.Function):
                     db += p.sum(0)
         # the HIP path leaves dh / dw unscaled (scale = 1 in the kernel: 1/n_valid lives on the device); backward folds
         # 1/n_valid into the incoming gradient
+        if padded and need[1]:
+            dw = dw_pad[:V]
         ctx.save_for_backward(dh, dw, db, inv if hip_ce else None)
         ctx.wdtype = weight.dtype
         return loss * inv

@@ -958,3 +958,37 @@ def test_mask_hint_is_checked_and_the_explicit_kwarg_takes_precedence():
         b = model.model(inputs_embeds=x, attention_mask=mask, attention_mask_all_ones=False).last_hidden_state
         c = model.model(inputs_embeds=x, attention_mask=mask.clone()).last_hidden_state   # no hint: the model reads the mask
     assert torch.equal(b, c) and not torch.equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,V,D,chunk", [(4096, 8193, 1024, None), (2048, 1000, 1024, 1024), (1024, 8193, 2048, 512)])
+def test_fused_linear_ce_padded_head(N, V, D, chunk, monkeypatch):
+    """losses.PADDED_HEAD (spark_llm.py:146-160, the lm_head + cross-entropy of the Spark layout): logits in a buffer padded to a multiple
+    of 256 columns with the logits GEMM on rwkv7_gemm_nt_bf16 and the loss kernel on a leading dimension, against the unpadded library
+    route: same loss to fp32 noise, same hidden / weight gradients to the bf16 rounding of the GEMM outputs."""
+    from rwkvtts_amd import losses
+    g = torch.Generator().manual_seed(N + V)
+    h = (torch.randn(N, D, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    w = (torch.randn(V, D, generator=g) * D ** -0.5).to(DEV, torch.bfloat16)
+    lab = torch.randint(0, V, (N,), generator=g).to(DEV)
+    lab[::7] = -100
+    lab[1] = V - 1
+    res = []
+    for padded in (True, False):
+        monkeypatch.setattr(losses, "PADDED_HEAD", padded)
+        hi, wi = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        hits = losses.PADDED_HEAD_HITS[0]
+        loss = fused_linear_cross_entropy(hi, lab, wi, None, -100, chunk=chunk)
+        assert losses.PADDED_HEAD_HITS[0] - hits == (1 if padded else 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.item(), hi.grad.clone(), wi.grad.clone()))
+    (l1, dh1, dw1), (l0, dh0, dw0) = res
+    assert abs(l1 - l0) <= 2e-4 * abs(l0), (l1, l0)
+
+    def rel(a, b):
+        return (a.float() - b.float()).norm().item() / b.float().norm().item()
+
+    assert rel(dh1, dh0) < 4e-3, rel(dh1, dh0)
+    assert rel(dw1, dw0) < 4e-3, rel(dw1, dw0)
+    assert dw1.shape == w.shape and dw1.is_contiguous()

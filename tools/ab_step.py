@@ -2,7 +2,7 @@
 the 0.4B Spark training step with each switch off and on, interleaved, median of the step times."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rwkvtts_amd import backbone, fused, trainer
+from rwkvtts_amd import backbone, fused, losses, trainer
 from rwkvtts_amd.layouts import synthetic_spark_batch
 from rwkvtts_amd.spark_llm import RWKV7ForSpeech, RWKV7SpeechConfig
 dev = torch.device("cuda:0")
@@ -25,7 +25,8 @@ def steps(n):
     return ts
 
 
-switches = [("weight gradient of [W_a ; W_b] (N = 576) on the own kernel rwkv7_wgrad_mid_bf16", fused, "MID_WGRAD", False, True),
+switches = [("head: logits in a buffer padded to 256 columns, logits GEMM on the own kernel (losses.PADDED_HEAD)", losses, "PADDED_HEAD", False, True),
+            ("weight gradient of [W_a ; W_b] (N = 576) on the own kernel rwkv7_wgrad_mid_bf16", fused, "MID_WGRAD", False, True),
             ("low-rank down projections: lerp as the A prologue of the own MFMA kernel (csrc/lora_down.hip)", fused, "LORA_DOWN_DIRECT", False, True),
             ("channel-mix backward: W_value^T through the own transpose kernel", fused, "TRANSPOSE_KERNEL", False, True),
             ("time-mix side: add + LayerNorm + three lerps one-pass forward (with mix_lora)", fused, "FUSED_ADD_LN_MIX_LORA_FWD", False, True),
