@@ -264,7 +264,8 @@ def lora_down_direct_supported(x, w1s):
         return False
     tiles = [b for b, r in enumerate(ranks) for _ in range(r // 32)]     # branch of every 32-column tile
     ok = lambda h: 1 <= len(h) <= 5 and len(set(h)) <= 2
-    return 2 <= len(tiles) <= 10 and any(ok(tiles[:c]) and ok(tiles[c:]) for c in range(1, len(tiles)))
+    lds = 2 * (3 * 129 * 72 + 2 * len(tiles) * 2048 + len(ranks) * D)      # x buffers + two W1 stage buffers + the coefficients (launch_lora_down)
+    return 2 <= len(tiles) <= 10 and lds <= 160 * 1024 and any(ok(tiles[:c]) and ok(tiles[c:]) for c in range(1, len(tiles)))
 
 
 class _MixLoraDirect(torch.autograd.Function):

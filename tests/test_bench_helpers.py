@@ -61,3 +61,27 @@ def test_committed_pmc_record_matches_the_shipped_kernel_sources():
         for name, h in rec[key]["sources"].items():
             got = hashlib.sha256(open(os.path.join(root, "rwkvtts_amd", "csrc", name), "rb").read()).hexdigest()[:len(h)]
             assert got == h, f"{name} changed since the PMC passes of {rec[key]['source']}: re-run tools/pmc_wkv.sh and tools/pmc_distill.py"
+
+
+def test_lora_down_direct_predicate_mirrors_the_kernels_limits():
+    """fused.lora_down_direct_supported must refuse exactly what rwkv7_lora_down_fwd_bf16 refuses (csrc/lora_down.hip: lora_down_cut and
+    the LDS budget of launch_lora_down) -- a shape it lets through that the C entry rejects would raise RWKV7_ESHAPE mid-training."""
+    import torch
+    from rwkvtts_amd import fused
+
+    def sup(B, T, D, ranks):
+        x = torch.empty(B, T, D, dtype=torch.bfloat16, device="meta")
+        return fused.lora_down_direct_supported(x, [torch.empty(r, D, dtype=torch.bfloat16, device="meta") for r in ranks])
+
+    assert fused.LORA_DOWN_DIRECT
+    assert sup(8, 4096, 1024, (64, 64, 32, 128))          # 0.4B
+    assert sup(8, 4096, 1024, (64, 64, 128))              # layer 0
+    assert sup(2, 2048, 768, (64, 64, 32, 128))           # 0.1B
+    assert sup(2, 2048, 2560, (64, 64, 32, 128))
+    assert not sup(4, 8192, 2048, (96, 96, 64, 256))      # 1.5B: 16 column tiles
+    assert not sup(2, 1000, 1024, (64, 64, 32, 128))      # rows not a multiple of 128
+    assert not sup(2, 2048, 1024, (64, 64, 40, 128))      # a rank that is not a multiple of 32
+    assert not sup(2, 2048, 4096, (64, 64, 64, 128))      # 10 tiles at D = 4096: 170 KB of LDS
+    assert sup(2, 2048, 1024, (32, 32, 32, 32))           # four one-tile branches: two per half
+    assert sup(2, 2048, 1024, (32, 32, 32))               # three one-tile branches: 2 + 1
+    assert not sup(2, 2048, 1024, (32,))                  # a single tile cannot be cut in two

@@ -885,6 +885,9 @@ def test_gather_rows_forward_and_backward_are_the_two_gathers():
     (2, 2048, 2048, (64, 64, 32, 128), True),       # D = 2048
     (2, 2048, 2048, (96, 96, 64, 256), True),       # 1.5B ranks: 16 column tiles -- not taken by the direct kernel, the round-4 pair runs
     (2, 2048, 768, (64, 64, 32, 128), False),       # 0.1B width
+    (2, 2048, 2560, (64, 64, 32, 128), False),      # a wider model (20 KB of coefficients in LDS)
+    (2, 2048, 1024, (32, 32, 32, 32), True),        # four one-tile branches: two per column half
+    (2, 2048, 1024, (32, 32, 32), False),           # three one-tile branches: 2 + 1
 ])
 def test_lora_down_with_the_lerp_as_gemm_prologue(B, T, D, ranks, masked, monkeypatch):
     """csrc/lora_down.hip through fused.mix_lora (rwkv_s2s_single_ffn.py:160-190): the branches' activated hidden states against the
